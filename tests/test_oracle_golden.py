@@ -1,0 +1,59 @@
+"""Pin the numpy oracle against fixtures produced by the reference itself (tests/golden/make_golden.py)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden
+from oracle import gast_oracle as go
+
+
+def _model(cfg, dtype=np.float64):
+    adj = go.adj_from_parents(cfg['parents'])
+    return go.OracleModel(adj, cfg['arc'], cfg['channels'], causal=cfg['causal'], dropout=0.0,
+                          variant=cfg['variant'], dtype=dtype)
+
+
+def test_adjacency_known_answer():
+    import os
+    from conftest import GOLDEN
+    ref = np.load(os.path.join(GOLDEN, 'adj_j17.npy'))
+    ours = go.adj_from_parents([-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15])
+    np.testing.assert_allclose(ours, ref, rtol=0, atol=1e-7)
+
+
+def test_patterns_known_answer():
+    # SURVEY.md App. B (probe of the reference): J=17 sym nnz 29, con nnz 54; 19 -> 33/62; 15 -> 27/47
+    from tests_helpers import PARENTS
+    for J, (ns, nc) in {17: (29, 54), 19: (33, 62), 15: (27, 47)}.items():
+        s, c = go.local_graph_adjacencies(go.adj_from_parents(PARENTS[J]))
+        assert int((s > 0).sum()) == ns and int((c > 0).sum()) == nc
+    with pytest.raises(KeyError):
+        go.local_graph_adjacencies(np.eye(14))
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_eval_forward_matches_reference(name):
+    cfg, z, state, grads, post = load_golden(name)
+    m = _model(cfg)
+    assert m.receptive_field() == cfg['receptive_field']
+    y, _ = m.forward(state, z['x'], training=False)
+    assert y.v.shape == z['y_eval'].shape
+    np.testing.assert_allclose(y.v, z['y_eval'], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_train_forward_backward_matches_reference(name):
+    cfg, z, state, grads, post = load_golden(name)
+    m = _model(cfg)
+    loss, y, g, buf = m.loss_and_grads(state, z['x'], z['y3d'], training=True)
+    np.testing.assert_allclose(y, z['y_train'], rtol=0, atol=2e-5)
+    assert abs(loss - float(z['loss'])) < 1e-5
+    assert set(g) == set(grads)
+    for k in grads:
+        scale = max(1e-3, float(np.abs(grads[k]).max()))
+        err = float(np.abs(g[k] - grads[k]).max()) / scale
+        assert err < 2e-3, (k, err)
+    for k in post:
+        if k.endswith('num_batches_tracked'):
+            assert int(buf[k]) == int(post[k])
+        else:
+            np.testing.assert_allclose(buf[k], post[k], rtol=1e-4, atol=1e-5, err_msg=k)
