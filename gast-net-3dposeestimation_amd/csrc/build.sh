@@ -1,0 +1,18 @@
+#!/bin/bash
+# Build libgast_hip.so (gfx950 only) in-tree, next to the ctypes binding.
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/../gast_hip/libgast_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
+mkdir -p "$HERE/build"
+pids=()
+for f in gemm wgrad graph_ops norm_ops; do
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/../../include/gast_hip.h" -nt "$HERE/build/$f.o" ]; then
+    $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/build/gemm.o" "$HERE/build/wgrad.o" "$HERE/build/graph_ops.o" "$HERE/build/norm_ops.o"
+echo "built $OUT"

@@ -1,0 +1,87 @@
+// Shared device helpers for the gfx950 GAST-Net kernels (wave = 64 lanes; no other target is supported).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/gast_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+
+// ---------------------------------------------------------------- bf16 <-> f32 (round to nearest even)
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int EPC = 4;  // elements per 16-byte chunk
+    __device__ static __forceinline__ float ld(const float* p) { return *p; }
+    __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+    __device__ static __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int EPC = 8;
+    __device__ static __forceinline__ float ld(const bf16_t* p) { return bf2f(*p); }
+    __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f2bf(v); }
+    __device__ static __forceinline__ float rnd(float v) { return bf2f(f2bf(v)); }
+};
+
+// 4 consecutive elements <-> float4 (fp32: one 16-byte access, bf16: one 8-byte access)
+__device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
+__device__ __forceinline__ float4 ld4(const bf16_t* p) {
+    uint2 u = *(const uint2*)p;
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
+__device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+    uint2 u;
+    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    *(uint2*)p = u;
+}
+__device__ __forceinline__ float4 rnd4(float4 v, const float*) { return v; }
+__device__ __forceinline__ float4 rnd4(float4 v, const bf16_t*) {
+    return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
+}
+
+// ---------------------------------------------------------------- dropout stream (see gast_dropout in gast_hip.h)
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ uint32_t drop_key(const gast_dropout& d, uint32_t salt) {
+    uint32_t seed = d.seed ? *d.seed : 0u;
+    return seed * 0x9E3779B9u + salt * 0x85EBCA6Bu;
+}
+// multiplier (0 or inv_keep) for the element at linear element offset e of its tensor
+__device__ __forceinline__ float drop_mul(uint32_t key, uint32_t thresh, float inv_keep, uint32_t e) {
+    uint32_t h = hash32((e >> 1) ^ key);
+    uint32_t bits = (e & 1u) ? (h >> 16) : (h & 0xffffu);
+    return bits >= thresh ? inv_keep : 0.f;
+}
+
+// ---------------------------------------------------------------- row maps
+// m in [0, B*Tn*J) -> (b, t, j);  mapped row or -1
+__device__ __forceinline__ long map_row(const gast_rowmap& mp, int b, int t, int j, int J) {
+    int ts = t * mp.t_stride + mp.t_off;
+    if (ts < 0 || ts >= mp.T_total) return -1;
+    return ((long)b * mp.T_total + ts) * J + j;
+}
+
+// ---------------------------------------------------------------- XCD-aware block remap (bijective; 8 XCDs)
+// Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b%8).  Give each XCD a contiguous chunk of the
+// logical tile order so that tiles sharing an operand panel hit the same L2 (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    int q = nblk >> 3, r = nblk & 7;
+    int xcd = bid & 7, slot = bid >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+#define GAST_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -1,0 +1,537 @@
+// Graph kernels of the GAST-Net hot path on gfx950: the channel-wise semantic graph convolution's masked-softmax
+// adjacency + neighbour aggregation (reference model/local_attention.py:35-53) and the additive global joint attention
+// (reference model/global_attention.py:52-82).  All of them are HBM/latency bound (AI < 5 F/B): coalesced channel-major
+// accesses, the J x J tiles live in LDS, no MFMA.
+#include "common.h"
+
+namespace {
+
+struct Pat {
+    int J, nnz;
+    const int32_t *row_ptr, *col, *col_ptr, *crow, *cedge;
+};
+__device__ __host__ __forceinline__ Pat make_pat(const int32_t* p, int J, int nnz) {
+    Pat q;
+    q.J = J; q.nnz = nnz;
+    q.row_ptr = p + 2;
+    q.col = q.row_ptr + (J + 1);
+    q.col_ptr = q.col + nnz;
+    q.crow = q.col_ptr + (J + 1);
+    q.cedge = q.crow + nnz;
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------------ adjacency softmax
+// one thread per (channel c, row i): A_t[k][c] = exp(e[c][k] - max) / sum over the edges k of row i
+__global__ void semch_adj_fwd_kernel(const float* __restrict__ e, int C, const int32_t* __restrict__ pat, float* __restrict__ A_t) {
+    const int J = pat[0], nnz = pat[1];
+    const Pat p = make_pat(pat, J, nnz);
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * J) return;
+    int i = idx / C, c = idx - i * C;
+    int k0 = p.row_ptr[i], k1 = p.row_ptr[i + 1];
+    float mx = -3.0e38f;
+    for (int k = k0; k < k1; ++k) mx = fmaxf(mx, e[(long)c * nnz + k]);
+    float sum = 0.f;
+    for (int k = k0; k < k1; ++k) sum += expf(e[(long)c * nnz + k] - mx);
+    float inv = 1.f / sum;
+    for (int k = k0; k < k1; ++k) A_t[(long)k * C + c] = expf(e[(long)c * nnz + k] - mx) * inv;
+}
+
+__global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
+                                     const int32_t* __restrict__ pat, float* __restrict__ de) {
+    const int J = pat[0], nnz = pat[1];
+    const Pat p = make_pat(pat, J, nnz);
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= C * J) return;
+    int i = idx / C, c = idx - i * C;
+    int k0 = p.row_ptr[i], k1 = p.row_ptr[i + 1];
+    float dot = 0.f;
+    for (int k = k0; k < k1; ++k) dot += A_t[(long)k * C + c] * dA_t[(long)k * C + c];
+    for (int k = k0; k < k1; ++k) de[(long)c * nnz + k] = A_t[(long)k * C + c] * (dA_t[(long)k * C + c] - dot);
+}
+
+// ------------------------------------------------------------------------------------------------ neighbour aggregation
+// thread <-> (frame slot, group of 4 channels).  TPF = threads per frame = min(C/4, 256), FB = 256 / TPF frame slots.
+__device__ __forceinline__ float4 fma4(float4 a, float4 b, float4 c) {
+    return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <typename T>
+__global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict__ H, int ldh, int F, int J, int C,
+                                                            const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
+                                                            const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
+                                                            T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB) {
+    __shared__ float sred[256][8];
+    const int tid = threadIdx.x;
+    const int slot = tid / TPF, ct = tid - slot * TPF;
+    const int C4 = C >> 2;
+    const bool active = slot < FB;
+    for (int cg0 = 0; cg0 < C4; cg0 += TPF) {
+        const int cg = cg0 + ct;
+        const bool cin = active && cg < C4;
+        const int c = cg * 4;
+        float4 s1[2], s2[2];
+        s1[0] = s1[1] = s2[0] = s2[1] = make_float4(0, 0, 0, 0);
+        if (cin) {
+            for (int f = blockIdx.x * FB + slot; f < F; f += gridDim.x * FB) {
+                const T* Hf = H + (long)f * J * ldh;
+                T* Yf = Y + (long)f * J * ldy;
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const int32_t* pat = g == 0 ? pat_sym : pat_con;
+                    const float* A = g == 0 ? A_sym : A_con;
+                    const Pat p = make_pat(pat, J, pat[1]);
+                    const int h0c = g * 2 * C + c, h1c = g * 2 * C + C + c;
+                    for (int i = 0; i < J; ++i) {
+                        float4 acc = make_float4(0, 0, 0, 0);
+                        for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) {
+                            int j = p.col[k];
+                            float4 av = *(const float4*)(A + (long)k * C + c);
+                            float4 hv = ld4(Hf + (long)j * ldh + (j == i ? h0c : h1c));
+                            acc = fma4(av, hv, acc);
+                        }
+                        acc = rnd4(acc, (const T*)nullptr);
+                        st4(Yf + (long)i * ldy + g * C + c, acc);
+                        s1[g] = add4(s1[g], acc);
+                        s2[g] = fma4(acc, acc, s2[g]);
+                    }
+                }
+            }
+        }
+        // reduce over the frame slots of this block, then one partial row per block
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            __syncthreads();
+            sred[tid][0] = s1[g].x; sred[tid][1] = s1[g].y; sred[tid][2] = s1[g].z; sred[tid][3] = s1[g].w;
+            sred[tid][4] = s2[g].x; sred[tid][5] = s2[g].y; sred[tid][6] = s2[g].z; sred[tid][7] = s2[g].w;
+            __syncthreads();
+            if (slot == 0 && cg < C4) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = 0.f;
+                for (int sl = 0; sl < FB; ++sl)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
+                float* pp = partials + ((long)blockIdx.x * 2 * C + g * C + c) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
+            }
+        }
+    }
+}
+
+// backward: dH[:, 0:4C] and dA (atomics into zero-filled [nnz][C] buffers)
+template <typename T>
+__global__ void __launch_bounds__(256) semch_agg_bwd_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
+                                                            int F, int J, int C,
+                                                            const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
+                                                            const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
+                                                            T* __restrict__ dH, int lddh, float* __restrict__ dA_sym,
+                                                            float* __restrict__ dA_con, int TPF, int FB, int FR) {
+    const int tid = threadIdx.x;
+    const int slot = tid / TPF, ct = tid - slot * TPF;
+    const int C4 = C >> 2;
+    if (slot >= FB) return;
+    const int f0 = (blockIdx.x * FB + slot) * FR;   // this thread owns frames [f0, f0+FR)
+    if (f0 >= F) return;
+    const int f1 = min(F, f0 + FR);
+    for (int cg = ct; cg < C4; cg += TPF) {
+        const int c = cg * 4;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int32_t* pat = g == 0 ? pat_sym : pat_con;
+            const float* A = g == 0 ? A_sym : A_con;
+            float* dA = g == 0 ? dA_sym : dA_con;
+            const Pat p = make_pat(pat, J, pat[1]);
+            const int h0c = g * 2 * C + c, h1c = g * 2 * C + C + c;
+            const int yc = g * C + c;
+            // dh0 / dh1 per frame (CSC view of the pattern)
+            for (int f = f0; f < f1; ++f) {
+                const T* dYf = dY + (long)f * J * ldy;
+                T* dHf = dH + (long)f * J * lddh;
+                for (int j = 0; j < J; ++j) {
+                    float4 d0 = make_float4(0, 0, 0, 0), d1 = make_float4(0, 0, 0, 0);
+                    for (int q = p.col_ptr[j]; q < p.col_ptr[j + 1]; ++q) {
+                        int i = p.crow[q], k = p.cedge[q];
+                        float4 av = *(const float4*)(A + (long)k * C + c);
+                        float4 dv = ld4(dYf + (long)i * ldy + yc);
+                        if (i == j) d0 = fma4(av, dv, d0); else d1 = fma4(av, dv, d1);
+                    }
+                    st4(dHf + (long)j * lddh + h0c, d0);
+                    st4(dHf + (long)j * lddh + h1c, d1);
+                }
+            }
+            // dA[k][c] = sum_f dY[f,i_k,c] * (h0[f,i,c] if diagonal else h1[f,j_k,c])
+            for (int i = 0; i < J; ++i) {
+                for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) {
+                    int j = p.col[k];
+                    float4 s = make_float4(0, 0, 0, 0);
+                    for (int f = f0; f < f1; ++f) {
+                        float4 dv = ld4(dY + ((long)f * J + i) * ldy + yc);
+                        float4 hv = ld4(H + ((long)f * J + j) * ldh + (j == i ? h0c : h1c));
+                        s = fma4(dv, hv, s);
+                    }
+                    float* d = dA + (long)k * C + c;
+                    atomicAdd(d, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ global attention
+// Work unit = (frame f, head h).  A block owns one head (h = blockIdx.x % nheads) and walks frames UB at a time.
+constexpr int UB = 4;       // max frames per block iteration (runtime `ub` <= UB, chosen so the g tiles fit in LDS)
+constexpr int JP = 20;      // padded row length of the J x J tiles (J <= 19 -> multiple of 4 floats, 16-byte rows)
+constexpr int JMAX = 19;
+
+// att[i][j] = softmax_j(leaky(a_i + c_j)) (+ C_k); also returns p (softmax part) and the LeakyReLU slope mask
+template <typename T>
+__device__ __forceinline__ void attn_rows(const T* __restrict__ AC, int ldac, const float* __restrict__ Ck, int F, int J, int nheads, int h,
+                                          int fbase, int ub, float (*sp)[JMAX][JP], float (*satt)[JMAX][JP], float (*sslope)[JMAX][JP],
+                                          float (*sa)[JMAX], float (*sc)[JMAX]) {
+    const int tid = threadIdx.x;
+    // stage a_i, c_j of the UB frames
+    for (int t = tid; t < ub * J; t += blockDim.x) {
+        int u = t / J, i = t - u * J;
+        int f = fbase + u;
+        float av = 0.f, cv = 0.f;
+        if (f < F) {
+            av = Elem<T>::ld(AC + ((long)f * J + i) * ldac + h);
+            cv = Elem<T>::ld(AC + ((long)f * J + i) * ldac + nheads + h);
+        }
+        sa[u][i] = av;
+        sc[u][i] = cv;
+    }
+    __syncthreads();
+    for (int t = tid; t < ub * J; t += blockDim.x) {
+        int u = t / J, i = t - u * J;
+        float a = sa[u][i];
+        float mx = -3.0e38f;
+        for (int j = 0; j < J; ++j) {
+            float s = a + sc[u][j];
+            s = s > 0.f ? s : 0.2f * s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < J; ++j) {
+            float s = a + sc[u][j];
+            float sl = s > 0.f ? 1.f : 0.2f;
+            s *= sl;
+            float ex = expf(s - mx);
+            sp[u][i][j] = ex;
+            if (sslope) sslope[u][i][j] = sl;
+            sum += ex;
+        }
+        float inv = 1.f / sum;
+        for (int j = 0; j < J; ++j) {
+            float pv = sp[u][i][j] * inv;
+            sp[u][i][j] = pv;
+            satt[u][i][j] = pv + Ck[((long)h * J + i) * J + j];
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_fwd_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ AC, int ldac,
+                                                       const float* __restrict__ Ck, int F, int J, int C, int nheads,
+                                                       T* __restrict__ Y, int ldy, int ub) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ci = C / nheads;
+    const int cpr = (Ci + 3) / 4;
+    const int GS = cpr * 4 + 4;  // LDS row stride of the g tile (floats): 16-byte rows, +16 B pad against bank conflicts
+    float (*sp)[JMAX][JP] = (float (*)[JMAX][JP])smem;
+    float (*satt)[JMAX][JP] = (float (*)[JMAX][JP])(smem + UB * JMAX * JP);
+    float (*sa)[JMAX] = (float (*)[JMAX])(smem + 2 * UB * JMAX * JP);
+    float (*scc)[JMAX] = (float (*)[JMAX])(smem + 2 * UB * JMAX * JP + UB * JMAX);
+    float* sg = smem + 2 * UB * JMAX * JP + 2 * UB * JMAX + 8;  // [UB][J][GS]
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x % nheads;
+    const int bstride = gridDim.x / nheads;
+    for (int fbase = (blockIdx.x / nheads) * ub; fbase < F; fbase += bstride * ub) {
+        attn_rows<T>(AC, ldac, Ck, F, J, nheads, h, fbase, ub, sp, satt, nullptr, sa, scc);
+        // stage g_h of the ub frames: [u][j][c]
+        const int nchunk = ub * J * cpr;
+        for (int t = tid; t < nchunk; t += blockDim.x) {
+            int c4 = t % cpr, rj = t / cpr;
+            int u = rj / J, j = rj - u * J;
+            int f = fbase + u;
+            float v[4] = {0, 0, 0, 0};
+            if (f < F) {
+                const T* src = G + ((long)f * J + j) * ldg + h * Ci + c4 * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (c4 * 4 + q < Ci) v[q] = Elem<T>::ld(src + q);
+            }
+            float* d = sg + ((long)u * J + j) * GS + c4 * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d[q] = v[q];
+        }
+        __syncthreads();
+        // y[u][i][c4] = sum_j att[u][i][j] * g[u][j][c4]
+        for (int t = tid; t < nchunk; t += blockDim.x) {
+            int c4 = t % cpr, ri = t / cpr;
+            int u = ri / J, i = ri - u * J;
+            int f = fbase + u;
+            if (f >= F) continue;
+            float4 acc = make_float4(0, 0, 0, 0);
+            for (int j = 0; j < J; ++j) {
+                float a = satt[u][i][j];
+                float4 gv = *(const float4*)(sg + ((long)u * J + j) * GS + c4 * 4);
+                acc.x = fmaf(a, gv.x, acc.x); acc.y = fmaf(a, gv.y, acc.y);
+                acc.z = fmaf(a, gv.z, acc.z); acc.w = fmaf(a, gv.w, acc.w);
+            }
+            T* dst = Y + ((long)f * J + i) * ldy + h * Ci + c4 * 4;
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c4 * 4 + q < Ci) Elem<T>::st(dst + q, o[q]);
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY, int lddy, const T* __restrict__ G, int ldg,
+                                                       const T* __restrict__ AC, int ldac, const float* __restrict__ Ck,
+                                                       int F, int J, int C, int nheads, T* __restrict__ dG, int lddg,
+                                                       T* __restrict__ dAC, int lddac, float* __restrict__ dCk, int ub) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int Ci = C / nheads;
+    const int cpr = (Ci + 3) / 4;
+    const int GS = cpr * 4 + 4;
+    const int TILE = UB * JMAX * JP;
+    float (*sp)[JMAX][JP] = (float (*)[JMAX][JP])smem;
+    float (*satt)[JMAX][JP] = (float (*)[JMAX][JP])(smem + TILE);
+    float (*sslope)[JMAX][JP] = (float (*)[JMAX][JP])(smem + 2 * TILE);
+    float (*sdat)[JMAX][JP] = (float (*)[JMAX][JP])(smem + 3 * TILE);
+    float (*sa)[JMAX] = (float (*)[JMAX])(smem + 4 * TILE);
+    float (*scc)[JMAX] = (float (*)[JMAX])(smem + 4 * TILE + UB * JMAX);
+    float* sg = smem + 4 * TILE + 2 * UB * JMAX + 8;   // [UB][J][GS]
+    float* sdy = sg + ub * J * GS;                     // [ub][J][GS]
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x % nheads;
+    const int bstride = gridDim.x / nheads;
+    const int nchunk = ub * J * cpr;
+    // per-thread accumulators of dC_k[h][i][j] for entries t = tid, tid + 256 (J*J <= 361 < 512)
+    float ck_acc0 = 0.f, ck_acc1 = 0.f;
+    for (int fbase = (blockIdx.x / nheads) * ub; fbase < F; fbase += bstride * ub) {
+        attn_rows<T>(AC, ldac, Ck, F, J, nheads, h, fbase, ub, sp, satt, sslope, sa, scc);
+        for (int t = tid; t < nchunk; t += blockDim.x) {
+            int c4 = t % cpr, rj = t / cpr;
+            int u = rj / J, j = rj - u * J;
+            int f = fbase + u;
+            float v[4] = {0, 0, 0, 0}, d[4] = {0, 0, 0, 0};
+            if (f < F) {
+                const T* src = G + ((long)f * J + j) * ldg + h * Ci + c4 * 4;
+                const T* dsrc = dY + ((long)f * J + j) * lddy + h * Ci + c4 * 4;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (c4 * 4 + q < Ci) { v[q] = Elem<T>::ld(src + q); d[q] = Elem<T>::ld(dsrc + q); }
+            }
+            float* pg = sg + ((long)u * J + j) * GS + c4 * 4;
+            float* pd = sdy + ((long)u * J + j) * GS + c4 * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { pg[q] = v[q]; pd[q] = d[q]; }
+        }
+        __syncthreads();
+        // datt[u][i][j] = sum_c dy[u][i][c] * g[u][j][c]
+        for (int t = tid; t < ub * J * J; t += blockDim.x) {
+            int u = t / (J * J), r = t - u * J * J;
+            int i = r / J, j = r - i * J;
+            const float* pd = sdy + ((long)u * J + i) * GS;
+            const float* pg = sg + ((long)u * J + j) * GS;
+            float acc = 0.f;
+            for (int c4 = 0; c4 < cpr; ++c4) {
+                float4 a = *(const float4*)(pd + c4 * 4);
+                float4 b = *(const float4*)(pg + c4 * 4);
+                acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+            }
+            sdat[u][i][j] = acc;
+        }
+        __syncthreads();
+        // dC_k accumulation (sum over the frames of this iteration)
+        {
+            int t = tid;
+            if (t < J * J) {
+                int i = t / J, j = t - i * J;
+                for (int u = 0; u < ub; ++u) if (fbase + u < F) ck_acc0 += sdat[u][i][j];
+            }
+            t = tid + 256;
+            if (t < J * J) {
+                int i = t / J, j = t - i * J;
+                for (int u = 0; u < ub; ++u) if (fbase + u < F) ck_acc1 += sdat[u][i][j];
+            }
+        }
+        // dg[u][j][c4] = sum_i att[u][i][j] * dy[u][i][c4]
+        for (int t = tid; t < nchunk; t += blockDim.x) {
+            int c4 = t % cpr, rj = t / cpr;
+            int u = rj / J, j = rj - u * J;
+            int f = fbase + u;
+            if (f >= F) continue;
+            float4 acc = make_float4(0, 0, 0, 0);
+            for (int i = 0; i < J; ++i) {
+                float a = satt[u][i][j];
+                float4 dv = *(const float4*)(sdy + ((long)u * J + i) * GS + c4 * 4);
+                acc.x = fmaf(a, dv.x, acc.x); acc.y = fmaf(a, dv.y, acc.y);
+                acc.z = fmaf(a, dv.z, acc.z); acc.w = fmaf(a, dv.w, acc.w);
+            }
+            T* dst = dG + ((long)f * J + j) * lddg + h * Ci + c4 * 4;
+            float o[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (c4 * 4 + q < Ci) Elem<T>::st(dst + q, o[q]);
+        }
+        // softmax + LeakyReLU backward, row-wise: ds[i][j] = p_ij (datt_ij - sum_j' p_ij' datt_ij') * slope_ij
+        for (int t = tid; t < ub * J; t += blockDim.x) {
+            int u = t / J, i = t - u * J;
+            float dot = 0.f;
+            for (int j = 0; j < J; ++j) dot += sp[u][i][j] * sdat[u][i][j];
+            float da = 0.f;
+            for (int j = 0; j < J; ++j) {
+                float ds = sp[u][i][j] * (sdat[u][i][j] - dot) * sslope[u][i][j];
+                sslope[u][i][j] = ds;   // reuse the slope tile for ds
+                da += ds;
+            }
+            int f = fbase + u;
+            if (f < F) Elem<T>::st(dAC + ((long)f * J + i) * lddac + h, da);
+        }
+        __syncthreads();
+        for (int t = tid; t < ub * J; t += blockDim.x) {
+            int u = t / J, j = t - u * J;
+            float dc = 0.f;
+            for (int i = 0; i < J; ++i) dc += sslope[u][i][j];
+            int f = fbase + u;
+            if (f < F) Elem<T>::st(dAC + ((long)f * J + j) * lddac + nheads + h, dc);
+        }
+        __syncthreads();
+    }
+    if (tid < J * J) atomicAdd(dCk + (long)h * J * J + tid, ck_acc0);
+    if (tid + 256 < J * J) atomicAdd(dCk + (long)h * J * J + tid + 256, ck_acc1);
+}
+
+inline int agg_tpf(int C) { int c4 = C / 4; return c4 < 256 ? c4 : 256; }
+
+}  // namespace
+
+extern "C" int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, gast_stream_t stream) {
+    if (!e || !pat || !A_t || C < 1) return GAST_EINVAL;
+    // J is read on the device; launch for the maximum J supported
+    int n = C * JMAX;
+    hipLaunchKernelGGL(semch_adj_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, e, C, pat, A_t);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t* pat, float* de, gast_stream_t stream) {
+    if (!dA_t || !A_t || !pat || !de || C < 1) return GAST_EINVAL;
+    int n = C * JMAX;
+    hipLaunchKernelGGL(semch_adj_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dA_t, A_t, C, pat, de);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_semch_agg_blocks(int F, int C) {
+    int TPF = agg_tpf(C), FB = 256 / TPF;
+    int nb = (F + FB - 1) / FB;
+    return nb < 512 ? nb : 512;
+}
+
+extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
+                                  const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
+                                  void* Y, int ldy, float* partials, gast_stream_t stream) {
+    if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || !partials) return GAST_EINVAL;
+    if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
+    if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
+    int TPF = agg_tpf(C), FB = 256 / TPF;
+    int nb = gast_semch_agg_blocks(F, C);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
+                           A_con, pat_con, (float*)Y, ldy, partials, TPF, FB);
+    else
+        hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym,
+                           A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                                  const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
+                                  void* dH, int lddh, float* dA_sym, float* dA_con, gast_stream_t stream) {
+    if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA_sym || !dA_con) return GAST_EINVAL;
+    if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
+    if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
+    int TPF = agg_tpf(C), FB = 256 / TPF;
+    // frames per thread: keep about 512 blocks in flight
+    int FR = (F + FB * 512 - 1) / (FB * 512);
+    if (FR < 1) FR = 1;
+    int nb = (F + FB * FR - 1) / (FB * FR);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((semch_agg_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dY, ldy, (const float*)H, ldh, F, J,
+                           C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, dA_sym, dA_con, TPF, FB, FR);
+    else
+        hipLaunchKernelGGL((semch_agg_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)H, ldh, F,
+                           J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, dA_sym, dA_con, TPF, FB, FR);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+static int attn_grid(int F, int nheads, int ub) {
+    int per_head = (F + ub - 1) / ub;
+    if (per_head > 512) per_head = 512;
+    return per_head * nheads;
+}
+
+extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
+                             int F, int J, int C, int nheads, void* Y, int ldy, gast_stream_t stream) {
+    if (!G || !AC || !C_k || !Y) return GAST_EINVAL;
+    if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
+    if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
+    const int Ci = C / nheads, GS = (Ci + 3) / 4 * 4 + 4;
+    int ub = UB;
+    size_t smem = 0;
+    for (;; ub >>= 1) {
+        smem = (size_t)(2 * UB * JMAX * JP + 2 * UB * JMAX + 8 + ub * J * GS) * sizeof(float);
+        if (smem <= 64 * 1024 || ub == 1) break;
+    }
+    if (smem > 160 * 1024) return GAST_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = attn_grid(F, nheads, ub);
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)G, ldg, (const float*)AC, ldac, C_k,
+                           F, J, C, nheads, (float*)Y, ldy, ub);
+    else
+        hipLaunchKernelGGL((attn_fwd_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)G, ldg, (const bf16_t*)AC, ldac,
+                           C_k, F, J, C, nheads, (bf16_t*)Y, ldy, ub);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                             const float* C_k, int F, int J, int C, int nheads,
+                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, gast_stream_t stream) {
+    if (!dY || !G || !AC || !C_k || !dG || !dAC || !dC_k) return GAST_EINVAL;
+    if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
+    if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
+    const int Ci = C / nheads, GS = (Ci + 3) / 4 * 4 + 4;
+    int ub = UB;
+    size_t smem = 0;
+    for (;; ub >>= 1) {
+        smem = (size_t)(4 * UB * JMAX * JP + 2 * UB * JMAX + 8 + 2 * ub * J * GS) * sizeof(float);
+        if (smem <= 64 * 1024 || ub == 1) break;
+    }
+    if (smem > 160 * 1024) return GAST_ERANGE;
+    hipStream_t st = (hipStream_t)stream;
+    int grid = attn_grid(F, nheads, ub);
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)dY, ldy, (const float*)G, ldg,
+                           (const float*)AC, ldac, C_k, F, J, C, nheads, (float*)dG, lddg, (float*)dAC, lddac, dC_k, ub);
+    else
+        hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dY, ldy, (const bf16_t*)G, ldg,
+                           (const bf16_t*)AC, ldac, C_k, F, J, C, nheads, (bf16_t*)dG, lddg, (bf16_t*)dAC, lddac, dC_k, ub);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}

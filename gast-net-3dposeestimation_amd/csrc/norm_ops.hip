@@ -1,0 +1,595 @@
+// BatchNorm (two-phase), residual, input-side (init_bn + expand_conv) and column-sum kernels for gfx950.
+// Reference: every nn.BatchNorm2d(momentum=0.1) of model/gast_net.py:20,58-59,147,149, model/local_attention.py:117-123,
+// model/global_attention.py:95; the residual adds gast_net.py:170-174 / :243-247; init_bn + expand_conv :163-164.
+// All kernels are pure streaming (HBM-bound): 4 channels per thread (16 B fp32 / 8 B bf16 accesses), channel-major
+// coalescing, column statistics reduced per block in LDS and written as partial rows that `gast_bn_finalize`
+// combines in double precision (deterministic, no atomics on the statistics).
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
+
+struct RowCfg { int TPR, RB; };
+inline RowCfg row_cfg(int N) {
+    RowCfg c;
+    int n4 = N / 4;
+    c.TPR = n4 < 256 ? n4 : 256;
+    if (c.TPR < 1) c.TPR = 1;
+    c.RB = 256 / c.TPR;
+    return c;
+}
+inline int row_blocks(long rows, int N) {
+    RowCfg c = row_cfg(N);
+    long nb = (rows + c.RB - 1) / c.RB;
+    return (int)(nb < 1024 ? nb : 1024);
+}
+
+// reduce NV float4 accumulators over the RB row slots of the block; slot 0 receives the totals
+template <int NV>
+__device__ __forceinline__ void slot_reduce(float4 (&v)[NV], float (*sred)[4 * NV], int tid, int slot, int ct, int TPR, int RB) {
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        sred[tid][4 * i] = v[i].x; sred[tid][4 * i + 1] = v[i].y; sred[tid][4 * i + 2] = v[i].z; sred[tid][4 * i + 3] = v[i].w;
+    }
+    __syncthreads();
+    if (slot == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = make_float4(0, 0, 0, 0);
+        for (int sl = 0; sl < RB; ++sl) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float* s = &sred[sl * TPR + ct][4 * i];
+                v[i].x += s[0]; v[i].y += s[1]; v[i].z += s[2]; v[i].w += s[3];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ BN finalize
+__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+                                   float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
+                                   float* mean_out, float* rstd_out) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = partials + ((long)b * ncol_total + col0 + n) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[n] * rstd;
+    scale[n] = sc;
+    shift[n] = beta[n] - (float)mean * sc;
+    mean_out[n] = (float)mean;
+    rstd_out[n] = rstd;
+    if (running_mean) {
+        double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unb;
+    }
+    if (n == 0 && nbt) *nbt += 1;
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
+                               const float* __restrict__ rv, float eps, int N, float* scale, float* shift) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float sc = gamma[n] / sqrtf(rv[n] + eps);
+    scale[n] = sc;
+    shift[n] = beta[n] - rm[n] * sc;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N, double count,
+                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
+                                       float* dgamma, float* dbeta, float* ka, float* kb, float* kc) {
+    int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        const float* p = partials + ((long)b * ncol_total + col0 + n) * 2;
+        s1 += (double)p[0];
+        s2 += (double)p[1];
+    }
+    double mu = mean[n], r = rstd[n], g = gamma[n];
+    double dg = r * (s2 - mu * s1);   // sum dz * xhat
+    double db = s1;
+    dgamma[n] = (float)dg;
+    dbeta[n] = (float)db;
+    double a = g * r;
+    double b = -g * r * r * dg / count;
+    ka[n] = (float)a;
+    kb[n] = (float)b;
+    kc[n] = (float)(-b * mu - a * db / count);
+}
+
+// ------------------------------------------------------------------------------------------------ elementwise
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, int lddz, const T* __restrict__ X, int ldx, long rows, int N,
+                                                           const float* __restrict__ ka, const float* __restrict__ kb,
+                                                           const float* __restrict__ kc, int TPR, int RB) {
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    if (slot >= RB) return;
+    const int N4 = N >> 2;
+    for (int cg = ct; cg < N4; cg += TPR) {
+        const int c = cg * 4;
+        const float4 a = *(const float4*)(ka + c), b = *(const float4*)(kb + c), k = *(const float4*)(kc + c);
+        for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+            float4 d = ld4(dz + r * lddz + c), x = ld4(X + r * ldx + c);
+            d.x = fmaf(a.x, d.x, fmaf(b.x, x.x, k.x));
+            d.y = fmaf(a.y, d.y, fmaf(b.y, x.y, k.y));
+            d.z = fmaf(a.z, d.z, fmaf(b.z, x.z, k.z));
+            d.w = fmaf(a.w, d.w, fmaf(b.w, x.w, k.w));
+            st4(dz + r * lddz + c, d);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           T* __restrict__ Y, int ldy, int TPR, int RB) {
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    if (slot >= RB) return;
+    const int N4 = N >> 2;
+    for (int cg = ct; cg < N4; cg += TPR) {
+        const int c = cg * 4;
+        const float4 s = *(const float4*)(scale + c), h = *(const float4*)(shift + c);
+        for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+            float4 x = ld4(X + r * ldx + c);
+            x.x = fmaxf(fmaf(x.x, s.x, h.x), 0.f);
+            x.y = fmaxf(fmaf(x.y, s.y, h.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, s.z, h.z), 0.f);
+            x.w = fmaxf(fmaf(x.w, s.w, h.w), 0.f);
+            st4(Y + r * ldy + c, x);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) bnrelu_bwd_mask_kernel(const T* dY, int lddy, const T* __restrict__ X, int ldx,
+                                                              long rows, int N, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, int use_drop, uint32_t salt,
+                                                              gast_dropout drop, T* dz, int lddz,
+                                                              float* __restrict__ partials, int TPR, int RB) {
+    __shared__ float sred[256][8];
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    const int N4 = N >> 2;
+    const bool dr = use_drop && drop.thresh != 0;
+    const uint32_t key = dr ? drop_key(drop, salt) : 0u;
+    for (int cg0 = 0; cg0 < N4; cg0 += TPR) {
+        const int cg = cg0 + ct;
+        const int c = cg * 4;
+        float4 acc[2];
+        acc[0] = acc[1] = make_float4(0, 0, 0, 0);
+        if (slot < RB && cg < N4) {
+            const float4 s = *(const float4*)(scale + c), h = *(const float4*)(shift + c);
+            for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+                float4 d = ld4(dY + r * lddy + c), x = ld4(X + r * ldx + c);
+                if (!(fmaf(x.x, s.x, h.x) > 0.f)) d.x = 0.f;
+                if (!(fmaf(x.y, s.y, h.y) > 0.f)) d.y = 0.f;
+                if (!(fmaf(x.z, s.z, h.z) > 0.f)) d.z = 0.f;
+                if (!(fmaf(x.w, s.w, h.w) > 0.f)) d.w = 0.f;
+                if (dr) {
+                    uint32_t e0 = (uint32_t)(r * ldx + c);
+                    d.x *= drop_mul(key, drop.thresh, drop.inv_keep, e0);
+                    d.y *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 1);
+                    d.z *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 2);
+                    d.w *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 3);
+                }
+                d = rnd4(d, (const T*)nullptr);
+                st4(dz + r * lddz + c, d);
+                acc[0].x += d.x; acc[0].y += d.y; acc[0].z += d.z; acc[0].w += d.w;
+                acc[1].x = fmaf(d.x, x.x, acc[1].x); acc[1].y = fmaf(d.y, x.y, acc[1].y);
+                acc[1].z = fmaf(d.z, x.z, acc[1].z); acc[1].w = fmaf(d.w, x.w, acc[1].w);
+            }
+        }
+        slot_reduce<2>(acc, sred, tid, slot, ct, TPR, RB);
+        if (slot == 0 && cg < N4) {
+            float* pp = partials + ((long)blockIdx.x * N + c) * 2;
+            pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
+            pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__ O, int ldo, gast_rowmap omap,
+                                                           const float* __restrict__ scO, const float* __restrict__ shO,
+                                                           const T* __restrict__ T2, int ldt, const float* __restrict__ sc2,
+                                                           const float* __restrict__ sh2, int use_drop, uint32_t salt,
+                                                           gast_dropout drop, int Tn, int J, long rows, int N,
+                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB) {
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    if (slot >= RB) return;
+    const int N4 = N >> 2;
+    const bool dr = use_drop && drop.thresh != 0;
+    const uint32_t key = dr ? drop_key(drop, salt) : 0u;
+    const int TJ = Tn * J;
+    for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+        int m = (int)r;
+        int b = m / TJ, rem = m - b * TJ;
+        int t = rem / J, j = rem - t * J;
+        long orow = map_row(omap, b, t, j, J);
+        for (int cg = ct; cg < N4; cg += TPR) {
+            const int c = cg * 4;
+            float4 res = make_float4(0, 0, 0, 0);
+            if (orow >= 0) {
+                float4 o = ld4(O + orow * ldo + c);
+                const float4 s = *(const float4*)(scO + c), h = *(const float4*)(shO + c);
+                res.x = fmaxf(fmaf(o.x, s.x, h.x), 0.f); res.y = fmaxf(fmaf(o.y, s.y, h.y), 0.f);
+                res.z = fmaxf(fmaf(o.z, s.z, h.z), 0.f); res.w = fmaxf(fmaf(o.w, s.w, h.w), 0.f);
+            }
+            float4 x = ld4(T2 + r * ldt + c);
+            const float4 s = *(const float4*)(sc2 + c), h = *(const float4*)(sh2 + c);
+            x.x = fmaxf(fmaf(x.x, s.x, h.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, h.y), 0.f);
+            x.z = fmaxf(fmaf(x.z, s.z, h.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, h.w), 0.f);
+            if (dr) {
+                uint32_t e0 = (uint32_t)(r * ldt + c);
+                x.x *= drop_mul(key, drop.thresh, drop.inv_keep, e0);
+                x.y *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 1);
+                x.z *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 2);
+                x.w *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 3);
+            }
+            res.x += x.x; res.y += x.y; res.z += x.z; res.w += x.w;
+            st4(Xn + r * ldxn + c, res);
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, int ldx, long rows, int N, float* __restrict__ out,
+                                                     int TPR, int RB) {
+    __shared__ float sred[256][4];
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    const int N4 = N >> 2;
+    for (int cg0 = 0; cg0 < N4; cg0 += TPR) {
+        const int cg = cg0 + ct;
+        const int c = cg * 4;
+        float4 acc[1];
+        acc[0] = make_float4(0, 0, 0, 0);
+        if (slot < RB && cg < N4) {
+            for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+                float4 x = ld4(X + r * ldx + c);
+                acc[0].x += x.x; acc[0].y += x.y; acc[0].z += x.z; acc[0].w += x.w;
+            }
+        }
+        slot_reduce<1>(acc, sred, tid, slot, ct, TPR, RB);
+        if (slot == 0 && cg < N4) {
+            atomicAdd(out + c, acc[0].x); atomicAdd(out + c + 1, acc[0].y);
+            atomicAdd(out + c + 2, acc[0].z); atomicAdd(out + c + 3, acc[0].w);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ input side
+constexpr int IN_ROWS_PER_BLOCK = 4096;
+
+__global__ void __launch_bounds__(256) input_stats_kernel(const float* __restrict__ x, long rows, int F_in, float* __restrict__ partials) {
+    // partials[blk][f][2]; F_in <= 8
+    __shared__ float sred[256][16];
+    const int tid = threadIdx.x;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { s1[f] = 0.f; s2[f] = 0.f; }
+    long r0 = (long)blockIdx.x * IN_ROWS_PER_BLOCK;
+    long r1 = r0 + IN_ROWS_PER_BLOCK < rows ? r0 + IN_ROWS_PER_BLOCK : rows;
+    for (long r = r0 + tid; r < r1; r += 256) {
+#pragma unroll
+        for (int f = 0; f < 8; ++f) {
+            if (f < F_in) { float v = x[r * F_in + f]; s1[f] += v; s2[f] = fmaf(v, v, s2[f]); }
+        }
+    }
+#pragma unroll
+    for (int f = 0; f < 8; ++f) { sred[tid][2 * f] = s1[f]; sred[tid][2 * f + 1] = s2[f]; }
+    __syncthreads();
+    if (tid < 2 * F_in) {
+        float t = 0.f;
+        for (int i = 0; i < 256; ++i) t += sred[i][tid];
+        partials[(long)blockIdx.x * F_in * 2 + tid] = t;
+    }
+}
+
+constexpr int KMAX = 16;  // F_in * k0 (2 features x up to 7 taps, or 3 x 5)
+
+template <typename T>
+__global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict__ x, int B, int T_in, int J, int F_in, int k0,
+                                                         int t_stride, int T_out, const float* __restrict__ W,
+                                                         const float* __restrict__ sc0, const float* __restrict__ sh0, int C,
+                                                         T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB) {
+    extern __shared__ __attribute__((aligned(16))) float sW[];  // [K0][C] then sred
+    __shared__ float sred[256][8];
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    const int K0 = F_in * k0;
+    for (int t = tid; t < K0 * C; t += 256) {
+        int c = t / K0, kk = t - c * K0;     // W is [c][f][tap] = [c][kk]
+        sW[kk * C + c] = W[t];
+    }
+    __syncthreads();
+    const int C4 = C >> 2;
+    const long rows = (long)B * T_out * J;
+    const int TJ = T_out * J;
+    for (int cg0 = 0; cg0 < C4; cg0 += TPR) {
+        const int cg = cg0 + ct;
+        const int c = cg * 4;
+        float4 acc[2];
+        acc[0] = acc[1] = make_float4(0, 0, 0, 0);
+        if (slot < RB && cg < C4) {
+            for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+                int m = (int)r;
+                int b = m / TJ, rem = m - b * TJ;
+                int t = rem / J, j = rem - t * J;
+                float4 e = make_float4(0, 0, 0, 0);
+                for (int f = 0; f < F_in; ++f) {
+                    float s = sc0[f], h = sh0[f];
+                    for (int tap = 0; tap < k0; ++tap) {
+                        long xr = ((long)b * T_in + t * t_stride + tap) * J + j;
+                        float xv = fmaf(x[xr * F_in + f], s, h);
+                        float4 w = *(const float4*)(sW + (f * k0 + tap) * C + c);
+                        e.x = fmaf(xv, w.x, e.x); e.y = fmaf(xv, w.y, e.y); e.z = fmaf(xv, w.z, e.z); e.w = fmaf(xv, w.w, e.w);
+                    }
+                }
+                e = rnd4(e, (const T*)nullptr);
+                st4(E + r * lde + c, e);
+                acc[0].x += e.x; acc[0].y += e.y; acc[0].z += e.z; acc[0].w += e.w;
+                acc[1].x = fmaf(e.x, e.x, acc[1].x); acc[1].y = fmaf(e.y, e.y, acc[1].y);
+                acc[1].z = fmaf(e.z, e.z, acc[1].z); acc[1].w = fmaf(e.w, e.w, acc[1].w);
+            }
+        }
+        slot_reduce<2>(acc, sred, tid, slot, ct, TPR, RB);
+        if (slot == 0 && cg < C4) {
+            float* pp = partials + ((long)blockIdx.x * C + c) * 2;
+            pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
+            pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
+        }
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ dE, int ldde, const float* __restrict__ x, int B, int T_in,
+                                                         int J, int F_in, int k0, int t_stride, int T_out,
+                                                         const float* __restrict__ mean0, const float* __restrict__ rstd0, int C,
+                                                         float* __restrict__ G, float* __restrict__ S, int TPR, int RB) {
+    __shared__ float sred[256][4];
+    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
+    const int K0 = F_in * k0;
+    const int C4 = C >> 2;
+    const long rows = (long)B * T_out * J;
+    const int TJ = T_out * J;
+    for (int cg0 = 0; cg0 < C4; cg0 += TPR) {
+        const int cg = cg0 + ct;
+        const int c = cg * 4;
+        float4 g[KMAX + 1];
+#pragma unroll
+        for (int kk = 0; kk <= KMAX; ++kk) g[kk] = make_float4(0, 0, 0, 0);
+        if (slot < RB && cg < C4) {
+            for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
+                int m = (int)r;
+                int b = m / TJ, rem = m - b * TJ;
+                int t = rem / J, j = rem - t * J;
+                float4 d = ld4(dE + r * ldde + c);
+                g[KMAX].x += d.x; g[KMAX].y += d.y; g[KMAX].z += d.z; g[KMAX].w += d.w;
+#pragma unroll
+                for (int kk = 0; kk < KMAX; ++kk) {
+                    if (kk < K0) {
+                        int f = kk / k0, tap = kk - f * k0;
+                        long xr = ((long)b * T_in + t * t_stride + tap) * J + j;
+                        float xh = (x[xr * F_in + f] - mean0[f]) * rstd0[f];
+                        g[kk].x = fmaf(d.x, xh, g[kk].x); g[kk].y = fmaf(d.y, xh, g[kk].y);
+                        g[kk].z = fmaf(d.z, xh, g[kk].z); g[kk].w = fmaf(d.w, xh, g[kk].w);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int kk = 0; kk <= KMAX; ++kk) {
+            if (kk < K0 || kk == KMAX) {
+                float4 v[1] = {g[kk]};
+                slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
+                if (slot == 0 && cg < C4) {
+                    if (kk == KMAX) {
+                        atomicAdd(S + c, v[0].x); atomicAdd(S + c + 1, v[0].y); atomicAdd(S + c + 2, v[0].z); atomicAdd(S + c + 3, v[0].w);
+                    } else {
+                        atomicAdd(G + (long)(c) * K0 + kk, v[0].x); atomicAdd(G + (long)(c + 1) * K0 + kk, v[0].y);
+                        atomicAdd(G + (long)(c + 2) * K0 + kk, v[0].z); atomicAdd(G + (long)(c + 3) * K0 + kk, v[0].w);
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+
+extern "C" int gast_rowwise_blocks(long rows, int N) { return row_blocks(rows, N); }
+
+extern "C" int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                int64_t* num_batches_tracked, float momentum, float eps,
+                                float* scale, float* shift, float* mean, float* rstd, gast_stream_t stream) {
+    if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return GAST_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0, N,
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                            float eps, int N, float* scale, float* shift, gast_stream_t stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || N < 1) return GAST_EINVAL;
+    hipLaunchKernelGGL(bn_eval_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var,
+                       eps, N, scale, shift);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
+                                    const float* gamma, const float* mean, const float* rstd,
+                                    float* dgamma, float* dbeta, float* ka, float* kb, float* kc, gast_stream_t stream) {
+    if (!partials || !gamma || !mean || !rstd || !dgamma || !dbeta || !ka || !kb || !kc || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0,
+                       N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline bool bad_dtype(int d) { return d != GAST_F32 && d != GAST_BF16; }
+
+extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
+                                 const float* ka, const float* kb, const float* kc, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1) return GAST_EINVAL;
+    if (N % 4 || lddz % 4 || ldx % 4) return GAST_EALIGN;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (float*)dz, lddz, (const float*)X, ldx,
+                           rows, N, ka, kb, kc, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz, (const bf16_t*)X,
+                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                                 void* Y, int ldy, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1) return GAST_EINVAL;
+    if (N % 4 || ldx % 4 || ldy % 4) return GAST_EALIGN;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((bnrelu_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)X, ldx, rows, N, scale,
+                           shift, (float*)Y, ldy, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
+                           shift, (bf16_t*)Y, ldy, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
+                                    const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
+                                    void* dz, int lddz, float* partials, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dY || !X || !scale || !shift || !dz || !partials || rows < 1) return GAST_EINVAL;
+    if (N % 4 || lddy % 4 || ldx % 4 || lddz % 4) return GAST_EALIGN;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((bnrelu_bwd_mask_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)dY, lddy,
+                           (const float*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (float*)dz, lddz, partials, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((bnrelu_bwd_mask_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)dY, lddy,
+                           (const bf16_t*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (bf16_t*)dz, lddz, partials, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
+                                 const void* T2, int ldt, const float* sc2, const float* sh2,
+                                 int use_drop, uint32_t salt, gast_dropout drop,
+                                 int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1) return GAST_EINVAL;
+    if (N % 4 || ldo % 4 || ldt % 4 || ldxn % 4) return GAST_EALIGN;
+    long rows = (long)B * Tn * J;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((residual_fwd_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)O, ldo, omap, scO, shO,
+                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)O, ldo, omap, scO, shO,
+                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out, int zero_first, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !X || !out || rows < 1) return GAST_EINVAL;
+    if (N % 4 || ldx % 4) return GAST_EALIGN;
+    hipStream_t st = (hipStream_t)stream;
+    if (zero_first) {
+        hipError_t e = hipMemsetAsync(out, 0, (size_t)N * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    RowCfg c = row_cfg(N);
+    int nb = row_blocks(rows, N);
+    if (nb > 256) nb = 256;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)X, ldx, rows, N, out, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((colsum_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, out, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_input_stats_blocks(long rows) { return (int)((rows + IN_ROWS_PER_BLOCK - 1) / IN_ROWS_PER_BLOCK); }
+
+extern "C" int gast_input_stats(const float* x, long rows, int F_in, float* partials, int* nblk_out, gast_stream_t stream) {
+    if (!x || !partials || rows < 1 || F_in < 1 || F_in > 8) return GAST_EINVAL;
+    int nb = gast_input_stats_blocks(rows);
+    if (nblk_out) *nblk_out = nb;
+    hipLaunchKernelGGL(input_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, F_in, partials);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+static inline int conv_t_out(int T_in, int k0, int t_stride) { return (T_in - k0) / t_stride + 1; }
+
+extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
+                               const float* W, const float* sc0, const float* sh0, int C,
+                               void* E, int lde, float* partials, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials) return GAST_EINVAL;
+    if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
+    if (C % 4 || lde % 4) return GAST_EALIGN;
+    size_t smem = (size_t)F_in * k0 * C * sizeof(float);
+    if (smem > 96 * 1024) return GAST_ERANGE;
+    int T_out = conv_t_out(T_in, k0, t_stride);
+    long rows = (long)B * T_out * J;
+    RowCfg c = row_cfg(C);
+    hipStream_t st = (hipStream_t)stream;
+    int nb = row_blocks(rows, C);
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
+                           C, (float*)E, lde, partials, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((expand_fwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0,
+                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
+                               int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,
+                               gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !G || !S) return GAST_EINVAL;
+    if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
+    if (C % 4 || ldde % 4) return GAST_EALIGN;
+    int T_out = conv_t_out(T_in, k0, t_stride);
+    long rows = (long)B * T_out * J;
+    RowCfg c = row_cfg(C);
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(G, 0, (size_t)C * F_in * k0 * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemsetAsync(S, 0, (size_t)C * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+    int nb = row_blocks(rows, C);
+    if (nb > 256) nb = 256;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
+                           T_out, mean0, rstd0, C, G, S, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
+                           t_stride, T_out, mean0, rstd0, C, G, S, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" const char* gast_version(void) { return "gast_hip 0.1 gfx950"; }

@@ -1,0 +1,374 @@
+// gast_wgrad: weight gradients of the channel-mixing GEMMs on MFMA (gfx950).
+//
+//   dW[r, wcol0_s + k] += sum_m P[pmap(m), r] * pro_s(Q_s[map_s(m), k])
+//
+// P is the output gradient of the forward GEMM ("dC"), Q_s its activation operands with the same BN+ReLU(+dropout)
+// load prologue and row maps as in the forward (so a dilated-conv tap or a concat segment is just another
+// (Q_s, map_s, wcol0_s)).  The reduction runs over the position axis m = (b,t,j), i.e. over the NON-contiguous axis
+// of both operands:
+//   * fp32: v_mfma_f32_32x32x2_f32 takes one float per lane per operand, so the [m][col] tiles are used as they
+//     are (conflict-free ds_read_b32 fragment reads, row stride 132 floats);
+//   * bf16: v_mfma_f32_32x32x16_bf16 wants 8 consecutive m per lane; every thread transposes an 8(m) x 8(col)
+//     block in registers while staging, so LDS holds [col][m] rows of 128 B (+16 B pad) and the MFMA loop is the
+//     same as gast_gemm's.
+// M is split over blockIdx (split-M) and partial 128x128 tiles are combined with fp32 atomics into the zero-filled
+// gradient buffer.
+#include "common.h"
+
+namespace {
+
+constexpr int BT = 128;      // output tile (rows of dW x cols of dW)
+constexpr int LSTR = 144;    // bf16: LDS row stride in bytes
+constexpr int FSTR = 132;    // fp32: LDS row stride in floats
+
+struct TileCoord { int rt, seg, st; };
+
+__device__ __forceinline__ TileCoord decode_tile(const gast_wgrad_args& a, int tile, int tilesS_total) {
+    TileCoord c;
+    c.rt = tile / tilesS_total;
+    int rem = tile - c.rt * tilesS_total;
+    c.seg = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        int ts = (a.seg[s].S + BT - 1) / BT;
+        if (rem < ts) { c.seg = s; break; }
+        rem -= ts;
+    }
+    c.st = rem;
+    return c;
+}
+
+__device__ __forceinline__ void rows_for(const gast_wgrad_args& a, const gast_wgrad_seg& sg, int m, int M,
+                                         int& prow, int& qrow) {
+    prow = -1; qrow = -1;
+    if (m < M) {
+        int TJ = a.Tn * a.J;
+        int b = m / TJ, rem = m - b * TJ;
+        int t = rem / a.J, j = rem - t * a.J;
+        prow = (int)map_row(a.pmap, b, t, j, a.J);
+        qrow = (int)map_row(sg.map, b, t, j, a.J);
+        if (prow < 0 || qrow < 0) { prow = -1; qrow = -1; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ fp32
+__global__ void __launch_bounds__(256) wgrad_f32_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
+                                                        int mchunk) {
+    constexpr int BKM = 32;
+    __shared__ __attribute__((aligned(16))) float sP[BKM * FSTR];
+    __shared__ __attribute__((aligned(16))) float sQ[BKM * FSTR];
+    __shared__ int sRowP[2][BKM];
+    __shared__ int sRowQ[2][BKM];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tile = blockIdx.x / splitM, sp = blockIdx.x - tile * splitM;
+    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const gast_wgrad_seg& sg = a.seg[tc.seg];
+    const int m_begin = sp * mchunk;
+    const int m_end = min(M, m_begin + mchunk);
+    if (m_begin >= m_end) return;
+    const int ntile = (m_end - m_begin + BKM - 1) / BKM;
+
+    const float* Pb = (const float*)a.P;
+    const float* Qb = (const float*)sg.Q;
+    const int c = tid & 31, rb0 = tid >> 5;
+    const int pcol = tc.rt * BT + c * 4;
+    const int qcol = tc.st * BT + c * 4;
+    const bool pin = pcol < a.R, qin = qcol < sg.S;
+    const bool pro = sg.pro != GAST_PRO_NONE;
+    const bool drop = sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
+    const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
+    float4 sc = make_float4(0, 0, 0, 0), sh = make_float4(0, 0, 0, 0);
+    if (pro && qin) { sc = *(const float4*)(sg.scale + qcol); sh = *(const float4*)(sg.shift + qcol); }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute_rows = [&](int it, int buf) {
+        if (tid < BKM) {
+            int pr, qr;
+            int m = m_begin + it * BKM + tid;
+            rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
+            sRowP[buf][tid] = pr;
+            sRowQ[buf][tid] = qr;
+        }
+    };
+
+    float4 rp[4], rq[4];
+    auto load_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = rb0 + 8 * i;
+            int pr = sRowP[buf][r], qr = sRowQ[buf][r];
+            rp[i] = make_float4(0, 0, 0, 0);
+            rq[i] = make_float4(0, 0, 0, 0);
+            if (pin && pr >= 0) rp[i] = *(const float4*)(Pb + (long)pr * a.ldp + pcol);
+            if (qin && qr >= 0) rq[i] = *(const float4*)(Qb + (long)qr * sg.ldq + qcol);
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int r = rb0 + 8 * i;
+            float4 q = rq[i];
+            if (pro && qin) {
+                int qr = sRowQ[buf][r];
+                if (qr >= 0) {
+                    q.x = fmaxf(fmaf(q.x, sc.x, sh.x), 0.f);
+                    q.y = fmaxf(fmaf(q.y, sc.y, sh.y), 0.f);
+                    q.z = fmaxf(fmaf(q.z, sc.z, sh.z), 0.f);
+                    q.w = fmaxf(fmaf(q.w, sc.w, sh.w), 0.f);
+                    if (drop) {
+                        uint32_t e0 = (uint32_t)((long)qr * sg.ldq + qcol);
+                        q.x *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0);
+                        q.y *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 1);
+                        q.z *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2);
+                        q.w *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 3);
+                    }
+                }
+            }
+            *(float4*)(sP + r * FSTR + c * 4) = rp[i];
+            *(float4*)(sQ + r * FSTR + c * 4) = q;
+        }
+    };
+
+    compute_rows(0, 0);
+    __syncthreads();
+    load_tile(0);
+    if (ntile > 1) compute_rows(1, 1);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        store_tile(it & 1);
+        __syncthreads();
+        if (it + 1 < ntile) load_tile((it + 1) & 1);
+        if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+#pragma unroll 4
+        for (int kk = 0; kk < BKM / 2; ++kk) {
+            float fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[mi] = sP[(kk * 2 + lh) * FSTR + wr * 64 + mi * 32 + li];
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) fb[ni] = sQ[(kk * 2 + lh) * FSTR + wc * 64 + ni * 32 + li];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        if (scol >= sg.S) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ bf16
+__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&out)[8]) {
+    // in[i] = row i (8 bf16: cols 0..7 packed in 4 u32); out[q] = col q (8 bf16: rows 0..7)
+    uint32_t w[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { w[i][0] = in[i].x; w[i][1] = in[i].y; w[i][2] = in[i].z; w[i][3] = in[i].w; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        uint32_t o[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            uint32_t lo = w[2 * p][q >> 1], hi = w[2 * p + 1][q >> 1];
+            o[p] = (q & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+        }
+        out[q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+__global__ void __launch_bounds__(256) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
+                                                         int mchunk) {
+    constexpr int BKM = 64;
+    __shared__ __attribute__((aligned(16))) unsigned char sP[BT * LSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char sQ[BT * LSTR];
+    __shared__ int sRowP[2][BKM];
+    __shared__ int sRowQ[2][BKM];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int tile = blockIdx.x / splitM, sp = blockIdx.x - tile * splitM;
+    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const gast_wgrad_seg& sg = a.seg[tc.seg];
+    const int m_begin = sp * mchunk;
+    const int m_end = min(M, m_begin + mchunk);
+    if (m_begin >= m_end) return;
+    const int ntile = (m_end - m_begin + BKM - 1) / BKM;
+
+    // staging role: waves 0-1 stage P, waves 2-3 stage Q; each thread owns an 8(m) x 8(col) block
+    const int op = tid >> 7, task = tid & 127;
+    const int mb = task & 7, rc = task >> 3;
+    const bf16_t* base = op == 0 ? (const bf16_t*)a.P : (const bf16_t*)sg.Q;
+    const int ld = op == 0 ? a.ldp : sg.ldq;
+    const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 8;
+    const bool cin = col < (op == 0 ? a.R : sg.S);
+    const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
+    const bool drop = op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
+    const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { sc[q] = 0.f; sh[q] = 0.f; }
+    if (pro && cin) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { sc[q] = sg.scale[col + q]; sh[q] = sg.shift[col + q]; }
+    }
+    unsigned char* sdst = op == 0 ? sP : sQ;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute_rows = [&](int it, int buf) {
+        if (tid < BKM) {
+            int pr, qr;
+            int m = m_begin + it * BKM + tid;
+            rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
+            sRowP[buf][tid] = pr;
+            sRowQ[buf][tid] = qr;
+        }
+    };
+
+    uint4 rg[8];
+    auto load_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
+            rg[i] = make_uint4(0, 0, 0, 0);
+            if (cin && row >= 0) rg[i] = *(const uint4*)(base + (long)row * ld + col);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        if (pro && cin) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                int row = sRowQ[buf][mb * 8 + i];
+                if (row < 0) continue;
+                uint32_t wv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+                uint32_t e0 = (uint32_t)((long)row * ld + col);
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float lo = __uint_as_float(wv[p] << 16), hi = __uint_as_float(wv[p] & 0xffff0000u);
+                    lo = fmaxf(fmaf(lo, sc[2 * p], sh[2 * p]), 0.f);
+                    hi = fmaxf(fmaf(hi, sc[2 * p + 1], sh[2 * p + 1]), 0.f);
+                    if (drop) {
+                        lo *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p);
+                        hi *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p + 1);
+                    }
+                    wv[p] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+                }
+                rg[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+        }
+        uint4 tr[8];
+        transpose8x8_bf16(rg, tr);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
+    };
+
+    compute_rows(0, 0);
+    __syncthreads();
+    load_tile(0);
+    if (ntile > 1) compute_rows(1, 1);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        store_tile(it & 1);
+        __syncthreads();
+        if (it + 1 < ntile) load_tile((it + 1) & 1);
+        if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            union { uint4 u; s16x8 s; } fa[2], fb[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+                fa[mi].u = *(const uint4*)(sP + (wr * 64 + mi * 32 + li) * LSTR + (kc * 2 + lh) * 16);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                fb[ni].u = *(const uint4*)(sQ + (wc * 64 + ni * 32 + li) * LSTR + (kc * 2 + lh) * 16);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi].s, fb[ni].s, acc[mi][ni], 0, 0, 0);
+        }
+    }
+
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        if (scol >= sg.S) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
+            }
+    }
+}
+
+inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
+    if (!args) return GAST_EINVAL;
+    const gast_wgrad_args& a = *args;
+    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
+    if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.P || !a.dW || a.R < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
+    const int epc = a.dtype == GAST_F32 ? 4 : 8;
+    if (a.R % epc || a.ldp % epc || !aligned16(a.P)) return GAST_EALIGN;
+    int tilesS = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const gast_wgrad_seg& g = a.seg[s];
+        if (!g.Q || g.S < 1) return GAST_EINVAL;
+        if (g.S % epc || g.ldq % epc || !aligned16(g.Q)) return GAST_EALIGN;
+        if (g.pro != GAST_PRO_NONE && (!g.scale || !g.shift || !aligned16(g.scale) || !aligned16(g.shift))) return GAST_EINVAL;
+        tilesS += (g.S + BT - 1) / BT;
+    }
+    long Ml = (long)a.B * a.Tn * a.J;
+    if (Ml > 0x7fffff00L) return GAST_ERANGE;
+    const int M = (int)Ml;
+    const int bkm = a.dtype == GAST_F32 ? 32 : 64;
+    const int tilesR = (a.R + BT - 1) / BT;
+    const int tiles = tilesR * tilesS;
+    int splitM = 1024 / tiles;
+    int maxsplit = (M + bkm * 4 - 1) / (bkm * 4);
+    if (splitM > maxsplit) splitM = maxsplit;
+    if (splitM < 1) splitM = 1;
+    int mchunk = (M + splitM - 1) / splitM;
+    mchunk = (mchunk + bkm - 1) / bkm * bkm;
+    splitM = (M + mchunk - 1) / mchunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (a.zero_first) {
+        hipError_t e = hipMemsetAsync(a.dW, 0, (size_t)a.R * a.ldw * sizeof(float), st);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(tiles * splitM), block(256);
+    if (a.dtype == GAST_F32)
+        hipLaunchKernelGGL(wgrad_f32_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}

@@ -1,0 +1,326 @@
+"""ctypes binding of libgast_hip.so (include/gast_hip.h) for torch tensors living on an MI355X.
+
+There is NO fallback: if the shared library is missing or a tensor is not on a HIP device, these functions raise.
+Every op enqueues on torch's current stream (so `torch.cuda.graph` capture and stream semantics just work) and
+never synchronises.
+"""
+import ctypes as C
+import os
+from collections import namedtuple
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libgast_hip.so')
+
+GAST_F32, GAST_BF16 = 0, 1
+MAX_SEG = 8
+PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
+EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
+
+RowMap = namedtuple('RowMap', 'T_total t_stride t_off')
+IDENT = lambda T: RowMap(T, 1, 0)  # noqa: E731
+
+
+class Dropout(namedtuple('Dropout', 'seed thresh inv_keep')):
+    """seed: int32/uint32 device tensor with one element; thresh = round(p*65536); inv_keep = 65536/(65536-thresh)."""
+    __slots__ = ()
+
+
+def dropout_params(p):
+    thresh = int(round(p * 65536))
+    inv_keep = 65536.0 / (65536 - thresh) if thresh else 1.0
+    return thresh, inv_keep
+
+
+class _RowMap(C.Structure):
+    _fields_ = [('T_total', C.c_int), ('t_stride', C.c_int), ('t_off', C.c_int)]
+
+
+class _Dropout(C.Structure):
+    _fields_ = [('seed', C.c_void_p), ('thresh', C.c_uint32), ('inv_keep', C.c_float)]
+
+
+class _GemmSeg(C.Structure):
+    _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('K', C.c_int), ('map', _RowMap), ('W', C.c_void_p), ('ldw', C.c_int),
+                ('pro', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('salt', C.c_uint32)]
+
+
+class _GemmArgs(C.Structure):
+    _fields_ = [('dtype', C.c_int), ('out_f32', C.c_int), ('B', C.c_int), ('Tn', C.c_int), ('J', C.c_int), ('N', C.c_int),
+                ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
+                ('bias', C.c_void_p), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
+                ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
+                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout)]
+
+
+class _WgradSeg(C.Structure):
+    _fields_ = [('Q', C.c_void_p), ('ldq', C.c_int), ('S', C.c_int), ('map', _RowMap), ('pro', C.c_int), ('scale', C.c_void_p),
+                ('shift', C.c_void_p), ('salt', C.c_uint32), ('wcol0', C.c_int)]
+
+
+class _WgradArgs(C.Structure):
+    _fields_ = [('dtype', C.c_int), ('B', C.c_int), ('Tn', C.c_int), ('J', C.c_int), ('P', C.c_void_p), ('ldp', C.c_int),
+                ('R', C.c_int), ('pmap', _RowMap), ('nseg', C.c_int), ('seg', _WgradSeg * MAX_SEG), ('dW', C.c_void_p),
+                ('ldw', C.c_int), ('zero_first', C.c_int), ('drop', _Dropout)]
+
+
+_lib = None
+
+
+def load_library():
+    """Load libgast_hip.so or raise -- the HIP path is the only path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError('gast_hip: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, ci, cl, cf, cd, cu = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint32
+    sig = {
+        'gast_gemm': [C.POINTER(_GemmArgs), vp],
+        'gast_gemm_row_blocks': [ci],
+        'gast_wgrad': [C.POINTER(_WgradArgs), vp],
+        'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
+        'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
+        'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp],
+        'gast_semch_agg_blocks': [ci, ci],
+        'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp],
+        'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
+        'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp],
+        'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp],
+        'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, vp],
+        'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
+        'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
+        'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, vp],
+        'gast_bnrelu_bwd_mask': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
+        'gast_rowwise_blocks': [cl, ci],
+        'gast_residual_fwd': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp],
+        'gast_input_stats': [vp, cl, ci, vp, vp, vp],
+        'gast_input_stats_blocks': [cl],
+        'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp],
+        'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp],
+        'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
+    }
+    for name, argtypes in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ci
+    lib.gast_version.restype = C.c_char_p
+    lib.gast_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
+                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_attn_fwd', 'gast_attn_bwd',
+                    'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
+                    'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
+                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_colsum', 'gast_version']
+
+
+def _check(rc, what):
+    if rc != 0:
+        names = {-1: 'GAST_EINVAL', -2: 'GAST_EALIGN', -3: 'GAST_ERANGE'}
+        raise RuntimeError('gast_hip: %s failed with %s' % (what, names.get(rc, 'hipError %d' % rc)))
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError('gast_hip: tensor is on %s; the HIP path needs device tensors (no CPU fallback)' % t.device)
+    return t.data_ptr()
+
+
+def _ld(t):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise RuntimeError('gast_hip: expected a 2-D row-major view, got shape %s strides %s' % (tuple(t.shape), t.stride()))
+    return t.stride(0)
+
+
+def _dt(t):
+    if t.dtype == torch.float32:
+        return GAST_F32
+    if t.dtype == torch.bfloat16:
+        return GAST_BF16
+    raise RuntimeError('gast_hip: unsupported dtype %s' % t.dtype)
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rm(m):
+    return _RowMap(int(m.T_total), int(m.t_stride), int(m.t_off))
+
+
+def _drop(d):
+    if d is None:
+        return _Dropout(None, 0, 1.0)
+    return _Dropout(_p(d.seed), int(d.thresh), float(d.inv_keep))
+
+
+class HipOps:
+    """The op set of include/gast_hip.h on torch device tensors.  tests/fake_backend.py mirrors this interface on
+    CPU tensors with the numpy oracle (tests only)."""
+    name = 'hip'
+
+    def __init__(self):
+        self.lib = load_library()
+        self.launches = 0
+
+    # -- GEMM family
+    def gemm_row_blocks(self, M):
+        return self.lib.gast_gemm_row_blocks(int(M))
+
+    def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
+             xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None):
+        a = _GemmArgs()
+        a.dtype = _dt(segs[0]['A'])
+        a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
+        a.B, a.Tn, a.J = (int(v) for v in dom)
+        a.N = int(N)
+        a.nseg = len(segs)
+        for i, s in enumerate(segs):
+            g = a.seg[i]
+            if _dt(s['A']) != a.dtype or _dt(s['W']) != a.dtype:
+                raise RuntimeError('gast_hip: mixed operand dtypes in gemm')
+            g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
+            g.W, g.ldw = _p(s['W']), _ld(s['W'])
+            g.pro = int(s.get('pro', PRO_NONE))
+            g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
+            g.salt = int(s.get('salt', 0))
+        a.C, a.ldc, a.cmap = _p(C_), _ld(C_), _rm(cmap)
+        a.bias = _p(bias)
+        if addend is not None:
+            a.addend, a.ldadd, a.addmap = _p(addend), _ld(addend), _rm(addmap)
+        a.epi = int(epi)
+        a.partials = _p(partials)
+        if X is not None:
+            a.X, a.ldx = _p(X), _ld(X)
+        a.xscale, a.xshift = _p(xscale), _p(xshift)
+        a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
+        a.drop = _drop(drop)
+        self.launches += 1
+        _check(self.lib.gast_gemm(C.byref(a), _stream()), 'gast_gemm')
+
+    def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
+        a = _WgradArgs()
+        a.dtype = _dt(P)
+        a.B, a.Tn, a.J = (int(v) for v in dom)
+        a.P, a.ldp, a.R, a.pmap = _p(P), _ld(P), int(R), _rm(pmap)
+        a.nseg = len(segs)
+        for i, s in enumerate(segs):
+            g = a.seg[i]
+            if _dt(s['Q']) != a.dtype:
+                raise RuntimeError('gast_hip: mixed operand dtypes in wgrad')
+            g.Q, g.ldq, g.S, g.map = _p(s['Q']), _ld(s['Q']), int(s['S']), _rm(s['map'])
+            g.pro = int(s.get('pro', PRO_NONE))
+            g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
+            g.salt, g.wcol0 = int(s.get('salt', 0)), int(s['wcol0'])
+        if dW.dtype != torch.float32:
+            raise RuntimeError('gast_hip: dW must be fp32')
+        a.dW, a.ldw, a.zero_first = _p(dW), _ld(dW), int(bool(zero_first))
+        a.drop = _drop(drop)
+        self.launches += 1
+        _check(self.lib.gast_wgrad(C.byref(a), _stream()), 'gast_wgrad')
+
+    # -- SemCH graph conv
+    def semch_adj_fwd(self, e, pat, A_t):
+        self.launches += 1
+        _check(self.lib.gast_semch_adj_fwd(_p(e), e.shape[0], _p(pat), _p(A_t), _stream()), 'gast_semch_adj_fwd')
+
+    def semch_adj_bwd(self, dA_t, A_t, pat, de):
+        self.launches += 1
+        _check(self.lib.gast_semch_adj_bwd(_p(dA_t), _p(A_t), de.shape[0], _p(pat), _p(de), _stream()), 'gast_semch_adj_bwd')
+
+    def semch_agg_blocks(self, F, C_):
+        return self.lib.gast_semch_agg_blocks(int(F), int(C_))
+
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials):
+        self.launches += 1
+        _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), _p(A_con), _p(pat_con),
+                                           _p(Y), _ld(Y), _p(partials), _stream()), 'gast_semch_agg_fwd')
+
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con):
+        self.launches += 1
+        _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), _p(A_con),
+                                           _p(pat_con), _p(dH), _ld(dH), _p(dA_sym), _p(dA_con), _stream()), 'gast_semch_agg_bwd')
+
+    # -- global attention
+    def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):
+        self.launches += 1
+        _check(self.lib.gast_attn_fwd(_dt(G), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads, _p(Y), _ld(Y), _stream()),
+               'gast_attn_fwd')
+
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k):
+        self.launches += 1
+        _check(self.lib.gast_attn_bwd(_dt(G), _p(dY), _ld(dY), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads,
+                                      _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _stream()), 'gast_attn_bwd')
+
+    # -- BatchNorm pieces
+    def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                    scale, shift, mean, rstd):
+        self.launches += 1
+        _check(self.lib.gast_bn_finalize(_p(partials), nblk, partials.shape[1], col0, N, float(count), _p(gamma), _p(beta),
+                                         _p(running_mean), _p(running_var), _p(nbt), momentum, eps, _p(scale), _p(shift),
+                                         _p(mean), _p(rstd), _stream()), 'gast_bn_finalize')
+
+    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift):
+        self.launches += 1
+        _check(self.lib.gast_bn_eval(_p(gamma), _p(beta), _p(rm), _p(rv), eps, N, _p(scale), _p(shift), _stream()), 'gast_bn_eval')
+
+    def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc):
+        self.launches += 1
+        _check(self.lib.gast_bn_bwd_finalize(_p(partials), nblk, partials.shape[1], col0, N, float(count), _p(gamma), _p(mean),
+                                             _p(rstd), _p(dgamma), _p(dbeta), _p(ka), _p(kb), _p(kc), _stream()),
+               'gast_bn_bwd_finalize')
+
+    def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc):
+        self.launches += 1
+        _check(self.lib.gast_bn_bwd_apply(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _stream()),
+               'gast_bn_bwd_apply')
+
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y):
+        self.launches += 1
+        _check(self.lib.gast_bnrelu_apply(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), _stream()),
+               'gast_bnrelu_apply')
+
+    def rowwise_blocks(self, rows, N):
+        return self.lib.gast_rowwise_blocks(int(rows), int(N))
+
+    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials):
+        self.launches += 1
+        _check(self.lib.gast_bnrelu_bwd_mask(_dt(X), _p(dY), _ld(dY), _p(X), _ld(X), rows, N, _p(scale), _p(shift),
+                                             int(bool(use_drop)), int(salt), _drop(drop), _p(dz), _ld(dz), _p(partials), _stream()),
+               'gast_bnrelu_bwd_mask')
+
+    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
+        self.launches += 1
+        _check(self.lib.gast_residual_fwd(_dt(O), _p(O), _ld(O), _rm(omap), _p(scO), _p(shO), _p(T2), _ld(T2), _p(sc2), _p(sh2),
+                                          int(bool(use_drop)), int(salt), _drop(drop), B, Tn, J, N, _p(Xn), _ld(Xn), _stream()),
+               'gast_residual_fwd')
+
+    def colsum(self, X, rows, N, out, zero_first=True):
+        self.launches += 1
+        _check(self.lib.gast_colsum(_dt(X), _p(X), _ld(X), rows, N, _p(out), int(bool(zero_first)), _stream()), 'gast_colsum')
+
+    # -- input side
+    def input_stats_blocks(self, rows):
+        return self.lib.gast_input_stats_blocks(int(rows))
+
+    def input_stats(self, x, rows, F_in, partials):
+        self.launches += 1
+        _check(self.lib.gast_input_stats(_p(x), rows, F_in, _p(partials), None, _stream()), 'gast_input_stats')
+
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials):
+        self.launches += 1
+        _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
+                                        _p(partials), _stream()), 'gast_expand_fwd')
+
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
+        self.launches += 1
+        _check(self.lib.gast_expand_bwd(_dt(dE), _p(dE), _ld(dE), _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
+                                        _p(G), _p(S), _stream()), 'gast_expand_bwd')

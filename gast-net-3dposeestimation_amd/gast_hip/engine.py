@@ -1,0 +1,449 @@
+"""Host-side plan of the GAST-Net spatio-temporal forward/backward on the `gast_hip` op set.
+
+The reference runs this path as ~900 ATen calls per step.  Here the same arithmetic is a short,
+explicit list of fused launches over position-major `(B*T*J, C)` tensors:
+
+  per GraphAttentionBlock (reference model/gast_net.py:22-33) with input X (P x C):
+    G1   H = X . [W_sym0 | W_sym1 | W_con0 | W_con1 | W_g(4 heads) | v_theta | v_phi]^T + bias      one GEMM, N = 5C+8
+    AGG  Y = [SemCH-aggregate(sym) | SemCH-aggregate(con)] (+ bn_1/bn_2 partial sums)          local_attention.py:40-48
+    ATT  Ya = (softmax_j(leaky(a_i + c_j)) + C_k) . g                                          global_attention.py:60-78
+    G2   Lpre = relu(bn_12(Y)) . W_lc^T          (+ stats)   local cat_conv/cat_bn             local_attention.py:142-143
+    G3   Gpre = Ya . W_gc^T                      (+ stats)   global cat_conv/cat_bn            global_attention.py:122
+    G4   Opre = [X | drop(relu(bn(Lpre))) | drop(relu(bn(Gpre)))] . W_bc^T  (+ stats)          gast_net.py:28-32
+  per temporal level (gast_net.py:167-176 / :242-249) with input Opre (lazy BN+ReLU):
+    T1pre = sum_tap relu(bn(Opre))[t*s + tap*d] . W_tap^T (+ stats);  T2pre = relu(bn(T1pre)) . W_1x1^T (+ stats)
+    Xnext = relu(bn(Opre))[residual slice] + drop(relu(bn(T2pre)))
+  BatchNorm is two-phase: producers emit partial column sums, `bn_finalize` makes scale/shift (and updates the running
+  statistics), consumers apply BN+ReLU(+dropout) while loading their operand.  Nothing is permuted, concatenated or
+  expanded in memory.
+
+`ops` is the op set: `gast_hip.binding.HipOps` in the product (device tensors, HIP kernels, no fallback).  The test-suite
+substitutes a numpy mirror of the same interface to check this file's composition on CPU against the reference's
+golden fixtures (tests/fake_backend.py); that mirror lives in tests/ and is never importable from here.
+"""
+from collections import namedtuple
+
+import torch
+
+RowMap = namedtuple('RowMap', 'T_total t_stride t_off')
+PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
+EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
+BN_MOMENTUM = 0.1
+BN_EPS = 1e-5
+NHEADS = 4
+
+
+def ident(T):
+    return RowMap(T, 1, 0)
+
+
+class BNState:
+    """scale/shift (+ mean/rstd in training) of one BatchNorm2d for the current batch."""
+    __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
+
+    def __init__(self, n, dev, count):
+        self.scale = torch.empty(n, dtype=torch.float32, device=dev)
+        self.shift = torch.empty(n, dtype=torch.float32, device=dev)
+        self.mean = torch.empty(n, dtype=torch.float32, device=dev)
+        self.rstd = torch.empty(n, dtype=torch.float32, device=dev)
+        self.count = count
+
+
+class Engine:
+    """Executes the plan for one model instance.  `spec` is built by model.gast_net (see `ModelSpec`)."""
+
+    def __init__(self, spec, ops):
+        self.spec = spec
+        self.ops = ops
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def _new(self, rows, cols, dt, dev, zero=False):
+        return (torch.zeros if zero else torch.empty)(rows, cols, dtype=dt, device=dev)
+
+    def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0):
+        """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n)."""
+        ops = self.ops
+        sl = slice(off, off + n)
+        if training:
+            ops.bn_finalize(partials, nblk, col0, n, count, bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'],
+                            bn['num_batches_tracked'], BN_MOMENTUM, BN_EPS, st.scale[sl], st.shift[sl], st.mean[sl], st.rstd[sl])
+        else:
+            ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl])
+
+    # ------------------------------------------------------------------------------------------ forward
+    def forward(self, x, inp, bufs, training, act_dtype, drop):
+        """x: (B,T,J,F_in) fp32 contiguous device tensor.  inp: dict of packed fp32 tensors (see ModelSpec.pack).
+        bufs: dict of BN buffer dicts.  Returns (pred (B,T',J,3) fp32, saved dict for backward)."""
+        sp, ops = self.spec, self.ops
+        dev = x.device
+        B, T_in, J, F_in = x.shape
+        L = len(sp.fw)
+        dt = act_dtype
+        cast = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
+        sv = {'B': B, 'T_in': T_in, 'dt': dt, 'drop': drop, 'training': training}
+        use_drop = training and drop is not None and drop.thresh != 0
+
+        # ---- init_bn statistics + expand conv (gast_net.py:163-164)
+        k0 = sp.fw[0]
+        s0 = k0 if sp.strided else 1
+        if T_in < k0:
+            raise RuntimeError('input has %d frames, receptive field needs at least %d' % (T_in, sp.receptive_field))
+        T = [(T_in - k0) // s0 + 1]
+        rows_in = B * T_in * J
+        bn0 = BNState(F_in, dev, rows_in)
+        if training:
+            nb = ops.input_stats_blocks(rows_in)
+            part = torch.empty(nb, F_in, 2, dtype=torch.float32, device=dev)
+            ops.input_stats(x, rows_in, F_in, part)
+            self._bn_forward(part, nb, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, True)
+        else:
+            self._bn_forward(None, 0, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, False)
+        C0 = sp.channels
+        P0 = B * T[0] * J
+        E = self._new(P0, C0, dt, dev)
+        nbE = ops.rowwise_blocks(P0, C0)
+        partE = torch.empty(nbE, C0, 2, dtype=torch.float32, device=dev)
+        ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE)
+        bnE = BNState(C0, dev, P0)
+        self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training)
+        X = self._new(P0, C0, dt, dev)
+        ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
+        sv.update(x=x, bn0=bn0, E=E, bnE=bnE, T=T)
+
+        stages, levels = [], []
+        for s in range(L):
+            C = C0 * (2 ** s)
+            if s > 0:
+                # ---- temporal level s (gast_net.py:167-174 / :242-247): input = previous block's Opre (lazy BN+ReLU)
+                prev = stages[-1]
+                k = sp.fw[s]
+                Tp = T[-1]
+                if sp.strided:
+                    Tn = (Tp - k) // k + 1
+                    taps = [RowMap(Tp, k, tap) for tap in range(k)]
+                    resmap = RowMap(Tp, k, sp.causal_shift[s] + k // 2)
+                else:
+                    d = sp.dil[s]
+                    Tn = Tp - (k - 1) * d
+                    taps = [RowMap(Tp, 1, tap * d) for tap in range(k)]
+                    resmap = RowMap(Tp, 1, sp.pad[s] + sp.causal_shift[s])
+                if Tn < 1:
+                    raise RuntimeError('input too short for the receptive field (%d frames needed)' % sp.receptive_field)
+                T.append(Tn)
+                P = B * Tn * J
+                Wc = cast(inp['l%d.conv' % s])        # [C][k*C], tap-major K
+                W1 = cast(inp['l%d.conv1' % s])       # [C][C]
+                nb = ops.gemm_row_blocks(P)
+                T1 = self._new(P, C, dt, dev)
+                part1 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+                segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
+                             scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
+                ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1)
+                bn1 = BNState(C, dev, P)
+                self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training)
+                T2 = self._new(P, C, dt, dev)
+                part2 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+                ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
+                         T2, ident(Tn), epi=EPI_STATS, partials=part2)
+                bn2 = BNState(C, dev, P)
+                self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training)
+                X = self._new(P, C, dt, dev)
+                ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
+                                 use_drop, 3 * s, drop, B, Tn, J, C, X)
+                levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, Wc=Wc, W1=W1, k=k))
+            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, cast))
+
+        # ---- shrink (gast_net.py:99)
+        last = stages[-1]
+        CL = 2 * C0 * (2 ** (L - 1))
+        PL = B * T[-1] * J
+        Wsh = cast(inp['shrink'])   # [3][CL]
+        pred = torch.empty(PL, 3, dtype=torch.float32, device=dev)
+        ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
+                                         scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
+        sv.update(stages=stages, levels=levels, Wsh=Wsh)
+        return pred.view(B, T[-1], J, 3), sv
+
+    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop, cast):
+        sp, ops = self.spec, self.ops
+        dev = X.device
+        P = B * Tn * J
+        F = B * Tn
+        N1 = 5 * C + 2 * NHEADS
+        g = 'g%d.' % s
+        dom = (B, Tn, J)
+        im = ident(Tn)
+        Wg1 = cast(inp[g + 'Bg1'])      # [N1][C]
+        Wlc = cast(inp[g + 'Blc'])      # [C][2C]
+        Wgc = cast(inp[g + 'Bgc'])      # [C][C]
+        Wbc = cast(inp[g + 'Bbc'])      # [2C][3C]
+        nb = ops.gemm_row_blocks(P)
+        # G1: everything that reads X in one pass (local_attention.py:37-38, global_attention.py:56-72)
+        H = self._new(P, N1, dt, dev)
+        ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1)], H, im, bias=inp[g + 'bias1'])
+        # masked-softmax adjacencies (parameters only; local_attention.py:40-42)
+        nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
+        A_s = torch.empty(nnz_s, C, dtype=torch.float32, device=dev)
+        A_c = torch.empty(nnz_c, C, dtype=torch.float32, device=dev)
+        ops.semch_adj_fwd(inp[g + 'e_sym'], sp.pat_sym(dev), A_s)
+        ops.semch_adj_fwd(inp[g + 'e_con'], sp.pat_con(dev), A_c)
+        # neighbour aggregation + bn_1/bn_2 statistics
+        Y = self._new(P, 2 * C, dt, dev)
+        nba = ops.semch_agg_blocks(F, C)
+        partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
+        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY)
+        bnY = BNState(2 * C, dev, P)
+        self._bn_forward(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, training, off=0)
+        self._bn_forward(partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, training, off=C)
+        # global attention core
+        Ya = self._new(P, C, dt, dev)
+        ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
+        # G2 / G3
+        Lp = self._new(P, C, dt, dev)
+        partL = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+        ops.gemm(dom, C, [dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)], Lp, im,
+                 epi=EPI_STATS, partials=partL)
+        bnL = BNState(C, dev, P)
+        self._bn_forward(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, training)
+        Gp = self._new(P, C, dt, dev)
+        partG = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+        ops.gemm(dom, C, [dict(A=Ya, K=C, map=im, W=Wgc)], Gp, im, epi=EPI_STATS, partials=partG)
+        bnG = BNState(C, dev, P)
+        self._bn_forward(partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, training)
+        # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised
+        pro = PRO_BNRELU_DROP if use_drop else PRO_BNRELU
+        O = self._new(P, 2 * C, dt, dev)
+        partO = torch.empty(nb, 2 * C, 2, dtype=torch.float32, device=dev)
+        segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]),
+                dict(A=Lp, K=C, map=im, W=Wbc[:, C:2 * C], pro=pro, scale=bnL.scale, shift=bnL.shift, salt=3 * s + 1),
+                dict(A=Gp, K=C, map=im, W=Wbc[:, 2 * C:3 * C], pro=pro, scale=bnG.scale, shift=bnG.shift, salt=3 * s + 2)]
+        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, drop=drop)
+        bnO = BNState(2 * C, dev, P)
+        self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training)
+        return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, Lp=Lp, bnL=bnL, Gp=Gp, bnG=bnG, O=O, bnO=bnO,
+                    Wg1=Wg1, Wlc=Wlc, Wgc=Wgc, Wbc=Wbc, C=C, Tn=Tn, P=P, pro=pro)
+
+    # ------------------------------------------------------------------------------------------ backward
+    def _bn_backward(self, partials, nblk, col0, n, st, gamma, grads, key, dz, Xpre, rows, off=0, dzcol=None):
+        """finalize {sum dz, sum dz*x} -> dgamma/dbeta + coefficients, then dz <- dx in place."""
+        ops = self.ops
+        dev = gamma.device
+        dg = torch.empty(n, dtype=torch.float32, device=dev)
+        db = torch.empty(n, dtype=torch.float32, device=dev)
+        ka = torch.empty(n, dtype=torch.float32, device=dev)
+        kb = torch.empty(n, dtype=torch.float32, device=dev)
+        kc = torch.empty(n, dtype=torch.float32, device=dev)
+        sl = slice(off, off + n)
+        ops.bn_bwd_finalize(partials, nblk, col0, n, st.count, gamma, st.mean[sl], st.rstd[sl], dg, db, ka, kb, kc)
+        grads[key + '.weight'] = dg
+        grads[key + '.bias'] = db
+        d = dz if dzcol is None else dz[:, dzcol:dzcol + n]
+        xx = Xpre if dzcol is None else Xpre[:, dzcol:dzcol + n]
+        ops.bn_bwd_apply(d, xx, rows, n, ka, kb, kc)
+
+    def backward(self, sv, inp, dpred):
+        """dpred: (B,T',J,3) fp32.  Returns dict key -> gradient for every key of `inp`."""
+        sp, ops = self.spec, self.ops
+        dev = dpred.device
+        B, dt, drop = sv['B'], sv['dt'], sv['drop']
+        J = sp.J
+        T = sv['T']
+        L = len(sp.fw)
+        C0 = sp.channels
+        stages, levels = sv['stages'], sv['levels']
+        grads = {}
+        f32 = torch.float32
+
+        # ---- shrink backward
+        last = stages[-1]
+        CL = 2 * last['C']
+        TL = T[-1]
+        PL = B * TL * J
+        KP = 8
+        dp = torch.zeros(PL, KP, dtype=dt, device=dev)
+        dp[:, :3] = dpred.reshape(PL, 3).to(dt)
+        dWsh = torch.empty(KP, CL, dtype=f32, device=dev)
+        ops.wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
+                                                        shift=last['bnO'].shift, wcol0=0)], dWsh)
+        grads['shrink'] = dWsh[:3]
+        WshT = torch.zeros(CL, KP, dtype=dt, device=dev)
+        WshT[:, :3] = sv['Wsh'].t()
+        dO = self._new(PL, CL, dt, dev)
+        nb = ops.gemm_row_blocks(PL)
+        part = torch.empty(nb, CL, 2, dtype=f32, device=dev)
+        ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, partials=part,
+                 X=last['O'], xscale=last['bnO'].scale, xshift=last['bnO'].shift)
+        g = 'g%d.' % (L - 1)
+        self._bn_backward(part, nb, 0, CL, last['bnO'], inp[g + 'cat_bn.weight'], grads, g + 'cat_bn', dO, last['O'], PL)
+
+        for s in range(L - 1, -1, -1):
+            st = stages[s]
+            dX = self._gab_backward(s, st, dO, B, J, inp, grads, dt, drop)
+            if s == 0:
+                break
+            # ---- temporal level s backward
+            lv = levels[s - 1]
+            prev = stages[s - 1]
+            C = st['C']
+            Tn, Tp = T[s], T[s - 1]
+            P, Pp = B * Tn * J, B * Tp * J
+            k = lv['k']
+            use_drop = sv['training'] and drop is not None and drop.thresh != 0
+            # branch 2: drop(relu(bn(T2pre)))
+            nbr = ops.rowwise_blocks(P, C)
+            part2 = torch.empty(nbr, C, 2, dtype=f32, device=dev)
+            dT2 = self._new(P, C, dt, dev)
+            ops.bnrelu_bwd_mask(dX, lv['T2'], P, C, lv['bn2'].scale, lv['bn2'].shift, use_drop, 3 * s, drop, dT2, part2)
+            lk = 'l%d.' % s
+            self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
+            # 1x1 conv
+            dW1 = torch.empty(C, C, dtype=f32, device=dev)
+            ops.wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
+                                                            shift=lv['bn1'].shift, wcol0=0)], dW1)
+            grads[lk + 'conv1'] = dW1
+            nbg = ops.gemm_row_blocks(P)
+            part1 = torch.empty(nbg, C, 2, dtype=f32, device=dev)
+            dT1 = self._new(P, C, dt, dev)
+            W1T = lv['W1'].t().contiguous()
+            ops.gemm((B, Tn, J), C, [dict(A=dT2, K=C, map=ident(Tn), W=W1T)], dT1, ident(Tn), epi=EPI_BNRELU_BWD, partials=part1,
+                     X=lv['T1'], xscale=lv['bn1'].scale, xshift=lv['bn1'].shift)
+            self._bn_backward(part1, nbg, 0, C, lv['bn1'], inp[lk + 'bn0.weight'], grads, lk + 'bn0', dT1, lv['T1'], P)
+            # temporal conv: weight gradient (k K-segments) ...
+            dWc = torch.empty(C, k * C, dtype=f32, device=dev)
+            ops.wgrad((B, Tn, J), dT1, C, ident(Tn),
+                      [dict(Q=prev['O'], S=C, map=lv['taps'][tap], pro=PRO_BNRELU, scale=prev['bnO'].scale, shift=prev['bnO'].shift,
+                            wcol0=tap * C) for tap in range(k)], dWc)
+            grads[lk + 'conv'] = dWc
+            # ... and input gradient, fused with the residual branch and the ReLU/BN backward of the previous block's output
+            WcT = [lv['Wc'][:, tap * C:(tap + 1) * C].t().contiguous() for tap in range(k)]
+            pg = 'g%d.' % (s - 1)
+            if sp.strided:
+                covered = k * Tn == Tp
+                dOp = self._new(Pp, C, dt, dev, zero=not covered)
+                nbt = ops.gemm_row_blocks(P)
+                partO = torch.zeros(k * nbt, C, 2, dtype=f32, device=dev)
+                res_tap = lv['resmap'].t_off
+                for tap in range(k):
+                    ops.gemm((B, Tn, J), C, [dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], dOp, RowMap(Tp, k, tap),
+                             addend=dX if tap == res_tap else None, addmap=ident(Tn) if tap == res_tap else None,
+                             epi=EPI_BNRELU_BWD, partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'],
+                             xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+                nbo = k * nbt
+            else:
+                d = sp.dil[s]
+                dOp = self._new(Pp, C, dt, dev)
+                nbo = ops.gemm_row_blocks(Pp)
+                partO = torch.empty(nbo, C, 2, dtype=f32, device=dev)
+                segs = [dict(A=dT1, K=C, map=RowMap(Tn, 1, -tap * d), W=WcT[tap]) for tap in range(k)]
+                ops.gemm((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
+                         epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+            self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
+            dO = dOp
+
+        # ---- expand conv + init_bn backward (dX is the gradient w.r.t. relu(expand_bn(E)))
+        P0 = B * T[0] * J
+        nbr = ops.rowwise_blocks(P0, C0)
+        partE = torch.empty(nbr, C0, 2, dtype=f32, device=dev)
+        dE = self._new(P0, C0, dt, dev)
+        ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE, partE)
+        self._bn_backward(partE, nbr, 0, C0, sv['bnE'], inp['expand_bn.weight'], grads, 'expand_bn', dE, sv['E'], P0)
+        x = sv['x']
+        F_in = x.shape[-1]
+        k0 = sp.fw[0]
+        s0 = k0 if sp.strided else 1
+        G = torch.empty(C0, F_in, k0, dtype=f32, device=dev)
+        S = torch.empty(C0, dtype=f32, device=dev)
+        ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, G, S)
+        # tiny parameter-sized epilogue (plumbing): xn = gamma0*xhat + beta0
+        g0 = inp['init_bn.weight'].view(1, F_in, 1)
+        b0 = inp['init_bn.bias'].view(1, F_in, 1)
+        W = inp['expand_w'].view(C0, F_in, k0)
+        grads['expand_w'] = (g0 * G + b0 * S.view(C0, 1, 1)).view_as(inp['expand_w'])
+        grads['init_bn.weight'] = (W * G).sum(dim=(0, 2))
+        grads['init_bn.bias'] = (W * S.view(C0, 1, 1)).sum(dim=(0, 2))
+        return grads
+
+    def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
+        """dO: gradient w.r.t. Opre (pre-BN output of the block's cat_conv), (P x 2C).  Returns dX (P x C)."""
+        sp, ops = self.spec, self.ops
+        dev = dO.device
+        f32 = torch.float32
+        C, Tn, P = st['C'], st['Tn'], st['P']
+        F = B * Tn
+        N1 = 5 * C + 2 * NHEADS
+        g = 'g%d.' % s
+        dom = (B, Tn, J)
+        im = ident(Tn)
+        nb = ops.gemm_row_blocks(P)
+        pro = st['pro']
+        xdrop = pro == PRO_BNRELU_DROP
+        # G4 weight gradient: three K segments
+        dWbc = torch.empty(2 * C, 3 * C, dtype=f32, device=dev)
+        ops.wgrad(dom, dO, 2 * C, im,
+                  [dict(Q=st['X'], S=C, map=im, wcol0=0),
+                   dict(Q=st['Lp'], S=C, map=im, pro=pro, scale=st['bnL'].scale, shift=st['bnL'].shift, salt=3 * s + 1, wcol0=C),
+                   dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
+                  dWbc, drop=drop)
+        grads[g + 'Bbc'] = dWbc
+        WbcT = st['Wbc'].t().contiguous()       # [3C][2C]
+        # input gradients of the local / global branches, fused with ReLU + dropout + BN-sum backward
+        dL = self._new(P, C, dt, dev)
+        partL = torch.empty(nb, C, 2, dtype=f32, device=dev)
+        ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:2 * C])], dL, im, epi=EPI_BNRELU_BWD, partials=partL, X=st['Lp'],
+                 xscale=st['bnL'].scale, xshift=st['bnL'].shift, xdrop=xdrop, xsalt=3 * s + 1, drop=drop)
+        self._bn_backward(partL, nb, 0, C, st['bnL'], inp[g + 'lcat_bn.weight'], grads, g + 'lcat_bn', dL, st['Lp'], P)
+        dG = self._new(P, C, dt, dev)
+        partG = torch.empty(nb, C, 2, dtype=f32, device=dev)
+        ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[2 * C:3 * C])], dG, im, epi=EPI_BNRELU_BWD, partials=partG, X=st['Gp'],
+                 xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2, drop=drop)
+        self._bn_backward(partG, nb, 0, C, st['bnG'], inp[g + 'gcat_bn.weight'], grads, g + 'gcat_bn', dG, st['Gp'], P)
+        # local cat conv
+        dWlc = torch.empty(C, 2 * C, dtype=f32, device=dev)
+        ops.wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
+                                        wcol0=0)], dWlc)
+        grads[g + 'Blc'] = dWlc
+        WlcT = st['Wlc'].t().contiguous()       # [2C][C]
+        dY = self._new(P, 2 * C, dt, dev)
+        partY = torch.empty(nb, 2 * C, 2, dtype=f32, device=dev)
+        ops.gemm(dom, 2 * C, [dict(A=dL, K=C, map=im, W=WlcT)], dY, im, epi=EPI_BNRELU_BWD, partials=partY, X=st['Y'],
+                 xscale=st['bnY'].scale, xshift=st['bnY'].shift)
+        self._bn_backward(partY, nb, 0, C, st['bnY'], inp[g + 'bn_1.weight'], grads, g + 'bn_1', dY, st['Y'], P, off=0, dzcol=0)
+        self._bn_backward(partY, nb, C, C, st['bnY'], inp[g + 'bn_2.weight'], grads, g + 'bn_2', dY, st['Y'], P, off=C, dzcol=C)
+        # global cat conv
+        dWgc = torch.empty(C, C, dtype=f32, device=dev)
+        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], dWgc)
+        grads[g + 'Bgc'] = dWgc
+        WgcT = st['Wgc'].t().contiguous()
+        dYa = self._new(P, C, dt, dev)
+        ops.gemm(dom, C, [dict(A=dG, K=C, map=im, W=WgcT)], dYa, im)
+        # attention core + aggregation backward fill the column blocks of dH
+        H = st['H']
+        dH = self._new(P, N1, dt, dev)
+        dCk = torch.zeros(NHEADS, J, J, dtype=f32, device=dev)
+        ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
+        grads[g + 'C_k'] = dCk
+        dA_s = torch.zeros_like(st['A_s'])
+        dA_c = torch.zeros_like(st['A_c'])
+        ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA_s, dA_c)
+        de_s = torch.empty_like(inp[g + 'e_sym'])
+        de_c = torch.empty_like(inp[g + 'e_con'])
+        ops.semch_adj_bwd(dA_s, st['A_s'], sp.pat_sym(dev), de_s)
+        ops.semch_adj_bwd(dA_c, st['A_c'], sp.pat_con(dev), de_c)
+        grads[g + 'e_sym'] = de_s
+        grads[g + 'e_con'] = de_c
+        # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
+        dWg1 = torch.empty(N1, C, dtype=f32, device=dev)
+        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], dWg1)
+        grads[g + 'Bg1'] = dWg1
+        dbias = torch.zeros(N1, dtype=f32, device=dev)
+        nbias = C + 2 * NHEADS
+        ops.colsum(dH[:, 4 * C:], P, nbias, dbias[4 * C:], zero_first=False)
+        grads[g + 'bias1'] = dbias
+        Wg1T = st['Wg1'].t().contiguous()       # [C][N1]
+        dX = self._new(P, C, dt, dev)
+        ops.gemm(dom, C, [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])], dX, im)
+        return dX
+
+
+def inp_bn(inp, key):
+    return {'weight': inp[key + '.weight'], 'bias': inp[key + '.bias']}

@@ -1,0 +1,343 @@
+"""GAST-Net spatio-temporal models on the MI355X HIP plan -- drop-in for the reference's `model/gast_net.py`.
+
+Public surface kept from the reference:
+  * `SpatioTemporalModel(adj, num_joints_in, in_features, num_joints_out, filter_widths, causal=False, dropout=0.25,
+    channels=64, dense=False)` (reference gast_net.py:113-114) and `SpatioTemporalModelOptimized1f(... same minus dense)`
+    (:191-192); `receptive_field()` (:62-69); `forward(x: (B,T,J,in_features)) -> (B,T',J,3)` (:84-104);
+  * the `state_dict` key/shape contract (same sub-module names, registration order and initialisers), so the shipped
+    checkpoints load with `load_state_dict(strict=True)` and `torch.manual_seed(s)` + construction reproduces the
+    reference's initial weights bit for bit;
+  * the module-level names `torch`, `nn`, `LocalGraph`, `MultiGlobalGraph`, `SingleGlobalGraph`: the reference's
+    `trainval.py:60` reaches `nn` only through `from model.gast_net import *`.
+
+What differs is everything below that surface: forward/backward run as one `torch.autograd.Function` whose body is the
+fused launch plan of `gast_hip/engine.py` over hand-written gfx950 kernels.  There is no PyTorch/CPU fallback: calling
+the model with CPU tensors, or without `libgast_hip.so`, raises.
+
+Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (default; parity 1e-4) or `bf16`
+(bf16 activations/weights, fp32 accumulate/statistics; parity 1e-2).
+"""
+import os
+
+import torch
+import torch.nn as nn
+from model.local_attention import LocalGraph
+from model.global_attention import MultiGlobalGraph, SingleGlobalGraph
+
+from model.local_attention import pattern_table, skeleton_patterns
+from gast_hip.engine import Engine, NHEADS
+
+
+class GraphAttentionBlock(nn.Module):
+    """cat(x, LocalGraph(x), MultiGlobalGraph(x)) -> 1x1 conv (3C -> 2C) -> BN -> ReLU (reference gast_net.py:8-33)."""
+
+    def __init__(self, adj, input_dim, output_dim, p_dropout):
+        super(GraphAttentionBlock, self).__init__()
+        hid_dim = output_dim
+        self.relu = nn.ReLU(inplace=True)
+        self.local_graph_layer = LocalGraph(adj, input_dim, hid_dim, p_dropout)
+        self.global_graph_layer = MultiGlobalGraph(adj, input_dim, input_dim // 4, dropout=p_dropout)
+        self.cat_conv = nn.Conv2d(3 * output_dim, 2 * output_dim, 1, bias=False)
+        self.cat_bn = nn.BatchNorm2d(2 * output_dim, momentum=0.1)
+
+    def forward(self, x):
+        raise NotImplementedError('GraphAttentionBlock runs inside the fused HIP plan of SpatioTemporalModel')
+
+
+class ModelSpec:
+    """Static description of one model instance for the engine."""
+
+    def __init__(self, adj, filter_widths, channels, causal, strided, in_features):
+        self.J = int(adj.shape[0])
+        self.fw = list(filter_widths)
+        self.channels = int(channels)
+        self.causal = bool(causal)
+        self.strided = bool(strided)
+        self.in_features = int(in_features)
+        # reference gast_net.py:57,139-143 (dilated) / :215-220 (strided)
+        self.pad = [self.fw[0] // 2]
+        self.causal_shift = [self.fw[0] // 2 if causal else 0]
+        self.dil = [1]
+        nd = self.fw[0]
+        for i in range(1, len(self.fw)):
+            self.pad.append((self.fw[i] - 1) * nd // 2)
+            if strided:
+                self.causal_shift.append((self.fw[i] // 2) if causal else 0)
+            else:
+                self.causal_shift.append((self.fw[i] // 2 * nd) if causal else 0)
+            self.dil.append(nd)
+            nd *= self.fw[i]
+        self.receptive_field = 1 + 2 * sum(self.pad)
+        sym, con = skeleton_patterns(adj)
+        self._tab_sym, self.nnz_sym = pattern_table(sym)
+        self._tab_con, self.nnz_con = pattern_table(con)
+        self._dev_tabs = {}
+
+    def _tab(self, which, dev):
+        key = (which, str(dev))
+        if key not in self._dev_tabs:
+            src = self._tab_sym if which == 0 else self._tab_con
+            self._dev_tabs[key] = src.to(dev)
+        return self._dev_tabs[key]
+
+    def pat_sym(self, dev):
+        return self._tab(0, dev)
+
+    def pat_con(self, dev):
+        return self._tab(1, dev)
+
+
+def _bn_keys(prefix, bn, inp, bufs):
+    inp[prefix + '.weight'] = bn.weight
+    inp[prefix + '.bias'] = bn.bias
+    bufs[prefix] = {'running_mean': bn.running_mean, 'running_var': bn.running_var,
+                    'num_batches_tracked': bn.num_batches_tracked}
+
+
+def pack_inputs(model):
+    """Parameters -> the fp32 operand layout of the plan, with ordinary differentiable torch ops on parameter-sized
+    tensors (so autograd scatters the plan's packed gradients back onto the reference-shaped parameters).
+    Returns (inp: key -> tensor that needs a gradient, bufs: key -> BatchNorm buffers)."""
+    inp, bufs = {}, {}
+    _bn_keys('init_bn', model.init_bn, inp, bufs)
+    _bn_keys('expand_bn', model.expand_bn, inp, bufs)
+    inp['expand_w'] = model.expand_conv.weight
+    inp['shrink'] = model.shrink.weight.flatten(1)
+    for s, gab in enumerate(model.layers_graph_conv):
+        g = 'g%d.' % s
+        loc, glb = gab.local_graph_layer, gab.global_graph_layer
+        C = loc.gcn_sym.in_features
+        rows = [loc.gcn_sym.W[0].t(), loc.gcn_sym.W[1].t(), loc.gcn_con.W[0].t(), loc.gcn_con.W[1].t()]
+        rows += [att.g.weight[:, :, 0] for att in glb.attentions]
+        vth, vph, bg, ath, aph = [], [], [], [], []
+        for att in glb.attentions:
+            Ci = att.inter_channels
+            w = att.concat_project[0].weight.view(2 * Ci)
+            # f_ij = w_theta.theta_i + w_phi.phi_j is rank-1: fold theta/phi into one C-vector (+ scalar) per head
+            vth.append(att.theta.weight[:, :, 0].t() @ w[:Ci])
+            vph.append(att.phi.weight[:, :, 0].t() @ w[Ci:])
+            ath.append((w[:Ci] * att.theta.bias).sum())
+            aph.append((w[Ci:] * att.phi.bias).sum())
+            bg.append(att.g.bias)
+        rows += [torch.stack(vth), torch.stack(vph)]
+        inp[g + 'Bg1'] = torch.cat(rows, dim=0)                                   # [5C+8][C]
+        inp[g + 'bias1'] = torch.cat([loc.gcn_sym.W.new_zeros(4 * C)] + bg + [torch.stack(ath), torch.stack(aph)])
+        inp[g + 'e_sym'] = loc.gcn_sym.e
+        inp[g + 'e_con'] = loc.gcn_con.e
+        inp[g + 'C_k'] = torch.stack([att.C_k for att in glb.attentions])          # [4][J][J]
+        inp[g + 'Blc'] = loc.cat_conv.weight.flatten(1)                            # [C][2C]
+        inp[g + 'Bgc'] = glb.cat_conv.weight.flatten(1)                            # [C][C]
+        inp[g + 'Bbc'] = gab.cat_conv.weight.flatten(1)                            # [2C][3C]
+        _bn_keys(g + 'bn_1', loc.bn_1, inp, bufs)
+        _bn_keys(g + 'bn_2', loc.bn_2, inp, bufs)
+        _bn_keys(g + 'lcat_bn', loc.cat_bn, inp, bufs)
+        _bn_keys(g + 'gcat_bn', glb.cat_bn, inp, bufs)
+        _bn_keys(g + 'cat_bn', gab.cat_bn, inp, bufs)
+    for i in range(len(model.layers_conv) // 2):
+        lk = 'l%d.' % (i + 1)
+        w = model.layers_conv[2 * i].weight                                        # (C,C,k,1)
+        inp[lk + 'conv'] = w[:, :, :, 0].permute(0, 2, 1).reshape(w.shape[0], -1)  # [C][k*C], tap-major K
+        inp[lk + 'conv1'] = model.layers_conv[2 * i + 1].weight.flatten(1)
+        _bn_keys(lk + 'bn0', model.layers_bn[2 * i], inp, bufs)
+        _bn_keys(lk + 'bn1', model.layers_bn[2 * i + 1], inp, bufs)
+    return inp, bufs
+
+
+class _GastFunction(torch.autograd.Function):
+    """forward/backward of the whole spatio-temporal path as one autograd node."""
+
+    @staticmethod
+    def forward(ctx, runner, x, training, keys, bufs, *tensors):
+        inp = dict(zip(keys, [t.detach() for t in tensors]))
+        pred, sv = runner.engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device))
+        ctx.runner, ctx.keys, ctx.inp, ctx.sv = runner, keys, inp, sv
+        return pred
+
+    @staticmethod
+    def backward(ctx, dpred):
+        grads = ctx.runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous())
+        ctx.sv = None
+        out = []
+        for k, t in zip(ctx.keys, ctx.inp.values()):
+            g = grads.get(k)
+            out.append(None if g is None else g.reshape(t.shape))
+        return (None, None, None, None, None) + tuple(out)
+
+
+class _Runner:
+    """Per-model glue: op set, activation dtype, dropout stream."""
+
+    def __init__(self, spec, p_dropout):
+        self.spec = spec
+        self.p_dropout = float(p_dropout)
+        self._engine = None
+        self._seeds = {}
+        # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
+        # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
+        self.ops_factory = None
+
+    def __getstate__(self):
+        return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_seeds': {}, 'ops_factory': None}
+
+    @property
+    def act_dtype(self):
+        v = os.environ.get('GAST_HIP_DTYPE', 'fp32').lower()
+        if v in ('fp32', 'f32', 'float32'):
+            return torch.float32
+        if v in ('bf16', 'bfloat16'):
+            return torch.bfloat16
+        raise ValueError('GAST_HIP_DTYPE must be fp32 or bf16, got %r' % v)
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            if self.ops_factory is not None:
+                ops = self.ops_factory()
+            else:
+                from gast_hip.binding import HipOps
+                ops = HipOps()
+            self._engine = Engine(self.spec, ops)
+        return self._engine
+
+    def dropout_state(self, training, dev):
+        """A fresh dropout stream per training forward: the seed lives on the device (graph-capture friendly)."""
+        if not training or self.p_dropout <= 0:
+            return None
+        from gast_hip.binding import Dropout, dropout_params
+        thresh, inv_keep = dropout_params(self.p_dropout)
+        key = str(dev)
+        if key not in self._seeds:
+            s = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            self._seeds[key] = torch.tensor([s], dtype=torch.int32, device=dev)
+        seed = self._seeds[key]
+        seed.add_(1)
+        return Dropout(seed.clone(), thresh, inv_keep)
+
+
+class SpatioTemporalModelBase(nn.Module):
+    """
+    Do not instantiate this class.
+    """
+
+    def __init__(self, adj, num_joints_in, in_features, num_joints_out,
+                 filter_widths, causal, dropout, channels):
+        super().__init__()
+        for fw in filter_widths:
+            assert fw % 2 != 0, 'Only odd filter widths are supported'
+        self.num_joints_in = num_joints_in
+        self.in_features = in_features
+        self.num_joints_out = num_joints_out
+        self.filter_widths = filter_widths
+        self.drop = nn.Dropout(dropout)
+        self.relu = nn.ReLU(inplace=True)
+        self.pad = [filter_widths[0] // 2]
+        self.init_bn = nn.BatchNorm2d(in_features, momentum=0.1)
+        self.expand_bn = nn.BatchNorm2d(channels, momentum=0.1)
+        self.shrink = nn.Conv2d(2 ** len(self.filter_widths) * channels, 3, 1, bias=False)
+
+    def _finish_init(self, adj, filter_widths, causal, dropout, channels, strided):
+        """Common tail of both variants' constructors: temporal stack + engine spec (reference :133-157 / :210-233)."""
+        layers_conv, layers_graph_conv, layers_bn = [], [], []
+        layers_graph_conv.append(GraphAttentionBlock(adj, channels, channels, p_dropout=dropout))
+        self.causal_shift = [(filter_widths[0]) // 2 if causal else 0]
+        next_dilation = filter_widths[0]
+        for i in range(1, len(filter_widths)):
+            width = 2 ** i * channels
+            self.pad.append((filter_widths[i] - 1) * next_dilation // 2)
+            if strided:
+                self.causal_shift.append((filter_widths[i] // 2) if causal else 0)
+                conv = nn.Conv2d(width, width, (filter_widths[i], 1), stride=(filter_widths[i], 1), bias=False)
+            else:
+                self.causal_shift.append((filter_widths[i] // 2 * next_dilation) if causal else 0)
+                conv = nn.Conv2d(width, width, (filter_widths[i], 1), dilation=(next_dilation, 1), bias=False)
+            layers_conv.append(conv)
+            layers_bn.append(nn.BatchNorm2d(width, momentum=0.1))
+            layers_conv.append(nn.Conv2d(width, width, 1, dilation=1, bias=False))
+            layers_bn.append(nn.BatchNorm2d(width, momentum=0.1))
+            layers_graph_conv.append(GraphAttentionBlock(adj, width, width, p_dropout=dropout))
+            next_dilation *= filter_widths[i]
+        self.layers_conv = nn.ModuleList(layers_conv)
+        self.layers_bn = nn.ModuleList(layers_bn)
+        self.layers_graph_conv = nn.ModuleList(layers_graph_conv)
+        if channels % 4 != 0:
+            raise ValueError('channels must be a multiple of 4 (4 attention heads, reference gast_net.py:16)')
+        spec = ModelSpec(adj, filter_widths, channels, causal, strided, self.in_features)
+        # kept out of nn.Module's registries (no parameters / buffers of its own -> state_dict is untouched)
+        object.__setattr__(self, '_runner', _Runner(spec, dropout))
+
+    def receptive_field(self):
+        """
+        Return the total receptive field of this model as # of frames.
+        """
+        frames = 0
+        for f in self.pad:
+            frames += f
+        return 1 + 2 * frames
+
+    def total_causal_shift(self):
+        """
+        Return the asymmetric offset for sequence padding (kept for API parity, reference gast_net.py:71-82).
+        """
+        frames = self.causal_shift[0]
+        next_dilation = self.filter_widths[0]
+        for i in range(1, len(self.filter_widths)):
+            frames += self.causal_shift[i] * next_dilation
+            next_dilation *= self.filter_widths[i]
+        return frames
+
+    def forward(self, x):
+        """
+        X: (B, T, N, C)  -- batch, frames, keypoints, features per keypoint (the reference's docstring says (B,C,T,N),
+        its asserts and callers use this layout: gast_net.py:93-95, main.py:219-230).
+        """
+        assert len(x.shape) == 4
+        assert x.shape[-2] == self.num_joints_in
+        assert x.shape[-1] == self.in_features
+        runner = self._runner
+        if not x.is_cuda and runner.ops_factory is None:
+            raise RuntimeError('gast_net (MI355X build): input is on %s. This implementation has no CPU fallback; move the '
+                               'model and the batch to the GPU (`.cuda()`).' % x.device)
+        x = x.contiguous().float()
+        inp, bufs = pack_inputs(self)
+        keys = tuple(inp.keys())
+        return _GastFunction.apply(runner, x, self.training, keys, bufs, *inp.values())
+
+
+class SpatioTemporalModel(SpatioTemporalModelBase):
+    """
+    Reference 3D pose estimation model with temporal (dilated) convolutions; usable for all use-cases.
+    """
+
+    def __init__(self, adj, num_joints_in, in_features, num_joints_out,
+                 filter_widths, causal=False, dropout=0.25, channels=64, dense=False):
+        """
+        Arguments (identical to the reference, gast_net.py:113-128):
+        num_joints_in -- number of input joints (e.g. 17 for Human3.6M)
+        in_features -- number of input features for each joint (typically 2 for 2D input)
+        num_joints_out -- number of output joints (can be different than input)
+        filter_widths -- list of convolution widths, which also determines the # of blocks and receptive field
+        causal -- use causal convolutions instead of symmetric convolutions (for real-time applications)
+        dropout -- dropout probability
+        channels -- number of convolution channels
+        dense -- use regular dense convolutions instead of dilated convolutions (ablation experiment)
+        """
+        super().__init__(adj, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels)
+        if dense:
+            raise NotImplementedError('dense=True (ablation, reference gast_net.py:145-146) is not on the accelerated path yet')
+        self.expand_conv = nn.Conv2d(in_features, channels, (filter_widths[0], 1), bias=False)
+        nn.init.kaiming_normal_(self.expand_conv.weight)
+        self._finish_init(adj, filter_widths, causal, dropout, channels, strided=False)
+
+
+class SpatioTemporalModelOptimized1f(SpatioTemporalModelBase):
+    """
+    Single-frame-batching variant (input length = receptive field, output length = 1): strided instead of dilated
+    convolutions, weights interchangeable with SpatioTemporalModel (reference gast_net.py:180-251).
+    """
+
+    def __init__(self, adj, num_joints_in, in_features, num_joints_out,
+                 filter_widths, causal=False, dropout=0.25, channels=64):
+        super().__init__(adj, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels)
+        self.expand_conv = nn.Conv2d(in_features, channels, (filter_widths[0], 1), stride=(filter_widths[0], 1), bias=False)
+        nn.init.kaiming_normal_(self.expand_conv.weight)
+        self._finish_init(adj, filter_widths, causal, dropout, channels, strided=True)

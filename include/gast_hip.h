@@ -1,0 +1,240 @@
+/*
+ * gast_hip.h -- C ABI of the MI355X (gfx950) GAST-Net spatio-temporal hot path.
+ *
+ * Drop-in boundary.  The reference has no FFI: its hot path is the Python module `model.gast_net`
+ * (reference model/gast_net.py:84-104,159-177,235-251; model/local_attention.py:35-53,130-151;
+ * model/global_attention.py:52-82,103-130), which issues only stock ATen ops.  The entry points below are what
+ * a binding for that path binds instead of ATen: each one replaces a cited group of reference lines.  The host
+ * side (the model package under gast-net-3dposeestimation_amd/) keeps the reference's class names, constructor signatures and
+ * state_dict and calls these through ctypes (gast-net-3dposeestimation_amd/gast_hip/binding.py).
+ *
+ * Conventions
+ *   - All pointers are DEVICE pointers owned by the caller (torch tensors).  Kernels never allocate or free.
+ *   - Activations are "position-major": one row per (b, t, j) position, channels contiguous; `ld*` are row strides
+ *     in ELEMENTS.  Activation/weight element type is selected by `dtype` (GAST_F32 / GAST_BF16); statistics,
+ *     scale/shift vectors, partial sums and parameter gradients are always fp32.
+ *   - Every function enqueues work on `stream` and returns immediately: 0 on success, a hipError_t code (>0) on a
+ *     launch failure, or a negative GAST_E* code on invalid arguments.  No exceptions cross the boundary, no
+ *     internal synchronisation, no global mutable state.
+ *   - A row map addresses a (B, T_total, J) tensor from a (B, Tn, J) iteration domain:
+ *       row(b, t, j) = (b * T_total + t * t_stride + t_off) * J + j,  "invalid" (reads as zero / not written)
+ *     when t * t_stride + t_off falls outside [0, T_total).  This is how the temporal taps of the dilated /
+ *     strided convolution (gast_net.py:145-146,173,222,246) and the residual slices (:170,:243) are expressed
+ *     without materialising anything.
+ */
+#ifndef GAST_HIP_H
+#define GAST_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* gast_stream_t; /* hipStream_t */
+
+#define GAST_F32 0
+#define GAST_BF16 1
+
+#define GAST_EINVAL (-1)   /* bad argument (null pointer, bad dtype, bad size) */
+#define GAST_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
+#define GAST_ERANGE (-3)   /* size outside the supported range */
+
+#define GAST_MAX_SEG 8
+
+#define GAST_PRO_NONE 0        /* operand used as stored */
+#define GAST_PRO_BNRELU 1      /* relu(x * scale[k] + shift[k])             (BatchNorm2d + ReLU applied on load) */
+#define GAST_PRO_BNRELU_DROP 2 /* relu(x * scale[k] + shift[k]) * keep / (1-p)   (+ nn.Dropout)                 */
+
+#define GAST_EPI_PLAIN 0       /* C = acc (+bias) (+addend)                                                     */
+#define GAST_EPI_STATS 1       /* as PLAIN, and per-column partial sums {sum c, sum c^2} for the following BN    */
+#define GAST_EPI_BNRELU_BWD 2  /* C = (acc + addend) * [xscale*X+xshift > 0] * keep/(1-p); partial sums {sum C, sum C*X} */
+
+typedef struct {
+    int T_total;  /* frames per sequence of the addressed tensor */
+    int t_stride; /* t_src = t * t_stride + t_off */
+    int t_off;
+} gast_rowmap;
+
+/* Dropout stream: element e (linear element offset inside its tensor) of tensor `salt` is kept iff
+ * bits16(hash32((e >> 1) ^ (seed*0x9E3779B9 + salt*0x85EBCA6B)), e & 1) >= thresh; kept values are multiplied by
+ * inv_keep.  thresh = round(p * 65536), inv_keep = 65536 / (65536 - thresh).  `seed` lives in device memory so
+ * a captured hipGraph can be replayed with a fresh mask per step. */
+typedef struct {
+    const uint32_t* seed; /* device pointer to one uint32 (may be null when thresh == 0) */
+    uint32_t thresh;
+    float inv_keep;
+} gast_dropout;
+
+typedef struct {
+    const void* A;       /* [rows][lda]  activation operand of this K segment */
+    int lda;
+    int K;               /* depth of the segment (multiple of 4 for f32, 8 for bf16) */
+    gast_rowmap map;     /* row map from the GEMM's (B,Tn,J) domain into A */
+    const void* W;       /* [N][ldw]  weight segment, K contiguous ("B transposed") */
+    int ldw;
+    int pro;             /* GAST_PRO_* */
+    const float* scale;  /* [K] when pro != NONE */
+    const float* shift;  /* [K] */
+    uint32_t salt;       /* dropout stream id of tensor A (pro == BNRELU_DROP) */
+} gast_gemm_seg;
+
+/* gast_gemm: the channel-mixing GEMM family on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16).
+ *   C[cmap(m), n] = epi( sum_s sum_k pro_s(A_s[map_s(m), k]) * W_s[n, k] + bias[n] + addend[addmap(m), n] )
+ * Replaces every Conv2d 1x1 / (k,1) dilated / strided conv, Conv1d 1x1 and X.W matmul of the path:
+ * gast_net.py:19,31-32,60,99,130,145-148,164,173-174,207,222; local_attention.py:37-38,122,143;
+ * global_attention.py:30-35,41,56-72,94,122; and, with transposed weights, their input gradients. */
+typedef struct {
+    int dtype;            /* element type of A, W, addend, X (and C unless out_f32) */
+    int out_f32;          /* store C as fp32 regardless of dtype */
+    int B, Tn, J;         /* iteration domain: M = B*Tn*J rows */
+    int N;                /* output columns */
+    int nseg;
+    gast_gemm_seg seg[GAST_MAX_SEG];
+    void* C;
+    int ldc;
+    gast_rowmap cmap;     /* where row m is stored */
+    const float* bias;    /* [N] or null */
+    const void* addend;   /* optional [rows][ldadd], added before the epilogue non-linearity */
+    int ldadd;
+    gast_rowmap addmap;
+    int epi;              /* GAST_EPI_* */
+    float* partials;      /* epi != PLAIN: [ceil(M/128)][N][2] fp32, fully overwritten */
+    const void* X;        /* epi == BNRELU_BWD: pre-BN tensor addressed with cmap, [rows][ldx] */
+    int ldx;
+    const float* xscale;  /* [N] */
+    const float* xshift;  /* [N] */
+    int xdrop;            /* forward applied dropout to relu(bn(X)) */
+    uint32_t xsalt;
+    gast_dropout drop;
+} gast_gemm_args;
+
+int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
+/* number of row blocks (first dimension of `partials`) gast_gemm uses for a domain of M rows */
+int gast_gemm_row_blocks(int M);
+
+typedef struct {
+    const void* Q;       /* [rows][ldq] activation operand (forward "A") */
+    int ldq;
+    int S;               /* columns of Q used = K extent of the weight segment */
+    gast_rowmap map;
+    int pro;
+    const float* scale;
+    const float* shift;
+    uint32_t salt;
+    int wcol0;           /* first column of dW this segment fills */
+} gast_wgrad_seg;
+
+/* gast_wgrad: weight gradient  dW[r, wcol0_s + k] (+)= sum_m P[pmap(m), r] * pro_s(Q_s[map_s(m), k])
+ * (autograd of the convs/matmuls listed under gast_gemm; reference main.py:237 `loss.backward()`).
+ * dW is fp32 [R][ldw]; the function zero-fills it (hipMemsetAsync) and accumulates split-M partial tiles with
+ * fp32 atomics. */
+typedef struct {
+    int dtype;
+    int B, Tn, J;
+    const void* P;       /* [rows][ldp]  output-gradient operand */
+    int ldp;
+    int R;               /* columns of P used = rows of dW */
+    gast_rowmap pmap;
+    int nseg;
+    gast_wgrad_seg seg[GAST_MAX_SEG];
+    float* dW;
+    int ldw;
+    int zero_first;      /* memset dW[R][ldw] before accumulating */
+    gast_dropout drop;
+} gast_wgrad_args;
+
+int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream);
+
+/* ---- semantic channel-wise graph convolution (local_attention.py:10-56) ------------------------------------
+ * Pattern (device int32 array, built once per skeleton by the host from local_attention.py:92-114):
+ *   pat[0]=J, pat[1]=nnz, then row_ptr[J+1], col[nnz] (edges sorted by row i, CSR), col_ptr[J+1], crow[nnz],
+ *   cedge[nnz] (CSC view: for column j the rows i and the CSR edge ids).  Edge k <-> e[:, k] exactly as the
+ *   reference's boolean-mask assignment enumerates (i, j) row-major (local_attention.py:41). */
+
+/* A_t[k][c] = softmax over the edges of row i(k) of e[c][k]   (local_attention.py:40-42) */
+int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, gast_stream_t stream);
+/* de[c][k] = A (dA - sum_row A dA)   (softmax backward) */
+int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t* pat, float* de, gast_stream_t stream);
+
+/* Y[f*J+i, p*C + c] = A_p[c,i,i] h0_p[f*J+i, c] + sum_{j in N_p(i), j != i} A_p[c,i,j] h1_p[f*J+j, c]
+ * for the two graphs p = 0 (symmetry) and 1 (connection); H holds [h0_sym | h1_sym | h0_con | h1_con] in columns
+ * [0,4C) (local_attention.py:44-48).  Also emits BatchNorm partial sums over the 2C output columns
+ * (bn_1 / bn_2, local_attention.py:139-140): partials[nblk][2C][2]; returns nblk through *nblk_out (host mirror:
+ * gast_semch_agg_blocks). */
+int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
+                       const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
+                       void* Y, int ldy, float* partials, gast_stream_t stream);
+int gast_semch_agg_blocks(int F, int C);
+/* Backward: dH columns [0,4C) and dA_t (atomically accumulated into zero-filled [nnz][C] buffers). */
+int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                       const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
+                       void* dH, int lddh, float* dA_sym, float* dA_con, gast_stream_t stream);
+
+/* ---- global additive joint attention, 4 heads (global_attention.py:52-82, App. A.2 of SURVEY.md) -----------
+ * G = base pointer of the g columns ([rows][ldg], C columns, head h owns columns [h*Ci,(h+1)*Ci));
+ * AC = base pointer of 2*nheads columns: a_h (nheads) then c_h (nheads), a_i = w_theta.theta_i, c_j = w_phi.phi_j.
+ * att = softmax_j(LeakyReLU_0.2(a_i + c_j)) + C_k[h,i,j];  Y[i, hCi+c] = sum_j att_ij g[j, hCi+c]. */
+int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
+                  int F, int J, int C, int nheads, void* Y, int ldy, gast_stream_t stream);
+/* Backward: dG (C cols), dAC (2*nheads cols) written; dC_k[nheads][J][J] accumulated atomically (caller zeroes). */
+int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                  const float* C_k, int F, int J, int C, int nheads,
+                  void* dG, int lddg, void* dAC, int lddac, float* dC_k, gast_stream_t stream);
+
+/* ---- BatchNorm2d (momentum 0.1, eps 1e-5; gast_net.py:20,58-59,147,149 etc.) as a two-phase scheme ---------
+ * Producers emit per-row-block partial sums; `gast_bn_finalize` turns them into the per-channel scale/shift that
+ * consumers apply on load, and updates the running statistics exactly as nn.BatchNorm2d does in train mode. */
+int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
+                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, float momentum, float eps,
+                     float* scale, float* shift, float* mean, float* rstd, gast_stream_t stream);
+int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                 float eps, int N, float* scale, float* shift, gast_stream_t stream);
+/* partials hold {sum dz, sum dz*x}; writes dgamma, dbeta and the per-channel coefficients of
+ * dx = ka*dz + kb*x + kc. */
+int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
+                         const float* gamma, const float* mean, const float* rstd,
+                         float* dgamma, float* dbeta, float* ka, float* kb, float* kc, gast_stream_t stream);
+/* dz <- ka*dz + kb*x + kc (in place) */
+int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
+                      const float* ka, const float* kb, const float* kc, gast_stream_t stream);
+/* Y = relu(scale*X + shift) */
+int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                      void* Y, int ldy, gast_stream_t stream);
+/* dz = dY * [scale*X+shift > 0] * keep/(1-p)  + partial sums {sum dz, sum dz*x}: partials[nblk][N][2] */
+int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
+                         const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
+                         void* dz, int lddz, float* partials, gast_stream_t stream);
+int gast_rowwise_blocks(long rows, int N);
+/* Residual of a temporal block (gast_net.py:170-174 / :243-247):
+ * Xn[m] = relu(scO*O[omap(m)] + shO) + keep/(1-p) * relu(sc2*T2[m] + sh2) */
+int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
+                      const void* T2, int ldt, const float* sc2, const float* sh2,
+                      int use_drop, uint32_t salt, gast_dropout drop,
+                      int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream);
+
+/* ---- input side: init_bn + expand_conv (gast_net.py:58,130-131,163-164,207) -------------------------------- */
+/* partial sums {sum x, sum x^2} of the (rows, F_in) fp32 network input: partials[nblk][F_in][2] */
+int gast_input_stats(const float* x, long rows, int F_in, float* partials, int* nblk_out, gast_stream_t stream);
+int gast_input_stats_blocks(long rows);
+/* E[(b,t,j), c] = sum_{f,tap} W[c][f][tap] * (sc0[f]*x[(b, t*t_stride+tap, j), f] + sh0[f]) + partial sums for expand_bn */
+int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
+                    const float* W, const float* sc0, const float* sh0, int C,
+                    void* E, int lde, float* partials, gast_stream_t stream);
+/* G[c][f][tap] = sum_m dE[m,c]*xhat[(b,t*ts+tap,j), f],  S[c] = sum_m dE[m,c]   (both fp32, zero-filled here) */
+int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
+                    int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,
+                    gast_stream_t stream);
+
+/* out[n] (+)= sum_m X[m, n]   (bias gradients of the g / theta / phi 1x1 convs, global_attention.py:30-35) */
+int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out, int zero_first, gast_stream_t stream);
+
+/* library identification: returns a static string "gast_hip <version> gfx950" */
+const char* gast_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GAST_HIP_H */

@@ -1,0 +1,448 @@
+"""Kernel-level CPU restatement (numpy) of what each `gast_*` C-ABI entry point computes -- TEST INFRASTRUCTURE ONLY.
+
+`include/gast_hip.h` is the contract; this file restates it op by op in float64 numpy so that
+(a) tests/test_kernels_gpu.py can check every HIP kernel against it on seeded inputs, and
+(b) tests/fake_backend.py can run the product's host-side plan on CPU tensors, which pins the *composition* of these
+    ops against the reference-generated golden fixtures (tests/test_plan_cpu.py).
+The formulas are the ones of SURVEY.md App. A, i.e. algebraic restatements of reference model/local_attention.py:35-53,
+model/global_attention.py:52-82 and nn.BatchNorm2d / ReLU / Dropout / Conv2d as used in model/gast_net.py.
+
+Nothing in the product imports this module.
+"""
+from collections import namedtuple
+
+import numpy as np
+
+RowMap = namedtuple('RowMap', 'T_total t_stride t_off')
+
+PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
+EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
+GEMM_BM = 128
+
+
+# ------------------------------------------------------------------------------------------------ dropout stream
+def hash32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xffffffff
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xffffffff
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xffffffff
+    x ^= x >> 16
+    return x
+
+
+def drop_key(seed, salt):
+    return (int(seed) * 0x9E3779B9 + int(salt) * 0x85EBCA6B) & 0xffffffff
+
+
+def drop_mul(key, thresh, inv_keep, e):
+    """multiplier (0 or inv_keep) for linear element offsets e (array)."""
+    e = np.asarray(e, dtype=np.uint64)
+    h = hash32((e >> 1) ^ np.uint64(key))
+    bits = np.where((e & 1) == 1, h >> 16, h & 0xffff)
+    return np.where(bits >= thresh, np.float64(inv_keep), 0.0)
+
+
+def dropout_params(p):
+    thresh = int(round(p * 65536))
+    inv_keep = 65536.0 / (65536 - thresh) if thresh else 1.0
+    return thresh, inv_keep
+
+
+# ------------------------------------------------------------------------------------------------ row maps
+def map_rows(rm, B, Tn, J):
+    """rows (int64, -1 = invalid) addressed by every m of the (B,Tn,J) domain."""
+    b, t, j = np.meshgrid(np.arange(B), np.arange(Tn), np.arange(J), indexing='ij')
+    ts = t * rm.t_stride + rm.t_off
+    rows = (b * rm.T_total + ts) * J + j
+    rows = np.where((ts >= 0) & (ts < rm.T_total), rows, -1)
+    return rows.reshape(-1)
+
+
+def _gather(A, rows, K):
+    out = np.zeros((rows.shape[0], K), dtype=np.float64)
+    ok = rows >= 0
+    out[ok] = A[rows[ok], :K]
+    return out, ok
+
+
+def _prologue(vals, ok, rows, lda, K, pro, scale, shift, salt, drop):
+    if pro == PRO_NONE:
+        return vals
+    y = np.maximum(vals * np.asarray(scale, np.float64)[:K] + np.asarray(shift, np.float64)[:K], 0.0)
+    if pro == PRO_BNRELU_DROP and drop is not None and drop[1] != 0:
+        seed, thresh, inv_keep = drop
+        e = rows[:, None].astype(np.int64) * lda + np.arange(K)[None, :]
+        mul = drop_mul(drop_key(seed, salt), thresh, inv_keep, np.where(ok[:, None], e, 0))
+        y = y * mul
+    y[~ok] = 0.0
+    return y
+
+
+def _ld(a):
+    return a.strides[0] // a.itemsize
+
+
+# ------------------------------------------------------------------------------------------------ gemm / wgrad
+def gemm(dom, N, segs, C, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
+         xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, round_fn=None):
+    """segs: list of dicts {A, K, map, W, pro, scale, shift, salt}.  drop = (seed, thresh, inv_keep) or None.
+    Writes C (and partials) in place.  round_fn emulates storage rounding (identity for fp32)."""
+    B, Tn, J = dom
+    M = B * Tn * J
+    acc = np.zeros((M, N), dtype=np.float64)
+    for s in segs:
+        rows = map_rows(s['map'], B, Tn, J)
+        a, ok = _gather(s['A'], rows, s['K'])
+        a = _prologue(a, ok, rows, _ld(s['A']), s['K'], s.get('pro', 0), s.get('scale'), s.get('shift'), s.get('salt', 0), drop)
+        acc += a @ np.asarray(s['W'][:N, :s['K']], np.float64).T
+    if bias is not None:
+        acc += np.asarray(bias, np.float64)[None, :N]
+    crow = map_rows(cmap, B, Tn, J)
+    if addend is not None:
+        ar = map_rows(addmap, B, Tn, J)
+        ad, _ = _gather(addend, ar, N)
+        acc += ad
+    okc = crow >= 0
+    s1 = s2 = None
+    if epi == EPI_BNRELU_BWD:
+        x = np.zeros((M, N))
+        x[okc] = X[crow[okc], :N]
+        z = x * np.asarray(xscale, np.float64)[None, :N] + np.asarray(xshift, np.float64)[None, :N]
+        acc = np.where(z > 0, acc, 0.0)
+        if xdrop and drop is not None and drop[1] != 0:
+            seed, thresh, inv_keep = drop
+            e = crow[:, None].astype(np.int64) * _ld(X) + np.arange(N)[None, :]
+            acc = acc * drop_mul(drop_key(seed, xsalt), thresh, inv_keep, np.where(okc[:, None], e, 0))
+        if round_fn is not None:
+            acc = round_fn(acc)
+        s1, s2 = acc, acc * x
+    elif epi == EPI_STATS:
+        if round_fn is not None:
+            acc = round_fn(acc)
+        s1, s2 = acc, acc * acc
+    C[crow[okc], :N] = acc[okc]
+    if epi != EPI_PLAIN:
+        nblk = (M + GEMM_BM - 1) // GEMM_BM
+        for b in range(nblk):
+            sl = slice(b * GEMM_BM, min(M, (b + 1) * GEMM_BM))
+            msk = okc[sl, None]
+            partials[b, :N, 0] = np.where(msk, s1[sl], 0).sum(axis=0)
+            partials[b, :N, 1] = np.where(msk, s2[sl], 0).sum(axis=0)
+
+
+def gemm_row_blocks(M):
+    return (M + GEMM_BM - 1) // GEMM_BM
+
+
+def wgrad(dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
+    """segs: list of dicts {Q, S, map, pro, scale, shift, salt, wcol0}.  dW fp32/64 [R][ldw] accumulated in place."""
+    B, Tn, J = dom
+    prow = map_rows(pmap, B, Tn, J)
+    p, okp = _gather(P, prow, R)
+    if zero_first:
+        dW[:R, :] = 0
+    for s in segs:
+        rows = map_rows(s['map'], B, Tn, J)
+        q, ok = _gather(s['Q'], rows, s['S'])
+        q = _prologue(q, ok, rows, _ld(s['Q']), s['S'], s.get('pro', 0), s.get('scale'), s.get('shift'), s.get('salt', 0), drop)
+        both = okp & ok
+        dW[:R, s['wcol0']:s['wcol0'] + s['S']] += (p[both].T @ q[both])
+
+
+# ------------------------------------------------------------------------------------------------ patterns
+def build_pattern(adj_pattern):
+    """int32 pattern array of gast_hip.h from a (J,J) 0/1 matrix (edges enumerated row-major, as the reference's
+    boolean-mask assignment does, local_attention.py:41)."""
+    m = np.asarray(adj_pattern) > 0
+    J = m.shape[0]
+    rows, cols = np.nonzero(m)  # row-major order
+    nnz = rows.shape[0]
+    row_ptr = np.zeros(J + 1, dtype=np.int32)
+    for i in rows:
+        row_ptr[i + 1] += 1
+    row_ptr = np.cumsum(row_ptr).astype(np.int32)
+    order = np.lexsort((rows, cols))  # by column then row
+    col_ptr = np.zeros(J + 1, dtype=np.int32)
+    for j in cols:
+        col_ptr[j + 1] += 1
+    col_ptr = np.cumsum(col_ptr).astype(np.int32)
+    crow = rows[order].astype(np.int32)
+    cedge = order.astype(np.int32)
+    return np.concatenate([[J, nnz], row_ptr, cols.astype(np.int32), col_ptr, crow, cedge]).astype(np.int32)
+
+
+def parse_pattern(pat):
+    J, nnz = int(pat[0]), int(pat[1])
+    o = 2
+    row_ptr = pat[o:o + J + 1]; o += J + 1
+    col = pat[o:o + nnz]; o += nnz
+    col_ptr = pat[o:o + J + 1]; o += J + 1
+    crow = pat[o:o + nnz]; o += nnz
+    cedge = pat[o:o + nnz]
+    erow = np.repeat(np.arange(J), np.diff(row_ptr))
+    return J, nnz, row_ptr, col, col_ptr, crow, cedge, erow
+
+
+# ------------------------------------------------------------------------------------------------ SemCH graph conv
+def semch_adj_fwd(e, pat, A_t):
+    J, nnz, row_ptr, col, _, _, _, erow = parse_pattern(pat)
+    e = np.asarray(e, np.float64)
+    for i in range(J):
+        ks = slice(row_ptr[i], row_ptr[i + 1])
+        z = e[:, ks] - e[:, ks].max(axis=1, keepdims=True)
+        ex = np.exp(z)
+        A_t[ks, :] = (ex / ex.sum(axis=1, keepdims=True)).T
+
+
+def semch_adj_bwd(dA_t, A_t, pat, de):
+    J, nnz, row_ptr, *_ = parse_pattern(pat)
+    A = np.asarray(A_t, np.float64)
+    dA = np.asarray(dA_t, np.float64)
+    for i in range(J):
+        ks = slice(row_ptr[i], row_ptr[i + 1])
+        dot = (A[ks] * dA[ks]).sum(axis=0, keepdims=True)
+        de[:, ks] = (A[ks] * (dA[ks] - dot)).T
+
+
+def semch_agg_blocks(F, C):
+    tpf = min(C // 4, 256)
+    fb = 256 // tpf
+    return min((F + fb - 1) // fb, 512)
+
+
+def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round_fn=None):
+    Hf = np.asarray(H[:F * J, :4 * C], np.float64).reshape(F, J, 4 * C)
+    out = np.zeros((F, J, 2 * C))
+    for g, (A, pat) in enumerate(((A_sym, pat_sym), (A_con, pat_con))):
+        _, nnz, row_ptr, col, _, _, _, erow = parse_pattern(pat)
+        A = np.asarray(A, np.float64)
+        h0 = Hf[:, :, g * 2 * C: g * 2 * C + C]
+        h1 = Hf[:, :, g * 2 * C + C: g * 2 * C + 2 * C]
+        for k in range(nnz):
+            i, j = erow[k], col[k]
+            src = h0 if i == j else h1
+            out[:, i, g * C:(g + 1) * C] += A[k][None, :] * src[:, j, :]
+    if round_fn is not None:
+        out = round_fn(out)
+    Y[:F * J, :2 * C] = out.reshape(F * J, 2 * C)
+    # partial sums: frames are dealt round-robin to (block, slot): f = (it*nblk + blk)*FB + slot
+    nblk = semch_agg_blocks(F, C)
+    tpf = min(C // 4, 256)
+    fb = 256 // tpf
+    partials[:nblk] = 0
+    blk_of_frame = (np.arange(F) // fb) % nblk
+    for b in range(nblk):
+        sel = out[blk_of_frame == b]
+        partials[b, :2 * C, 0] = sel.sum(axis=(0, 1))
+        partials[b, :2 * C, 1] = (sel * sel).sum(axis=(0, 1))
+
+
+def semch_agg_bwd(dY, H, F, J, C, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con, round_fn=None):
+    """dA_* are accumulated (+=) like the kernel's atomics; the caller zeroes them."""
+    Hf = np.asarray(H[:F * J, :4 * C], np.float64).reshape(F, J, 4 * C)
+    dYf = np.asarray(dY[:F * J, :2 * C], np.float64).reshape(F, J, 2 * C)
+    dHo = np.zeros((F, J, 4 * C))
+    for g, (A, pat, dA) in enumerate(((A_sym, pat_sym, dA_sym), (A_con, pat_con, dA_con))):
+        _, nnz, row_ptr, col, _, _, _, erow = parse_pattern(pat)
+        A = np.asarray(A, np.float64)
+        dy = dYf[:, :, g * C:(g + 1) * C]
+        for k in range(nnz):
+            i, j = erow[k], col[k]
+            off = g * 2 * C + (0 if i == j else C)
+            dHo[:, j, off:off + C] += A[k][None, :] * dy[:, i, :]
+            dA[k, :] += (dy[:, i, :] * Hf[:, j, off:off + C]).sum(axis=0)
+    if round_fn is not None:
+        dHo = round_fn(dHo)
+    dH[:F * J, :4 * C] = dHo.reshape(F * J, 4 * C)
+
+
+# ------------------------------------------------------------------------------------------------ global attention
+def _attn_common(AC, C_k, F, J, nheads):
+    ac = np.asarray(AC[:F * J, :2 * nheads], np.float64).reshape(F, J, 2 * nheads)
+    a = ac[:, :, :nheads].transpose(0, 2, 1)            # (F,h,J)  a_i
+    c = ac[:, :, nheads:].transpose(0, 2, 1)            # (F,h,J)  c_j
+    s = a[:, :, :, None] + c[:, :, None, :]             # (F,h,i,j)
+    slope = np.where(s > 0, 1.0, 0.2)
+    f = s * slope
+    f = f - f.max(axis=-1, keepdims=True)
+    ex = np.exp(f)
+    p = ex / ex.sum(axis=-1, keepdims=True)
+    att = p + np.asarray(C_k, np.float64).reshape(1, nheads, J, J)
+    return p, att, slope
+
+
+def attn_fwd(G, AC, C_k, F, J, C, nheads, Y, round_fn=None):
+    Ci = C // nheads
+    p, att, _ = _attn_common(AC, C_k, F, J, nheads)
+    g = np.asarray(G[:F * J, :C], np.float64).reshape(F, J, nheads, Ci)
+    y = np.einsum('fhij,fjhc->fihc', att, g).reshape(F * J, C)
+    if round_fn is not None:
+        y = round_fn(y)
+    Y[:F * J, :C] = y
+
+
+def attn_bwd(dY, G, AC, C_k, F, J, C, nheads, dG, dAC, dC_k, round_fn=None):
+    """dC_k is accumulated (+=); the caller zeroes it."""
+    Ci = C // nheads
+    p, att, slope = _attn_common(AC, C_k, F, J, nheads)
+    g = np.asarray(G[:F * J, :C], np.float64).reshape(F, J, nheads, Ci)
+    dy = np.asarray(dY[:F * J, :C], np.float64).reshape(F, J, nheads, Ci)
+    datt = np.einsum('fihc,fjhc->fhij', dy, g)
+    dg = np.einsum('fhij,fihc->fjhc', att, dy).reshape(F * J, C)
+    dC_k += datt.sum(axis=0).reshape(dC_k.shape)
+    ds = p * (datt - (p * datt).sum(axis=-1, keepdims=True)) * slope
+    da = ds.sum(axis=3).transpose(0, 2, 1)              # (F,J,h)
+    dc = ds.sum(axis=2).transpose(0, 2, 1)
+    dac = np.concatenate([da, dc], axis=2).reshape(F * J, 2 * nheads)
+    if round_fn is not None:
+        dg, dac = round_fn(dg), round_fn(dac)
+    dG[:F * J, :C] = dg
+    dAC[:F * J, :2 * nheads] = dac
+
+
+# ------------------------------------------------------------------------------------------------ BatchNorm pieces
+def bn_finalize(partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
+                scale, shift, mean, rstd):
+    p = np.asarray(partials[:nblk, col0:col0 + N], np.float64)
+    s1, s2 = p[:, :, 0].sum(axis=0), p[:, :, 1].sum(axis=0)
+    mu = s1 / count
+    var = np.maximum(s2 / count - mu * mu, 0.0)
+    r = 1.0 / np.sqrt(var + eps)
+    sc = np.asarray(gamma, np.float64) * r
+    scale[:N] = sc
+    shift[:N] = np.asarray(beta, np.float64) - mu * sc
+    mean[:N] = mu
+    rstd[:N] = r
+    if running_mean is not None:
+        unb = var * (count / (count - 1.0)) if count > 1 else var
+        running_mean[:N] = (1 - momentum) * running_mean[:N] + momentum * mu
+        running_var[:N] = (1 - momentum) * running_var[:N] + momentum * unb
+    if nbt is not None:
+        nbt[...] = nbt + 1
+
+
+def bn_eval(gamma, beta, rm, rv, eps, N, scale, shift):
+    sc = np.asarray(gamma, np.float64) / np.sqrt(np.asarray(rv, np.float64) + eps)
+    scale[:N] = sc
+    shift[:N] = np.asarray(beta, np.float64) - np.asarray(rm, np.float64) * sc
+
+
+def bn_bwd_finalize(partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc):
+    p = np.asarray(partials[:nblk, col0:col0 + N], np.float64)
+    s1, s2 = p[:, :, 0].sum(axis=0), p[:, :, 1].sum(axis=0)
+    mu, r, g = (np.asarray(v, np.float64)[:N] for v in (mean, rstd, gamma))
+    dg = r * (s2 - mu * s1)
+    db = s1
+    dgamma[:N] = dg
+    dbeta[:N] = db
+    a = g * r
+    b = -g * r * r * dg / count
+    ka[:N] = a
+    kb[:N] = b
+    kc[:N] = -b * mu - a * db / count
+
+
+def bn_bwd_apply(dz, X, rows, N, ka, kb, kc, round_fn=None):
+    v = np.asarray(ka, np.float64)[:N] * dz[:rows, :N] + np.asarray(kb, np.float64)[:N] * X[:rows, :N] + np.asarray(kc, np.float64)[:N]
+    dz[:rows, :N] = round_fn(v) if round_fn else v
+
+
+def bnrelu_apply(X, rows, N, scale, shift, Y, round_fn=None):
+    v = np.maximum(np.asarray(X[:rows, :N], np.float64) * np.asarray(scale, np.float64)[:N] + np.asarray(shift, np.float64)[:N], 0)
+    Y[:rows, :N] = round_fn(v) if round_fn else v
+
+
+def rowwise_blocks(rows, N):
+    tpr = max(1, min(N // 4, 256))
+    rb = 256 // tpr
+    return min((rows + rb - 1) // rb, 1024)
+
+
+def _rowwise_partials(vals_list, rows, N, partials):
+    nblk = rowwise_blocks(rows, N)
+    tpr = max(1, min(N // 4, 256))
+    rb = 256 // tpr
+    blk_of_row = (np.arange(rows) // rb) % nblk
+    for b in range(nblk):
+        sel = blk_of_row == b
+        for q, v in enumerate(vals_list):
+            partials[b, :N, q] = v[sel].sum(axis=0)
+
+
+def bnrelu_bwd_mask(dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials, round_fn=None):
+    x = np.asarray(X[:rows, :N], np.float64)
+    z = x * np.asarray(scale, np.float64)[:N] + np.asarray(shift, np.float64)[:N]
+    d = np.where(z > 0, np.asarray(dY[:rows, :N], np.float64), 0.0)
+    if use_drop and drop is not None and drop[1] != 0:
+        seed, thresh, inv_keep = drop
+        e = np.arange(rows)[:, None].astype(np.int64) * _ld(X) + np.arange(N)[None, :]
+        d = d * drop_mul(drop_key(seed, salt), thresh, inv_keep, e)
+    if round_fn is not None:
+        d = round_fn(d)
+    dz[:rows, :N] = d
+    _rowwise_partials([d, d * x], rows, N, partials)
+
+
+def residual_fwd(O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, round_fn=None):
+    rows = B * Tn * J
+    orow = map_rows(omap, B, Tn, J)
+    o, ok = _gather(O, orow, N)
+    res = np.maximum(o * np.asarray(scO, np.float64)[:N] + np.asarray(shO, np.float64)[:N], 0.0)
+    res[~ok] = 0
+    t = np.maximum(np.asarray(T2[:rows, :N], np.float64) * np.asarray(sc2, np.float64)[:N] + np.asarray(sh2, np.float64)[:N], 0.0)
+    if use_drop and drop is not None and drop[1] != 0:
+        seed, thresh, inv_keep = drop
+        e = np.arange(rows)[:, None].astype(np.int64) * _ld(T2) + np.arange(N)[None, :]
+        t = t * drop_mul(drop_key(seed, salt), thresh, inv_keep, e)
+    v = res + t
+    Xn[:rows, :N] = round_fn(v) if round_fn else v
+
+
+def colsum(X, rows, N, out, zero_first=True):
+    if zero_first:
+        out[:N] = 0
+    out[:N] += np.asarray(X[:rows, :N], np.float64).sum(axis=0)
+
+
+# ------------------------------------------------------------------------------------------------ input side
+IN_ROWS_PER_BLOCK = 4096
+
+
+def input_stats_blocks(rows):
+    return (rows + IN_ROWS_PER_BLOCK - 1) // IN_ROWS_PER_BLOCK
+
+
+def input_stats(x, rows, F_in, partials):
+    xv = np.asarray(x, np.float64).reshape(rows, F_in)
+    for b in range(input_stats_blocks(rows)):
+        sl = xv[b * IN_ROWS_PER_BLOCK:(b + 1) * IN_ROWS_PER_BLOCK]
+        partials[b, :F_in, 0] = sl.sum(axis=0)
+        partials[b, :F_in, 1] = (sl * sl).sum(axis=0)
+
+
+def _expand_taps(x, B, T_in, J, F_in, k0, t_stride):
+    T_out = (T_in - k0) // t_stride + 1
+    xv = np.asarray(x, np.float64).reshape(B, T_in, J, F_in)
+    taps = np.stack([xv[:, tap: tap + (T_out - 1) * t_stride + 1: t_stride] for tap in range(k0)], axis=-1)  # (B,T_out,J,F,k0)
+    return T_out, taps
+
+
+def expand_fwd(x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, partials, round_fn=None):
+    T_out, taps = _expand_taps(x, B, T_in, J, F_in, k0, t_stride)
+    xn = taps * np.asarray(sc0, np.float64)[None, None, None, :, None] + np.asarray(sh0, np.float64)[None, None, None, :, None]
+    w = np.asarray(W, np.float64).reshape(C, F_in, k0)
+    e = np.einsum('btjfk,cfk->btjc', xn, w).reshape(B * T_out * J, C)
+    if round_fn is not None:
+        e = round_fn(e)
+    rows = B * T_out * J
+    E[:rows, :C] = e
+    _rowwise_partials([e, e * e], rows, C, partials)
+
+
+def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, G, S):
+    T_out, taps = _expand_taps(x, B, T_in, J, F_in, k0, t_stride)
+    xh = (taps - np.asarray(mean0, np.float64)[None, None, None, :, None]) * np.asarray(rstd0, np.float64)[None, None, None, :, None]
+    d = np.asarray(dE[:B * T_out * J, :C], np.float64).reshape(B, T_out, J, C)
+    G[...] = np.einsum('btjc,btjfk->cfk', d, xh).reshape(G.shape)
+    S[:C] = d.sum(axis=(0, 1, 2))

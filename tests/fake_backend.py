@@ -1,0 +1,131 @@
+"""numpy mirror of `gast_hip.binding.HipOps` on CPU torch tensors -- TEST INFRASTRUCTURE ONLY.
+
+It lets the product's host-side plan (gast_hip/engine.py) run on CPU so that its *composition* of ops can be pinned
+against the reference-generated golden fixtures without a GPU (tests/test_plan_cpu.py).  Every op forwards to
+oracle/kernel_contract.py.  It lives under tests/ and is injected through the model's documented test seam
+(`model._runner.ops_factory`); nothing in the product imports it.
+"""
+import numpy as np
+import torch
+
+from oracle import kernel_contract as kc
+
+
+def _np(t):
+    if t is None:
+        return None
+    assert not t.is_cuda
+    return t.detach().numpy()
+
+
+def _segs(segs, a_key):
+    out = []
+    for s in segs:
+        d = dict(s)
+        d[a_key] = _np(s[a_key])
+        if 'W' in d:
+            d['W'] = _np(d['W'])
+        d['scale'] = _np(s.get('scale'))
+        d['shift'] = _np(s.get('shift'))
+        d['map'] = kc.RowMap(*s['map'])
+        out.append(d)
+    return out
+
+
+def _drop(d):
+    if d is None:
+        return None
+    return (int(d.seed.item()) & 0xffffffff, int(d.thresh), float(d.inv_keep))
+
+
+class OracleOps:
+    name = 'oracle-mirror'
+
+    def __init__(self):
+        self.launches = 0
+
+    def gemm_row_blocks(self, M):
+        return kc.gemm_row_blocks(M)
+
+    def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, xscale=None,
+             xshift=None, xdrop=False, xsalt=0, drop=None):
+        self.launches += 1
+        kc.gemm(dom, N, _segs(segs, 'A'), _np(C_), kc.RowMap(*cmap), _np(bias), _np(addend),
+                kc.RowMap(*addmap) if addmap is not None else None, epi, _np(partials), _np(X), _np(xscale), _np(xshift),
+                xdrop, xsalt, _drop(drop))
+
+    def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
+        self.launches += 1
+        kc.wgrad(dom, _np(P), R, kc.RowMap(*pmap), _segs(segs, 'Q'), _np(dW), _drop(drop), zero_first)
+
+    def semch_adj_fwd(self, e, pat, A_t):
+        kc.semch_adj_fwd(_np(e), _np(pat), _np(A_t))
+
+    def semch_adj_bwd(self, dA_t, A_t, pat, de):
+        kc.semch_adj_bwd(_np(dA_t), _np(A_t), _np(pat), _np(de))
+
+    def semch_agg_blocks(self, F, C_):
+        return kc.semch_agg_blocks(F, C_)
+
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials):
+        kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials))
+
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con):
+        kc.semch_agg_bwd(_np(dY), _np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(dH), _np(dA_sym),
+                         _np(dA_con))
+
+    def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):
+        kc.attn_fwd(_np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(Y))
+
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k):
+        kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k))
+
+    def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale,
+                    shift, mean, rstd):
+        kc.bn_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(beta), _np(running_mean), _np(running_var), _np(nbt),
+                       momentum, eps, _np(scale), _np(shift), _np(mean), _np(rstd))
+
+    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift):
+        kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift))
+
+    def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc_):
+        kc.bn_bwd_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(mean), _np(rstd), _np(dgamma), _np(dbeta), _np(ka),
+                           _np(kb), _np(kc_))
+
+    def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc_):
+        kc.bn_bwd_apply(_np(dz), _np(X), rows, N, _np(ka), _np(kb), _np(kc_))
+
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y):
+        kc.bnrelu_apply(_np(X), rows, N, _np(scale), _np(shift), _np(Y))
+
+    def rowwise_blocks(self, rows, N):
+        return kc.rowwise_blocks(rows, N)
+
+    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials):
+        kc.bnrelu_bwd_mask(_np(dY), _np(X), rows, N, _np(scale), _np(shift), use_drop, salt, _drop(drop), _np(dz), _np(partials))
+
+    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
+        kc.residual_fwd(_np(O), kc.RowMap(*omap), _np(scO), _np(shO), _np(T2), _np(sc2), _np(sh2), use_drop, salt, _drop(drop),
+                        B, Tn, J, N, _np(Xn))
+
+    def colsum(self, X, rows, N, out, zero_first=True):
+        kc.colsum(_np(X), rows, N, _np(out), zero_first)
+
+    def input_stats_blocks(self, rows):
+        return kc.input_stats_blocks(rows)
+
+    def input_stats(self, x, rows, F_in, partials):
+        kc.input_stats(_np(x), rows, F_in, _np(partials))
+
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials):
+        kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials))
+
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
+        kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(G), _np(S))
+
+
+def use_oracle_ops(model):
+    """Route a model instance through the numpy mirror (CPU tensors allowed)."""
+    model._runner.ops_factory = OracleOps
+    model._runner._engine = None
+    return model

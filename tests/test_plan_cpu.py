@@ -1,0 +1,53 @@
+"""Host plan (gast_hip/engine.py + model/gast_net.py) on CPU through the numpy op mirror, pinned to the reference goldens.
+
+This checks everything ABOVE the C ABI without a GPU: constructor/state_dict contract, weight packing, the launch plan of
+forward and backward, BatchNorm running-stat updates.  The HIP kernels themselves are checked on the GPU box
+(tests/test_kernels_gpu.py, tests/test_model_gpu.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from fake_backend import use_oracle_ops
+
+
+def build(cfg, dropout=0.0):
+    from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
+    from oracle.gast_oracle import adj_from_parents
+    adj = torch.from_numpy(adj_from_parents(cfg['parents']))
+    cls = SpatioTemporalModel if cfg['variant'] == 'dilated' else SpatioTemporalModelOptimized1f
+    m = cls(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'], dropout=dropout, channels=cfg['channels'])
+    return m
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_plan_matches_reference_golden(name):
+    cfg, z, state, grads, post = load_golden(name)
+    m = build(cfg)
+    assert m.receptive_field() == cfg['receptive_field']
+    assert sum(p.numel() for p in m.parameters()) == cfg['n_params']
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    use_oracle_ops(m)
+    x = torch.from_numpy(z['x'])
+    m.eval()
+    with torch.no_grad():
+        y = m(x)
+    np.testing.assert_allclose(y.numpy(), z['y_eval'], rtol=0, atol=2e-5)
+
+    m.train()
+    y = m(x)
+    np.testing.assert_allclose(y.detach().numpy(), z['y_train'], rtol=0, atol=2e-5)
+    y3d = torch.from_numpy(z['y3d'])
+    loss = torch.mean(torch.norm(y - y3d, dim=-1))
+    assert abs(loss.item() - float(z['loss'])) < 1e-5
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = grads[k]
+        scale = max(1e-3, float(np.abs(ref).max()))
+        err = float(np.abs(p.grad.numpy() - ref).max()) / scale
+        assert err < 2e-3, (k, err)
+    for k, b in m.named_buffers():
+        if k.endswith('num_batches_tracked'):
+            assert int(b) == int(post[k]), k
+        else:
+            np.testing.assert_allclose(b.numpy(), post[k], rtol=1e-4, atol=1e-5, err_msg=k)
