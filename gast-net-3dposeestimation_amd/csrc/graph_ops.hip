@@ -500,6 +500,12 @@ extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, 
     if (smem > 160 * 1024) return GAST_ERANGE;
     hipStream_t st = (hipStream_t)stream;
     int grid = attn_grid(F, nheads, ub);
+    if (smem > 48 * 1024) {
+        hipError_t e = dtype == GAST_F32
+            ? hipFuncSetAttribute((const void*)attn_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+            : hipFuncSetAttribute((const void*)attn_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((attn_fwd_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)G, ldg, (const float*)AC, ldac, C_k,
                            F, J, C, nheads, (float*)Y, ldy, ub);
@@ -526,6 +532,12 @@ extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, 
     if (smem > 160 * 1024) return GAST_ERANGE;
     hipStream_t st = (hipStream_t)stream;
     int grid = attn_grid(F, nheads, ub);
+    if (smem > 48 * 1024) {
+        hipError_t e = dtype == GAST_F32
+            ? hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+            : hipFuncSetAttribute((const void*)attn_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)dY, ldy, (const float*)G, ldg,
                            (const float*)AC, ldac, C_k, F, J, C, nheads, (float*)dG, lddg, (float*)dAC, lddac, dC_k, ub);

@@ -556,6 +556,12 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
     RowCfg c = row_cfg(C);
     hipStream_t st = (hipStream_t)stream;
     int nb = row_blocks(rows, C);
+    if (smem > 48 * 1024) {
+        hipError_t e = dtype == GAST_F32
+            ? hipFuncSetAttribute((const void*)expand_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+            : hipFuncSetAttribute((const void*)expand_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
                            C, (float*)E, lde, partials, c.TPR, c.RB);

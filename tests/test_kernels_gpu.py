@@ -1,0 +1,442 @@
+"""Every `gast_*` C-ABI kernel against its numpy contract (oracle/kernel_contract.py) on seeded inputs -- GPU only.
+
+fp32: tight tolerances (MFMA fp32 is an exact fmaf chain; only summation order differs from numpy/float64).
+bf16: inputs are rounded to bf16 first, the contract computes in float64 on those rounded inputs, outputs are compared
+with a tolerance of a few bf16 ulps of the result magnitude.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import kernel_contract as kc
+from tests_helpers import PARENTS
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from gast_hip.binding import HipOps
+    return HipOps()
+
+
+def dev(t, dt=None):
+    t = torch.as_tensor(t)
+    if dt is not None:
+        t = t.to(dt)
+    return t.cuda()
+
+
+def host(t):
+    return t.detach().float().cpu().numpy().astype(np.float64)
+
+
+def rand(gen, *shape, scale=1.0):
+    return torch.randn(*shape, generator=gen) * scale
+
+
+def tol(dt, ref, fp32=2e-5, bf16=2e-2):
+    mag = max(1e-6, float(np.abs(ref).max()))
+    return (fp32 if dt == torch.float32 else bf16) * mag
+
+
+def close(a, ref, dt, what, fp32=2e-5, bf16=2e-2):
+    err = float(np.abs(a - ref).max())
+    assert err <= tol(dt, ref, fp32, bf16), '%s: max err %.3e (ref max %.3e)' % (what, err, np.abs(ref).max())
+
+
+def patterns(J):
+    from oracle.gast_oracle import adj_from_parents, local_graph_adjacencies
+    sym, con = local_graph_adjacencies(adj_from_parents(PARENTS[J]))
+    return kc.build_pattern(sym), kc.build_pattern(con)
+
+
+def seed_tensor(v):
+    return torch.tensor([v], dtype=torch.int32).cuda()
+
+
+# ------------------------------------------------------------------------------------------------ dropout stream
+def test_dropout_stream_matches_contract(ops):
+    """bnrelu_bwd_mask with scale=1, shift=1 (always positive) exposes the keep mask exactly."""
+    from gast_hip.binding import Dropout, dropout_params
+    rows, N = 300, 64
+    thresh, inv_keep = dropout_params(0.25)
+    dY = torch.ones(rows, N).cuda()
+    X = torch.zeros(rows, N).cuda()
+    sc = torch.ones(N).cuda()
+    sh = torch.ones(N).cuda()
+    dz = torch.empty(rows, N).cuda()
+    part = torch.empty(ops.rowwise_blocks(rows, N), N, 2).cuda()
+    ops.bnrelu_bwd_mask(dY, X, rows, N, sc, sh, True, 7, Dropout(seed_tensor(12345), thresh, inv_keep), dz, part)
+    e = np.arange(rows)[:, None] * N + np.arange(N)[None, :]
+    ref = kc.drop_mul(kc.drop_key(12345, 7), thresh, inv_keep, e)
+    got = host(dz)
+    assert np.array_equal(got != 0, ref != 0)
+    frac = (got == 0).mean()
+    assert abs(frac - 0.25) < 0.02
+    np.testing.assert_allclose(got[got != 0], inv_keep, rtol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_CASES = [
+    # name, (B,Tn,J), N, list of (K, T_total, t_stride, t_off, pro), epi, addend?, bias?
+    ('plain_small', (2, 3, 17), 40, [(16, 3, 1, 0, 0)], 0, False, True),
+    ('stats_two_tiles', (3, 5, 17), 200, [(32, 5, 1, 0, 1)], 1, False, False),
+    ('concat3_drop', (2, 7, 17), 96, [(32, 7, 1, 0, 0), (32, 7, 1, 0, 2), (32, 7, 1, 0, 2)], 1, False, False),
+    ('dilated_taps', (2, 5, 17), 64, [(64, 11, 1, 0, 1), (64, 11, 1, 3, 1), (64, 11, 1, 6, 1)], 1, False, False),
+    ('strided_taps', (3, 3, 19), 48, [(24, 9, 3, 0, 1), (24, 9, 3, 1, 1), (24, 9, 3, 2, 1)], 1, False, False),
+    ('dgrad_gather_addend_bwd', (2, 11, 17), 64, [(64, 5, 1, 0, 0), (64, 5, 1, -3, 0), (64, 5, 1, -6, 0)], 2, True, False),
+    ('ktail', (1, 9, 15), 33 * 4, [(5 * 32 + 8, 9, 1, 0, 0), (72, 9, 1, 0, 0)], 0, False, False),
+    ('big', (8, 9, 17), 256, [(256, 9, 1, 0, 1)], 1, False, False),
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm(ops, case, dt):
+    from gast_hip.binding import Dropout, dropout_params
+    name, dom, N, segdefs, epi, use_add, use_bias = case
+    gen = torch.Generator().manual_seed(sum(map(ord, name)))
+    B, Tn, J = dom
+    M = B * Tn * J
+    thresh, inv_keep = dropout_params(0.1)
+    seed = 777
+    segs_d, segs_h = [], []
+    for si, (K, Tt, ts, toff, pro) in enumerate(segdefs):
+        rowsA = B * Tt * J
+        lda = K + 8   # exercise lda != K
+        A = rand(gen, rowsA, lda).to(dt)
+        W = (rand(gen, N, K) / np.sqrt(K)).to(dt)
+        sc = torch.rand(K, generator=gen) + 0.5
+        sh = rand(gen, K, scale=0.3)
+        d = dict(A=A.cuda()[:, :K], K=K, map=kc.RowMap(Tt, ts, toff), W=W.cuda(), pro=pro, scale=sc.cuda(), shift=sh.cuda(), salt=si + 1)
+        h = dict(A=host(A)[:, :K], K=K, map=kc.RowMap(Tt, ts, toff), W=host(W), pro=pro, scale=host(sc), shift=host(sh), salt=si + 1)
+        # host view must have the same row stride as the device view for the dropout element index
+        hA = np.zeros((rowsA, lda))
+        hA[:] = host(A)
+        h['A'] = hA[:, :K]
+        segs_d.append(d)
+        segs_h.append(h)
+    cT = Tn + 2
+    cmap = kc.RowMap(cT, 1, 1)
+    ldc = N + 4
+    Cd = torch.full((B * cT * J, ldc), 7.0).to(dt).cuda()
+    Ch = np.full((B * cT * J, ldc), 7.0)
+    bias = rand(gen, N) if use_bias else None
+    add = rand(gen, B * (Tn + 1) * J, N).to(dt) if use_add else None
+    addmap = kc.RowMap(Tn + 1, 1, 0) if use_add else None
+    nb = ops.gemm_row_blocks(M)
+    pd = torch.zeros(nb, N, 2).cuda() if epi else None
+    ph = np.zeros((nb, N, 2)) if epi else None
+    X = rand(gen, B * cT * J, N).to(dt) if epi == 2 else None
+    xs = (torch.rand(N, generator=gen) + 0.5) if epi == 2 else None
+    xh = rand(gen, N, scale=0.3) if epi == 2 else None
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    ops.gemm(dom, N, segs_d, Cd[:, :N], cmap, bias=bias.cuda() if use_bias else None, addend=add.cuda() if use_add else None,
+             addmap=addmap, epi=epi, partials=pd, X=X.cuda() if X is not None else None,
+             xscale=xs.cuda() if xs is not None else None, xshift=xh.cuda() if xh is not None else None,
+             xdrop=epi == 2, xsalt=9, drop=Dropout(seed_tensor(seed), thresh, inv_keep))
+    kc.gemm(dom, N, segs_h, Ch[:, :N], cmap, bias=host(bias) if use_bias else None, addend=host(add) if use_add else None,
+            addmap=addmap, epi=epi, partials=ph, X=host(X) if X is not None else None, xscale=host(xs) if xs is not None else None,
+            xshift=host(xh) if xh is not None else None, xdrop=epi == 2, xsalt=9, drop=(seed, thresh, inv_keep), round_fn=rnd)
+    torch.cuda.synchronize()
+    got = host(Cd)
+    close(got[:, :N], Ch[:, :N], dt, name + ' C')
+    assert np.all(got[:, N:] == 7.0), 'wrote outside the N columns'
+    if epi:
+        close(host(pd).sum(axis=0), ph.sum(axis=0), dt, name + ' partial totals', fp32=1e-4, bf16=3e-2)
+
+
+def test_gemm_out_f32_from_bf16(ops):
+    gen = torch.Generator().manual_seed(5)
+    dom, N, K = (2, 4, 17), 3, 64
+    M = 2 * 4 * 17
+    A = rand(gen, M, K).to(torch.bfloat16)
+    W = rand(gen, N, K).to(torch.bfloat16)
+    C = torch.zeros(M, N).cuda()
+    ops.gemm(dom, N, [dict(A=A.cuda(), K=K, map=kc.RowMap(4, 1, 0), W=W.cuda())], C, kc.RowMap(4, 1, 0))
+    ref = host(A) @ host(W).T
+    close(host(C), ref, torch.float32, 'bf16->f32 gemm', fp32=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ WGRAD
+WGRAD_CASES = [
+    ('one_seg', (2, 5, 17), 48, [(64, 5, 1, 0, 0, 0)]),
+    ('concat3_drop', (3, 7, 17), 64, [(32, 7, 1, 0, 0, 0), (32, 7, 1, 0, 2, 32), (32, 7, 1, 0, 2, 64)]),
+    ('dilated_taps', (2, 5, 17), 32, [(32, 11, 1, 0, 1, 0), (32, 11, 1, 3, 1, 32), (32, 11, 1, 6, 1, 64)]),
+    ('strided_taps', (4, 3, 15), 24, [(24, 9, 3, 0, 1, 0), (24, 9, 3, 1, 1, 24), (24, 9, 3, 2, 1, 48)]),
+    ('big', (8, 27, 17), 136, [(160, 27, 1, 0, 1, 0)]),
+    ('pad8', (2, 1, 17), 8, [(128, 1, 1, 0, 1, 0)]),
+]
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_wgrad(ops, case, dt):
+    from gast_hip.binding import Dropout, dropout_params
+    name, dom, R, segdefs = case
+    gen = torch.Generator().manual_seed(sum(map(ord, name)) + 1)
+    B, Tn, J = dom
+    M = B * Tn * J
+    thresh, inv_keep = dropout_params(0.1)
+    P = rand(gen, M, R + 8).to(dt)
+    segs_d, segs_h = [], []
+    ldw = max(w0 + S for (S, _, _, _, _, w0) in segdefs) + 4
+    for si, (S, Tt, ts, toff, pro, w0) in enumerate(segdefs):
+        rowsQ = B * Tt * J
+        Q = rand(gen, rowsQ, S + 8).to(dt)
+        sc = torch.rand(S, generator=gen) + 0.5
+        sh = rand(gen, S, scale=0.3)
+        segs_d.append(dict(Q=Q.cuda()[:, :S], S=S, map=kc.RowMap(Tt, ts, toff), pro=pro, scale=sc.cuda(), shift=sh.cuda(), salt=si + 3, wcol0=w0))
+        hQ = host(Q)
+        segs_h.append(dict(Q=hQ[:, :S], S=S, map=kc.RowMap(Tt, ts, toff), pro=pro, scale=host(sc), shift=host(sh), salt=si + 3, wcol0=w0))
+    dWd = torch.full((R, ldw), 3.0).cuda()
+    dWh = np.full((R, ldw), 3.0)
+    ops.wgrad(dom, P.cuda()[:, :R], R, kc.RowMap(Tn, 1, 0), segs_d, dWd, drop=Dropout(seed_tensor(99), thresh, inv_keep))
+    kc.wgrad(dom, host(P)[:, :R], R, kc.RowMap(Tn, 1, 0), segs_h, dWh, drop=(99, thresh, inv_keep))
+    torch.cuda.synchronize()
+    close(host(dWd), dWh, dt, name, fp32=3e-5, bf16=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ SemCH
+@pytest.mark.parametrize('J', [15, 16, 17, 19])
+def test_semch_adj(ops, J):
+    gen = torch.Generator().manual_seed(J)
+    ps, pc = patterns(J)
+    C = 24
+    for pat in (ps, pc):
+        nnz = int(pat[1])
+        e = 1 + rand(gen, C, nnz, scale=0.5)
+        A = torch.zeros(nnz, C).cuda()
+        ops.semch_adj_fwd(e.cuda(), dev(pat), A)
+        Ah = np.zeros((nnz, C))
+        kc.semch_adj_fwd(host(e), pat, Ah)
+        close(host(A), Ah, torch.float32, 'adj fwd')
+        dA = rand(gen, nnz, C)
+        de = torch.zeros(C, nnz).cuda()
+        ops.semch_adj_bwd(dA.cuda(), A, dev(pat), de)
+        deh = np.zeros((C, nnz))
+        kc.semch_adj_bwd(host(dA), Ah, pat, deh)
+        close(host(de), deh, torch.float32, 'adj bwd')
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('J,C,F', [(17, 16, 37), (19, 128, 50), (15, 8, 9), (16, 1024 + 64, 3), (17, 256, 700)])
+def test_semch_agg(ops, J, C, F, dt):
+    gen = torch.Generator().manual_seed(J * C)
+    ps, pc = patterns(J)
+    P = F * J
+    ldh = 5 * C + 8
+    H = rand(gen, P, ldh).to(dt)
+    As, Ac = torch.rand(int(ps[1]), C, generator=gen), torch.rand(int(pc[1]), C, generator=gen)
+    Y = torch.zeros(P, 2 * C).to(dt).cuda()
+    nb = ops.semch_agg_blocks(F, C)
+    part = torch.zeros(nb, 2 * C, 2).cuda()
+    ops.semch_agg_fwd(H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), Y, part)
+    Yh = np.zeros((P, 2 * C))
+    ph = np.zeros((nb, 2 * C, 2))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    kc.semch_agg_fwd(host(H), F, J, C, host(As), ps, host(Ac), pc, Yh, ph, round_fn=rnd)
+    close(host(Y), Yh, dt, 'agg fwd')
+    close(host(part).sum(0), ph.sum(0), dt, 'agg partial totals', fp32=1e-4, bf16=3e-2)
+    close(host(part), ph, dt, 'agg partials per block', fp32=1e-4, bf16=3e-2)
+    # backward
+    dY = rand(gen, P, 2 * C).to(dt)
+    dH = torch.full((P, ldh), 5.0).to(dt).cuda()
+    dAs, dAc = torch.zeros_like(As).cuda(), torch.zeros_like(Ac).cuda()
+    ops.semch_agg_bwd(dY.cuda(), H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), dH, dAs, dAc)
+    dHh = np.full((P, ldh), 5.0)
+    dAsh, dAch = np.zeros((int(ps[1]), C)), np.zeros((int(pc[1]), C))
+    kc.semch_agg_bwd(host(dY), host(H), F, J, C, host(As), ps, host(Ac), pc, dHh, dAsh, dAch, round_fn=rnd)
+    got = host(dH)
+    close(got[:, :4 * C], dHh[:, :4 * C], dt, 'agg bwd dH')
+    assert np.all(got[:, 4 * C:] == 5.0)
+    close(host(dAs), dAsh, dt, 'agg bwd dA_sym', fp32=1e-4, bf16=2e-2)
+    close(host(dAc), dAch, dt, 'agg bwd dA_con', fp32=1e-4, bf16=2e-2)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('J,C,F', [(17, 16, 37), (19, 128, 50), (15, 8, 9), (17, 512, 6), (16, 2048, 3), (17, 256, 2200)])
+def test_attention(ops, J, C, F, dt):
+    gen = torch.Generator().manual_seed(J + C)
+    nh = 4
+    P = F * J
+    ld = C + 2 * nh + 16
+    Hx = rand(gen, P, ld).to(dt)
+    Ck = rand(gen, nh, J, J, scale=0.1)
+    Hd = Hx.cuda()
+    G, AC = Hd[:, :C], Hd[:, C:C + 2 * nh]
+    Y = torch.full((P, C + 4), 3.0).to(dt).cuda()
+    ops.attn_fwd(G, AC, Ck.cuda(), F, J, C, nh, Y[:, :C])
+    Hh = host(Hx)
+    Yh = np.zeros((P, C))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    kc.attn_fwd(Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, Yh, round_fn=rnd)
+    got = host(Y)
+    close(got[:, :C], Yh, dt, 'attn fwd')
+    assert np.all(got[:, C:] == 3.0)
+    dY = rand(gen, P, C).to(dt)
+    dHd = torch.full((P, ld), 2.0).to(dt).cuda()
+    dCk = torch.zeros(nh, J, J).cuda()
+    ops.attn_bwd(dY.cuda(), G, AC, Ck.cuda(), F, J, C, nh, dHd[:, :C], dHd[:, C:C + 2 * nh], dCk)
+    dG, dAC, dCkh = np.zeros((P, C)), np.zeros((P, 2 * nh)), np.zeros((nh, J, J))
+    kc.attn_bwd(host(dY), Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, dG, dAC, dCkh, round_fn=rnd)
+    got = host(dHd)
+    close(got[:, :C], dG, dt, 'attn bwd dG')
+    close(got[:, C:C + 2 * nh], dAC, dt, 'attn bwd dAC', fp32=1e-4, bf16=3e-2)
+    assert np.all(got[:, C + 2 * nh:] == 2.0)
+    close(host(dCk), dCkh, dt, 'attn bwd dC_k', fp32=1e-4, bf16=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ BN / elementwise
+def test_bn_finalize_and_backward(ops):
+    gen = torch.Generator().manual_seed(3)
+    nblk, ncol, col0, N, count = 7, 40, 8, 24, 5000.0
+    x = rand(gen, 5000, N) * 2 + 0.7
+    part = torch.zeros(nblk, ncol, 2)
+    chunks = torch.chunk(x, nblk)
+    for b, ch in enumerate(chunks):
+        part[b, col0:col0 + N, 0] = ch.sum(0)
+        part[b, col0:col0 + N, 1] = (ch * ch).sum(0)
+    gamma, beta = torch.rand(N, generator=gen) + 0.5, rand(gen, N)
+    rm, rv = rand(gen, N), torch.rand(N, generator=gen) + 0.5
+    nbt = torch.tensor(4, dtype=torch.int64)
+    outs = [torch.zeros(N).cuda() for _ in range(4)]
+    rmd, rvd, nbtd = rm.cuda(), rv.cuda(), nbt.cuda()
+    ops.bn_finalize(part.cuda(), nblk, col0, N, count, gamma.cuda(), beta.cuda(), rmd, rvd, nbtd, 0.1, 1e-5, *outs)
+    ho = [np.zeros(N) for _ in range(4)]
+    rmh, rvh, nbth = host(rm), host(rv), np.array(4)
+    kc.bn_finalize(host(part), nblk, col0, N, count, host(gamma), host(beta), rmh, rvh, nbth, 0.1, 1e-5, *ho)
+    for a, b, nme in zip(outs, ho, ('scale', 'shift', 'mean', 'rstd')):
+        close(host(a), b, torch.float32, 'bn_finalize ' + nme)
+    close(host(rmd), rmh, torch.float32, 'running_mean')
+    close(host(rvd), rvh, torch.float32, 'running_var')
+    assert int(nbtd.item()) == 5
+    # torch cross-check of the running stats semantics
+    bn = torch.nn.BatchNorm1d(N, momentum=0.1)
+    with torch.no_grad():
+        bn.running_mean.copy_(rm); bn.running_var.copy_(rv)
+    bn.train(); bn(x)
+    close(host(rmd), host(bn.running_mean), torch.float32, 'running_mean vs torch', fp32=1e-5)
+    close(host(rvd), host(bn.running_var), torch.float32, 'running_var vs torch', fp32=1e-5)
+    # eval
+    sc, sh = torch.zeros(N).cuda(), torch.zeros(N).cuda()
+    ops.bn_eval(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5, N, sc, sh)
+    sch, shh = np.zeros(N), np.zeros(N)
+    kc.bn_eval(host(gamma), host(beta), host(rm), host(rv), 1e-5, N, sch, shh)
+    close(host(sc), sch, torch.float32, 'bn_eval scale'); close(host(sh), shh, torch.float32, 'bn_eval shift')
+    # backward finalize
+    mean, rstd = outs[2], outs[3]
+    bo = [torch.zeros(N).cuda() for _ in range(5)]
+    ops.bn_bwd_finalize(part.cuda(), nblk, col0, N, count, gamma.cuda(), mean, rstd, *bo)
+    bh = [np.zeros(N) for _ in range(5)]
+    kc.bn_bwd_finalize(host(part), nblk, col0, N, count, host(gamma), host(mean), host(rstd), *bh)
+    for a, b, nme in zip(bo, bh, ('dgamma', 'dbeta', 'ka', 'kb', 'kc')):
+        close(host(a), b, torch.float32, 'bn_bwd_finalize ' + nme, fp32=1e-4)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,N', [(301, 16), (1000, 128), (77, 2048 + 64), (5000, 8)])
+def test_rowwise_kernels(ops, rows, N, dt):
+    from gast_hip.binding import Dropout, dropout_params
+    gen = torch.Generator().manual_seed(rows + N)
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    ld = N + 8
+    X = rand(gen, rows, ld).to(dt)
+    sc, sh = torch.rand(N, generator=gen) + 0.5, rand(gen, N, scale=0.5)
+    # bnrelu_apply
+    Y = torch.full((rows, ld), 9.0).to(dt).cuda()
+    ops.bnrelu_apply(X.cuda()[:, :N], rows, N, sc.cuda(), sh.cuda(), Y[:, :N])
+    Yh = np.full((rows, ld), 9.0)
+    kc.bnrelu_apply(host(X)[:, :N], rows, N, host(sc), host(sh), Yh[:, :N], round_fn=rnd)
+    close(host(Y), Yh, dt, 'bnrelu_apply')
+    # bn_bwd_apply
+    ka, kb, kcc = rand(gen, N), rand(gen, N, scale=0.1), rand(gen, N, scale=0.1)
+    dz = rand(gen, rows, ld).to(dt)
+    dzd = dz.cuda().clone()
+    ops.bn_bwd_apply(dzd[:, :N], X.cuda()[:, :N], rows, N, ka.cuda(), kb.cuda(), kcc.cuda())
+    dzh = host(dz)
+    kc.bn_bwd_apply(dzh[:, :N], host(X)[:, :N], rows, N, host(ka), host(kb), host(kcc), round_fn=rnd)
+    close(host(dzd), dzh, dt, 'bn_bwd_apply')
+    # bnrelu_bwd_mask (+dropout)
+    thresh, inv_keep = dropout_params(0.2)
+    dY = rand(gen, rows, ld).to(dt)
+    out = torch.full((rows, ld), 4.0).to(dt).cuda()
+    nb = ops.rowwise_blocks(rows, N)
+    part = torch.zeros(nb, N, 2).cuda()
+    Xd = X.cuda()
+    ops.bnrelu_bwd_mask(dY.cuda()[:, :N], Xd[:, :N], rows, N, sc.cuda(), sh.cuda(), True, 5, Dropout(seed_tensor(42), thresh, inv_keep),
+                        out[:, :N], part)
+    outh = np.full((rows, ld), 4.0)
+    ph = np.zeros((nb, N, 2))
+    hX = host(X)
+    kc.bnrelu_bwd_mask(host(dY)[:, :N], hX[:, :N], rows, N, host(sc), host(sh), True, 5, (42, thresh, inv_keep), outh[:, :N], ph, round_fn=rnd)
+    close(host(out), outh, dt, 'bnrelu_bwd_mask dz')
+    close(host(part), ph, dt, 'bnrelu_bwd_mask partials', fp32=1e-4, bf16=3e-2)
+    # colsum
+    cs = torch.full((N,), 1.0).cuda()
+    ops.colsum(Xd[:, :N], rows, N, cs, zero_first=False)
+    close(host(cs), 1.0 + hX[:, :N].sum(0), dt, 'colsum', fp32=1e-4, bf16=1e-2)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+def test_residual_fwd(ops, dt):
+    from gast_hip.binding import Dropout, dropout_params
+    gen = torch.Generator().manual_seed(8)
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    B, Tp, Tn, J, N = 3, 11, 5, 17, 64
+    O = rand(gen, B * Tp * J, N).to(dt)
+    T2 = rand(gen, B * Tn * J, N).to(dt)
+    scO, shO = torch.rand(N, generator=gen) + 0.5, rand(gen, N, scale=0.3)
+    sc2, sh2 = torch.rand(N, generator=gen) + 0.5, rand(gen, N, scale=0.3)
+    thresh, inv_keep = dropout_params(0.3)
+    for omap in (kc.RowMap(Tp, 1, 3), kc.RowMap(Tp, 2, 1)):
+        Xn = torch.zeros(B * Tn * J, N).to(dt).cuda()
+        ops.residual_fwd(O.cuda(), omap, scO.cuda(), shO.cuda(), T2.cuda(), sc2.cuda(), sh2.cuda(), True, 6,
+                         Dropout(seed_tensor(11), thresh, inv_keep), B, Tn, J, N, Xn)
+        Xh = np.zeros((B * Tn * J, N))
+        kc.residual_fwd(host(O), omap, host(scO), host(shO), host(T2), host(sc2), host(sh2), True, 6, (11, thresh, inv_keep), B, Tn, J, N, Xh,
+                        round_fn=rnd)
+        close(host(Xn), Xh, dt, 'residual_fwd')
+
+
+# ------------------------------------------------------------------------------------------------ input side
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('B,T,J,k0,ts,C', [(3, 29, 17, 3, 1, 16), (5, 27, 17, 3, 3, 128), (2, 17, 19, 5, 1, 32), (2, 15, 15, 5, 5, 8)])
+def test_input_side(ops, B, T, J, k0, ts, C, dt):
+    gen = torch.Generator().manual_seed(B * T)
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    F_in = 2
+    x = torch.rand(B, T, J, F_in, generator=gen) * 2 - 1
+    rows = B * T * J
+    nb = ops.input_stats_blocks(rows)
+    part = torch.zeros(nb, F_in, 2).cuda()
+    ops.input_stats(x.cuda(), rows, F_in, part)
+    ph = np.zeros((nb, F_in, 2))
+    kc.input_stats(host(x), rows, F_in, ph)
+    close(host(part), ph, torch.float32, 'input_stats', fp32=1e-5)
+    W = rand(gen, C, F_in, k0, 1)
+    sc0, sh0 = torch.rand(F_in, generator=gen) + 0.5, rand(gen, F_in, scale=0.2)
+    T_out = (T - k0) // ts + 1
+    P = B * T_out * J
+    E = torch.zeros(P, C).to(dt).cuda()
+    nbe = ops.rowwise_blocks(P, C)
+    pe = torch.zeros(nbe, C, 2).cuda()
+    ops.expand_fwd(x.cuda(), B, T, J, F_in, k0, ts, W.cuda(), sc0.cuda(), sh0.cuda(), C, E, pe)
+    Eh = np.zeros((P, C))
+    peh = np.zeros((nbe, C, 2))
+    kc.expand_fwd(host(x), B, T, J, F_in, k0, ts, host(W), host(sc0), host(sh0), C, Eh, peh, round_fn=rnd)
+    close(host(E), Eh, dt, 'expand_fwd')
+    close(host(pe), peh, dt, 'expand_fwd partials', fp32=1e-4, bf16=3e-2)
+    dE = rand(gen, P, C).to(dt)
+    mean0, rstd0 = rand(gen, F_in, scale=0.1), torch.rand(F_in, generator=gen) + 1.0
+    G = torch.full((C, F_in, k0), 3.0).cuda()
+    S = torch.full((C,), 3.0).cuda()
+    ops.expand_bwd(dE.cuda(), x.cuda(), B, T, J, F_in, k0, ts, mean0.cuda(), rstd0.cuda(), C, G, S)
+    Gh, Sh = np.zeros((C, F_in, k0)), np.zeros(C)
+    kc.expand_bwd(host(dE), host(x), B, T, J, F_in, k0, ts, host(mean0), host(rstd0), C, Gh, Sh)
+    close(host(G), Gh, dt, 'expand_bwd G', fp32=1e-4, bf16=1e-2)
+    close(host(S), Sh, dt, 'expand_bwd S', fp32=1e-4, bf16=1e-2)
