@@ -1,0 +1,340 @@
+#!/usr/bin/env python3
+"""Benchmark of the GAST-Net spatio-temporal hot path on MI355X (BASELINE.json metric: sequences/sec, fwd+bwd).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = the reference's training step on one synthetic batch (reference main.py:227-239): zero_grad -> forward ->
+mpjpe -> backward -> [gradient all-reduce over RCCL when N>1] -> Adam(amsgrad) step, on
+BASELINE.json configs[1]: SpatioTemporalModel, J=17, filter_widths 3,3,3 (27-frame receptive field), channels=128,
+B=128 sequences of T=27 frames per GPU (weak scaling), dropout 0.05, bf16 activations/weights (fp32 accumulate, statistics,
+master weights).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline     -- for the dominant kernel (the MFMA GEMM `gemm_kernel`): algorithmic FLOPs/bytes per launch (SURVEY.md
+                  App. C formulas, evaluated per launch from its arguments) / average launch duration measured live with
+                  HIP events on the launch stream during the timed steps.
+  cpu_baseline -- the numpy oracle (oracle/gast_oracle.py, a port: the reference itself cannot travel to the GPU box) timed
+                  on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'gast-net-3dposeestimation_amd')
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PARENTS17 = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]   # reference reconstruction.py:95
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense peaks
+
+
+def adj_from_parents(parents):
+    J = len(parents)
+    a = np.zeros((J, J))
+    for i, p in enumerate(parents):
+        if p >= 0:
+            a[i, p] = a[p, i] = 1.0
+    a += np.eye(J)
+    return torch.from_numpy((a / a.sum(1, keepdims=True)).astype(np.float32))
+
+
+# --------------------------------------------------------------------------------------------------------- kernel timer
+class KernelTimer:
+    """Wraps the HipOps methods with HIP-event pairs (recorded on the launch stream) and algorithmic cost models."""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.records = []      # (name, start_event, end_event, flops, bytes)
+        self.enabled = False
+        for name in ('gemm', 'wgrad', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bn_bwd_apply', 'bnrelu_apply',
+                     'bnrelu_bwd_mask', 'residual_fwd', 'expand_fwd', 'expand_bwd', 'colsum', 'bn_finalize', 'bn_bwd_finalize',
+                     'semch_adj_fwd', 'semch_adj_bwd', 'input_stats'):
+            self._wrap(name)
+
+    def _wrap(self, name):
+        orig = getattr(self.ops, name)
+        cost = getattr(self, 'cost_' + name, None)
+
+        def wrapped(*a, **k):
+            if not self.enabled:
+                return orig(*a, **k)
+            fl, by = cost(*a, **k) if cost else (0.0, 0.0)
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            r = orig(*a, **k)
+            e1.record()
+            self.records.append((name, e0, e1, fl, by))
+            return r
+        setattr(self.ops, name, wrapped)
+
+    @staticmethod
+    def _es(t):
+        return t.element_size()
+
+    def cost_gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, **kw):
+        B, Tn, J = dom
+        M = B * Tn * J
+        Ktot = sum(s['K'] for s in segs)
+        flops = 2.0 * M * N * Ktot
+        es = self._es(segs[0]['A'])
+        by = 0.0
+        seen = {}
+        for s in segs:   # distinct input rows are read once (taps of one tensor overlap)
+            key = s['A'].data_ptr()
+            rows_tensor = B * s['map'].T_total * J
+            seen.setdefault(key, [0, rows_tensor, s['K']])
+            seen[key][0] += M
+        for cnt, rows_tensor, K in seen.values():
+            by += min(cnt, rows_tensor) * K * es
+        by += N * Ktot * es                       # weights once
+        by += M * N * self._es(C_)                # output once
+        if X is not None:
+            by += M * N * es
+        if addend is not None:
+            by += min(M, B * addmap.T_total * J) * N * es
+        return flops, by
+
+    def cost_wgrad(self, dom, P, R, pmap, segs, dW, **kw):
+        B, Tn, J = dom
+        M = B * Tn * J
+        Stot = sum(s['S'] for s in segs)
+        flops = 2.0 * M * R * Stot
+        es = self._es(P)
+        by = M * R * es + R * Stot * 4.0
+        seen = {}
+        for s in segs:
+            key = s['Q'].data_ptr()
+            seen.setdefault(key, [0, B * s['map'].T_total * J, s['S']])
+            seen[key][0] += M
+        for cnt, rows_tensor, S in seen.values():
+            by += min(cnt, rows_tensor) * S * es
+        return flops, by
+
+    def summary(self):
+        agg = {}
+        for name, e0, e1, fl, by in self.records:
+            ms = e0.elapsed_time(e1)
+            a = agg.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, roof_ms=0.0, roof_hbm_ms=0.0, roof_mfma_ms=0.0))
+            a['launches'] += 1
+            a['ms'] += ms
+            a['flops'] += fl
+            a['bytes'] += by
+        return agg
+
+
+# --------------------------------------------------------------------------------------------------------- cpu baseline
+def cpu_baseline(seconds_budget=20.0):
+    """The numpy oracle on this host's cores, fwd+bwd of the same model, bounded sample."""
+    from oracle import gast_oracle as go
+    from model.gast_net import SpatioTemporalModel
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([p.get('num_threads', 1) for p in threadpool_info() if p.get('user_api') == 'blas'] or [1])
+    except Exception:
+        threads = 1
+    adj = adj_from_parents(PARENTS17)
+    torch.manual_seed(0)
+    m = SpatioTemporalModel(adj, 17, 2, 17, filter_widths=[3, 3, 3], channels=128, dropout=0.05)
+    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    om = go.OracleModel(adj.numpy(), [3, 3, 3], 128, dropout=0.0, dtype=np.float32)
+    rng = np.random.default_rng(1234)
+    Bs = 8
+    x = (rng.random((Bs, 27, 17, 2)) * 2 - 1).astype(np.float32)
+    y = (rng.standard_normal((Bs, 1, 17, 3)) * 0.3).astype(np.float32)
+    om.loss_and_grads(state, x[:2], y[:2])          # warm-up (BLAS threads, page faults)
+    t0 = time.time()
+    reps = 0
+    while True:
+        om.loss_and_grads(state, x, y)
+        reps += 1
+        if time.time() - t0 > seconds_budget or reps >= 3:
+            break
+    dt = time.time() - t0
+    return dict(value=round(Bs * reps / dt, 3), unit='sequences/s', cores=int(threads), kind='port',
+                host_cpus=os.cpu_count(),
+                sample='numpy fp32 oracle (oracle/gast_oracle.py), fwd+bwd of %d x %d of the 128 sequences (B=%d per pass), '
+                       'J=17 T=27 C=128; the reference itself (PyTorch CPU) cannot travel to this box -- it measured 13.6 seq/s '
+                       'fwd+bwd+Adam on 8 Xeon cores in the build container (BASELINE.md section 2)' % (reps, Bs, Bs))
+
+
+# --------------------------------------------------------------------------------------------------------- main
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16'), choices=['bf16', 'fp32'])
+    ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
+    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+    elif args.gpus > 1:
+        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 '
+                         '--master-port P bench.py --gpus N ...')
+    dev = torch.device('cuda', local_rank)
+    os.environ['GAST_HIP_DTYPE'] = args.dtype
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()          # before touching the GPU
+
+    from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
+    from gast_hip.dist import FlatGradAllReduce
+    B, T, J, C = args.batch, 27, 17, 128
+    torch.manual_seed(0)
+    cls = SpatioTemporalModel if args.variant == 'dilated' else SpatioTemporalModelOptimized1f
+    model = cls(adj_from_parents(PARENTS17), J, 2, J, filter_widths=[3, 3, 3], causal=False, dropout=0.05, channels=C).to(dev)
+    model.train()
+    g = torch.Generator().manual_seed(1234 + rank)     # reference generator seed (common/generators.py:26), per-rank shard
+    x = (torch.rand(B, T, J, 2, generator=g) * 2 - 1).to(dev)
+    y3d = torch.randn(B, 1, J, 3, generator=g) * 0.3
+    y3d[:, :, 0] = 0                                     # reference main.py:225
+    y3d = y3d.to(dev)
+    sync = FlatGradAllReduce(model.parameters())
+    use_graph = not args.no_graph
+    try:      # reference trainval.py:78: Adam(amsgrad=True); fused + capturable so the step can live in a hipGraph
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, fused=True, capturable=use_graph)
+    except Exception:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, capturable=use_graph)
+
+    timer = None
+    if not args.no_kernel_timer and rank == 0:
+        timer = KernelTimer(model._runner.engine.ops)
+
+    def step():
+        sync.zero_()
+        pred = model(x)
+        loss = torch.mean(torch.norm(pred - y3d, dim=-1))    # mpjpe, reference common/loss.py:5-11
+        loss.backward()
+        sync.sync()
+        opt.step()
+        return loss
+
+    # ---- untimed warm-up (also the side-stream warm-up torch requires before capture), then capture ONE step
+    graph = None
+    graph_note = 'eager'
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(max(3, args.warmup)):
+                    step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = step()
+            graph_note = 'hipGraph replay of the whole step (captured through torch.cuda.graph)'
+        except Exception as e:   # noqa: BLE001 -- report and fall back to eager launches (same kernels)
+            graph = None
+            graph_note = 'eager (graph capture failed: %s)' % (str(e).splitlines()[0][:120],)
+            torch.cuda.synchronize()
+    if graph is None:
+        for _ in range(args.warmup):
+            step()
+    else:
+        for _ in range(args.warmup):
+            graph.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        if graph is None:
+            loss = step()
+        else:
+            graph.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if graph is not None:
+        loss = static_loss
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    # ---- per-kernel durations: the same step, eagerly, with a HIP-event pair around every launch (events cannot be
+    # recorded inside a replayed graph; the kernels and their arguments are identical to the replayed ones)
+    if timer and rank == 0:
+        timer.enabled = True
+        for _ in range(max(1, args.timer_steps)):
+            step()
+        torch.cuda.synchronize()
+        timer.enabled = False
+        tsteps = max(1, args.timer_steps)
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = world * B * args.steps / elapsed
+        out = {
+            'metric': 'sequences/sec (B=128, T=27, J=17) fwd+bwd', 'value': round(value, 1), 'unit': 'sequences/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': 'BASELINE.json configs[1]: SpatioTemporalModel J=17 arc 3,3,3 (RF 27) channels=128, '
+                                   'B=%d/GPU x T=27, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)'
+                                   % (B, '+RCCL grad all-reduce' if world > 1 else ''),
+                       'variant': args.variant, 'global_batch': world * B, 'parallelism': 'dp%d' % world,
+                       'loss_last': round(float(loss.item()), 6), 'launch': graph_note},
+        }
+        if timer:
+            agg = timer.summary()
+            peak_tf = MFMA_PEAK_TFLOPS[args.dtype]
+            for a in agg.values():
+                a['roof_hbm_ms'] = a['bytes'] / (HBM_PEAK_GBS * 1e9) * 1e3
+                a['roof_mfma_ms'] = a['flops'] / (peak_tf * 1e12) * 1e3
+                a['roof_ms'] = max(a['roof_hbm_ms'], a['roof_mfma_ms'])
+            gm = agg.get('gemm')
+            if gm and gm['ms'] > 0:
+                bound = 'hbm' if gm['roof_hbm_ms'] >= gm['roof_mfma_ms'] else 'mfma'
+                avg_ms = gm['ms'] / gm['launches']
+                if bound == 'hbm':
+                    ach = gm['bytes'] / gm['launches'] / (avg_ms * 1e-3) / 1e9
+                    peak, unit = HBM_PEAK_GBS, 'GB/s'
+                else:
+                    ach = gm['flops'] / gm['launches'] / (avg_ms * 1e-3) / 1e12
+                    peak, unit = peak_tf, 'TFLOP/s'
+                out['roofline'] = {'kernel': 'gemm_kernel<%s> (gast_gemm)' % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
+                                   'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': None,
+                                   'launches_per_step': gm['launches'] / tsteps, 'avg_launch_us': round(avg_ms * 1e3, 2),
+                                   'alg_gflop_per_launch': round(gm['flops'] / gm['launches'] / 1e9, 3),
+                                   'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
+            out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
+                                  'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
+            out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)
+            tot_roof = sum(v['roof_ms'] for v in agg.values()) / tsteps
+            out['path_roofline'] = {'sum_kernel_roofline_ms_per_step': round(tot_roof, 4), 'frac_of_step': round(tot_roof / ms, 4)}
+        if cpu is not None:
+            out['cpu_baseline'] = cpu
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -123,62 +123,85 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
     }
 }
 
-// backward: dH[:, 0:4C] and dA (atomics into zero-filled [nnz][C] buffers)
+// backward: dH[:, 0:4C] and dA.
+// Block = (frame block fb, channel chunk of CC <= 128 channels); thread = (frame slot, 4 channels).  dA[k][c] sums over ALL
+// frames: every thread adds its products into a per-block LDS accumulator [nnz_sym+nnz_con][CC] with ds_add_f32
+// (conflict-free: consecutive lanes hit consecutive channels), the block then stores one partial row to global memory
+// and `reduce_rows_kernel` combines the partial rows.  (The first version issued one global atomic per thread, edge and
+// channel: 34 M atomics per launch at B=128, 0.66 ms.)
 template <typename T>
 __global__ void __launch_bounds__(256) semch_agg_bwd_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
                                                             int F, int J, int C,
                                                             const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                             const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
-                                                            T* __restrict__ dH, int lddh, float* __restrict__ dA_sym,
-                                                            float* __restrict__ dA_con, int TPF, int FB, int FR) {
+                                                            T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb,
+                                                            int nchunk, int CC, int TPF, int FB) {
+    extern __shared__ __attribute__((aligned(16))) float sacc[];   // [nnz_sym + nnz_con][CC]
     const int tid = threadIdx.x;
+    const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
     const int slot = tid / TPF, ct = tid - slot * TPF;
-    const int C4 = C >> 2;
-    if (slot >= FB) return;
-    const int f0 = (blockIdx.x * FB + slot) * FR;   // this thread owns frames [f0, f0+FR)
-    if (f0 >= F) return;
-    const int f1 = min(F, f0 + FR);
-    for (int cg = ct; cg < C4; cg += TPF) {
-        const int c = cg * 4;
+    const int nnz_s = pat_sym[1], nnz_c = pat_con[1], nnz_t = nnz_s + nnz_c;
+    for (int t = tid; t < nnz_t * CC; t += 256) sacc[t] = 0.f;
+    __syncthreads();
+    const int cl = ct * 4;               // channel inside the chunk
+    const int c = ch * CC + cl;          // global channel
+    if (slot < FB && cl < CC && c < C) {
+        for (int f = fb * FB + slot; f < F; f += nfb * FB) {
+            const T* dYf = dY + (long)f * J * ldy;
+            const T* Hf = H + (long)f * J * ldh;
+            T* dHf = dH + (long)f * J * lddh;
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const int32_t* pat = g == 0 ? pat_sym : pat_con;
-            const float* A = g == 0 ? A_sym : A_con;
-            float* dA = g == 0 ? dA_sym : dA_con;
-            const Pat p = make_pat(pat, J, pat[1]);
-            const int h0c = g * 2 * C + c, h1c = g * 2 * C + C + c;
-            const int yc = g * C + c;
-            // dh0 / dh1 per frame (CSC view of the pattern)
-            for (int f = f0; f < f1; ++f) {
-                const T* dYf = dY + (long)f * J * ldy;
-                T* dHf = dH + (long)f * J * lddh;
+            for (int g = 0; g < 2; ++g) {
+                const int32_t* pat = g == 0 ? pat_sym : pat_con;
+                const float* A = g == 0 ? A_sym : A_con;
+                const Pat p = make_pat(pat, J, pat[1]);
+                const int h0c = g * 2 * C + c, h1c = g * 2 * C + C + c;
+                const int yc = g * C + c;
+                float* acc = sacc + (g == 0 ? 0 : nnz_s) * CC + cl;
                 for (int j = 0; j < J; ++j) {
                     float4 d0 = make_float4(0, 0, 0, 0), d1 = make_float4(0, 0, 0, 0);
                     for (int q = p.col_ptr[j]; q < p.col_ptr[j + 1]; ++q) {
                         int i = p.crow[q], k = p.cedge[q];
                         float4 av = *(const float4*)(A + (long)k * C + c);
                         float4 dv = ld4(dYf + (long)i * ldy + yc);
+                        float4 hv = ld4(Hf + (long)j * ldh + (i == j ? h0c : h1c));
                         if (i == j) d0 = fma4(av, dv, d0); else d1 = fma4(av, dv, d1);
+                        float* a4 = acc + k * CC;
+                        atomicAdd(a4, dv.x * hv.x); atomicAdd(a4 + 1, dv.y * hv.y);
+                        atomicAdd(a4 + 2, dv.z * hv.z); atomicAdd(a4 + 3, dv.w * hv.w);
                     }
                     st4(dHf + (long)j * lddh + h0c, d0);
                     st4(dHf + (long)j * lddh + h1c, d1);
                 }
             }
-            // dA[k][c] = sum_f dY[f,i_k,c] * (h0[f,i,c] if diagonal else h1[f,j_k,c])
-            for (int i = 0; i < J; ++i) {
-                for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) {
-                    int j = p.col[k];
-                    float4 s = make_float4(0, 0, 0, 0);
-                    for (int f = f0; f < f1; ++f) {
-                        float4 dv = ld4(dY + ((long)f * J + i) * ldy + yc);
-                        float4 hv = ld4(H + ((long)f * J + j) * ldh + (j == i ? h0c : h1c));
-                        s = fma4(dv, hv, s);
-                    }
-                    float* d = dA + (long)k * C + c;
-                    atomicAdd(d, s.x); atomicAdd(d + 1, s.y); atomicAdd(d + 2, s.z); atomicAdd(d + 3, s.w);
-                }
-            }
         }
+    }
+    __syncthreads();
+    // one partial row per frame block: part[fb][k][c]
+    for (int t = tid; t < nnz_t * CC; t += 256) {
+        int k = t / CC, cc = t - k * CC;
+        int cg = ch * CC + cc;
+        if (cg < C) part[((long)fb * nnz_t + k) * C + cg] = sacc[t];
+    }
+}
+
+// out[n] = sum_r part[r][n]   (256 threads = 32 columns x 8 row lanes)
+__global__ void __launch_bounds__(256) reduce_rows_kernel(const float* __restrict__ part, int nrow, long ncol, float* __restrict__ out) {
+    __shared__ float sred[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const long n = (long)blockIdx.x * 32 + cx;
+    float a = 0.f;
+    if (n < ncol) {
+#pragma unroll 4
+        for (int r = ry; r < nrow; r += 8) a += part[(long)r * ncol + n];
+    }
+    sred[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && n < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += sred[r][cx];
+        out[n] = t;
     }
 }
 
@@ -457,24 +480,52 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     return 0;
 }
 
+struct AggBwdCfg { int CC, nchunk, TPF, FB, nfb; };
+static AggBwdCfg agg_bwd_cfg(int F, int C) {
+    AggBwdCfg c;
+    c.CC = C < 128 ? C : 128;
+    c.nchunk = (C + c.CC - 1) / c.CC;
+    c.TPF = c.CC / 4;
+    c.FB = 256 / c.TPF;
+    int want = 512 / c.nchunk;
+    if (want < 1) want = 1;
+    int maxfb = (F + c.FB - 1) / c.FB;
+    c.nfb = want < maxfb ? want : maxfb;
+    return c;
+}
+
+extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con) {
+    AggBwdCfg c = agg_bwd_cfg(F, C);
+    return (long)c.nfb * (nnz_sym + nnz_con) * C;
+}
+
 extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
-                                  const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
-                                  void* dH, int lddh, float* dA_sym, float* dA_con, gast_stream_t stream) {
-    if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA_sym || !dA_con) return GAST_EINVAL;
+                                  const float* A_sym, const int32_t* pat_sym, int nnz_sym, const float* A_con,
+                                  const int32_t* pat_con, int nnz_con, void* dH, int lddh, float* dA, float* ws,
+                                  gast_stream_t stream) {
+    if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA || !ws) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
-    if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
-    int TPF = agg_tpf(C), FB = 256 / TPF;
-    // frames per thread: keep about 512 blocks in flight
-    int FR = (F + FB * 512 - 1) / (FB * 512);
-    if (FR < 1) FR = 1;
-    int nb = (F + FB * FR - 1) / (FB * FR);
+    if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
+    AggBwdCfg c = agg_bwd_cfg(F, C);
+    const int nnz_t = nnz_sym + nnz_con;
+    size_t smem = (size_t)nnz_t * c.CC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
+    if (smem > 48 * 1024) {
+        hipError_t e = dtype == GAST_F32
+            ? hipFuncSetAttribute((const void*)semch_agg_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+            : hipFuncSetAttribute((const void*)semch_agg_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    dim3 grid(c.nfb * c.nchunk);
     if (dtype == GAST_F32)
-        hipLaunchKernelGGL((semch_agg_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dY, ldy, (const float*)H, ldh, F, J,
-                           C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, dA_sym, dA_con, TPF, FB, FR);
+        hipLaunchKernelGGL((semch_agg_bwd_kernel<float>), grid, dim3(256), smem, st, (const float*)dY, ldy, (const float*)H, ldh, F, J,
+                           C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, c.CC, c.TPF, c.FB);
     else
-        hipLaunchKernelGGL((semch_agg_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dY, ldy, (const bf16_t*)H, ldh, F,
-                           J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, dA_sym, dA_con, TPF, FB, FR);
+        hipLaunchKernelGGL((semch_agg_bwd_kernel<bf16_t>), grid, dim3(256), smem, st, (const bf16_t*)dY, ldy, (const bf16_t*)H, ldh, F,
+                           J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk, c.CC, c.TPF, c.FB);
+    GAST_CHECK_LAUNCH();
+    long ncol = (long)nnz_t * C;
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol + 31) / 32)), dim3(256), 0, st, ws, c.nfb, ncol, dA);
     GAST_CHECK_LAUNCH();
     return 0;
 }

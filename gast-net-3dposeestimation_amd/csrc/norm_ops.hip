@@ -48,18 +48,40 @@ __device__ __forceinline__ void slot_reduce(float4 (&v)[NV], float (*sred)[4 * N
 }
 
 // ------------------------------------------------------------------------------------------------ BN finalize
-__global__ void bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N, double count,
-                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
+// 256 threads = 32 columns x 8 partial-row lanes; each lane sums every 8th partial row (independent loads, unrolled),
+// then the 8 lanes are combined in LDS in double precision.  (One thread per column walking all row blocks serially
+// exposed one L2 latency per row block: 80 us for 425 blocks.)
+constexpr int FIN_COLS = 32, FIN_LANES = 8;
+
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
+                                              double (*sred)[FIN_COLS][2], int cx, int ry, double& s1, double& s2) {
+    double a1 = 0.0, a2 = 0.0;
+    if (valid) {
+#pragma unroll 4
+        for (int b = ry; b < nblk; b += FIN_LANES) {
+            const float2 p = *(const float2*)(partials + ((long)b * ncol_total + col) * 2);
+            a1 += (double)p.x;
+            a2 += (double)p.y;
+        }
+    }
+    sred[ry][cx][0] = a1;
+    sred[ry][cx][1] = a2;
+    __syncthreads();
+    s1 = 0.0; s2 = 0.0;
+#pragma unroll
+    for (int r = 0; r < FIN_LANES; ++r) { s1 += sred[r][cx][0]; s2 += sred[r][cx][1]; }
+}
+
+__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
+                                   double count, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
                                    float* mean_out, float* rstd_out) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* p = partials + ((long)b * ncol_total + col0 + n) * 2;
-        s1 += (double)p[0];
-        s2 += (double)p[1];
-    }
+    __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
+    const int n = blockIdx.x * FIN_COLS + cx;
+    double s1, s2;
+    finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    if (ry != 0 || n >= N) return;
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -86,17 +108,15 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
     shift[n] = beta[n] - rm[n] * sc;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N, double count,
-                                       const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ rstd,
-                                       float* dgamma, float* dbeta, float* ka, float* kb, float* kc) {
-    int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        const float* p = partials + ((long)b * ncol_total + col0 + n) * 2;
-        s1 += (double)p[0];
-        s2 += (double)p[1];
-    }
+__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
+                                       double count, const float* __restrict__ gamma, const float* __restrict__ mean,
+                                       const float* __restrict__ rstd, float* dgamma, float* dbeta, float* ka, float* kb, float* kc) {
+    __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
+    const int n = blockIdx.x * FIN_COLS + cx;
+    double s1, s2;
+    finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    if (ry != 0 || n >= N) return;
     double mu = mean[n], r = rstd[n], g = gamma[n];
     double dg = r * (s2 - mu * s1);   // sum dz * xhat
     double db = s1;
@@ -416,7 +436,7 @@ extern "C" int gast_bn_finalize(const float* partials, int nblk, int ncol_total,
                                 float* scale, float* shift, float* mean, float* rstd, gast_stream_t stream) {
     if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return GAST_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0, N,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0, N,
                        count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd);
     GAST_CHECK_LAUNCH();
     return 0;
@@ -435,7 +455,7 @@ extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_to
                                     const float* gamma, const float* mean, const float* rstd,
                                     float* dgamma, float* dbeta, float* ka, float* kb, float* kc, gast_stream_t stream) {
     if (!partials || !gamma || !mean || !rstd || !dgamma || !dbeta || !ka || !kb || !kc || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0,
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0,
                        N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc);
     GAST_CHECK_LAUNCH();
     return 0;

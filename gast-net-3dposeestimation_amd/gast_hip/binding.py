@@ -86,7 +86,8 @@ def load_library():
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
         'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp],
         'gast_semch_agg_blocks': [ci, ci],
-        'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp],
+        'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp],
+        'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
         'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp],
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp],
@@ -107,6 +108,7 @@ def load_library():
         fn = getattr(lib, name)
         fn.argtypes = argtypes
         fn.restype = ci
+    lib.gast_semch_agg_bwd_ws_floats.restype = C.c_long
     lib.gast_version.restype = C.c_char_p
     lib.gast_version.argtypes = []
     _lib = lib
@@ -114,7 +116,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
-                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_attn_fwd', 'gast_attn_bwd',
+                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_colsum', 'gast_version']
@@ -244,10 +246,15 @@ class HipOps:
         _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), _p(A_con), _p(pat_con),
                                            _p(Y), _ld(Y), _p(partials), _stream()), 'gast_semch_agg_fwd')
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con):
-        self.launches += 1
-        _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), _p(A_con),
-                                           _p(pat_con), _p(dH), _ld(dH), _p(dA_sym), _p(dA_con), _stream()), 'gast_semch_agg_bwd')
+    def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
+        return self.lib.gast_semch_agg_bwd_ws_floats(int(F), int(C_), int(nnz_sym), int(nnz_con))
+
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws):
+        """dA: [nnz_sym + nnz_con][C] fp32 (sym rows first), fully written; ws: workspace of semch_agg_bwd_ws() floats."""
+        self.launches += 2
+        _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), A_sym.shape[0],
+                                           _p(A_con), _p(pat_con), A_con.shape[0], _p(dH), _ld(dH), _p(dA), _p(ws), _stream()),
+               'gast_semch_agg_bwd')
 
     # -- global attention
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):

@@ -422,13 +422,14 @@ class Engine:
         dCk = torch.zeros(NHEADS, J, J, dtype=f32, device=dev)
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
         grads[g + 'C_k'] = dCk
-        dA_s = torch.zeros_like(st['A_s'])
-        dA_c = torch.zeros_like(st['A_c'])
-        ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA_s, dA_c)
+        nnz_s, nnz_c = st['A_s'].shape[0], st['A_c'].shape[0]
+        dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
+        ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
+        ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws)
         de_s = torch.empty_like(inp[g + 'e_sym'])
         de_c = torch.empty_like(inp[g + 'e_con'])
-        ops.semch_adj_bwd(dA_s, st['A_s'], sp.pat_sym(dev), de_s)
-        ops.semch_adj_bwd(dA_c, st['A_c'], sp.pat_con(dev), de_c)
+        ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), de_s)
+        ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), de_c)
         grads[g + 'e_sym'] = de_s
         grads[g + 'e_con'] = de_c
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM

@@ -167,10 +167,12 @@ int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
                        const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
                        void* Y, int ldy, float* partials, gast_stream_t stream);
 int gast_semch_agg_blocks(int F, int C);
-/* Backward: dH columns [0,4C) and dA_t (atomically accumulated into zero-filled [nnz][C] buffers). */
+/* Backward: dH columns [0,4C) and dA = [dA_sym (nnz_sym rows) ; dA_con (nnz_con rows)] x C, fully written (no zero-fill
+ * needed).  ws: workspace of gast_semch_agg_bwd_ws_floats() floats for the per-block partial rows. */
 int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
-                       const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
-                       void* dH, int lddh, float* dA_sym, float* dA_con, gast_stream_t stream);
+                       const float* A_sym, const int32_t* pat_sym, int nnz_sym, const float* A_con, const int32_t* pat_con,
+                       int nnz_con, void* dH, int lddh, float* dA, float* ws, gast_stream_t stream);
+long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con);
 
 /* ---- global additive joint attention, 4 heads (global_attention.py:52-82, App. A.2 of SURVEY.md) -----------
  * G = base pointer of the g columns ([rows][ldg], C columns, head h owns columns [h*Ci,(h+1)*Ci));

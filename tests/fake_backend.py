@@ -70,9 +70,14 @@ class OracleOps:
     def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials):
         kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials))
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con):
-        kc.semch_agg_bwd(_np(dY), _np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(dH), _np(dA_sym),
-                         _np(dA_con))
+    def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
+        return 1
+
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws):
+        dAn = _np(dA)
+        dAn[...] = 0
+        ns = A_sym.shape[0]
+        kc.semch_agg_bwd(_np(dY), _np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(dH), dAn[:ns], dAn[ns:])
 
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):
         kc.attn_fwd(_np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(Y))

@@ -1,0 +1,53 @@
+"""The N>1 path on CPU: 2 processes, gloo, flat-gradient all-reduce around the model's host plan (numpy op mirror)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from fake_backend import use_oracle_ops
+    from gast_hip.dist import FlatGradAllReduce, shard_batch
+    from model.gast_net import SpatioTemporalModelOptimized1f
+    from oracle.gast_oracle import adj_from_parents
+    from tests_helpers import PARENTS
+    torch.manual_seed(0)                                   # identical replicas
+    adj = torch.from_numpy(adj_from_parents(PARENTS[17]))
+    m = use_oracle_ops(SpatioTemporalModelOptimized1f(adj, 17, 2, 17, filter_widths=[3, 3], channels=16, dropout=0.0))
+    sync = FlatGradAllReduce(m.parameters())
+    g = torch.Generator().manual_seed(7)
+    X = torch.rand(6, 9, 17, 2, generator=g) * 2 - 1       # the global batch; sharded on dim 0
+    Y = torch.randn(6, 1, 17, 3, generator=g) * 0.3
+    idx = shard_batch(6, rank, world)
+    m.train()
+    sync.zero_()
+    loss = torch.mean(torch.norm(m(X[idx]) - Y[idx], dim=-1))
+    loss.backward()
+    local = sync.flat.clone()
+    sync.sync()
+    torch.save({'local': local, 'synced': sync.flat.clone(), 'views_ok': all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in m.parameters())},
+               os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.destroy_process_group()
+
+
+def test_flat_grad_allreduce_world2(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(os.path.join(tmp_path, 'rank0.pt'))
+    r1 = torch.load(os.path.join(tmp_path, 'rank1.pt'))
+    assert r0['views_ok'] and r1['views_ok']
+    expect = (r0['local'] + r1['local']) / 2
+    assert torch.allclose(r0['synced'], expect, atol=1e-7) and torch.equal(r0['synced'], r1['synced'])
+    assert (r0['local'] - r1['local']).abs().max() > 1e-6    # the ranks really saw different shards

@@ -245,8 +245,11 @@ def test_semch_agg(ops, J, C, F, dt):
     # backward
     dY = rand(gen, P, 2 * C).to(dt)
     dH = torch.full((P, ldh), 5.0).to(dt).cuda()
-    dAs, dAc = torch.zeros_like(As).cuda(), torch.zeros_like(Ac).cuda()
-    ops.semch_agg_bwd(dY.cuda(), H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), dH, dAs, dAc)
+    ns, nc = int(ps[1]), int(pc[1])
+    dA = torch.full((ns + nc, C), 9.0).cuda()
+    ws = torch.empty(ops.semch_agg_bwd_ws(F, C, ns, nc)).cuda()
+    ops.semch_agg_bwd(dY.cuda(), H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), dH, dA, ws)
+    dAs, dAc = dA[:ns], dA[ns:]
     dHh = np.full((P, ldh), 5.0)
     dAsh, dAch = np.zeros((int(ps[1]), C)), np.zeros((int(pc[1]), C))
     kc.semch_agg_bwd(host(dY), host(H), F, J, C, host(As), ps, host(Ac), pc, dHh, dAsh, dAch, round_fn=rnd)
