@@ -10,11 +10,15 @@ typedef uint16_t bf16_t;  // raw bfloat16 bits
 
 // ---------------------------------------------------------------- bf16 <-> f32 (round to nearest even)
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+// hardware conversions (gfx950): v_cvt_pk_bf16_f32, round to nearest even
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};
+    return *(uint32_t*)&v;
+}
 __device__ __forceinline__ bf16_t f2bf(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // NaN
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    __bf16 b = (__bf16)f;
+    return *(bf16_t*)&b;
 }
 
 template <typename T> struct Elem;
@@ -41,8 +45,8 @@ __device__ __forceinline__ float4 ld4(const bf16_t* p) {
 __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = (uint32_t)f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
-    u.y = (uint32_t)f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+    u.x = pack_bf16x2(v.x, v.y);
+    u.y = pack_bf16x2(v.z, v.w);
     *(uint2*)p = u;
 }
 __device__ __forceinline__ float4 rnd4(float4 v, const float*) { return v; }
@@ -82,6 +86,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     int xcd = bid & 7, slot = bid >> 3;
     int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return base + slot;
+}
+
+// ---------------------------------------------------------------- asynchronous 16-byte global loads
+// Inline asm so that (a) the destination is an early-clobber tuple the allocator cannot alias with the address, (b) no
+// exec-masked branch / compiler-inserted s_waitcnt separates consecutive loads.  The compiler does not count these loads:
+// gload_wait_n<N>() (s_waitcnt vmcnt(N)) must precede the first use of the destination registers.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gload16(u32x4& dst, const void* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N> __device__ __forceinline__ void gload_wait_n() {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
 #define GAST_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

@@ -18,6 +18,7 @@
 // tile's global loads are issued before the MFMAs of the current one.  Blocks are remapped so that the N-tiles of
 // one M-panel run on the same XCD (shared L2).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -69,21 +70,22 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
             lo *= drop_mul(key, thresh, inv_keep, e0 + 2 * p);
             hi *= drop_mul(key, thresh, inv_keep, e0 + 2 * p + 1);
         }
-        w[p] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        w[p] = pack_bf16x2(lo, hi);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN) {
+__global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
-    __shared__ __attribute__((aligned(16))) unsigned char sA[BM * LSTR];
-    __shared__ __attribute__((aligned(16))) unsigned char sB[BN * LSTR];
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
     __shared__ int sRow[GAST_MAX_SEG][BM];
     __shared__ int sCrow[BM];
     __shared__ int sAddRow[BM];
-    __shared__ float sRed[2][BN][2];
+    __shared__ float sRed[4][BN][2];
+    unsigned char* const sA = smem;
+    unsigned char* const sB = smem + BM * LSTR;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
@@ -112,6 +114,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M
     const int chunk = tid & 7, rbase = tid >> 3;
     const uint32_t thresh = a.drop.thresh;
     const float inv_keep = a.drop.inv_keep;
+    const uint32_t seedv = (thresh != 0 && a.drop.seed) ? *a.drop.seed : 0u;   // read once: no compiler-tracked VMEM load in the K loop
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -121,67 +124,90 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    uint4 ra[4], rb[4];
-    float sc[EPC], sh[EPC];
-    int cur_s = 0, cur_k0 = 0;  // tile held in registers
-
-    auto load_tile = [&](int s, int k0) {
+    // ---- main loop: 2-deep register-staged pipeline.
+    // Two register sets (each: 4 A chunks + 4 W chunks + scale/shift chunks = NL 16-byte loads) hold the tiles t+1 and t+2
+    // while tile t is multiplied out of LDS, so ~64 KB per block are in flight across a whole tile period (one tile in flight
+    // left the kernel bound by exposed HBM/L2 latency: 3 us per K tile).  Loads are inline-asm (see gload16) and waited for
+    // with counted s_waitcnt vmcnt(NL): the newer set stays in flight.  All per-segment fields live in scalar registers and
+    // are re-fetched only when the segment changes; addresses are clamped instead of branching, zero rows / K tails are
+    // applied when the tile is written to LDS.
+    struct SegRegs {
+        const T* A; const T* W; const float* scale; const float* shift;
+        int lda, ldw, K, pro; uint32_t key; bool drop;
+        int row[4];      // source rows of this thread's 4 tile rows (-1 = zero row)
+    };
+    auto fetch_seg = [&](int s, SegRegs& R) {
         const gast_gemm_seg& sg = a.seg[s];
-        const int k = k0 + chunk * EPC;
-        const bool kin = k < sg.K;
-        const T* Ab = (const T*)sg.A;
-        const T* Wb = (const T*)sg.W;
+        R.A = (const T*)sg.A; R.W = (const T*)sg.W;
+        R.pro = sg.pro;
+        R.scale = sg.pro != GAST_PRO_NONE ? sg.scale : (const float*)sg.W;   // dummy but valid address: the load count per set is constant
+        R.shift = sg.pro != GAST_PRO_NONE ? sg.shift : (const float*)sg.W;
+        R.lda = sg.lda; R.ldw = sg.ldw; R.K = sg.K;
+        R.drop = sg.pro == GAST_PRO_BNRELU_DROP && thresh != 0;
+        R.key = seedv * 0x9E3779B9u + sg.salt * 0x85EBCA6Bu;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) R.row[i] = sRow[s][rbase + 32 * i];
+    };
+    int nrow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { int n = nt * BN + rbase + 32 * i; nrow[i] = n < a.N ? n : -1; }
+
+    constexpr int NSS = EPC / 4;               // 16-byte chunks of scale (and of shift) per thread
+    constexpr int NL = 8 + 2 * NSS;            // loads per register set
+    struct RegSet { u32x4 a[4], b[4], sc[NSS], sh[NSS]; };
+    RegSet R0, R1;
+    SegRegs L, S0, S1;     // L: segment of the next tile to load; S0/S1: segments of the tiles held by R0/R1
+    int l_s = 0, l_k0 = 0, k0_0 = 0, k0_1 = 0;
+
+    auto load_set = [&](RegSet& R, SegRegs& S, int& sk0) {
+        S = L; sk0 = l_k0;
+        const int k = l_k0 + chunk * EPC;
+        const int kc_ = k < L.K ? k : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int r = rbase + 32 * i;
-            int row = sRow[s][r];
-            ra[i] = make_uint4(0, 0, 0, 0);
-            rb[i] = make_uint4(0, 0, 0, 0);
-            if (kin && row >= 0) ra[i] = *(const uint4*)(Ab + (long)row * sg.lda + k);
-            int n = nt * BN + r;
-            if (kin && n < a.N) rb[i] = *(const uint4*)(Wb + (long)n * sg.ldw + k);
+            const int row = L.row[i];
+            gload16(R.a[i], L.A + (long)(row < 0 ? 0 : row) * L.lda + kc_);
+            gload16(R.b[i], L.W + (long)(nrow[i] < 0 ? 0 : nrow[i]) * L.ldw + kc_);
         }
-        if (sg.pro != GAST_PRO_NONE && kin) {
+        const int ks = L.pro != GAST_PRO_NONE ? kc_ : 0;
 #pragma unroll
-            for (int q = 0; q < EPC; q += 4) {
-                float4 s4 = *(const float4*)(sg.scale + k + q);
-                float4 h4 = *(const float4*)(sg.shift + k + q);
-                sc[q] = s4.x; sc[q + 1] = s4.y; sc[q + 2] = s4.z; sc[q + 3] = s4.w;
-                sh[q] = h4.x; sh[q + 1] = h4.y; sh[q + 2] = h4.z; sh[q + 3] = h4.w;
-            }
+        for (int q = 0; q < NSS; ++q) {
+            gload16(R.sc[q], L.scale + ks + 4 * q);
+            gload16(R.sh[q], L.shift + ks + 4 * q);
         }
+        // advance L to the next tile
+        l_k0 += BK;
+        if (l_k0 >= L.K) { ++l_s; l_k0 = 0; if (l_s < a.nseg) fetch_seg(l_s, L); }
     };
 
-    auto store_tile = [&](int s, int k0) {
-        const gast_gemm_seg& sg = a.seg[s];
-        const int k = k0 + chunk * EPC;
-        const bool kin = k < sg.K;
-        const bool pro = sg.pro != GAST_PRO_NONE;
-        const bool drop = sg.pro == GAST_PRO_BNRELU_DROP && thresh != 0;
-        uint32_t key = 0;
-        if (drop) key = drop_key(a.drop, sg.salt);
+    auto store_set = [&](const RegSet& R, const SegRegs& S, int sk0) {
+        const int k = sk0 + chunk * EPC;
+        const bool kin = k < S.K;
+        float sc[EPC], sh[EPC];
+#pragma unroll
+        for (int q = 0; q < NSS; ++q) {
+            sc[4 * q] = __uint_as_float(R.sc[q].x); sc[4 * q + 1] = __uint_as_float(R.sc[q].y);
+            sc[4 * q + 2] = __uint_as_float(R.sc[q].z); sc[4 * q + 3] = __uint_as_float(R.sc[q].w);
+            sh[4 * q] = __uint_as_float(R.sh[q].x); sh[4 * q + 1] = __uint_as_float(R.sh[q].y);
+            sh[4 * q + 2] = __uint_as_float(R.sh[q].z); sh[4 * q + 3] = __uint_as_float(R.sh[q].w);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int r = rbase + 32 * i;
-            uint4 v = ra[i];
-            if (pro && kin) {
-                int row = sRow[s][r];
-                if (row >= 0)
-                    v = prologue<T>(v, sc, sh, drop, key, thresh, inv_keep, (uint32_t)((long)row * sg.lda + k));
-            }
+            const int r = rbase + 32 * i;
+            const int row = S.row[i];
+            uint4 v = make_uint4(R.a[i].x, R.a[i].y, R.a[i].z, R.a[i].w);
+            if (S.pro != GAST_PRO_NONE)
+                v = prologue<T>(v, sc, sh, S.drop, S.key, thresh, inv_keep, (uint32_t)((long)(row < 0 ? 0 : row) * S.lda + k));
+            const bool oka = kin && row >= 0;      // zero rows / K tail stay zero (relu(shift) must not leak in)
+            const bool okb = kin && nrow[i] >= 0;
+            v = make_uint4(oka ? v.x : 0u, oka ? v.y : 0u, oka ? v.z : 0u, oka ? v.w : 0u);
+            const uint4 wv = make_uint4(okb ? R.b[i].x : 0u, okb ? R.b[i].y : 0u, okb ? R.b[i].z : 0u, okb ? R.b[i].w : 0u);
             *(uint4*)(sA + r * LSTR + chunk * 16) = v;
-            *(uint4*)(sB + r * LSTR + chunk * 16) = rb[i];
+            *(uint4*)(sB + r * LSTR + chunk * 16) = wv;
         }
     };
 
-    load_tile(0, 0);
-    while (cur_s < a.nseg) {
-        __syncthreads();  // everyone finished reading the previous tile
-        store_tile(cur_s, cur_k0);
-        __syncthreads();
-        int nxt_s = cur_s, nxt_k0 = cur_k0 + BK;
-        if (nxt_k0 >= a.seg[cur_s].K) { nxt_s = cur_s + 1; nxt_k0 = 0; }
-        if (nxt_s < a.nseg) load_tile(nxt_s, nxt_k0);
+    auto compute_tile = [&]() {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             uint4 fa[2], fb[2];
@@ -196,15 +222,177 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) Mma<T>::run(acc[mi][ni], fa[mi], fb[ni]);
         }
-        cur_s = nxt_s;
-        cur_k0 = nxt_k0;
+    };
+
+    fetch_seg(0, L);
+    load_set(R0, S0, k0_0);
+    bool have1 = l_s < a.nseg;
+    if (have1) load_set(R1, S1, k0_1);
+    while (true) {
+        // ---- R0 holds the current tile
+        if (have1) gload_wait_n<NL>(); else gload_wait_n<0>();
+        __syncthreads();                // everyone finished reading the previous tile
+        store_set(R0, S0, k0_0);
+        __syncthreads();
+        const bool have0 = l_s < a.nseg;
+        if (have0) load_set(R0, S0, k0_0);
+        compute_tile();
+        if (!have1) break;
+        // ---- R1 holds the current tile
+        if (have0) gload_wait_n<NL>(); else gload_wait_n<0>();
+        __syncthreads();
+        store_set(R1, S1, k0_1);
+        __syncthreads();
+        have1 = l_s < a.nseg;
+        if (have1) load_set(R1, S1, k0_1);
+        compute_tile();
+        if (!have0) break;
     }
 
     // ------------------------------------------------------------------ epilogue
+    if (dbg & 1) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     const int epi = a.epi;
     const bool xdrop = epi == GAST_EPI_BNRELU_BWD && a.xdrop && thresh != 0;
     uint32_t xkey = 0;
     if (xdrop) xkey = drop_key(a.drop, a.xsalt);
+    if (vec_epi) {
+        // ---- coalesced epilogue: acc (+bias) -> LDS staging tile (TO) -> 16-byte row chunks -> math -> 16-byte stores.
+        // The accumulator layout (lane = column, 16 rows per register file) would give 2-byte scattered stores and
+        // scattered loads of X / addend; in the staged layout a wave touches 4 full 256-byte rows per instruction.
+        constexpr int EPO = 16 / (int)sizeof(TO);        // elements per 16-byte chunk of the output
+        constexpr int CPR = BN / EPO;                    // chunks per tile row
+        constexpr int CSTR = BN * (int)sizeof(TO) + 16;  // staging row stride (bytes), 16-byte pad against bank conflicts
+        constexpr int NH = sizeof(TO) == 4 ? 2 : 1;      // fp32 tiles are staged in two 64-row halves
+        constexpr int RPP = 256 / CPR;                   // rows covered per pass of the 256 threads
+        unsigned char* const sC = smem;
+        const int cc = tid % CPR, rq = tid / CPR;
+        const int n0 = nt * BN + cc * EPO;
+        const bool nin = n0 < a.N;
+        float xs[EPO], xh[EPO], st1[EPO], st2[EPO];
+#pragma unroll
+        for (int q = 0; q < EPO; ++q) { xs[q] = 0.f; xh[q] = 0.f; st1[q] = 0.f; st2[q] = 0.f; }
+        if (epi == GAST_EPI_BNRELU_BWD && nin) {
+#pragma unroll
+            for (int q = 0; q < EPO; ++q) { xs[q] = a.xscale[n0 + q]; xh[q] = a.xshift[n0 + q]; }
+        }
+        const TO* Addv = (const TO*)a.addend;
+        const TO* Xv = (const TO*)a.X;
+        TO* Cv = (TO*)a.C;
+        __syncthreads();   // every wave is done reading the A/B tiles
+#pragma unroll
+        for (int h = 0; h < NH; ++h) {
+            if (NH == 1 || wr == h) {
+                const int rbase_w = NH == 1 ? wr * 64 : 0;
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const int nl = wc * 64 + ni * 32 + li;
+                    const int n = nt * BN + nl;
+                    const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+                    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int rl = rbase_w + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            Elem<TO>::st((TO*)(sC + rl * CSTR) + nl, acc[mi][ni][r] + bias);
+                        }
+                }
+            }
+            __syncthreads();
+            constexpr int ROWS = NH == 1 ? BM : BM / 2;
+#pragma unroll 2
+            for (int i = 0; i < ROWS / RPP; ++i) {
+                const int rl = rq + i * RPP;
+                const int ml = (NH == 1 ? 0 : h * 64) + rl;
+                const int crow = sCrow[ml];
+                if (!nin || crow < 0) continue;
+                const uint4 raw = *(const uint4*)(sC + rl * CSTR + cc * 16);
+                float v[EPO];
+                if (sizeof(TO) == 4) {
+                    v[0] = __uint_as_float(raw.x); v[1] = __uint_as_float(raw.y); v[2] = __uint_as_float(raw.z); v[3] = __uint_as_float(raw.w);
+                } else {
+                    const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+                    for (int p2 = 0; p2 < 4; ++p2) { v[(2 * p2) % EPO] = __uint_as_float(w4[p2] << 16); v[(2 * p2 + 1) % EPO] = __uint_as_float(w4[p2] & 0xffff0000u); }
+                }
+                if (Addv) {
+                    const int arow = sAddRow[ml];
+                    if (arow >= 0) {
+                        const uint4 ar = *(const uint4*)(Addv + (long)arow * a.ldadd + n0);
+                        if (sizeof(TO) == 4) {
+                            v[0] += __uint_as_float(ar.x); v[1] += __uint_as_float(ar.y); v[2] += __uint_as_float(ar.z); v[3] += __uint_as_float(ar.w);
+                        } else {
+                            const uint32_t w4[4] = {ar.x, ar.y, ar.z, ar.w};
+#pragma unroll
+                            for (int p2 = 0; p2 < 4; ++p2) { v[(2 * p2) % EPO] += __uint_as_float(w4[p2] << 16); v[(2 * p2 + 1) % EPO] += __uint_as_float(w4[p2] & 0xffff0000u); }
+                        }
+                    }
+                }
+                if (epi == GAST_EPI_BNRELU_BWD) {
+                    const uint4 xr = *(const uint4*)(Xv + (long)crow * a.ldx + n0);
+                    float x[EPO];
+                    if (sizeof(TO) == 4) {
+                        x[0] = __uint_as_float(xr.x); x[1] = __uint_as_float(xr.y); x[2] = __uint_as_float(xr.z); x[3] = __uint_as_float(xr.w);
+                    } else {
+                        const uint32_t w4[4] = {xr.x, xr.y, xr.z, xr.w};
+#pragma unroll
+                        for (int p2 = 0; p2 < 4; ++p2) { x[(2 * p2) % EPO] = __uint_as_float(w4[p2] << 16); x[(2 * p2 + 1) % EPO] = __uint_as_float(w4[p2] & 0xffff0000u); }
+                    }
+                    const uint32_t e0 = (uint32_t)((long)crow * a.ldx + n0);
+#pragma unroll
+                    for (int q = 0; q < EPO; ++q) {
+                        float y = v[q];
+                        if (!(fmaf(x[q], xs[q], xh[q]) > 0.f)) y = 0.f;
+                        if (xdrop) y *= drop_mul(xkey, thresh, inv_keep, e0 + q);
+                        y = Elem<TO>::rnd(y);
+                        v[q] = y;
+                        st1[q] += y;
+                        st2[q] = fmaf(y, x[q], st2[q]);
+                    }
+                } else if (epi == GAST_EPI_STATS) {
+#pragma unroll
+                    for (int q = 0; q < EPO; ++q) {
+                        const float y = Elem<TO>::rnd(v[q]);
+                        v[q] = y;
+                        st1[q] += y;
+                        st2[q] = fmaf(y, y, st2[q]);
+                    }
+                }
+                uint4 o;
+                if (sizeof(TO) == 4) {
+                    o = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+                } else {
+                    o = make_uint4(pack_bf16x2(v[0], v[1 % EPO]), pack_bf16x2(v[2 % EPO], v[3 % EPO]), pack_bf16x2(v[4 % EPO], v[5 % EPO]),
+                                   pack_bf16x2(v[6 % EPO], v[7 % EPO]));
+                }
+                *(uint4*)(Cv + (long)crow * a.ldc + n0) = o;
+            }
+            if (h + 1 < NH) __syncthreads();
+        }
+        if (epi != GAST_EPI_PLAIN) {
+            // threads with the same column chunk: lanes l, l+CPR, ... of every wave
+#pragma unroll
+            for (int q = 0; q < EPO; ++q) {
+                if (CPR <= 16) { st1[q] += __shfl_xor(st1[q], 16); st2[q] += __shfl_xor(st2[q], 16); }
+                st1[q] += __shfl_xor(st1[q], 32);
+                st2[q] += __shfl_xor(st2[q], 32);
+            }
+            if (lane < CPR) {
+#pragma unroll
+                for (int q = 0; q < EPO; ++q) { sRed[w][lane * EPO + q][0] = st1[q]; sRed[w][lane * EPO + q][1] = st2[q]; }
+            }
+            __syncthreads();
+            if (tid < BN) {
+                const int n = nt * BN + tid;
+                if (n < a.N) {
+                    float* pp = a.partials + ((long)mt * a.N + n) * 2;
+                    pp[0] = sRed[0][tid][0] + sRed[1][tid][0] + sRed[2][tid][0] + sRed[3][tid][0];
+                    pp[1] = sRed[0][tid][1] + sRed[1][tid][1] + sRed[2][tid][1] + sRed[3][tid][1];
+                }
+            }
+        }
+        return;
+    }
+    // ---- scalar epilogue (fallback for unaligned / narrow outputs such as the N=3 shrink layer)
     TO* Cb = (TO*)a.C;
     const T* Addb = (const T*)a.addend;
     const T* Xb = (const T*)a.X;
@@ -295,12 +483,17 @@ extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) {
     const int gridM = (M + BM - 1) / BM, gridN = (a.N + BN - 1) / BN;
     dim3 grid(gridM * gridN), block(256);
     hipStream_t st = (hipStream_t)stream;
+    // the coalesced (LDS-staged, 16-byte) epilogue needs same-width in/out element types and 16-byte aligned rows
+    int vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
+    if (a.addend && (a.ldadd % epc || !aligned16(a.addend))) vec_epi = 0;
+    if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
+    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling ablations only
     if (a.dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN);
+        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
     else if (a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
     else
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -6,9 +6,12 @@
 
 namespace {
 
+constexpr int JMAX = 19;   // largest supported skeleton (Human3.6M + toes)
+
 struct Pat {
-    int J, nnz;
+    int J, nnz, Dr, Dc;
     const int32_t *row_ptr, *col, *col_ptr, *crow, *cedge;
+    const int32_t *ell_rj, *ell_rk, *ell_ci, *ell_ck;   // padded fixed-degree views: [J][Dr] / [J][Dc]; padding -> edge id nnz
 };
 __device__ __host__ __forceinline__ Pat make_pat(const int32_t* p, int J, int nnz) {
     Pat q;
@@ -18,6 +21,12 @@ __device__ __host__ __forceinline__ Pat make_pat(const int32_t* p, int J, int nn
     q.col_ptr = q.col + nnz;
     q.crow = q.col_ptr + (J + 1);
     q.cedge = q.crow + nnz;
+    const int32_t* e = q.cedge + nnz;
+    q.Dr = e[0]; q.Dc = e[1];
+    q.ell_rj = e + 2;
+    q.ell_rk = q.ell_rj + J * q.Dr;
+    q.ell_ci = q.ell_rk + J * q.Dr;
+    q.ell_ck = q.ell_ci + J * q.Dc;
     return q;
 }
 
@@ -36,6 +45,7 @@ __global__ void semch_adj_fwd_kernel(const float* __restrict__ e, int C, const i
     for (int k = k0; k < k1; ++k) sum += expf(e[(long)c * nnz + k] - mx);
     float inv = 1.f / sum;
     for (int k = k0; k < k1; ++k) A_t[(long)k * C + c] = expf(e[(long)c * nnz + k] - mx) * inv;
+    if (i == 0) A_t[(long)nnz * C + c] = 0.f;   // the all-zero weight row that padded (ELL) edge slots point at
 }
 
 __global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
@@ -120,6 +130,169 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
                 for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
             }
         }
+    }
+}
+
+// ---- fixed-degree variants: every row (column) of the pattern is padded to D slots (padding -> zero weight row nnz), so
+// the edge loops have compile-time trip counts, all (j,k) lookups are hoisted and the D weight/feature loads of a row are
+// issued back to back (the CSR version exposes one scalar-load + one vector-load latency per edge).
+template <typename T, int D>
+__device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, T* __restrict__ Yf, int ldy, int J, int C,
+                                             const float* __restrict__ A, const int32_t* __restrict__ ell_j,
+                                             const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2) {
+    for (int i = 0; i < J; ++i) {
+        int jj[D], kk[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { jj[d] = ell_j[i * D + d]; kk[d] = ell_k[i * D + d]; }
+        float4 av[D], hv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            av[d] = *(const float4*)(A + (long)kk[d] * C + (h0c % C));
+            hv[d] = ld4(Hf + (long)jj[d] * ldh + (jj[d] == i ? h0c : h1c));
+        }
+        float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) acc = fma4(av[d], hv[d], acc);
+        acc = rnd4(acc, (const T*)nullptr);
+        st4(Yf + (long)i * ldy + yc, acc);
+        s1 = add4(s1, acc);
+        s2 = fma4(acc, acc, s2);
+    }
+}
+
+template <typename T, int DS, int DC>
+__global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restrict__ H, int ldh, int F, int J, int C,
+                                                                const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
+                                                                const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
+                                                                T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB) {
+    __shared__ float sred[256][8];
+    const int tid = threadIdx.x;
+    const int slot = tid / TPF, ct = tid - slot * TPF;
+    const int C4 = C >> 2;
+    const bool active = slot < FB;
+    const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
+    for (int cg0 = 0; cg0 < C4; cg0 += TPF) {
+        const int cg = cg0 + ct;
+        const bool cin = active && cg < C4;
+        const int c = cg * 4;
+        float4 s1[2], s2[2];
+        s1[0] = s1[1] = s2[0] = s2[1] = make_float4(0, 0, 0, 0);
+        if (cin) {
+            for (int f = blockIdx.x * FB + slot; f < F; f += gridDim.x * FB) {
+                const T* Hf = H + (long)f * J * ldh;
+                T* Yf = Y + (long)f * J * ldy;
+                agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, A_sym, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0]);
+                agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, A_con, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            __syncthreads();
+            sred[tid][0] = s1[g].x; sred[tid][1] = s1[g].y; sred[tid][2] = s1[g].z; sred[tid][3] = s1[g].w;
+            sred[tid][4] = s2[g].x; sred[tid][5] = s2[g].y; sred[tid][6] = s2[g].z; sred[tid][7] = s2[g].w;
+            __syncthreads();
+            if (slot == 0 && cg < C4) {
+                float t[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) t[q] = 0.f;
+                for (int sl = 0; sl < FB; ++sl)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
+                float* pp = partials + ((long)blockIdx.x * 2 * C + g * C + c) * 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
+            }
+        }
+    }
+}
+
+// backward, fixed-degree column view: for column j the slots (i, k) give dh0 / dh1
+template <typename T, int D>
+__device__ __forceinline__ void agg_cols_ell(const T* __restrict__ dYf, int ldy, T* __restrict__ dHf, int lddh, int J, int C,
+                                             const float* __restrict__ A, const int32_t* __restrict__ ell_i,
+                                             const int32_t* __restrict__ ell_k, int c, int h0c, int h1c, int yc) {
+    for (int j = 0; j < J; ++j) {
+        int ii[D], kk[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) { ii[d] = ell_i[j * D + d]; kk[d] = ell_k[j * D + d]; }
+        float4 av[D], dv[D];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            av[d] = *(const float4*)(A + (long)kk[d] * C + c);
+            dv[d] = ld4(dYf + (long)ii[d] * ldy + yc);
+        }
+        float4 d0 = make_float4(0, 0, 0, 0), d1 = make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            if (ii[d] == j) d0 = fma4(av[d], dv[d], d0); else d1 = fma4(av[d], dv[d], d1);
+        }
+        st4(dHf + (long)j * lddh + h0c, d0);
+        st4(dHf + (long)j * lddh + h1c, d1);
+    }
+}
+
+// Phase A: dh0/dh1, thread = (frame slot, 4 channels).  Phase B: dA[k][c] = sum_f dY[f,i_k,c] * h[f,j_k,c], thread = (edge k,
+// 4 channels) walking the block's frames with 4 independent frame loads in flight -- one owner per (k, c): no atomics, no LDS
+// (the first versions used one global / LDS atomic per thread, edge and channel and were bound by atomic contention).
+template <typename T, int DS, int DC>
+__global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
+                                                                int F, int J, int C,
+                                                                const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
+                                                                const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
+                                                                T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb,
+                                                                int nchunk, int CC, int TPF, int FB) {
+    __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
+    const int tid = threadIdx.x;
+    const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
+    const int slot = tid / TPF, ct = tid - slot * TPF;
+    const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
+    const int nnz_s = ps.nnz, nnz_c = pc.nnz, nnz_t = nnz_s + nnz_c;
+    for (int t = tid; t < 2 * J; t += 256) {
+        const Pat& p = t < J ? ps : pc;
+        const int i = t < J ? t : t - J, base = t < J ? 0 : nnz_s;
+        for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) { s_ei[base + k] = i; s_ej[base + k] = p.col[k]; }
+    }
+    const int cl = ct * 4;
+    const int c = ch * CC + cl;
+    if (slot < FB && cl < CC && c < C) {
+        for (int f = fb * FB + slot; f < F; f += nfb * FB) {
+            const T* dYf = dY + (long)f * J * ldy;
+            T* dHf = dH + (long)f * J * lddh;
+            agg_cols_ell<T, DS>(dYf, ldy, dHf, lddh, J, C, A_sym, ps.ell_ci, ps.ell_ck, c, c, C + c, c);
+            agg_cols_ell<T, DC>(dYf, ldy, dHf, lddh, J, C, A_con, pc.ell_ci, pc.ell_ck, c, 2 * C + c, 3 * C + c, C + c);
+        }
+    }
+    __syncthreads();
+    const int CC4 = CC >> 2;
+    const int fstep = nfb;          // frames of this block: fb, fb + nfb, ... in units of single frames (slot-interleaved)
+    for (int pidx = tid; pidx < nnz_t * CC4; pidx += 256) {
+        const int k = pidx / CC4, c4 = pidx - k * CC4;
+        const int cg = ch * CC + c4 * 4;
+        if (cg >= C) continue;
+        const int g = k < nnz_s ? 0 : 1;
+        const int i = s_ei[k], j = s_ej[k];
+        const int yc = g * C + cg;
+        const int hc = g * 2 * C + (i == j ? 0 : C) + cg;
+        float4 acc0 = make_float4(0, 0, 0, 0), acc1 = acc0, acc2 = acc0, acc3 = acc0;
+        // the block's frames are f = (fb + q * nfb) * FB + slot, slot < FB
+        for (int fq = fb * FB; fq < F; fq += fstep * FB) {
+            const int nf = min(FB, F - fq);
+            int s0 = 0;
+            for (; s0 + 4 <= nf; s0 += 4) {
+                const long f0 = fq + s0;
+                const float4 d0 = ld4(dY + ((f0 + 0) * J + i) * ldy + yc), h0 = ld4(H + ((f0 + 0) * J + j) * ldh + hc);
+                const float4 d1 = ld4(dY + ((f0 + 1) * J + i) * ldy + yc), h1 = ld4(H + ((f0 + 1) * J + j) * ldh + hc);
+                const float4 d2 = ld4(dY + ((f0 + 2) * J + i) * ldy + yc), h2 = ld4(H + ((f0 + 2) * J + j) * ldh + hc);
+                const float4 d3 = ld4(dY + ((f0 + 3) * J + i) * ldy + yc), h3 = ld4(H + ((f0 + 3) * J + j) * ldh + hc);
+                acc0 = fma4(d0, h0, acc0); acc1 = fma4(d1, h1, acc1); acc2 = fma4(d2, h2, acc2); acc3 = fma4(d3, h3, acc3);
+            }
+            for (; s0 < nf; ++s0) {
+                const long f0 = fq + s0;
+                acc0 = fma4(ld4(dY + (f0 * J + i) * ldy + yc), ld4(H + (f0 * J + j) * ldh + hc), acc0);
+            }
+        }
+        float4 r = add4(add4(acc0, acc1), add4(acc2, acc3));
+        *(float4*)(part + ((long)fb * nnz_t + k) * C + cg) = r;
     }
 }
 
@@ -209,7 +382,6 @@ __global__ void __launch_bounds__(256) reduce_rows_kernel(const float* __restric
 // Work unit = (frame f, head h).  A block owns one head (h = blockIdx.x % nheads) and walks frames UB at a time.
 constexpr int UB = 4;       // max frames per block iteration (runtime `ub` <= UB, chosen so the g tiles fit in LDS)
 constexpr int JP = 20;      // padded row length of the J x J tiles (J <= 19 -> multiple of 4 floats, 16-byte rows)
-constexpr int JMAX = 19;
 
 // att[i][j] = softmax_j(leaky(a_i + c_j)) (+ C_k); also returns p (softmax part) and the LeakyReLU slope mask
 template <typename T>
@@ -462,20 +634,34 @@ extern "C" int gast_semch_agg_blocks(int F, int C) {
 }
 
 extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
-                                  const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
-                                  void* Y, int ldy, float* partials, gast_stream_t stream) {
+                                  const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
+                                  const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials, gast_stream_t stream) {
     if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || !partials) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
     int TPF = agg_tpf(C), FB = 256 / TPF;
     int nb = gast_semch_agg_blocks(F, C);
     hipStream_t st = (hipStream_t)stream;
-    if (dtype == GAST_F32)
+#define AGG_FWD_ELL(DS, DC)                                                                                                  \
+    do {                                                                                                                     \
+        if (dtype == GAST_F32)                                                                                               \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, \
+                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB);                           \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, \
+                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB);                       \
+    } while (0)
+    // the fixed-degree kernels walk exactly DS / DC padded slots per row: the pattern tables must have been built with
+    // these degrees, which is the case for deg_sym == 2 (every supported skeleton) and deg_con in {5, 6}
+    if (deg_sym == 2 && deg_con == 5) AGG_FWD_ELL(2, 5);
+    else if (deg_sym == 2 && deg_con == 6) AGG_FWD_ELL(2, 6);
+    else if (dtype == GAST_F32)
         hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
                            A_con, pat_con, (float*)Y, ldy, partials, TPF, FB);
     else
         hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym,
                            A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB);
+#undef AGG_FWD_ELL
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -500,23 +686,52 @@ extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_
 }
 
 extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
-                                  const float* A_sym, const int32_t* pat_sym, int nnz_sym, const float* A_con,
-                                  const int32_t* pat_con, int nnz_con, void* dH, int lddh, float* dA, float* ws,
+                                  const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                                  const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
                                   gast_stream_t stream) {
     if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA || !ws) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
     AggBwdCfg c = agg_bwd_cfg(F, C);
     const int nnz_t = nnz_sym + nnz_con;
-    size_t smem = (size_t)nnz_t * c.CC * sizeof(float);
+    size_t smem = 0;   // the fixed-degree kernel needs no dynamic LDS
     hipStream_t st = (hipStream_t)stream;
+    dim3 grid(c.nfb * c.nchunk);
+#define AGG_BWD_ELL(DS, DC)                                                                                                   \
+    do {                                                                                                                      \
+        if (dtype == GAST_F32) {                                                                                              \
+            if (smem > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_ell_kernel<float, DS, DC>,                  \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<float, DS, DC>), grid, dim3(256), smem, st, (const float*)dY, ldy,   \
+                               (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb,    \
+                               c.nchunk, c.CC, c.TPF, c.FB);                                                                  \
+        } else {                                                                                                              \
+            if (smem > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_ell_kernel<bf16_t, DS, DC>,                 \
+                                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
+            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<bf16_t, DS, DC>), grid, dim3(256), smem, st, (const bf16_t*)dY, ldy, \
+                               (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb,  \
+                               c.nchunk, c.CC, c.TPF, c.FB);                                                                  \
+        }                                                                                                                     \
+    } while (0)
+    bool fast = true;
+    if (cdeg_sym == 2 && cdeg_con == 5) AGG_BWD_ELL(2, 5);
+    else if (cdeg_sym == 2 && cdeg_con == 6) AGG_BWD_ELL(2, 6);
+    else fast = false;
+#undef AGG_BWD_ELL
+    if (fast) {
+        GAST_CHECK_LAUNCH();
+        long ncol_f = (long)nnz_t * C;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol_f + 31) / 32)), dim3(256), 0, st, ws, c.nfb, ncol_f, dA);
+        GAST_CHECK_LAUNCH();
+        return 0;
+    }
+    smem = (size_t)nnz_t * c.CC * sizeof(float);
     if (smem > 48 * 1024) {
         hipError_t e = dtype == GAST_F32
             ? hipFuncSetAttribute((const void*)semch_agg_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
             : hipFuncSetAttribute((const void*)semch_agg_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    dim3 grid(c.nfb * c.nchunk);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((semch_agg_bwd_kernel<float>), grid, dim3(256), smem, st, (const float*)dY, ldy, (const float*)H, ldh, F, J,
                            C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, c.CC, c.TPF, c.FB);

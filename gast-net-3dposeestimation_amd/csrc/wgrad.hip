@@ -99,25 +99,31 @@ __global__ void __launch_bounds__(256) wgrad_f32_kernel(const gast_wgrad_args a,
         }
     };
 
-    float4 rp[4], rq[4];
+    // raw, unconditional (clamped) asm loads; zero rows / column tails are applied when the tile is written to LDS
+    u32x4 rp[4], rq[4];
+    const int pcolc = pin ? pcol : 0, qcolc = qin ? qcol : 0;
     auto load_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = rb0 + 8 * i;
             int pr = sRowP[buf][r], qr = sRowQ[buf][r];
-            rp[i] = make_float4(0, 0, 0, 0);
-            rq[i] = make_float4(0, 0, 0, 0);
-            if (pin && pr >= 0) rp[i] = *(const float4*)(Pb + (long)pr * a.ldp + pcol);
-            if (qin && qr >= 0) rq[i] = *(const float4*)(Qb + (long)qr * sg.ldq + qcol);
+            gload16(rp[i], Pb + (long)(pr < 0 ? 0 : pr) * a.ldp + pcolc);
+            gload16(rq[i], Qb + (long)(qr < 0 ? 0 : qr) * sg.ldq + qcolc);
         }
     };
     auto store_tile = [&](int buf) {
+        gload_wait_n<0>();
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = rb0 + 8 * i;
-            float4 q = rq[i];
+            const int pr_ = sRowP[buf][r], qr_ = sRowQ[buf][r];
+            const bool okp = pin && pr_ >= 0, okq = qin && qr_ >= 0;
+            float4 pv = make_float4(okp ? __uint_as_float(rp[i].x) : 0.f, okp ? __uint_as_float(rp[i].y) : 0.f,
+                                    okp ? __uint_as_float(rp[i].z) : 0.f, okp ? __uint_as_float(rp[i].w) : 0.f);
+            float4 q = make_float4(okq ? __uint_as_float(rq[i].x) : 0.f, okq ? __uint_as_float(rq[i].y) : 0.f,
+                                   okq ? __uint_as_float(rq[i].z) : 0.f, okq ? __uint_as_float(rq[i].w) : 0.f);
             if (pro && qin) {
-                int qr = sRowQ[buf][r];
+                int qr = qr_;
                 if (qr >= 0) {
                     q.x = fmaxf(fmaf(q.x, sc.x, sh.x), 0.f);
                     q.y = fmaxf(fmaf(q.y, sc.y, sh.y), 0.f);
@@ -132,7 +138,7 @@ __global__ void __launch_bounds__(256) wgrad_f32_kernel(const gast_wgrad_args a,
                     }
                 }
             }
-            *(float4*)(sP + r * FSTR + c * 4) = rp[i];
+            *(float4*)(sP + r * FSTR + c * 4) = pv;
             *(float4*)(sQ + r * FSTR + c * 4) = q;
         }
     };
@@ -249,16 +255,24 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const gast_wgrad_args a
         }
     };
 
+    u32x4 rl[8];
     uint4 rg[8];
+    const int colc = cin ? col : 0;
     auto load_tile = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
-            rg[i] = make_uint4(0, 0, 0, 0);
-            if (cin && row >= 0) rg[i] = *(const uint4*)(base + (long)row * ld + col);
+            gload16(rl[i], base + (long)(row < 0 ? 0 : row) * ld + colc);
         }
     };
     auto store_tile = [&](int buf) {
+        gload_wait_n<0>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
+            const bool ok = cin && row >= 0;
+            rg[i] = make_uint4(ok ? rl[i].x : 0u, ok ? rl[i].y : 0u, ok ? rl[i].z : 0u, ok ? rl[i].w : 0u);
+        }
         if (pro && cin) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -275,7 +289,7 @@ __global__ void __launch_bounds__(256) wgrad_bf16_kernel(const gast_wgrad_args a
                         lo *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p);
                         hi *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p + 1);
                     }
-                    wv[p] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+                    wv[p] = pack_bf16x2(lo, hi);
                 }
                 rg[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
             }

@@ -84,9 +84,9 @@ def load_library():
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
-        'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp],
+        'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp],
         'gast_semch_agg_blocks': [ci, ci],
-        'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp],
+        'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
         'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
         'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp],
@@ -241,20 +241,22 @@ class HipOps:
     def semch_agg_blocks(self, F, C_):
         return self.lib.gast_semch_agg_blocks(int(F), int(C_))
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials):
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0)):
+        """A_*: [nnz+1][C] (row nnz all zero); deg = (Dr_sym, Dr_con) of the pattern tables selects the unrolled kernels."""
         self.launches += 1
-        _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), _p(A_con), _p(pat_con),
-                                           _p(Y), _ld(Y), _p(partials), _stream()), 'gast_semch_agg_fwd')
+        _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), int(deg[0]), _p(A_con),
+                                           _p(pat_con), int(deg[1]), _p(Y), _ld(Y), _p(partials), _stream()), 'gast_semch_agg_fwd')
 
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return self.lib.gast_semch_agg_bwd_ws_floats(int(F), int(C_), int(nnz_sym), int(nnz_con))
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws):
-        """dA: [nnz_sym + nnz_con][C] fp32 (sym rows first), fully written; ws: workspace of semch_agg_bwd_ws() floats."""
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0)):
+        """dA: [nnz_sym + nnz_con][C] fp32 (sym rows first), fully written; ws: workspace of semch_agg_bwd_ws() floats;
+        cdeg = (Dc_sym, Dc_con)."""
         self.launches += 2
-        _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), A_sym.shape[0],
-                                           _p(A_con), _p(pat_con), A_con.shape[0], _p(dH), _ld(dH), _p(dA), _p(ws), _stream()),
-               'gast_semch_agg_bwd')
+        _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym),
+                                           A_sym.shape[0] - 1, int(cdeg[0]), _p(A_con), _p(pat_con), A_con.shape[0] - 1, int(cdeg[1]),
+                                           _p(dH), _ld(dH), _p(dA), _p(ws), _stream()), 'gast_semch_agg_bwd')
 
     # -- global attention
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):

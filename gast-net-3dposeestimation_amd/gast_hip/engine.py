@@ -183,15 +183,15 @@ class Engine:
         ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1)], H, im, bias=inp[g + 'bias1'])
         # masked-softmax adjacencies (parameters only; local_attention.py:40-42)
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
-        A_s = torch.empty(nnz_s, C, dtype=torch.float32, device=dev)
-        A_c = torch.empty(nnz_c, C, dtype=torch.float32, device=dev)
+        A_s = torch.empty(nnz_s + 1, C, dtype=torch.float32, device=dev)    # + the zero row padded edge slots point at
+        A_c = torch.empty(nnz_c + 1, C, dtype=torch.float32, device=dev)
         ops.semch_adj_fwd(inp[g + 'e_sym'], sp.pat_sym(dev), A_s)
         ops.semch_adj_fwd(inp[g + 'e_con'], sp.pat_con(dev), A_c)
         # neighbour aggregation + bn_1/bn_2 statistics
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
-        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY)
+        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]))
         bnY = BNState(2 * C, dev, P)
         self._bn_forward(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, training, off=0)
         self._bn_forward(partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, training, off=C)
@@ -422,10 +422,11 @@ class Engine:
         dCk = torch.zeros(NHEADS, J, J, dtype=f32, device=dev)
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
         grads[g + 'C_k'] = dCk
-        nnz_s, nnz_c = st['A_s'].shape[0], st['A_c'].shape[0]
+        nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
         ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
-        ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws)
+        ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws,
+                          cdeg=(sp.deg_sym[1], sp.deg_con[1]))
         de_s = torch.empty_like(inp[g + 'e_sym'])
         de_c = torch.empty_like(inp[g + 'e_con'])
         ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), de_s)

@@ -71,6 +71,10 @@ class ModelSpec:
         sym, con = skeleton_patterns(adj)
         self._tab_sym, self.nnz_sym = pattern_table(sym)
         self._tab_con, self.nnz_con = pattern_table(con)
+        # max row / column degrees (Dr, Dc) stored right after the CSR/CSC sections of the tables
+        off_s, off_c = 2 + 2 * (self.J + 1) + 3 * self.nnz_sym, 2 + 2 * (self.J + 1) + 3 * self.nnz_con
+        self.deg_sym = (int(self._tab_sym[off_s]), int(self._tab_sym[off_s + 1]))
+        self.deg_con = (int(self._tab_con[off_c]), int(self._tab_con[off_c + 1]))
         self._dev_tabs = {}
 
     def _tab(self, which, dev):

@@ -53,7 +53,27 @@ def pattern_table(pat):
     row_ptr = np.concatenate([[0], np.cumsum(np.bincount(rows, minlength=J))])
     col_ptr = np.concatenate([[0], np.cumsum(np.bincount(cols, minlength=J))])
     order = np.lexsort((rows, cols))
-    tab = np.concatenate([[J, nnz], row_ptr, cols, col_ptr, rows[order], order]).astype(np.int32)
+    # padded fixed-degree (ELL) views for the unrolled kernels: row i -> Dr slots (j, k), column j -> Dc slots (i, k);
+    # padding slots point at the row/column itself with edge id nnz, whose weight row is all zero
+    Dr = int(np.bincount(rows, minlength=J).max())
+    Dc = int(np.bincount(cols, minlength=J).max())
+    ell_rj = np.repeat(np.arange(J), Dr).reshape(J, Dr)
+    ell_rk = np.full((J, Dr), nnz)
+    ell_ci = np.repeat(np.arange(J), Dc).reshape(J, Dc)
+    ell_ck = np.full((J, Dc), nnz)
+    fill_r = np.zeros(J, dtype=int)
+    for k, (i, j) in enumerate(zip(rows, cols)):
+        ell_rj[i, fill_r[i]] = j
+        ell_rk[i, fill_r[i]] = k
+        fill_r[i] += 1
+    fill_c = np.zeros(J, dtype=int)
+    for q in order:
+        i, j = rows[q], cols[q]
+        ell_ci[j, fill_c[j]] = i
+        ell_ck[j, fill_c[j]] = q
+        fill_c[j] += 1
+    tab = np.concatenate([[J, nnz], row_ptr, cols, col_ptr, rows[order], order, [Dr, Dc], ell_rj.ravel(), ell_rk.ravel(),
+                          ell_ci.ravel(), ell_ck.ravel()]).astype(np.int32)
     return torch.from_numpy(tab), nnz
 
 

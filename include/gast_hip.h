@@ -150,10 +150,12 @@ int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream);
 /* ---- semantic channel-wise graph convolution (local_attention.py:10-56) ------------------------------------
  * Pattern (device int32 array, built once per skeleton by the host from local_attention.py:92-114):
  *   pat[0]=J, pat[1]=nnz, then row_ptr[J+1], col[nnz] (edges sorted by row i, CSR), col_ptr[J+1], crow[nnz],
- *   cedge[nnz] (CSC view: for column j the rows i and the CSR edge ids).  Edge k <-> e[:, k] exactly as the
- *   reference's boolean-mask assignment enumerates (i, j) row-major (local_attention.py:41). */
+ *   cedge[nnz] (CSC view: for column j the rows i and the CSR edge ids), then Dr, Dc (max row / column degree) and the
+ *   padded fixed-degree views ell_rj[J][Dr], ell_rk[J][Dr], ell_ci[J][Dc], ell_ck[J][Dc] whose padding slots carry the
+ *   edge id nnz.  Edge k <-> e[:, k] exactly as the reference's boolean-mask assignment enumerates (i, j) row-major
+ *   (local_attention.py:41).  Adjacency buffers A_t have nnz+1 rows: row nnz is all zero (target of the padding). */
 
-/* A_t[k][c] = softmax over the edges of row i(k) of e[c][k]   (local_attention.py:40-42) */
+/* A_t[k][c] = softmax over the edges of row i(k) of e[c][k]   (local_attention.py:40-42); A_t[nnz][c] = 0 */
 int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, gast_stream_t stream);
 /* de[c][k] = A (dA - sum_row A dA)   (softmax backward) */
 int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t* pat, float* de, gast_stream_t stream);
@@ -164,14 +166,15 @@ int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t
  * (bn_1 / bn_2, local_attention.py:139-140): partials[nblk][2C][2]; returns nblk through *nblk_out (host mirror:
  * gast_semch_agg_blocks). */
 int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
-                       const float* A_sym, const int32_t* pat_sym, const float* A_con, const int32_t* pat_con,
-                       void* Y, int ldy, float* partials, gast_stream_t stream);
+                       const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con, const int32_t* pat_con,
+                       int deg_con, void* Y, int ldy, float* partials, gast_stream_t stream);   /* deg_* = Dr of the tables */
 int gast_semch_agg_blocks(int F, int C);
 /* Backward: dH columns [0,4C) and dA = [dA_sym (nnz_sym rows) ; dA_con (nnz_con rows)] x C, fully written (no zero-fill
  * needed).  ws: workspace of gast_semch_agg_bwd_ws_floats() floats for the per-block partial rows. */
 int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
-                       const float* A_sym, const int32_t* pat_sym, int nnz_sym, const float* A_con, const int32_t* pat_con,
-                       int nnz_con, void* dH, int lddh, float* dA, float* ws, gast_stream_t stream);
+                       const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                       const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                       gast_stream_t stream);   /* cdeg_* = Dc of the tables */
 long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con);
 
 /* ---- global additive joint attention, 4 heads (global_attention.py:52-82, App. A.2 of SURVEY.md) -----------

@@ -169,7 +169,21 @@ def build_pattern(adj_pattern):
     col_ptr = np.cumsum(col_ptr).astype(np.int32)
     crow = rows[order].astype(np.int32)
     cedge = order.astype(np.int32)
-    return np.concatenate([[J, nnz], row_ptr, cols.astype(np.int32), col_ptr, crow, cedge]).astype(np.int32)
+    # padded fixed-degree (ELL) views (see include/gast_hip.h): padding slots carry edge id nnz (an all-zero weight row)
+    Dr = int(np.diff(row_ptr).max())
+    Dc = int(np.diff(col_ptr).max())
+    ell_rj = np.repeat(np.arange(J), Dr).reshape(J, Dr)
+    ell_rk = np.full((J, Dr), nnz)
+    ell_ci = np.repeat(np.arange(J), Dc).reshape(J, Dc)
+    ell_ck = np.full((J, Dc), nnz)
+    for i in range(J):
+        for d, k in enumerate(range(row_ptr[i], row_ptr[i + 1])):
+            ell_rj[i, d], ell_rk[i, d] = cols[k], k
+    for j in range(J):
+        for d, q in enumerate(range(col_ptr[j], col_ptr[j + 1])):
+            ell_ci[j, d], ell_ck[j, d] = crow[q], cedge[q]
+    return np.concatenate([[J, nnz], row_ptr, cols.astype(np.int32), col_ptr, crow, cedge, [Dr, Dc], ell_rj.ravel(), ell_rk.ravel(),
+                           ell_ci.ravel(), ell_ck.ravel()]).astype(np.int32)
 
 
 def parse_pattern(pat):
@@ -193,6 +207,8 @@ def semch_adj_fwd(e, pat, A_t):
         z = e[:, ks] - e[:, ks].max(axis=1, keepdims=True)
         ex = np.exp(z)
         A_t[ks, :] = (ex / ex.sum(axis=1, keepdims=True)).T
+    if A_t.shape[0] > nnz:
+        A_t[nnz:, :] = 0      # the zero weight row the padded (ELL) edge slots point at
 
 
 def semch_adj_bwd(dA_t, A_t, pat, de):

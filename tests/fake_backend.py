@@ -67,16 +67,16 @@ class OracleOps:
     def semch_agg_blocks(self, F, C_):
         return kc.semch_agg_blocks(F, C_)
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials):
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0)):
         kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials))
 
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return 1
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws):
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0)):
         dAn = _np(dA)
         dAn[...] = 0
-        ns = A_sym.shape[0]
+        ns = A_sym.shape[0] - 1
         kc.semch_agg_bwd(_np(dY), _np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(dH), dAn[:ns], dAn[ns:])
 
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):

@@ -209,16 +209,17 @@ def test_semch_adj(ops, J):
     for pat in (ps, pc):
         nnz = int(pat[1])
         e = 1 + rand(gen, C, nnz, scale=0.5)
-        A = torch.zeros(nnz, C).cuda()
+        A = torch.full((nnz + 1, C), 7.0).cuda()
         ops.semch_adj_fwd(e.cuda(), dev(pat), A)
-        Ah = np.zeros((nnz, C))
+        Ah = np.full((nnz + 1, C), 7.0)
         kc.semch_adj_fwd(host(e), pat, Ah)
         close(host(A), Ah, torch.float32, 'adj fwd')
+        assert float(A[nnz].abs().max()) == 0.0
         dA = rand(gen, nnz, C)
         de = torch.zeros(C, nnz).cuda()
         ops.semch_adj_bwd(dA.cuda(), A, dev(pat), de)
         deh = np.zeros((C, nnz))
-        kc.semch_adj_bwd(host(dA), Ah, pat, deh)
+        kc.semch_adj_bwd(host(dA), Ah[:nnz], pat, deh)
         close(host(de), deh, torch.float32, 'adj bwd')
 
 
@@ -230,15 +231,19 @@ def test_semch_agg(ops, J, C, F, dt):
     P = F * J
     ldh = 5 * C + 8
     H = rand(gen, P, ldh).to(dt)
-    As, Ac = torch.rand(int(ps[1]), C, generator=gen), torch.rand(int(pc[1]), C, generator=gen)
+    As, Ac = torch.rand(int(ps[1]) + 1, C, generator=gen), torch.rand(int(pc[1]) + 1, C, generator=gen)
+    As[-1] = 0
+    Ac[-1] = 0
+    o_s, o_c = 2 + 2 * (J + 1) + 3 * int(ps[1]), 2 + 2 * (J + 1) + 3 * int(pc[1])
+    deg, cdeg = (int(ps[o_s]), int(pc[o_c])), (int(ps[o_s + 1]), int(pc[o_c + 1]))
     Y = torch.zeros(P, 2 * C).to(dt).cuda()
     nb = ops.semch_agg_blocks(F, C)
     part = torch.zeros(nb, 2 * C, 2).cuda()
-    ops.semch_agg_fwd(H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), Y, part)
+    ops.semch_agg_fwd(H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), Y, part, deg=deg)
     Yh = np.zeros((P, 2 * C))
     ph = np.zeros((nb, 2 * C, 2))
     rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
-    kc.semch_agg_fwd(host(H), F, J, C, host(As), ps, host(Ac), pc, Yh, ph, round_fn=rnd)
+    kc.semch_agg_fwd(host(H), F, J, C, host(As)[:-1], ps, host(Ac)[:-1], pc, Yh, ph, round_fn=rnd)
     close(host(Y), Yh, dt, 'agg fwd')
     close(host(part).sum(0), ph.sum(0), dt, 'agg partial totals', fp32=1e-4, bf16=3e-2)
     close(host(part), ph, dt, 'agg partials per block', fp32=1e-4, bf16=3e-2)
@@ -248,11 +253,11 @@ def test_semch_agg(ops, J, C, F, dt):
     ns, nc = int(ps[1]), int(pc[1])
     dA = torch.full((ns + nc, C), 9.0).cuda()
     ws = torch.empty(ops.semch_agg_bwd_ws(F, C, ns, nc)).cuda()
-    ops.semch_agg_bwd(dY.cuda(), H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), dH, dA, ws)
+    ops.semch_agg_bwd(dY.cuda(), H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), dH, dA, ws, cdeg=cdeg)
     dAs, dAc = dA[:ns], dA[ns:]
     dHh = np.full((P, ldh), 5.0)
     dAsh, dAch = np.zeros((int(ps[1]), C)), np.zeros((int(pc[1]), C))
-    kc.semch_agg_bwd(host(dY), host(H), F, J, C, host(As), ps, host(Ac), pc, dHh, dAsh, dAch, round_fn=rnd)
+    kc.semch_agg_bwd(host(dY), host(H), F, J, C, host(As)[:-1], ps, host(Ac)[:-1], pc, dHh, dAsh, dAch, round_fn=rnd)
     got = host(dH)
     close(got[:, :4 * C], dHh[:, :4 * C], dt, 'agg bwd dH')
     assert np.all(got[:, 4 * C:] == 5.0)
