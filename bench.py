@@ -212,7 +212,7 @@ def main():
     y3d = torch.randn(B, 1, J, 3, generator=g) * 0.3
     y3d[:, :, 0] = 0                                     # reference main.py:225
     y3d = y3d.to(dev)
-    sync = FlatGradAllReduce(model.parameters())
+    sync = FlatGradAllReduce(model.parameters(), model=model)
     use_graph = not args.no_graph
     try:      # reference trainval.py:78: Adam(amsgrad=True); fused + capturable so the step can live in a hipGraph
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, fused=True, capturable=use_graph)

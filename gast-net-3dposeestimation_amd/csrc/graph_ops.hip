@@ -492,7 +492,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY, int lddy, const T* __restrict__ G, int ldg,
                                                        const T* __restrict__ AC, int ldac, const float* __restrict__ Ck,
                                                        int F, int J, int C, int nheads, T* __restrict__ dG, int lddg,
-                                                       T* __restrict__ dAC, int lddac, float* __restrict__ dCk, int ub) {
+                                                       T* __restrict__ dAC, int lddac, float* __restrict__ dCk,
+                                                       float* __restrict__ dbias_ac, int ub) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int Ci = C / nheads;
     const int cpr = (Ci + 3) / 4;
@@ -512,6 +513,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
     const int nchunk = ub * J * cpr;
     // per-thread accumulators of dC_k[h][i][j] for entries t = tid, tid + 256 (J*J <= 361 < 512)
     float ck_acc0 = 0.f, ck_acc1 = 0.f;
+    float da_sum = 0.f, dc_sum = 0.f;     // fp32 sums of da / dc over this thread's rows (bias gradients of theta / phi)
     for (int fbase = (blockIdx.x / nheads) * ub; fbase < F; fbase += bstride * ub) {
         attn_rows<T>(AC, ldac, Ck, F, J, nheads, h, fbase, ub, sp, satt, sslope, sa, scc);
         for (int t = tid; t < nchunk; t += blockDim.x) {
@@ -590,7 +592,7 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
                 da += ds;
             }
             int f = fbase + u;
-            if (f < F) Elem<T>::st(dAC + ((long)f * J + i) * lddac + h, da);
+            if (f < F) { Elem<T>::st(dAC + ((long)f * J + i) * lddac + h, da); da_sum += da; }
         }
         __syncthreads();
         for (int t = tid; t < ub * J; t += blockDim.x) {
@@ -598,12 +600,21 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
             float dc = 0.f;
             for (int i = 0; i < J; ++i) dc += sslope[u][i][j];
             int f = fbase + u;
-            if (f < F) Elem<T>::st(dAC + ((long)f * J + j) * lddac + nheads + h, dc);
+            if (f < F) { Elem<T>::st(dAC + ((long)f * J + j) * lddac + nheads + h, dc); dc_sum += dc; }
         }
         __syncthreads();
     }
     if (tid < J * J) atomicAdd(dCk + (long)h * J * J + tid, ck_acc0);
     if (tid + 256 < J * J) atomicAdd(dCk + (long)h * J * J + tid + 256, ck_acc1);
+    if (dbias_ac) {
+        // only threads < ub*J hold non-zero sums; one wave-level reduction each, then one atomic per wave
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { da_sum += __shfl_xor(da_sum, off); dc_sum += __shfl_xor(dc_sum, off); }
+        if ((tid & 63) == 0 && tid < ((ub * J + 63) & ~63)) {
+            atomicAdd(dbias_ac + h, da_sum);
+            atomicAdd(dbias_ac + nheads + h, dc_sum);
+        }
+    }
 }
 
 inline int agg_tpf(int C) { int c4 = C / 4; return c4 < 256 ? c4 : 256; }
@@ -784,7 +795,7 @@ extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, 
 
 extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
                              const float* C_k, int F, int J, int C, int nheads,
-                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, gast_stream_t stream) {
+                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias_ac, gast_stream_t stream) {
     if (!dY || !G || !AC || !C_k || !dG || !dAC || !dC_k) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
@@ -806,10 +817,10 @@ extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, 
     }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((attn_bwd_kernel<float>), dim3(grid), dim3(256), smem, st, (const float*)dY, ldy, (const float*)G, ldg,
-                           (const float*)AC, ldac, C_k, F, J, C, nheads, (float*)dG, lddg, (float*)dAC, lddac, dC_k, ub);
+                           (const float*)AC, ldac, C_k, F, J, C, nheads, (float*)dG, lddg, (float*)dAC, lddac, dC_k, dbias_ac, ub);
     else
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dY, ldy, (const bf16_t*)G, ldg,
-                           (const bf16_t*)AC, ldac, C_k, F, J, C, nheads, (bf16_t*)dG, lddg, (bf16_t*)dAC, lddac, dC_k, ub);
+                           (const bf16_t*)AC, ldac, C_k, F, J, C, nheads, (bf16_t*)dG, lddg, (bf16_t*)dAC, lddac, dC_k, dbias_ac, ub);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -371,6 +371,9 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
     }
 }
 
+// Accumulators are indexed [f][tap] with compile-time bounds (F_in <= 2 features, k0 <= 8 taps) so they stay in registers and
+// no integer division by the runtime filter width runs per row.
+constexpr int XF = 2, XT = 8;
 template <typename T>
 __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ dE, int ldde, const float* __restrict__ x, int B, int T_in,
                                                          int J, int F_in, int k0, int t_stride, int T_out,
@@ -382,44 +385,59 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
     const int C4 = C >> 2;
     const long rows = (long)B * T_out * J;
     const int TJ = T_out * J;
+    float mu[XF], rs[XF];
+#pragma unroll
+    for (int f = 0; f < XF; ++f) { mu[f] = f < F_in ? mean0[f] : 0.f; rs[f] = f < F_in ? rstd0[f] : 0.f; }
     for (int cg0 = 0; cg0 < C4; cg0 += TPR) {
         const int cg = cg0 + ct;
         const int c = cg * 4;
-        float4 g[KMAX + 1];
+        float4 g[XF][XT], gs = make_float4(0, 0, 0, 0);
 #pragma unroll
-        for (int kk = 0; kk <= KMAX; ++kk) g[kk] = make_float4(0, 0, 0, 0);
+        for (int f = 0; f < XF; ++f)
+#pragma unroll
+            for (int tap = 0; tap < XT; ++tap) g[f][tap] = make_float4(0, 0, 0, 0);
         if (slot < RB && cg < C4) {
             for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
                 int m = (int)r;
                 int b = m / TJ, rem = m - b * TJ;
                 int t = rem / J, j = rem - t * J;
-                float4 d = ld4(dE + r * ldde + c);
-                g[KMAX].x += d.x; g[KMAX].y += d.y; g[KMAX].z += d.z; g[KMAX].w += d.w;
+                const float4 d = ld4(dE + r * ldde + c);
+                gs.x += d.x; gs.y += d.y; gs.z += d.z; gs.w += d.w;
+                const float* xb = x + (((long)b * T_in + t * t_stride) * J + j) * F_in;
 #pragma unroll
-                for (int kk = 0; kk < KMAX; ++kk) {
-                    if (kk < K0) {
-                        int f = kk / k0, tap = kk - f * k0;
-                        long xr = ((long)b * T_in + t * t_stride + tap) * J + j;
-                        float xh = (x[xr * F_in + f] - mean0[f]) * rstd0[f];
-                        g[kk].x = fmaf(d.x, xh, g[kk].x); g[kk].y = fmaf(d.y, xh, g[kk].y);
-                        g[kk].z = fmaf(d.z, xh, g[kk].z); g[kk].w = fmaf(d.w, xh, g[kk].w);
+                for (int tap = 0; tap < XT; ++tap) {
+                    if (tap < k0) {
+#pragma unroll
+                        for (int f = 0; f < XF; ++f) {
+                            if (f < F_in) {
+                                const float xh = (xb[(long)tap * J * F_in + f] - mu[f]) * rs[f];
+                                g[f][tap].x = fmaf(d.x, xh, g[f][tap].x); g[f][tap].y = fmaf(d.y, xh, g[f][tap].y);
+                                g[f][tap].z = fmaf(d.z, xh, g[f][tap].z); g[f][tap].w = fmaf(d.w, xh, g[f][tap].w);
+                            }
+                        }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int kk = 0; kk <= KMAX; ++kk) {
-            if (kk < K0 || kk == KMAX) {
-                float4 v[1] = {g[kk]};
-                slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
-                if (slot == 0 && cg < C4) {
-                    if (kk == KMAX) {
-                        atomicAdd(S + c, v[0].x); atomicAdd(S + c + 1, v[0].y); atomicAdd(S + c + 2, v[0].z); atomicAdd(S + c + 3, v[0].w);
-                    } else {
+        for (int f = 0; f < XF; ++f)
+#pragma unroll
+            for (int tap = 0; tap < XT; ++tap) {
+                if (f < F_in && tap < k0) {
+                    float4 v[1] = {g[f][tap]};
+                    slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
+                    if (slot == 0 && cg < C4) {
+                        const int kk = f * k0 + tap;
                         atomicAdd(G + (long)(c) * K0 + kk, v[0].x); atomicAdd(G + (long)(c + 1) * K0 + kk, v[0].y);
                         atomicAdd(G + (long)(c + 2) * K0 + kk, v[0].z); atomicAdd(G + (long)(c + 3) * K0 + kk, v[0].w);
                     }
                 }
+            }
+        {
+            float4 v[1] = {gs};
+            slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
+            if (slot == 0 && cg < C4) {
+                atomicAdd(S + c, v[0].x); atomicAdd(S + c + 1, v[0].y); atomicAdd(S + c + 2, v[0].z); atomicAdd(S + c + 3, v[0].w);
             }
         }
     }
@@ -596,7 +614,7 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
                                int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,
                                gast_stream_t stream) {
     if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !G || !S) return GAST_EINVAL;
-    if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
+    if (F_in < 1 || k0 < 1 || F_in > XF || k0 > XT || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || ldde % 4) return GAST_EALIGN;
     int T_out = conv_t_out(T_in, k0, t_stride);
     long rows = (long)B * T_out * J;
@@ -607,7 +625,7 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
     e = hipMemsetAsync(S, 0, (size_t)C * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
     int nb = row_blocks(rows, C);
-    if (nb > 256) nb = 256;
+    if (nb > 128) nb = 128;     // every block ends with (F_in*k0+1)*C atomics: few, long-running blocks
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
                            T_out, mean0, rstd0, C, G, S, c.TPR, c.RB);

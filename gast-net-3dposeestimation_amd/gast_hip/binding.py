@@ -89,7 +89,7 @@ def load_library():
         'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
         'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
-        'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp],
+        'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp],
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp],
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -103,6 +103,9 @@ def load_library():
         'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp],
         'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
+        'gast_strided_copy': [vp, vp, ci, vp, vp],
+        'gast_fold': [vp, ci, vp, vp],
+        'gast_unfold': [vp, ci, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -119,7 +122,8 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_sem
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
-                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_colsum', 'gast_version']
+                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
+                    'gast_unfold', 'gast_version']
 
 
 def _check(rc, what):
@@ -264,10 +268,10 @@ class HipOps:
         _check(self.lib.gast_attn_fwd(_dt(G), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads, _p(Y), _ld(Y), _stream()),
                'gast_attn_fwd')
 
-    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k):
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias_ac=None):
         self.launches += 1
         _check(self.lib.gast_attn_bwd(_dt(G), _p(dY), _ld(dY), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads,
-                                      _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _stream()), 'gast_attn_bwd')
+                                      _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _p(dbias_ac), _stream()), 'gast_attn_bwd')
 
     # -- BatchNorm pieces
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
@@ -333,3 +337,86 @@ class HipOps:
         self.launches += 1
         _check(self.lib.gast_expand_bwd(_dt(dE), _p(dE), _ld(dE), _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
                                         _p(G), _p(S), _stream()), 'gast_expand_bwd')
+
+    # -- parameter packing / gradient unpacking (gast_hip/packer.py job lists -> device tables, one launch per list)
+    @staticmethod
+    def _word(ref, itemsize):
+        from gast_hip.packer import BASE_ABS
+        if ref.base == BASE_ABS:
+            return ((ref.tensor.data_ptr() + ref.off * ref.tensor.element_size()) << 4) | 0
+        return ((ref.off * itemsize) << 4) | ref.base
+
+    def _copy_table(self, jobs, dev, w_itemsize, accumulate):
+        """jobs: (src Ref, dst Ref, R, S[, fp32dst]) -> (int64 job table, int32 tile table, ntiles)"""
+        from gast_hip.packer import BASE_W
+        words, tiles = [], []
+        for ji, job in enumerate(jobs):
+            src, dst, R, S = job[0], job[1], job[2], job[3]
+            src_size = w_itemsize if src.base == BASE_W else 4
+            dst_size = w_itemsize if dst.base == BASE_W else 4
+            flags = (1 if src_size == 2 else 0) | (2 if dst_size == 2 else 0) | (4 if accumulate else 0)
+            words += [self._word(src, src_size), self._word(dst, dst_size), R, S, src.rs, src.cs, dst.rs, dst.cs, flags, 0]
+            for tr in range((R + 31) // 32):
+                for tc in range((S + 31) // 32):
+                    tiles += [ji, tr, tc]
+        jt = torch.tensor(words, dtype=torch.int64).to(dev)
+        tt = torch.tensor(tiles, dtype=torch.int32).to(dev)
+        return jt, tt, len(tiles) // 3
+
+    def _tables(self, packer, st, dev):
+        tb = st.get('tables')
+        if tb is None:
+            wsize = st['Wb'].element_size()
+            tb = {'pack': self._copy_table(packer.copy_jobs, dev, wsize, False)}
+            fw = []
+            for j in packer.fold_jobs:
+                wt = j['w']
+                fw += [(j['W'].data_ptr() << 4), ((wt.data_ptr() + j['woff'] * 4) << 4), (j['b'].data_ptr() << 4), j['Ci'], j['C'],
+                       self._word(j['row'], wsize), j['row'].cs, self._word(j['col'], wsize), j['col'].cs, self._word(j['bias'], 4),
+                       1 if wsize == 2 else 0, 0]
+            tb['fold'] = (torch.tensor(fw, dtype=torch.int64).to(dev), len(packer.fold_jobs))
+            st['tables'] = tb
+        return tb
+
+    def _unpack_tables(self, packer, st, dev, accumulate):
+        tb = self._tables(packer, st, dev)
+        key = 'unpack%d' % int(accumulate)
+        if key not in tb:
+            from gast_hip.packer import BASE_G
+            cp = self._copy_table(packer.unpack_jobs, dev, 4, accumulate)
+            uw = []
+            for j in packer.unfold_jobs:
+                gW = packer.goff[packer.index[id(j['W'])]] * 4
+                gw = (packer.goff[packer.index[id(j['w'])]] + j['woff']) * 4
+                gb = packer.goff[packer.index[id(j['b'])]] * 4
+                uw += [self._word(j['dv'], 4), self._word(j['da'], 4), (j['W'].data_ptr() << 4), ((j['w'].data_ptr() + j['woff'] * 4) << 4),
+                       (j['b'].data_ptr() << 4), (gW << 4) | BASE_G, (gw << 4) | BASE_G, (gb << 4) | BASE_G, j['Ci'], j['C'],
+                       int(accumulate), 0]
+            tb[key] = (cp, torch.tensor(uw, dtype=torch.int64).to(dev), len(packer.unfold_jobs))
+        return tb[key]
+
+    def _bases(self, **kw):
+        from gast_hip.packer import BASE_W, BASE_F, BASE_S, BASE_G
+        arr = (C.c_int64 * 8)()
+        for name, idx in (('W', BASE_W), ('F', BASE_F), ('S', BASE_S), ('G', BASE_G)):
+            t = kw.get(name)
+            arr[idx] = t.data_ptr() if t is not None else 0
+        return arr
+
+    def run_pack(self, packer, st):
+        dev = st['Wb'].device
+        tb = self._tables(packer, st, dev)
+        bases = self._bases(W=st['Wb'], F=st['Fb'])
+        jt, tt, nt = tb['pack']
+        self.launches += 2
+        _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
+        ft, nf = tb['fold']
+        _check(self.lib.gast_fold(_p(ft), nf, C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
+
+    def run_unpack(self, packer, st, Sb, G, accumulate):
+        dev = G.device
+        (jt, tt, nt), ut, nu = self._unpack_tables(packer, st, dev, accumulate)
+        bases = self._bases(S=Sb, G=G)
+        self.launches += 2
+        _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
+        _check(self.lib.gast_unfold(_p(ut), nu, C.cast(bases, C.c_void_p), _stream()), 'gast_unfold')

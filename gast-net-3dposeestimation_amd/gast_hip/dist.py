@@ -13,7 +13,9 @@ import torch.distributed as dist
 class FlatGradAllReduce:
     """Makes every `p.grad` a view into one flat buffer and averages that buffer over the process group."""
 
-    def __init__(self, params, process_group=None):
+    def __init__(self, params, process_group=None, model=None):
+        """model: optional GAST model whose backward should accumulate straight into the flat buffer (skips 165 per-parameter
+        AccumulateGrad kernels); `params` must then be `model.parameters()` in order."""
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError('no trainable parameters')
@@ -24,6 +26,10 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        if model is not None and hasattr(model, '_runner'):
+            if [id(p) for p in model.parameters()] != [id(p) for p in self.params]:
+                raise ValueError('FlatGradAllReduce(model=...) needs params == list(model.parameters())')
+            model._runner.grad_sink = self.flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
 

@@ -79,7 +79,6 @@ class Engine:
         B, T_in, J, F_in = x.shape
         L = len(sp.fw)
         dt = act_dtype
-        cast = (lambda w: w) if dt == torch.float32 else (lambda w: w.to(dt))
         sv = {'B': B, 'T_in': T_in, 'dt': dt, 'drop': drop, 'training': training}
         use_drop = training and drop is not None and drop.thresh != 0
 
@@ -131,8 +130,8 @@ class Engine:
                     raise RuntimeError('input too short for the receptive field (%d frames needed)' % sp.receptive_field)
                 T.append(Tn)
                 P = B * Tn * J
-                Wc = cast(inp['l%d.conv' % s])        # [C][k*C], tap-major K
-                W1 = cast(inp['l%d.conv1' % s])       # [C][C]
+                Wc = inp['l%d.conv' % s]        # [C][k*C], tap-major K (packed by gast_hip.packer)
+                W1 = inp['l%d.conv1' % s]       # [C][C]
                 nb = ops.gemm_row_blocks(P)
                 T1 = self._new(P, C, dt, dev)
                 part1 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
@@ -150,21 +149,21 @@ class Engine:
                 X = self._new(P, C, dt, dev)
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
                                  use_drop, 3 * s, drop, B, Tn, J, C, X)
-                levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, Wc=Wc, W1=W1, k=k))
-            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, cast))
+                levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, k=k))
+            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop))
 
         # ---- shrink (gast_net.py:99)
         last = stages[-1]
         CL = 2 * C0 * (2 ** (L - 1))
         PL = B * T[-1] * J
-        Wsh = cast(inp['shrink'])   # [3][CL]
+        Wsh = inp['shrink']   # [3][CL]
         pred = torch.empty(PL, 3, dtype=torch.float32, device=dev)
         ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
                                          scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
-        sv.update(stages=stages, levels=levels, Wsh=Wsh)
+        sv.update(stages=stages, levels=levels)
         return pred.view(B, T[-1], J, 3), sv
 
-    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop, cast):
+    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop):
         sp, ops = self.spec, self.ops
         dev = X.device
         P = B * Tn * J
@@ -173,10 +172,10 @@ class Engine:
         g = 'g%d.' % s
         dom = (B, Tn, J)
         im = ident(Tn)
-        Wg1 = cast(inp[g + 'Bg1'])      # [N1][C]
-        Wlc = cast(inp[g + 'Blc'])      # [C][2C]
-        Wgc = cast(inp[g + 'Bgc'])      # [C][C]
-        Wbc = cast(inp[g + 'Bbc'])      # [2C][3C]
+        Wg1 = inp[g + 'Bg1']      # [N1][C]
+        Wlc = inp[g + 'Blc']      # [C][2C]
+        Wgc = inp[g + 'Bgc']      # [C][C]
+        Wbc = inp[g + 'Bbc']      # [2C][3C]
         nb = ops.gemm_row_blocks(P)
         # G1: everything that reads X in one pass (local_attention.py:37-38, global_attention.py:56-72)
         H = self._new(P, N1, dt, dev)
@@ -221,28 +220,27 @@ class Engine:
         bnO = BNState(2 * C, dev, P)
         self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training)
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, Lp=Lp, bnL=bnL, Gp=Gp, bnG=bnG, O=O, bnO=bnO,
-                    Wg1=Wg1, Wlc=Wlc, Wgc=Wgc, Wbc=Wbc, C=C, Tn=Tn, P=P, pro=pro)
+                    C=C, Tn=Tn, P=P, pro=pro)
 
     # ------------------------------------------------------------------------------------------ backward
-    def _bn_backward(self, partials, nblk, col0, n, st, gamma, grads, key, dz, Xpre, rows, off=0, dzcol=None):
-        """finalize {sum dz, sum dz*x} -> dgamma/dbeta + coefficients, then dz <- dx in place."""
+    def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
+        """finalize {sum dz, sum dz*x} -> dgamma/dbeta (written to their destinations) + coefficients, then dz <- dx in place."""
         ops = self.ops
         dev = gamma.device
-        dg = torch.empty(n, dtype=torch.float32, device=dev)
-        db = torch.empty(n, dtype=torch.float32, device=dev)
+        dg = gout[key + '.weight']
+        db = gout[key + '.bias']
         ka = torch.empty(n, dtype=torch.float32, device=dev)
         kb = torch.empty(n, dtype=torch.float32, device=dev)
         kc = torch.empty(n, dtype=torch.float32, device=dev)
         sl = slice(off, off + n)
         ops.bn_bwd_finalize(partials, nblk, col0, n, st.count, gamma, st.mean[sl], st.rstd[sl], dg, db, ka, kb, kc)
-        grads[key + '.weight'] = dg
-        grads[key + '.bias'] = db
         d = dz if dzcol is None else dz[:, dzcol:dzcol + n]
         xx = Xpre if dzcol is None else Xpre[:, dzcol:dzcol + n]
         ops.bn_bwd_apply(d, xx, rows, n, ka, kb, kc)
 
-    def backward(self, sv, inp, dpred):
-        """dpred: (B,T',J,3) fp32.  Returns dict key -> gradient for every key of `inp`."""
+    def backward(self, sv, inp, dpred, gout):
+        """dpred: (B,T',J,3) fp32.  Every gradient is written into its destination `gout[key]` (packed fp32 scratch
+        regions for the GEMM operands, views of the flat gradient buffer for directly-held parameters)."""
         sp, ops = self.spec, self.ops
         dev = dpred.device
         B, dt, drop = sv['B'], sv['dt'], sv['drop']
@@ -251,7 +249,7 @@ class Engine:
         L = len(sp.fw)
         C0 = sp.channels
         stages, levels = sv['stages'], sv['levels']
-        grads = {}
+        grads = gout
         f32 = torch.float32
 
         # ---- shrink backward
@@ -262,12 +260,9 @@ class Engine:
         KP = 8
         dp = torch.zeros(PL, KP, dtype=dt, device=dev)
         dp[:, :3] = dpred.reshape(PL, 3).to(dt)
-        dWsh = torch.empty(KP, CL, dtype=f32, device=dev)
         ops.wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
-                                                        shift=last['bnO'].shift, wcol0=0)], dWsh)
-        grads['shrink'] = dWsh[:3]
-        WshT = torch.zeros(CL, KP, dtype=dt, device=dev)
-        WshT[:, :3] = sv['Wsh'].t()
+                                                        shift=last['bnO'].shift, wcol0=0)], gout['shrink'])
+        WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
         dO = self._new(PL, CL, dt, dev)
         nb = ops.gemm_row_blocks(PL)
         part = torch.empty(nb, CL, 2, dtype=f32, device=dev)
@@ -297,25 +292,21 @@ class Engine:
             lk = 'l%d.' % s
             self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
             # 1x1 conv
-            dW1 = torch.empty(C, C, dtype=f32, device=dev)
             ops.wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
-                                                            shift=lv['bn1'].shift, wcol0=0)], dW1)
-            grads[lk + 'conv1'] = dW1
+                                                            shift=lv['bn1'].shift, wcol0=0)], gout[lk + 'conv1'])
             nbg = ops.gemm_row_blocks(P)
             part1 = torch.empty(nbg, C, 2, dtype=f32, device=dev)
             dT1 = self._new(P, C, dt, dev)
-            W1T = lv['W1'].t().contiguous()
+            W1T = inp[lk + 'conv1T']
             ops.gemm((B, Tn, J), C, [dict(A=dT2, K=C, map=ident(Tn), W=W1T)], dT1, ident(Tn), epi=EPI_BNRELU_BWD, partials=part1,
                      X=lv['T1'], xscale=lv['bn1'].scale, xshift=lv['bn1'].shift)
             self._bn_backward(part1, nbg, 0, C, lv['bn1'], inp[lk + 'bn0.weight'], grads, lk + 'bn0', dT1, lv['T1'], P)
             # temporal conv: weight gradient (k K-segments) ...
-            dWc = torch.empty(C, k * C, dtype=f32, device=dev)
             ops.wgrad((B, Tn, J), dT1, C, ident(Tn),
                       [dict(Q=prev['O'], S=C, map=lv['taps'][tap], pro=PRO_BNRELU, scale=prev['bnO'].scale, shift=prev['bnO'].shift,
-                            wcol0=tap * C) for tap in range(k)], dWc)
-            grads[lk + 'conv'] = dWc
+                            wcol0=tap * C) for tap in range(k)], gout[lk + 'conv'])
             # ... and input gradient, fused with the residual branch and the ReLU/BN backward of the previous block's output
-            WcT = [lv['Wc'][:, tap * C:(tap + 1) * C].t().contiguous() for tap in range(k)]
+            WcT = [inp[lk + 'convT'][tap * C:(tap + 1) * C] for tap in range(k)]     # [tap][cin][cout]
             pg = 'g%d.' % (s - 1)
             if sp.strided:
                 covered = k * Tn == Tp
@@ -358,10 +349,9 @@ class Engine:
         g0 = inp['init_bn.weight'].view(1, F_in, 1)
         b0 = inp['init_bn.bias'].view(1, F_in, 1)
         W = inp['expand_w'].view(C0, F_in, k0)
-        grads['expand_w'] = (g0 * G + b0 * S.view(C0, 1, 1)).view_as(inp['expand_w'])
-        grads['init_bn.weight'] = (W * G).sum(dim=(0, 2))
-        grads['init_bn.bias'] = (W * S.view(C0, 1, 1)).sum(dim=(0, 2))
-        return grads
+        gout['expand_w'].copy_((g0 * G + b0 * S.view(C0, 1, 1)).view_as(inp['expand_w']))
+        gout['init_bn.weight'].copy_((W * G).sum(dim=(0, 2)))
+        gout['init_bn.bias'].copy_((W * S.view(C0, 1, 1)).sum(dim=(0, 2)))
 
     def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
         """dO: gradient w.r.t. Opre (pre-BN output of the block's cat_conv), (P x 2C).  Returns dX (P x C)."""
@@ -378,14 +368,12 @@ class Engine:
         pro = st['pro']
         xdrop = pro == PRO_BNRELU_DROP
         # G4 weight gradient: three K segments
-        dWbc = torch.empty(2 * C, 3 * C, dtype=f32, device=dev)
         ops.wgrad(dom, dO, 2 * C, im,
                   [dict(Q=st['X'], S=C, map=im, wcol0=0),
                    dict(Q=st['Lp'], S=C, map=im, pro=pro, scale=st['bnL'].scale, shift=st['bnL'].shift, salt=3 * s + 1, wcol0=C),
                    dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
-                  dWbc, drop=drop)
-        grads[g + 'Bbc'] = dWbc
-        WbcT = st['Wbc'].t().contiguous()       # [3C][2C]
+                  grads[g + 'Bbc'], drop=drop)
+        WbcT = inp[g + 'BbcT']       # [3C][2C]
         # input gradients of the local / global branches, fused with ReLU + dropout + BN-sum backward
         dL = self._new(P, C, dt, dev)
         partL = torch.empty(nb, C, 2, dtype=f32, device=dev)
@@ -398,11 +386,9 @@ class Engine:
                  xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2, drop=drop)
         self._bn_backward(partG, nb, 0, C, st['bnG'], inp[g + 'gcat_bn.weight'], grads, g + 'gcat_bn', dG, st['Gp'], P)
         # local cat conv
-        dWlc = torch.empty(C, 2 * C, dtype=f32, device=dev)
         ops.wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
-                                        wcol0=0)], dWlc)
-        grads[g + 'Blc'] = dWlc
-        WlcT = st['Wlc'].t().contiguous()       # [2C][C]
+                                        wcol0=0)], grads[g + 'Blc'])
+        WlcT = inp[g + 'BlcT']       # [2C][C]
         dY = self._new(P, 2 * C, dt, dev)
         partY = torch.empty(nb, 2 * C, 2, dtype=f32, device=dev)
         ops.gemm(dom, 2 * C, [dict(A=dL, K=C, map=im, W=WlcT)], dY, im, epi=EPI_BNRELU_BWD, partials=partY, X=st['Y'],
@@ -410,38 +396,28 @@ class Engine:
         self._bn_backward(partY, nb, 0, C, st['bnY'], inp[g + 'bn_1.weight'], grads, g + 'bn_1', dY, st['Y'], P, off=0, dzcol=0)
         self._bn_backward(partY, nb, C, C, st['bnY'], inp[g + 'bn_2.weight'], grads, g + 'bn_2', dY, st['Y'], P, off=C, dzcol=C)
         # global cat conv
-        dWgc = torch.empty(C, C, dtype=f32, device=dev)
-        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], dWgc)
-        grads[g + 'Bgc'] = dWgc
-        WgcT = st['Wgc'].t().contiguous()
+        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'])
+        WgcT = inp[g + 'BgcT']
         dYa = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dG, K=C, map=im, W=WgcT)], dYa, im)
         # attention core + aggregation backward fill the column blocks of dH
         H = st['H']
         dH = self._new(P, N1, dt, dev)
-        dCk = torch.zeros(NHEADS, J, J, dtype=f32, device=dev)
+        dCk = grads[g + 'C_k']
+        dCk.zero_()
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
-        grads[g + 'C_k'] = dCk
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
         ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
         ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws,
                           cdeg=(sp.deg_sym[1], sp.deg_con[1]))
-        de_s = torch.empty_like(inp[g + 'e_sym'])
-        de_c = torch.empty_like(inp[g + 'e_con'])
-        ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), de_s)
-        ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), de_c)
-        grads[g + 'e_sym'] = de_s
-        grads[g + 'e_con'] = de_c
+        ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym'])
+        ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
-        dWg1 = torch.empty(N1, C, dtype=f32, device=dev)
-        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], dWg1)
-        grads[g + 'Bg1'] = dWg1
-        dbias = torch.zeros(N1, dtype=f32, device=dev)
-        nbias = C + 2 * NHEADS
-        ops.colsum(dH[:, 4 * C:], P, nbias, dbias[4 * C:], zero_first=False)
-        grads[g + 'bias1'] = dbias
-        Wg1T = st['Wg1'].t().contiguous()       # [C][N1]
+        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'])
+        nbias = C + 2 * NHEADS      # bias gradients of g / theta / phi = column sums of their dH columns
+        ops.colsum(dH[:, 4 * C:], P, nbias, grads[g + 'bias1'][4 * C:], zero_first=True)
+        Wg1T = inp[g + 'Bg1T']       # [C][N1]
         dX = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])], dX, im)
         return dX

@@ -1,0 +1,200 @@
+"""Parameter packing / gradient unpacking tables for one model instance.
+
+The state_dict contract fixes 165 parameter tensors in PyTorch layouts.  The plan wants a handful of
+`[N][K]` K-contiguous GEMM operands in the activation dtype, in both orientations, with the attention's theta/phi folded
+(see csrc/pack_ops.hip).  `Packer` describes that mapping ONCE as three job lists
+
+  copy jobs    strided 2-D copies  parameter -> packed operand region (+ its transposed twin)
+  fold jobs    v_theta/v_phi/a_theta/a_phi of every attention head
+  unpack jobs  packed weight gradient (fp32 scratch) -> parameter-shaped gradient; unfold jobs for theta/phi/concat_project
+
+and runs each list with ONE launch (`ops.run_copy/run_fold/run_unfold`).  Addresses in the tables are (base id, byte offset)
+pairs, so the tables survive buffers that move between calls (the gradient buffer).  The numpy mirror used by the CPU tests
+interprets the same python-level job descriptions through tensor views instead of raw addresses.
+"""
+import torch
+
+NHEADS = 4
+BASE_ABS, BASE_W, BASE_F, BASE_S, BASE_G = 0, 1, 2, 3, 4   # absolute, packed weights (act dtype), packed fp32, grad scratch, grad buffer
+
+
+class Ref:
+    """A strided 2-D view: base (a tensor for BASE_ABS, else a base id), element offset, element strides."""
+    __slots__ = ('base', 'tensor', 'off', 'rs', 'cs')
+
+    def __init__(self, base, tensor, off, rs, cs):
+        self.base, self.tensor, self.off, self.rs, self.cs = base, tensor, int(off), int(rs), int(cs)
+
+
+class Layout:
+    """Named 2-D regions inside one flat buffer (offsets in elements, 16-byte aligned)."""
+
+    def __init__(self, align=8):
+        self.regions = {}
+        self.size = 0
+        self.align = align
+
+    def add(self, name, rows, cols):
+        self.regions[name] = (self.size, rows, cols)
+        self.size += (rows * cols + self.align - 1) // self.align * self.align
+
+    def view(self, buf, name):
+        off, r, c = self.regions[name]
+        return buf[off:off + r * c].view(r, c)
+
+    def ref(self, base, name, row0=0, col0=0, transposed=False):
+        off, r, c = self.regions[name]
+        if transposed:      # element (i, j) of the logical block lands at [col0 + j... ] of the region -> swap strides
+            return Ref(base, None, off + row0 * c + col0, 1, c)
+        return Ref(base, None, off + row0 * c + col0, c, 1)
+
+
+class Packer:
+    def __init__(self, model, spec):
+        self.spec = spec
+        self.params = [p for p in model.parameters()]
+        self.names = [n for n, _ in model.named_parameters()]
+        self.index = {id(p): i for i, p in enumerate(self.params)}
+        self.goff = []
+        off = 0
+        for p in self.params:
+            self.goff.append(off)
+            off += p.numel()
+        self.gsize = off
+        self.W = Layout()      # act-dtype operands
+        self.F = Layout()      # fp32 packed values (bias1, C_k)
+        self.S = Layout()      # fp32 packed gradients (same names as W/F regions that have gradients)
+        self.copy_jobs, self.fold_jobs, self.unpack_jobs, self.unfold_jobs = [], [], [], []
+        self.direct = {}       # engine key -> parameter (read directly / gradient written directly into the grad buffer)
+        self._build(model)
+        self._dev = {}
+
+    # ------------------------------------------------------------------------------------------ description
+    def _pref(self, p, off, rs, cs):
+        return Ref(BASE_ABS, p, off, rs, cs)
+
+    def _gref(self, p, off, rs, cs):
+        return Ref(BASE_G, None, self.goff[self.index[id(p)]] + off, rs, cs)
+
+    def _block(self, p, poff, R, S, prs, pcs, region, row0, regionT=None, fp32=False, grad=True):
+        """logical block B[r][s] = p.flat[poff + r*prs + s*pcs]  ->  region[row0 + r][s]  (and regionT[s][row0 + r])."""
+        base = BASE_F if fp32 else BASE_W
+        lay = self.F if fp32 else self.W
+        self.copy_jobs.append((self._pref(p, poff, prs, pcs), lay.ref(base, region, row0), R, S, fp32))
+        if regionT is not None:
+            self.copy_jobs.append((self._pref(p, poff, prs, pcs), lay.ref(base, regionT, 0, row0, transposed=True), R, S, fp32))
+        if grad:
+            self.unpack_jobs.append((self.S.ref(BASE_S, region, row0), self._gref(p, poff, prs, pcs), R, S))
+
+    def _build(self, m):
+        sp = self.spec
+        J = sp.J
+        C0 = sp.channels
+        L = len(sp.fw)
+        d = self.direct
+        d['init_bn.weight'], d['init_bn.bias'] = m.init_bn.weight, m.init_bn.bias
+        d['expand_bn.weight'], d['expand_bn.bias'] = m.expand_bn.weight, m.expand_bn.bias
+        d['expand_w'] = m.expand_conv.weight
+        for s, gab in enumerate(m.layers_graph_conv):
+            g = 'g%d.' % s
+            C = C0 * 2 ** s
+            Ci = C // NHEADS
+            N1 = 5 * C + 2 * NHEADS
+            loc, glb = gab.local_graph_layer, gab.global_graph_layer
+            for name, r, c in ((g + 'Bg1', N1, C), (g + 'Bg1T', C, N1), (g + 'Blc', C, 2 * C), (g + 'BlcT', 2 * C, C),
+                               (g + 'Bgc', C, C), (g + 'BgcT', C, C), (g + 'Bbc', 2 * C, 3 * C), (g + 'BbcT', 3 * C, 2 * C)):
+                self.W.add(name, r, c)
+            for name, r, c in ((g + 'Bg1', N1, C), (g + 'Blc', C, 2 * C), (g + 'Bgc', C, C), (g + 'Bbc', 2 * C, 3 * C),
+                               (g + 'bias1', 1, N1), (g + 'C_k', NHEADS, J * J)):
+                self.S.add(name, r, c)
+            self.F.add(g + 'bias1', 1, N1)
+            self.F.add(g + 'C_k', NHEADS, J * J)
+            # SemCH weights W (2, Cin, Cout): Bg1 rows n <- W[q][k][n]  (local_attention.py:37-38)
+            for q, (mod, row0) in enumerate(((loc.gcn_sym, 0), (loc.gcn_sym, C), (loc.gcn_con, 2 * C), (loc.gcn_con, 3 * C))):
+                self._block(mod.W, (q % 2) * C * C, C, C, 1, C, g + 'Bg1', row0, g + 'Bg1T')
+            for h, att in enumerate(glb.attentions):
+                # g conv1d (Ci, C, 1) rows 4C + h*Ci.., bias -> bias1
+                self._block(att.g.weight, 0, Ci, C, C, 1, g + 'Bg1', 4 * C + h * Ci, g + 'Bg1T')
+                self._block(att.g.bias, 0, 1, Ci, Ci, 1, g + 'bias1', 0, None, fp32=True, grad=False)
+                # the bias block lives at columns 4C + h*Ci of the single bias row
+                self.copy_jobs[-1] = (self.copy_jobs[-1][0], self.F.ref(BASE_F, g + 'bias1', 0, 4 * C + h * Ci), 1, Ci, True)
+                self.unpack_jobs.append((self.S.ref(BASE_S, g + 'bias1', 0, 4 * C + h * Ci), self._gref(att.g.bias, 0, Ci, 1), 1, Ci))
+                self._block(att.C_k, 0, 1, J * J, J * J, 1, g + 'C_k', h, None, fp32=True)
+                w = att.concat_project[0].weight          # (1, 2Ci, 1, 1)
+                for t, (conv, woff, row) in enumerate(((att.theta, 0, 5 * C + h), (att.phi, Ci, 5 * C + NHEADS + h))):
+                    self.fold_jobs.append(dict(W=conv.weight, w=w, woff=woff, b=conv.bias, Ci=Ci, C=C,
+                                               row=self.W.ref(BASE_W, g + 'Bg1', row), col=self.W.ref(BASE_W, g + 'Bg1T', 0, row, transposed=True),
+                                               bias=self.F.ref(BASE_F, g + 'bias1', 0, row)))
+                    self.unfold_jobs.append(dict(dv=self.S.ref(BASE_S, g + 'Bg1', row), da=self.S.ref(BASE_S, g + 'bias1', 0, row),
+                                                 W=conv.weight, w=w, woff=woff, b=conv.bias, Ci=Ci, C=C))
+            self._block(loc.cat_conv.weight, 0, C, 2 * C, 2 * C, 1, g + 'Blc', 0, g + 'BlcT')
+            self._block(glb.cat_conv.weight, 0, C, C, C, 1, g + 'Bgc', 0, g + 'BgcT')
+            self._block(gab.cat_conv.weight, 0, 2 * C, 3 * C, 3 * C, 1, g + 'Bbc', 0, g + 'BbcT')
+            d[g + 'e_sym'], d[g + 'e_con'] = loc.gcn_sym.e, loc.gcn_con.e
+            for key, bn in ((g + 'bn_1', loc.bn_1), (g + 'bn_2', loc.bn_2), (g + 'lcat_bn', loc.cat_bn), (g + 'gcat_bn', glb.cat_bn),
+                            (g + 'cat_bn', gab.cat_bn)):
+                d[key + '.weight'], d[key + '.bias'] = bn.weight, bn.bias
+        for i in range(1, L):
+            lk = 'l%d.' % i
+            C = C0 * 2 ** i
+            k = sp.fw[i]
+            conv, conv1 = m.layers_conv[2 * i - 2], m.layers_conv[2 * i - 1]
+            self.W.add(lk + 'conv', C, k * C)
+            self.W.add(lk + 'convT', k * C, C)
+            self.W.add(lk + 'conv1', C, C)
+            self.W.add(lk + 'conv1T', C, C)
+            self.S.add(lk + 'conv', C, k * C)
+            self.S.add(lk + 'conv1', C, C)
+            for tap in range(k):   # weight (Cout, Cin, k, 1): conv[n][tap*C + c] = w[n][c][tap];  convT[tap*C + c][n]
+                self.copy_jobs.append((self._pref(conv.weight, tap, C * k, k), self.W.ref(BASE_W, lk + 'conv', 0, tap * C), C, C, False))
+                self.copy_jobs.append((self._pref(conv.weight, tap, C * k, k), self.W.ref(BASE_W, lk + 'convT', tap * C, 0, transposed=True), C, C, False))
+                self.unpack_jobs.append((self.S.ref(BASE_S, lk + 'conv', 0, tap * C), self._gref(conv.weight, tap, C * k, k), C, C))
+            self._block(conv1.weight, 0, C, C, C, 1, lk + 'conv1', 0, lk + 'conv1T')
+            for key, bn in ((lk + 'bn0', m.layers_bn[2 * i - 2]), (lk + 'bn1', m.layers_bn[2 * i - 1])):
+                d[key + '.weight'], d[key + '.bias'] = bn.weight, bn.bias
+        CL = C0 * 2 ** L
+        self.W.add('shrink', 3, CL)
+        self.W.add('shrinkT', CL, 8)       # columns 3..7 stay zero (buffer is zero-initialised)
+        self.S.add('shrink', 8, CL)        # the weight-gradient GEMM runs on 8 padded rows
+        self._block(m.shrink.weight, 0, 3, CL, CL, 1, 'shrink', 0, 'shrinkT')
+        self.direct_index = {k: self.index[id(p)] for k, p in d.items()}
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def state(self, dev, dt):
+        """Per (device, dtype) persistent buffers + device job tables."""
+        key = (str(dev), dt)
+        st = self._dev.get(key)
+        ptrs = tuple(p.data_ptr() for p in self.params)
+        if st is None or st['ptrs'] != ptrs:
+            st = {'ptrs': ptrs, 'Wb': torch.zeros(self.W.size, dtype=dt, device=dev),
+                  'Fb': torch.zeros(self.F.size, dtype=torch.float32, device=dev), 'tables': None}
+            self._dev[key] = st
+        return st
+
+    def inputs(self, st):
+        """engine `inp` dict: operand views (act dtype), fp32 packed views, raw parameters."""
+        inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
+        for n in self.F.regions:
+            v = self.F.view(st['Fb'], n)
+            inp[n] = v.view(-1) if n.endswith('bias1') else v.view(NHEADS, self.spec.J, self.spec.J)
+        for k, p in self.direct.items():
+            inp[k] = p.detach()
+        return inp
+
+    def grad_outputs(self, G, Sb):
+        """engine `gout` dict: where every gradient is written (packed scratch views / views into the flat grad buffer)."""
+        out = {}
+        for n in self.S.regions:
+            v = self.S.view(Sb, n)
+            if n.endswith('bias1'):
+                v = v.view(-1)
+            elif n.endswith('C_k'):
+                v = v.view(NHEADS, self.spec.J, self.spec.J)
+            out[n] = v
+        for k, i in self.direct_index.items():
+            p = self.params[i]
+            out[k] = G[self.goff[i]:self.goff[i] + p.numel()].view(p.shape)
+        return out
+
+    def grad_views(self, G):
+        return [G[o:o + p.numel()].view(p.shape) for o, p in zip(self.goff, self.params)]

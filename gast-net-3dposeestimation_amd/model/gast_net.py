@@ -91,81 +91,64 @@ class ModelSpec:
         return self._tab(1, dev)
 
 
-def _bn_keys(prefix, bn, inp, bufs):
-    inp[prefix + '.weight'] = bn.weight
-    inp[prefix + '.bias'] = bn.bias
-    bufs[prefix] = {'running_mean': bn.running_mean, 'running_var': bn.running_var,
-                    'num_batches_tracked': bn.num_batches_tracked}
+def bn_buffers(model):
+    """key -> BatchNorm buffers (updated in place by the finalize kernels in train mode)."""
+    bufs = {}
 
-
-def pack_inputs(model):
-    """Parameters -> the fp32 operand layout of the plan, with ordinary differentiable torch ops on parameter-sized
-    tensors (so autograd scatters the plan's packed gradients back onto the reference-shaped parameters).
-    Returns (inp: key -> tensor that needs a gradient, bufs: key -> BatchNorm buffers)."""
-    inp, bufs = {}, {}
-    _bn_keys('init_bn', model.init_bn, inp, bufs)
-    _bn_keys('expand_bn', model.expand_bn, inp, bufs)
-    inp['expand_w'] = model.expand_conv.weight
-    inp['shrink'] = model.shrink.weight.flatten(1)
+    def add(key, bn):
+        bufs[key] = {'running_mean': bn.running_mean, 'running_var': bn.running_var, 'num_batches_tracked': bn.num_batches_tracked}
+    add('init_bn', model.init_bn)
+    add('expand_bn', model.expand_bn)
     for s, gab in enumerate(model.layers_graph_conv):
         g = 'g%d.' % s
         loc, glb = gab.local_graph_layer, gab.global_graph_layer
-        C = loc.gcn_sym.in_features
-        rows = [loc.gcn_sym.W[0].t(), loc.gcn_sym.W[1].t(), loc.gcn_con.W[0].t(), loc.gcn_con.W[1].t()]
-        rows += [att.g.weight[:, :, 0] for att in glb.attentions]
-        vth, vph, bg, ath, aph = [], [], [], [], []
-        for att in glb.attentions:
-            Ci = att.inter_channels
-            w = att.concat_project[0].weight.view(2 * Ci)
-            # f_ij = w_theta.theta_i + w_phi.phi_j is rank-1: fold theta/phi into one C-vector (+ scalar) per head
-            vth.append(att.theta.weight[:, :, 0].t() @ w[:Ci])
-            vph.append(att.phi.weight[:, :, 0].t() @ w[Ci:])
-            ath.append((w[:Ci] * att.theta.bias).sum())
-            aph.append((w[Ci:] * att.phi.bias).sum())
-            bg.append(att.g.bias)
-        rows += [torch.stack(vth), torch.stack(vph)]
-        inp[g + 'Bg1'] = torch.cat(rows, dim=0)                                   # [5C+8][C]
-        inp[g + 'bias1'] = torch.cat([loc.gcn_sym.W.new_zeros(4 * C)] + bg + [torch.stack(ath), torch.stack(aph)])
-        inp[g + 'e_sym'] = loc.gcn_sym.e
-        inp[g + 'e_con'] = loc.gcn_con.e
-        inp[g + 'C_k'] = torch.stack([att.C_k for att in glb.attentions])          # [4][J][J]
-        inp[g + 'Blc'] = loc.cat_conv.weight.flatten(1)                            # [C][2C]
-        inp[g + 'Bgc'] = glb.cat_conv.weight.flatten(1)                            # [C][C]
-        inp[g + 'Bbc'] = gab.cat_conv.weight.flatten(1)                            # [2C][3C]
-        _bn_keys(g + 'bn_1', loc.bn_1, inp, bufs)
-        _bn_keys(g + 'bn_2', loc.bn_2, inp, bufs)
-        _bn_keys(g + 'lcat_bn', loc.cat_bn, inp, bufs)
-        _bn_keys(g + 'gcat_bn', glb.cat_bn, inp, bufs)
-        _bn_keys(g + 'cat_bn', gab.cat_bn, inp, bufs)
+        for key, bn in ((g + 'bn_1', loc.bn_1), (g + 'bn_2', loc.bn_2), (g + 'lcat_bn', loc.cat_bn), (g + 'gcat_bn', glb.cat_bn),
+                        (g + 'cat_bn', gab.cat_bn)):
+            add(key, bn)
     for i in range(len(model.layers_conv) // 2):
-        lk = 'l%d.' % (i + 1)
-        w = model.layers_conv[2 * i].weight                                        # (C,C,k,1)
-        inp[lk + 'conv'] = w[:, :, :, 0].permute(0, 2, 1).reshape(w.shape[0], -1)  # [C][k*C], tap-major K
-        inp[lk + 'conv1'] = model.layers_conv[2 * i + 1].weight.flatten(1)
-        _bn_keys(lk + 'bn0', model.layers_bn[2 * i], inp, bufs)
-        _bn_keys(lk + 'bn1', model.layers_bn[2 * i + 1], inp, bufs)
-    return inp, bufs
+        add('l%d.bn0' % (i + 1), model.layers_bn[2 * i])
+        add('l%d.bn1' % (i + 1), model.layers_bn[2 * i + 1])
+    return bufs
 
 
 class _GastFunction(torch.autograd.Function):
-    """forward/backward of the whole spatio-temporal path as one autograd node."""
+    """forward/backward of the whole spatio-temporal path as one autograd node.  Inputs: x and the raw parameters (in
+    `model.parameters()` order); the packed operands are produced by one pack launch, the parameter gradients by one unpack
+    launch out of a single flat fp32 buffer."""
 
     @staticmethod
-    def forward(ctx, runner, x, training, keys, bufs, *tensors):
-        inp = dict(zip(keys, [t.detach() for t in tensors]))
+    def forward(ctx, runner, x, training, packer, st, bufs, *params):
+        ops = runner.engine.ops
+        ops.run_pack(packer, st)
+        inp = st.get('inp')
+        if inp is None:
+            inp = st['inp'] = packer.inputs(st)
         pred, sv = runner.engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device))
-        ctx.runner, ctx.keys, ctx.inp, ctx.sv = runner, keys, inp, sv
+        ctx.runner, ctx.packer, ctx.st, ctx.inp, ctx.sv = runner, packer, st, inp, sv
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
-        grads = ctx.runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous())
+        runner, packer, st = ctx.runner, ctx.packer, ctx.st
+        dev = dpred.device
+        sink = runner.grad_sink
+        G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+        Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
+        if sink is not None:     # accumulate semantics: directly-written gradients go through a scratch buffer first
+            Gd = torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+            gout = packer.grad_outputs(Gd, Sb)
+        else:
+            gout = packer.grad_outputs(G, Sb)
+        runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
         ctx.sv = None
-        out = []
-        for k, t in zip(ctx.keys, ctx.inp.values()):
-            g = grads.get(k)
-            out.append(None if g is None else g.reshape(t.shape))
-        return (None, None, None, None, None) + tuple(out)
+        if sink is not None:
+            for i in packer.direct_index.values():
+                o, n = packer.goff[i], packer.params[i].numel()
+                G[o:o + n].add_(Gd[o:o + n])
+            runner.engine.ops.run_unpack(packer, st, Sb, G, True)
+            return (None,) * 6 + (None,) * len(packer.params)
+        runner.engine.ops.run_unpack(packer, st, Sb, G, False)
+        return (None,) * 6 + tuple(packer.grad_views(G))
 
 
 class _Runner:
@@ -175,13 +158,16 @@ class _Runner:
         self.spec = spec
         self.p_dropout = float(p_dropout)
         self._engine = None
+        self._packer = None
+        self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
         self._seeds = {}
         # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
         # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
         self.ops_factory = None
 
     def __getstate__(self):
-        return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_seeds': {}, 'ops_factory': None}
+        return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_packer': None, 'grad_sink': None, '_seeds': {},
+                'ops_factory': None}
 
     @property
     def act_dtype(self):
@@ -302,9 +288,12 @@ class SpatioTemporalModelBase(nn.Module):
             raise RuntimeError('gast_net (MI355X build): input is on %s. This implementation has no CPU fallback; move the '
                                'model and the batch to the GPU (`.cuda()`).' % x.device)
         x = x.contiguous().float()
-        inp, bufs = pack_inputs(self)
-        keys = tuple(inp.keys())
-        return _GastFunction.apply(runner, x, self.training, keys, bufs, *inp.values())
+        if runner._packer is None or runner._packer.params[0] is not next(self.parameters()):
+            from gast_hip.packer import Packer
+            runner._packer = Packer(self, runner.spec)
+        packer = runner._packer
+        st = packer.state(x.device, runner.act_dtype)
+        return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), *packer.params)
 
 
 class SpatioTemporalModel(SpatioTemporalModelBase):

@@ -183,10 +183,11 @@ long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con);
  * att = softmax_j(LeakyReLU_0.2(a_i + c_j)) + C_k[h,i,j];  Y[i, hCi+c] = sum_j att_ij g[j, hCi+c]. */
 int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
                   int F, int J, int C, int nheads, void* Y, int ldy, gast_stream_t stream);
-/* Backward: dG (C cols), dAC (2*nheads cols) written; dC_k[nheads][J][J] accumulated atomically (caller zeroes). */
+/* Backward: dG (C cols), dAC (2*nheads cols) written; dC_k[nheads][J][J] and (optional) dbias_ac[2*nheads] = column sums of
+ * dAC taken in fp32 before rounding (bias gradients of theta / phi) are accumulated atomically (caller zeroes). */
 int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
                   const float* C_k, int F, int J, int C, int nheads,
-                  void* dG, int lddg, void* dAC, int lddac, float* dC_k, gast_stream_t stream);
+                  void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias_ac, gast_stream_t stream);
 
 /* ---- BatchNorm2d (momentum 0.1, eps 1e-5; gast_net.py:20,58-59,147,149 etc.) as a two-phase scheme ---------
  * Producers emit per-row-block partial sums; `gast_bn_finalize` turns them into the per-channel scale/shift that
@@ -235,6 +236,21 @@ int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, 
 
 /* out[n] (+)= sum_m X[m, n]   (bias gradients of the g / theta / phi 1x1 convs, global_attention.py:30-35) */
 int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out, int zero_first, gast_stream_t stream);
+
+/* ---- parameter packing / gradient unpacking (replaces ~600 tiny ATen kernels per step; reference layouts: App. D) ----
+ * Pointer words: (byte_offset << 4) | base_id, address = bases[base_id] + byte_offset; `bases` is a HOST array of 8 byte
+ * addresses copied into the launch (base 0 is conventionally 0, i.e. absolute addresses; the others let a table built once
+ * address buffers that move between calls, e.g. the gradient buffer).  Strides are in elements of the respective type.
+ * copy job (10 int64): src word, dst word, R, S, src_row_stride, src_col_stride, dst_row_stride, dst_col_stride,
+ *   flags (1 = src bf16, 2 = dst bf16, 4 = accumulate into fp32 dst, 8 = zero-fill dst), reserved.
+ *   `tiles`: int32 triples (job, row tile, col tile) of 32x32 tiles, one block each.
+ * fold job (12 int64): W word [Ci][C] fp32, w word [Ci], b word [Ci], Ci, C, dst_row word, dst_row stride, dst_col word,
+ *   dst_col stride, bias_dst word (fp32), dst_bf16, reserved:   v[k] = sum_m W[m][k] w[m];  bias = sum_m w[m] b[m]
+ *   (theta/phi folding of the additive attention, global_attention.py:60-74).
+ * unfold job (12 int64): dv word, da word, W, w, b, dW, dw, db words, Ci, C, accumulate, reserved. */
+int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int ntiles, const int64_t* bases, gast_stream_t stream);
+int gast_fold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream);
+int gast_unfold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream);
 
 /* library identification: returns a static string "gast_hip <version> gfx950" */
 const char* gast_version(void);

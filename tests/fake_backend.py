@@ -82,8 +82,8 @@ class OracleOps:
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):
         kc.attn_fwd(_np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(Y))
 
-    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k):
-        kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k))
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias_ac=None):
+        kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k), dbias_ac=_np(dbias_ac))
 
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale,
                     shift, mean, rstd):
@@ -127,6 +127,54 @@ class OracleOps:
 
     def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
         kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(G), _np(S))
+
+
+def _resolve(ref, bases, R, S):
+    from gast_hip.packer import BASE_ABS
+    flat = ref.tensor.detach().view(-1) if ref.base == BASE_ABS else bases[ref.base]
+    return torch.as_strided(flat, (R, S), (ref.rs, ref.cs), ref.off)
+
+
+def _run_pack(self, packer, st):
+    from gast_hip.packer import BASE_W, BASE_F
+    bases = {BASE_W: st['Wb'], BASE_F: st['Fb']}
+    for job in packer.copy_jobs:
+        src, dst, R, S = job[:4]
+        _resolve(dst, bases, R, S).copy_(_resolve(src, bases, R, S))
+    for j in packer.fold_jobs:
+        Ci, Cc = j['Ci'], j['C']
+        W = j['W'].detach().view(Ci, Cc).double()
+        w = j['w'].detach().view(-1)[j['woff']:j['woff'] + Ci].double()
+        v = (W * w[:, None]).sum(0)
+        torch.as_strided(bases[BASE_W], (Cc,), (j['row'].cs,), j['row'].off).copy_(v)
+        torch.as_strided(bases[BASE_W], (Cc,), (j['col'].cs,), j['col'].off).copy_(v)
+        bases[BASE_F][j['bias'].off] = float((w * j['b'].detach().double()).sum())
+
+
+def _run_unpack(self, packer, st, Sb, G, accumulate):
+    from gast_hip.packer import BASE_S, BASE_G
+    bases = {BASE_S: Sb, BASE_G: G}
+    for src, dst, R, S in packer.unpack_jobs:
+        d = _resolve(dst, bases, R, S)
+        v = _resolve(src, bases, R, S)
+        d.add_(v) if accumulate else d.copy_(v)
+    for j in packer.unfold_jobs:
+        Ci, Cc = j['Ci'], j['C']
+        dv = torch.as_strided(Sb, (Cc,), (1,), j['dv'].off).double()
+        da = float(Sb[j['da'].off])
+        W = j['W'].detach().view(Ci, Cc).double()
+        w = j['w'].detach().view(-1)[j['woff']:j['woff'] + Ci].double()
+        b = j['b'].detach().double()
+        gW = packer.goff[packer.index[id(j['W'])]]
+        gw = packer.goff[packer.index[id(j['w'])]] + j['woff']
+        gb = packer.goff[packer.index[id(j['b'])]]
+        outs = ((G[gW:gW + Ci * Cc].view(Ci, Cc), w[:, None] * dv[None, :]), (G[gw:gw + Ci], W @ dv + b * da), (G[gb:gb + Ci], w * da))
+        for dst, val in outs:
+            dst.add_(val.to(dst.dtype)) if accumulate else dst.copy_(val.to(dst.dtype))
+
+
+OracleOps.run_pack = _run_pack
+OracleOps.run_unpack = _run_unpack
 
 
 def use_oracle_ops(model):

@@ -26,7 +26,7 @@ def _worker(rank, world, port, out_dir):
     torch.manual_seed(0)                                   # identical replicas
     adj = torch.from_numpy(adj_from_parents(PARENTS[17]))
     m = use_oracle_ops(SpatioTemporalModelOptimized1f(adj, 17, 2, 17, filter_widths=[3, 3], channels=16, dropout=0.0))
-    sync = FlatGradAllReduce(m.parameters())
+    sync = FlatGradAllReduce(m.parameters(), model=m)     # backward accumulates straight into the flat buffer
     g = torch.Generator().manual_seed(7)
     X = torch.rand(6, 9, 17, 2, generator=g) * 2 - 1       # the global batch; sharded on dim 0
     Y = torch.randn(6, 1, 17, 3, generator=g) * 0.3

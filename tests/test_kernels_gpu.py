@@ -289,9 +289,11 @@ def test_attention(ops, J, C, F, dt):
     dY = rand(gen, P, C).to(dt)
     dHd = torch.full((P, ld), 2.0).to(dt).cuda()
     dCk = torch.zeros(nh, J, J).cuda()
-    ops.attn_bwd(dY.cuda(), G, AC, Ck.cuda(), F, J, C, nh, dHd[:, :C], dHd[:, C:C + 2 * nh], dCk)
-    dG, dAC, dCkh = np.zeros((P, C)), np.zeros((P, 2 * nh)), np.zeros((nh, J, J))
-    kc.attn_bwd(host(dY), Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, dG, dAC, dCkh, round_fn=rnd)
+    dbac = torch.zeros(2 * nh).cuda()
+    ops.attn_bwd(dY.cuda(), G, AC, Ck.cuda(), F, J, C, nh, dHd[:, :C], dHd[:, C:C + 2 * nh], dCk, dbias_ac=dbac)
+    dG, dAC, dCkh, dbach = np.zeros((P, C)), np.zeros((P, 2 * nh)), np.zeros((nh, J, J)), np.zeros(2 * nh)
+    kc.attn_bwd(host(dY), Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, dG, dAC, dCkh, round_fn=rnd, dbias_ac=dbach)
+    assert np.abs(host(dbac) - dbach).max() <= (2e-4 if dt == torch.float32 else 2e-2) * max(1.0, np.abs(dbach).max()), 'attn bwd dbias_ac'
     got = host(dHd)
     close(got[:, :C], dG, dt, 'attn bwd dG')
     close(got[:, C:C + 2 * nh], dAC, dt, 'attn bwd dAC', fp32=1e-4, bf16=3e-2)
@@ -448,3 +450,37 @@ def test_input_side(ops, B, T, J, k0, ts, C, dt):
     kc.expand_bwd(host(dE), host(x), B, T, J, F_in, k0, ts, host(mean0), host(rstd0), C, Gh, Sh)
     close(host(G), Gh, dt, 'expand_bwd G', fp32=1e-4, bf16=1e-2)
     close(host(S), Sh, dt, 'expand_bwd S', fp32=1e-4, bf16=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ pack / unpack
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+def test_pack_unpack_tables(ops, dt):
+    """gast_strided_copy / gast_fold / gast_unfold driven by the real job tables of a model, against the tensor-view mirror."""
+    import copy
+    from fake_backend import OracleOps
+    from gast_hip.packer import Packer
+    from model.gast_net import SpatioTemporalModel
+    from oracle.gast_oracle import adj_from_parents
+    torch.manual_seed(3)
+    m = SpatioTemporalModel(torch.from_numpy(adj_from_parents(PARENTS[17])), 17, 2, 17, filter_widths=[3, 3, 3], channels=32)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.1)
+    mg = copy.deepcopy(m).cuda()
+    pk_c, pk_g = Packer(m, m._runner.spec), Packer(mg, mg._runner.spec)
+    st_c, st_g = pk_c.state(torch.device('cpu'), torch.float32), pk_g.state(torch.device('cuda'), dt)
+    mirror = OracleOps()
+    mirror.run_pack(pk_c, st_c)
+    ops.run_pack(pk_g, st_g)
+    torch.cuda.synchronize()
+    close(host(st_g['Wb']), host(st_c['Wb']), dt, 'packed operands', fp32=1e-6, bf16=8e-3)
+    close(host(st_g['Fb']), host(st_c['Fb']), torch.float32, 'packed fp32 values', fp32=1e-6)
+    gen = torch.Generator().manual_seed(4)
+    Sb = torch.randn(pk_c.S.size, generator=gen)
+    for acc in (False, True):
+        Gc = torch.full((pk_c.gsize,), 0.5)
+        Gg = torch.full((pk_g.gsize,), 0.5).cuda()
+        mirror.run_unpack(pk_c, st_c, Sb, Gc, acc)
+        ops.run_unpack(pk_g, st_g, Sb.cuda(), Gg, acc)
+        torch.cuda.synchronize()
+        close(host(Gg), host(Gc), torch.float32, 'unpacked gradients acc=%s' % acc, fp32=2e-5)
