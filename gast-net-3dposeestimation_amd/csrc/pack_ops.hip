@@ -61,28 +61,41 @@ __global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restric
 }
 
 // fold: v[k] = sum_m W[m][k] * w[m]  (k < C, m < Ci), a = sum_m w[m] * b[m]
-//   -> dst_row[k * ds_row]  and dst_col[k * ds_col] (both optional, activation dtype), bias_dst (fp32)
+//   -> dst_row[k * ds_row]  and dst_col[k * ds_col] (activation dtype), bias_dst (fp32)
+// grid = (njobs, ceil(C/32)); 256 threads = 32 columns x 8 m-lanes (each lane sums every 8th m, LDS combine)
 constexpr int FJ_WORDS = 12;
 __global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs, const Bases bs) {
     const long* bases = bs.v;
+    __shared__ float sred[8][32];
     const long* j = jobs + (long)blockIdx.x * FJ_WORDS;
     const float* W = (const float*)(bases[j[0] & 7] + (j[0] >> 4));
     const float* w = (const float*)(bases[j[1] & 7] + (j[1] >> 4));
     const float* b = (const float*)(bases[j[2] & 7] + (j[2] >> 4));
     const int Ci = (int)j[3], C = (int)j[4];
+    if ((int)blockIdx.y * 32 >= C) return;
     char* d_row = (char*)(bases[j[5] & 7] + (j[5] >> 4));
     const long ds_row = j[6];
     char* d_col = (char*)(bases[j[7] & 7] + (j[7] >> 4));
     const long ds_col = j[8];
     float* d_bias = (float*)(bases[j[9] & 7] + (j[9] >> 4));
     const int dst_bf16 = (int)j[10];
-    for (int k = threadIdx.x; k < C; k += 256) {
-        float acc = 0.f;
-        for (int m = 0; m < Ci; ++m) acc = fmaf(W[(long)m * C + k], w[m], acc);
-        if (dst_bf16) { ((bf16_t*)d_row)[k * ds_row] = f2bf(acc); ((bf16_t*)d_col)[k * ds_col] = f2bf(acc); }
-        else { ((float*)d_row)[k * ds_row] = acc; ((float*)d_col)[k * ds_col] = acc; }
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int k = blockIdx.y * 32 + cx;
+    float acc = 0.f;
+    if (k < C) {
+#pragma unroll 4
+        for (int m = ry; m < Ci; m += 8) acc = fmaf(W[(long)m * C + k], w[m], acc);
     }
-    if (threadIdx.x == 0) {
+    sred[ry][cx] = acc;
+    __syncthreads();
+    if (ry == 0 && k < C) {
+        float v = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v += sred[r][cx];
+        if (dst_bf16) { ((bf16_t*)d_row)[k * ds_row] = f2bf(v); ((bf16_t*)d_col)[k * ds_col] = f2bf(v); }
+        else { ((float*)d_row)[k * ds_row] = v; ((float*)d_col)[k * ds_col] = v; }
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) {
         float a = 0.f;
         for (int m = 0; m < Ci; ++m) a = fmaf(w[m], b[m], a);
         *d_bias = a;
@@ -91,10 +104,10 @@ __global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs
 
 // unfold (gradient of fold): given dv[k] (fp32, stride 1) and da (fp32 scalar):
 //   dW[m][k] (+)= w[m] * dv[k];   dw[m] (+)= sum_k W[m][k] * dv[k] + b[m] * da;   db[m] (+)= w[m] * da
+// grid = (njobs, ceil(Ci/4)): one wave per row m, wave-shuffle reduction over k (no barriers)
 constexpr int UJ_WORDS = 12;
 __global__ void __launch_bounds__(256) unfold_kernel(const long* __restrict__ jobs, const Bases bs) {
     const long* bases = bs.v;
-    __shared__ float sred[4];
     const long* j = jobs + (long)blockIdx.x * UJ_WORDS;
     const float* dv = (const float*)(bases[j[0] & 7] + (j[0] >> 4));
     const float* da = (const float*)(bases[j[1] & 7] + (j[1] >> 4));
@@ -105,26 +118,23 @@ __global__ void __launch_bounds__(256) unfold_kernel(const long* __restrict__ jo
     float* dw = (float*)(bases[j[6] & 7] + (j[6] >> 4));
     float* db = (float*)(bases[j[7] & 7] + (j[7] >> 4));
     const int Ci = (int)j[8], C = (int)j[9], accumulate = (int)j[10];
-    const float dav = *da;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int m = 0; m < Ci; ++m) {
-        const float wm = w[m];
-        float part = 0.f;
-        for (int k = threadIdx.x; k < C; k += 256) {
-            const float d = dv[k];
-            part = fmaf(W[(long)m * C + k], d, part);
-            const long o = (long)m * C + k;
-            if (accumulate) dW[o] += wm * d; else dW[o] = wm * d;
-        }
+    const int m = blockIdx.y * 4 + wv;
+    if (m >= Ci) return;
+    const float dav = *da;
+    const float wm = w[m];
+    float part = 0.f;
+    for (int k = lane; k < C; k += 64) {
+        const float d = dv[k];
+        const long o = (long)m * C + k;
+        part = fmaf(W[o], d, part);
+        if (accumulate) dW[o] += wm * d; else dW[o] = wm * d;
+    }
 #pragma unroll
-        for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-        __syncthreads();
-        if (lane == 0) sred[wv] = part;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const float tot = sred[0] + sred[1] + sred[2] + sred[3] + b[m] * dav;
-            if (accumulate) { dw[m] += tot; db[m] += wm * dav; } else { dw[m] = tot; db[m] = wm * dav; }
-        }
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) {
+        const float tot = part + b[m] * dav;
+        if (accumulate) { dw[m] += tot; db[m] += wm * dav; } else { dw[m] = tot; db[m] = wm * dav; }
     }
 }
 
@@ -140,22 +150,24 @@ extern "C" int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int 
     return 0;
 }
 
-extern "C" int gast_fold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream) {
-    if (!jobs || !bases || njobs < 0) return GAST_EINVAL;
+extern "C" int gast_fold(const int64_t* jobs, int njobs, int max_C, const int64_t* bases, gast_stream_t stream) {
+    if (!jobs || !bases || njobs < 0 || max_C < 1) return GAST_EINVAL;
+    const int max_c32 = (max_C + 31) / 32;
     if (njobs == 0) return 0;
     Bases b;
     for (int i = 0; i < 8; ++i) b.v[i] = bases[i];
-    hipLaunchKernelGGL(fold_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, b);
+    hipLaunchKernelGGL(fold_kernel, dim3(njobs, max_c32), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int gast_unfold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream) {
-    if (!jobs || !bases || njobs < 0) return GAST_EINVAL;
+extern "C" int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases, gast_stream_t stream) {
+    if (!jobs || !bases || njobs < 0 || max_Ci < 1) return GAST_EINVAL;
+    const int max_ci4 = (max_Ci + 3) / 4;
     if (njobs == 0) return 0;
     Bases b;
     for (int i = 0; i < 8; ++i) b.v[i] = bases[i];
-    hipLaunchKernelGGL(unfold_kernel, dim3(njobs), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, b);
+    hipLaunchKernelGGL(unfold_kernel, dim3(njobs, max_ci4), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -104,8 +104,8 @@ def load_library():
         'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
-        'gast_fold': [vp, ci, vp, vp],
-        'gast_unfold': [vp, ci, vp, vp],
+        'gast_fold': [vp, ci, ci, vp, vp],
+        'gast_unfold': [vp, ci, ci, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -411,7 +411,7 @@ class HipOps:
         self.launches += 2
         _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
         ft, nf = tb['fold']
-        _check(self.lib.gast_fold(_p(ft), nf, C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
+        _check(self.lib.gast_fold(_p(ft), nf, max(j['C'] for j in packer.fold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
 
     def run_unpack(self, packer, st, Sb, G, accumulate):
         dev = G.device
@@ -419,4 +419,4 @@ class HipOps:
         bases = self._bases(S=Sb, G=G)
         self.launches += 2
         _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
-        _check(self.lib.gast_unfold(_p(ut), nu, C.cast(bases, C.c_void_p), _stream()), 'gast_unfold')
+        _check(self.lib.gast_unfold(_p(ut), nu, max(j['Ci'] for j in packer.unfold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_unfold')

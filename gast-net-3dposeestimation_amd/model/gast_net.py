@@ -134,17 +134,15 @@ class _GastFunction(torch.autograd.Function):
         sink = runner.grad_sink
         G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
         Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
-        if sink is not None:     # accumulate semantics: directly-written gradients go through a scratch buffer first
-            Gd = torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+        if sink is not None:     # accumulate semantics: directly-written gradients go through a zeroed scratch buffer first
+            Gd = torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
             gout = packer.grad_outputs(Gd, Sb)
         else:
             gout = packer.grad_outputs(G, Sb)
         runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
         ctx.sv = None
         if sink is not None:
-            for i in packer.direct_index.values():
-                o, n = packer.goff[i], packer.params[i].numel()
-                G[o:o + n].add_(Gd[o:o + n])
+            G.add_(Gd)                                                     # one fused add for all directly-written gradients
             runner.engine.ops.run_unpack(packer, st, Sb, G, True)
             return (None,) * 6 + (None,) * len(packer.params)
         runner.engine.ops.run_unpack(packer, st, Sb, G, False)

@@ -249,8 +249,8 @@ int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out,
  *   (theta/phi folding of the additive attention, global_attention.py:60-74).
  * unfold job (12 int64): dv word, da word, W, w, b, dW, dw, db words, Ci, C, accumulate, reserved. */
 int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int ntiles, const int64_t* bases, gast_stream_t stream);
-int gast_fold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream);
-int gast_unfold(const int64_t* jobs, int njobs, const int64_t* bases, gast_stream_t stream);
+int gast_fold(const int64_t* jobs, int njobs, int max_C, const int64_t* bases, gast_stream_t stream);      /* max_C  = largest C of the jobs */
+int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases, gast_stream_t stream);  /* max_Ci = largest Ci */
 
 /* library identification: returns a static string "gast_hip <version> gfx950" */
 const char* gast_version(void);
