@@ -76,7 +76,7 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
 }
 
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg) {
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -155,9 +155,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M
     constexpr int NSS = EPC / 4;               // 16-byte chunks of scale (and of shift) per thread
     constexpr int NL = 8 + 2 * NSS;            // loads per register set
     struct RegSet { u32x4 a[4], b[4], sc[NSS], sh[NSS]; };
-    RegSet R0, R1;
-    SegRegs L, S0, S1;     // L: segment of the next tile to load; S0/S1: segments of the tiles held by R0/R1
-    int l_s = 0, l_k0 = 0, k0_0 = 0, k0_1 = 0;
+    RegSet R0;
+    SegRegs L, S0;     // L: segment of the next tile to load; S0/S1: segments of the tiles held by R0/R1
+    int l_s = 0, l_k0 = 0, k0_0 = 0;
 
     auto load_set = [&](RegSet& R, SegRegs& S, int& sk0) {
         S = L; sk0 = l_k0;
@@ -224,29 +224,19 @@ __global__ void __launch_bounds__(256) gemm_kernel(const gast_gemm_args a, int M
         }
     };
 
+    // single register set, three blocks per CU: measured equal to the 2-deep ring per block, and 3 resident blocks overlap the
+    // load / stage / MFMA / epilogue phases of different tiles better than 2
     fetch_seg(0, L);
     load_set(R0, S0, k0_0);
-    bool have1 = l_s < a.nseg;
-    if (have1) load_set(R1, S1, k0_1);
     while (true) {
-        // ---- R0 holds the current tile
-        if (have1) gload_wait_n<NL>(); else gload_wait_n<0>();
+        gload_wait_n<0>();
         __syncthreads();                // everyone finished reading the previous tile
         store_set(R0, S0, k0_0);
         __syncthreads();
-        const bool have0 = l_s < a.nseg;
-        if (have0) load_set(R0, S0, k0_0);
+        const bool more = l_s < a.nseg;
+        if (more) load_set(R0, S0, k0_0);
         compute_tile();
-        if (!have1) break;
-        // ---- R1 holds the current tile
-        if (have0) gload_wait_n<NL>(); else gload_wait_n<0>();
-        __syncthreads();
-        store_set(R1, S1, k0_1);
-        __syncthreads();
-        have1 = l_s < a.nseg;
-        if (have1) load_set(R1, S1, k0_1);
-        compute_tile();
-        if (!have0) break;
+        if (!more) break;
     }
 
     // ------------------------------------------------------------------ epilogue

@@ -51,7 +51,7 @@ __device__ __forceinline__ void rows_for(const gast_wgrad_args& a, const gast_wg
 }
 
 // ------------------------------------------------------------------------------------------------ fp32
-__global__ void __launch_bounds__(256) wgrad_f32_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
+__global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
                                                         int mchunk) {
     constexpr int BKM = 32;
     __shared__ __attribute__((aligned(16))) float sP[BKM * FSTR];
@@ -200,7 +200,7 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&
     }
 }
 
-__global__ void __launch_bounds__(256) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
+__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
                                                          int mchunk) {
     constexpr int BKM = 64;
     __shared__ __attribute__((aligned(16))) unsigned char sP[BT * LSTR];
