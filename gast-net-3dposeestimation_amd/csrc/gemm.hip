@@ -76,7 +76,7 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
 }
 
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg) {
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -90,7 +90,9 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
     const int tid = threadIdx.x;
     const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int logical = xcd_remap(blockIdx.x, gridM * gridN);
+    // split-K (small-M GEMMs: few output tiles, long K): blockIdx.x = tile * splitk + split
+    const int sp = blockIdx.x % splitk;
+    const int logical = xcd_remap(blockIdx.x / splitk, gridM * gridN);
     const int mt = logical / gridN, nt = logical - mt * gridN;
 
     if (tid < BM) {
@@ -226,17 +228,51 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
 
     // single register set, three blocks per CU: measured equal to the 2-deep ring per block, and 3 resident blocks overlap the
     // load / stage / MFMA / epilogue phases of different tiles better than 2
-    fetch_seg(0, L);
-    load_set(R0, S0, k0_0);
-    while (true) {
-        gload_wait_n<0>();
-        __syncthreads();                // everyone finished reading the previous tile
-        store_set(R0, S0, k0_0);
-        __syncthreads();
-        const bool more = l_s < a.nseg;
-        if (more) load_set(R0, S0, k0_0);
-        compute_tile();
-        if (!more) break;
+    // this block's K-tile range [t_begin, t_end) of the flattened (segment, k0) tile list
+    int ntiles_all = 0;
+    for (int sgi = 0; sgi < a.nseg; ++sgi) ntiles_all += (a.seg[sgi].K + BK - 1) / BK;
+    const int tps = (ntiles_all + splitk - 1) / splitk;
+    const int t_begin = sp * tps;
+    int t_left = min(ntiles_all, t_begin + tps) - t_begin;
+    if (t_left > 0) {
+        int skip = t_begin;
+        while (true) {     // advance to the segment that contains tile t_begin
+            const int nts = (a.seg[l_s].K + BK - 1) / BK;
+            if (skip < nts) break;
+            skip -= nts;
+            ++l_s;
+        }
+        l_k0 = skip * BK;
+        fetch_seg(l_s, L);
+        load_set(R0, S0, k0_0);
+        while (true) {
+            gload_wait_n<0>();
+            __syncthreads();                // everyone finished reading the previous tile
+            store_set(R0, S0, k0_0);
+            __syncthreads();
+            --t_left;
+            const bool more = t_left > 0;
+            if (more) load_set(R0, S0, k0_0);
+            compute_tile();
+            if (!more) break;
+        }
+    }
+    if (splitk > 1) {
+        // raw fp32 partial tile -> workspace [split][M][N]; bias / addend / epilogue run in splitk_finish_kernel
+        float* wsp = ws + (long)sp * M * a.N;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int n = nt * BN + wc * 64 + ni * 32 + li;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mt * BM + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) wsp[(long)m * a.N + n] = acc[mi][ni][r];
+                }
+        }
+        return;
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -445,13 +481,91 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
     }
 }
 
+// ---- split-K finish: C = epi(sum_split ws + bias + addend), same epilogue semantics and partial-sum layout as gemm_kernel.
+// grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
+// are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args a, int M, int gridN, int splitk, const float* __restrict__ ws) {
+    __shared__ float sRed[8][BN][2];
+    const int tid = threadIdx.x;
+    const int rg = blockIdx.x / gridN, nt = blockIdx.x - rg * gridN;
+    const int cc = tid & 31, rq = tid >> 5;
+    const int n0 = nt * BN + cc * 4;
+    const int m = rg * 8 + rq;
+    const int epi = a.epi;
+    const uint32_t thresh = a.drop.thresh;
+    const float inv_keep = a.drop.inv_keep;
+    const bool xdrop = epi == GAST_EPI_BNRELU_BWD && a.xdrop && thresh != 0;
+    const uint32_t xkey = xdrop ? drop_key(a.drop, a.xsalt) : 0u;
+    float st1[4] = {0, 0, 0, 0}, st2[4] = {0, 0, 0, 0};
+    if (m < M && n0 < a.N) {
+        const int TJ = a.Tn * a.J;
+        const int b = m / TJ, rem = m - b * TJ;
+        const int t = rem / a.J, j = rem - t * a.J;
+        const long crow = map_row(a.cmap, b, t, j, a.J);
+        const long arow = a.addend ? map_row(a.addmap, b, t, j, a.J) : -1;
+        if (crow >= 0) {
+            float v4[4] = {0, 0, 0, 0};
+            const bool full = n0 + 3 < a.N && (a.N & 3) == 0;
+            for (int s = 0; s < splitk; ++s) {
+                const float* p = ws + ((long)s * M + m) * a.N + n0;
+                if (full) { const float4 q = *(const float4*)p; v4[0] += q.x; v4[1] += q.y; v4[2] += q.z; v4[3] += q.w; }
+                else { for (int q = 0; q < 4; ++q) if (n0 + q < a.N) v4[q] += p[q]; }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + q;
+                if (n >= a.N) continue;
+                float v = v4[q];
+                if (a.bias) v += a.bias[n];
+                if (arow >= 0) v += Elem<T>::ld((const T*)a.addend + arow * a.ldadd + n);
+                if (epi == GAST_EPI_BNRELU_BWD) {
+                    const float x = Elem<T>::ld((const T*)a.X + crow * a.ldx + n);
+                    if (!(fmaf(x, a.xscale[n], a.xshift[n]) > 0.f)) v = 0.f;
+                    if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(crow * a.ldx + n));
+                    v = Elem<TO>::rnd(v);
+                    st1[q] = v;
+                    st2[q] = v * x;
+                } else if (epi == GAST_EPI_STATS) {
+                    v = Elem<TO>::rnd(v);
+                    st1[q] = v;
+                    st2[q] = v * v;
+                }
+                Elem<TO>::st((TO*)a.C + crow * a.ldc + n, v);
+            }
+        }
+    }
+    if (epi != GAST_EPI_PLAIN) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sRed[rq][cc * 4 + q][0] = st1[q]; sRed[rq][cc * 4 + q][1] = st2[q]; }
+        __syncthreads();
+        if (tid < BN) {
+            const int n = nt * BN + tid;
+            if (n < a.N) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int r = 0; r < 8; ++r) { t1 += sRed[r][tid][0]; t2 += sRed[r][tid][1]; }
+                float* pp = a.partials + ((long)((rg * 8) / BM) * a.N + n) * 2;
+                atomicAdd(pp, t1);
+                atomicAdd(pp + 1, t2);
+            }
+        }
+    }
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 }  // namespace
 
 extern "C" int gast_gemm_row_blocks(int M) { return (M + BM - 1) / BM; }
 
-extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) {
+// fp32 workspace the caller may provide to let small-M GEMMs split their K loop over several blocks
+extern "C" long gast_gemm_splitk_ws_bytes(long M, int N) { return 8L * M * N * (long)sizeof(float); }
+
+extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
+extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) { return gast_gemm_ws(args, nullptr, 0, stream); }
+
+extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream) {
     if (!args) return GAST_EINVAL;
     const gast_gemm_args& a = *args;
     if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
@@ -471,7 +585,22 @@ extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) {
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
     const int M = (int)Ml;
     const int gridM = (M + BM - 1) / BM, gridN = (a.N + BN - 1) / BN;
-    dim3 grid(gridM * gridN), block(256);
+    // split-K: few output tiles and a long K loop (the M = B*J rows of the last stage): up to 8 K ranges per tile
+    int ntiles = 0;
+    for (int s2 = 0; s2 < a.nseg; ++s2) ntiles += (a.seg[s2].K + 8 * epc - 1) / (8 * epc);
+    int splitk = 1;
+    if (ws && gridM * gridN <= 160 && ntiles >= 4) {
+        splitk = 512 / (gridM * gridN);
+        if (splitk > 8) splitk = 8;
+        if (splitk > ntiles / 2) splitk = ntiles / 2;
+        if (splitk < 1) splitk = 1;
+        if ((long)splitk * M * a.N * (long)sizeof(float) > ws_bytes) splitk = 1;
+        if (splitk > 1) {
+            const int tps = (ntiles + splitk - 1) / splitk;
+            splitk = (ntiles + tps - 1) / tps;      // no empty K ranges
+        }
+    }
+    dim3 grid(gridM * gridN * splitk), block(256);
     hipStream_t st = (hipStream_t)stream;
     // the coalesced (LDS-staged, 16-byte) epilogue needs same-width in/out element types and 16-byte aligned rows
     int vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
@@ -479,11 +608,25 @@ extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) {
     if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
     static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling ablations only
     if (a.dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
+        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     else if (a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     else
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     GAST_CHECK_LAUNCH();
+    if (splitk > 1) {
+        if (a.epi != GAST_EPI_PLAIN) {
+            hipError_t e = hipMemsetAsync(a.partials, 0, (size_t)gridM * a.N * 2 * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        dim3 fgrid(gridN * ((M + 7) / 8));
+        if (a.dtype == GAST_F32)
+            hipLaunchKernelGGL((splitk_finish_kernel<float, float>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
+        else if (a.out_f32)
+            hipLaunchKernelGGL((splitk_finish_kernel<bf16_t, float>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
+        else
+            hipLaunchKernelGGL((splitk_finish_kernel<bf16_t, bf16_t>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
+        GAST_CHECK_LAUNCH();
+    }
     return 0;
 }

@@ -81,6 +81,8 @@ def load_library():
     sig = {
         'gast_gemm': [C.POINTER(_GemmArgs), vp],
         'gast_gemm_row_blocks': [ci],
+        'gast_gemm_ws': [C.POINTER(_GemmArgs), vp, cl, vp],
+        'gast_gemm_splitk_ws_bytes': [cl, ci],
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
@@ -112,13 +114,14 @@ def load_library():
         fn.argtypes = argtypes
         fn.restype = ci
     lib.gast_semch_agg_bwd_ws_floats.restype = C.c_long
+    lib.gast_gemm_splitk_ws_bytes.restype = C.c_long
     lib.gast_version.restype = C.c_char_p
     lib.gast_version.argtypes = []
     _lib = lib
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
@@ -176,6 +179,15 @@ class HipOps:
     def __init__(self):
         self.lib = load_library()
         self.launches = 0
+        self._ws = {}            # per device: fp32 split-K workspace (allocated once, before any graph capture)
+
+    SPLITK_WS_BYTES = 96 << 20
+
+    def _splitk_ws(self, dev):
+        ws = self._ws.get(dev)
+        if ws is None:
+            ws = self._ws[dev] = torch.empty(self.SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
+        return ws
 
     # -- GEMM family
     def gemm_row_blocks(self, M):
@@ -210,7 +222,8 @@ class HipOps:
         a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
         a.drop = _drop(drop)
         self.launches += 1
-        _check(self.lib.gast_gemm(C.byref(a), _stream()), 'gast_gemm')
+        ws = self._splitk_ws(C_.device)
+        _check(self.lib.gast_gemm_ws(C.byref(a), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm')
 
     def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         a = _WgradArgs()

@@ -111,6 +111,11 @@ typedef struct {
 } gast_gemm_args;
 
 int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
+/* Same, with an fp32 workspace: GEMMs with few output tiles and a long K loop (the M = B*J rows of the last stage) split K
+ * over up to 8 blocks per tile and a finish kernel applies bias / addend / epilogue.  ws_bytes >= gast_gemm_splitk_ws_bytes(M, N)
+ * enables every split the heuristic may pick; a smaller or null workspace simply disables splitting. */
+int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
+long gast_gemm_splitk_ws_bytes(long M, int N);
 /* number of row blocks (first dimension of `partials`) gast_gemm uses for a domain of M rows */
 int gast_gemm_row_blocks(int M);
 

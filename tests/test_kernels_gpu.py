@@ -90,6 +90,9 @@ GEMM_CASES = [
     ('dgrad_gather_addend_bwd', (2, 11, 17), 64, [(64, 5, 1, 0, 0), (64, 5, 1, -3, 0), (64, 5, 1, -6, 0)], 2, True, False),
     ('ktail', (1, 9, 15), 33 * 4, [(5 * 32 + 8, 9, 1, 0, 0), (72, 9, 1, 0, 0)], 0, False, False),
     ('big', (8, 9, 17), 256, [(256, 9, 1, 0, 1)], 1, False, False),
+    ('splitk_stats', (4, 1, 17), 200, [(512, 1, 1, 0, 1), (512, 1, 1, 0, 2)], 1, False, True),
+    ('splitk_bwd_taps', (3, 1, 17), 64, [(256, 3, 1, 0, 0), (256, 3, 1, 1, 0), (256, 3, 1, 2, 0)], 2, True, False),
+    ('splitk_plain', (2, 2, 19), 36, [(1288, 2, 1, 0, 0)], 0, False, False),
 ]
 
 
