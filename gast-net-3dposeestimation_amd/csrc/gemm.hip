@@ -313,7 +313,7 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
                 for (int ni = 0; ni < 2; ++ni) {
                     const int nl = wc * 64 + ni * 32 + li;
                     const int n = nt * BN + nl;
-                    const float bias = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+                    const float bias = (a.bias && n < a.N) ? (a.bias_neg ? -a.bias[n] : a.bias[n]) : 0.f;
 #pragma unroll
                     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
         const int nl = wc * 64 + ni * 32 + li;
         const int n = nt * BN + nl;
         const bool nin = n < a.N;
-        float bias = (a.bias && nin) ? a.bias[n] : 0.f;
+        float bias = (a.bias && nin) ? (a.bias_neg ? -a.bias[n] : a.bias[n]) : 0.f;
         float xs = 0.f, xh = 0.f;
         if (epi == GAST_EPI_BNRELU_BWD && nin) { xs = a.xscale[n]; xh = a.xshift[n]; }
 #pragma unroll
@@ -517,7 +517,7 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args
                 const int n = n0 + q;
                 if (n >= a.N) continue;
                 float v = v4[q];
-                if (a.bias) v += a.bias[n];
+                if (a.bias) v += a.bias_neg ? -a.bias[n] : a.bias[n];
                 if (arow >= 0) v += Elem<T>::ld((const T*)a.addend + arow * a.ldadd + n);
                 if (epi == GAST_EPI_BNRELU_BWD) {
                     const float x = Elem<T>::ld((const T*)a.X + crow * a.ldx + n);

@@ -73,7 +73,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict__ H, int ldh, int F, int J, int C,
                                                             const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                             const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
-                                                            T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB) {
+                                                            T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB,
+                                                            const float* __restrict__ ctr_s, const float* __restrict__ ctr_c) {
     __shared__ float sred[256][8];
     const int tid = threadIdx.x;
     const int slot = tid / TPF, ct = tid - slot * TPF;
@@ -103,6 +104,8 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
                             float4 hv = ld4(Hf + (long)j * ldh + (j == i ? h0c : h1c));
                             acc = fma4(av, hv, acc);
                         }
+                        const float* ctr = g == 0 ? ctr_s : ctr_c;
+                        if (ctr) { const float4 c4v = *(const float4*)(ctr + c); acc.x -= c4v.x; acc.y -= c4v.y; acc.z -= c4v.z; acc.w -= c4v.w; }
                         acc = rnd4(acc, (const T*)nullptr);
                         st4(Yf + (long)i * ldy + g * C + c, acc);
                         s1[g] = add4(s1[g], acc);
@@ -139,7 +142,8 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
 template <typename T, int D>
 __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, T* __restrict__ Yf, int ldy, int J, int C,
                                              const float* __restrict__ A, const int32_t* __restrict__ ell_j,
-                                             const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2) {
+                                             const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2,
+                                             float4 ctr) {
     for (int i = 0; i < J; ++i) {
         int jj[D], kk[D];
 #pragma unroll
@@ -153,6 +157,7 @@ __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, 
         float4 acc = make_float4(0, 0, 0, 0);
 #pragma unroll
         for (int d = 0; d < D; ++d) acc = fma4(av[d], hv[d], acc);
+        acc.x -= ctr.x; acc.y -= ctr.y; acc.z -= ctr.z; acc.w -= ctr.w;
         acc = rnd4(acc, (const T*)nullptr);
         st4(Yf + (long)i * ldy + yc, acc);
         s1 = add4(s1, acc);
@@ -164,7 +169,8 @@ template <typename T, int DS, int DC>
 __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restrict__ H, int ldh, int F, int J, int C,
                                                                 const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
-                                                                T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB) {
+                                                                T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB,
+                                                                const float* __restrict__ ctr_s, const float* __restrict__ ctr_c) {
     __shared__ float sred[256][8];
     const int tid = threadIdx.x;
     const int slot = tid / TPF, ct = tid - slot * TPF;
@@ -181,8 +187,11 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
             for (int f = blockIdx.x * FB + slot; f < F; f += gridDim.x * FB) {
                 const T* Hf = H + (long)f * J * ldh;
                 T* Yf = Y + (long)f * J * ldy;
-                agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, A_sym, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0]);
-                agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, A_con, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1]);
+                const float4 z4 = make_float4(0, 0, 0, 0);
+                agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, A_sym, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0],
+                                    ctr_s ? *(const float4*)(ctr_s + c) : z4);
+                agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, A_con, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1],
+                                    ctr_c ? *(const float4*)(ctr_c + c) : z4);
             }
         }
 #pragma unroll
@@ -646,7 +655,8 @@ extern "C" int gast_semch_agg_blocks(int F, int C) {
 
 extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
                                   const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
-                                  const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials, gast_stream_t stream) {
+                                  const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials,
+                                  const float* center_sym, const float* center_con, gast_stream_t stream) {
     if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || !partials) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
@@ -657,10 +667,10 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     do {                                                                                                                     \
         if (dtype == GAST_F32)                                                                                               \
             hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, \
-                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB);                           \
+                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);   \
         else                                                                                                                 \
             hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, \
-                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB);                       \
+                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con); \
     } while (0)
     // the fixed-degree kernels walk exactly DS / DC padded slots per row: the pattern tables must have been built with
     // these degrees, which is the case for deg_sym == 2 (every supported skeleton) and deg_con in {5, 6}
@@ -668,10 +678,10 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     else if (deg_sym == 2 && deg_con == 6) AGG_FWD_ELL(2, 6);
     else if (dtype == GAST_F32)
         hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
-                           A_con, pat_con, (float*)Y, ldy, partials, TPF, FB);
+                           A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);
     else
         hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym,
-                           A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB);
+                           A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con);
 #undef AGG_FWD_ELL
     GAST_CHECK_LAUNCH();
     return 0;

@@ -75,7 +75,7 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
 __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
                                    double count, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
                                    float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
-                                   float* mean_out, float* rstd_out) {
+                                   float* mean_out, float* rstd_out, int centered) {
     __shared__ double sred[FIN_LANES][FIN_COLS][2];
     const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
     const int n = blockIdx.x * FIN_COLS + cx;
@@ -93,19 +93,21 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     rstd_out[n] = rstd;
     if (running_mean) {
         double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+        // centred storage: the statistics are those of x - running_mean, so the true batch mean is running_mean + mean
+        running_mean[n] = centered ? running_mean[n] + momentum * (float)mean
+                                   : (1.f - momentum) * running_mean[n] + momentum * (float)mean;
         running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unb;
     }
     if (n == 0 && nbt) *nbt += 1;
 }
 
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
-                               const float* __restrict__ rv, float eps, int N, float* scale, float* shift) {
+                               const float* __restrict__ rv, float eps, int N, float* scale, float* shift, int centered) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float sc = gamma[n] / sqrtf(rv[n] + eps);
     scale[n] = sc;
-    shift[n] = beta[n] - rm[n] * sc;
+    shift[n] = centered ? beta[n] : beta[n] - rm[n] * sc;
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
@@ -322,7 +324,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict__ x, int B, int T_in, int J, int F_in, int k0,
                                                          int t_stride, int T_out, const float* __restrict__ W,
                                                          const float* __restrict__ sc0, const float* __restrict__ sh0, int C,
-                                                         T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB) {
+                                                         T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB,
+                                                         const float* __restrict__ center) {
     extern __shared__ __attribute__((aligned(16))) float sW[];  // [K0][C] then sred
     __shared__ float sred[256][8];
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
@@ -355,6 +358,7 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
                         e.x = fmaf(xv, w.x, e.x); e.y = fmaf(xv, w.y, e.y); e.z = fmaf(xv, w.z, e.z); e.w = fmaf(xv, w.w, e.w);
                     }
                 }
+                if (center) { const float4 cv = *(const float4*)(center + c); e.x -= cv.x; e.y -= cv.y; e.z -= cv.z; e.w -= cv.w; }
                 e = rnd4(e, (const T*)nullptr);
                 st4(E + r * lde + c, e);
                 acc[0].x += e.x; acc[0].y += e.y; acc[0].z += e.z; acc[0].w += e.w;
@@ -451,20 +455,20 @@ extern "C" int gast_rowwise_blocks(long rows, int N) { return row_blocks(rows, N
 extern "C" int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float momentum, float eps,
-                                float* scale, float* shift, float* mean, float* rstd, gast_stream_t stream) {
+                                float* scale, float* shift, float* mean, float* rstd, int centered, gast_stream_t stream) {
     if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
     if ((running_mean == nullptr) != (running_var == nullptr)) return GAST_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0, N,
-                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd);
+                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd, centered);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
 extern "C" int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                            float eps, int N, float* scale, float* shift, gast_stream_t stream) {
+                            float eps, int N, float* scale, float* shift, int centered, gast_stream_t stream) {
     if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || N < 1) return GAST_EINVAL;
     hipLaunchKernelGGL(bn_eval_kernel, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, gamma, beta, running_mean, running_var,
-                       eps, N, scale, shift);
+                       eps, N, scale, shift, centered);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -583,7 +587,7 @@ static inline int conv_t_out(int T_in, int k0, int t_stride) { return (T_in - k0
 
 extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                                const float* W, const float* sc0, const float* sh0, int C,
-                               void* E, int lde, float* partials, gast_stream_t stream) {
+                               void* E, int lde, float* partials, const float* center, gast_stream_t stream) {
     if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials) return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || lde % 4) return GAST_EALIGN;
@@ -602,10 +606,10 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
     }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
-                           C, (float*)E, lde, partials, c.TPR, c.RB);
+                           C, (float*)E, lde, partials, c.TPR, c.RB, center);
     else
         hipLaunchKernelGGL((expand_fwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0,
-                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB);
+                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -49,7 +49,7 @@ class _GemmSeg(C.Structure):
 class _GemmArgs(C.Structure):
     _fields_ = [('dtype', C.c_int), ('out_f32', C.c_int), ('B', C.c_int), ('Tn', C.c_int), ('J', C.c_int), ('N', C.c_int),
                 ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
-                ('bias', C.c_void_p), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
+                ('bias', C.c_void_p), ('bias_neg', C.c_int), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
                 ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
                 ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout)]
 
@@ -86,14 +86,14 @@ def load_library():
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
-        'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp],
+        'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp],
         'gast_semch_agg_blocks': [ci, ci],
         'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
         'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
         'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp],
-        'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, vp],
-        'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, vp],
+        'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp],
+        'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, vp],
@@ -102,7 +102,7 @@ def load_library():
         'gast_residual_fwd': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp],
         'gast_input_stats': [vp, cl, ci, vp, vp, vp],
         'gast_input_stats_blocks': [cl],
-        'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp],
+        'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp],
         'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
@@ -194,7 +194,7 @@ class HipOps:
         return self.lib.gast_gemm_row_blocks(int(M))
 
     def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-             xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None):
+             xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         a = _GemmArgs()
         a.dtype = _dt(segs[0]['A'])
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
@@ -212,6 +212,7 @@ class HipOps:
             g.salt = int(s.get('salt', 0))
         a.C, a.ldc, a.cmap = _p(C_), _ld(C_), _rm(cmap)
         a.bias = _p(bias)
+        a.bias_neg = int(bool(bias_neg))
         if addend is not None:
             a.addend, a.ldadd, a.addmap = _p(addend), _ld(addend), _rm(addmap)
         a.epi = int(epi)
@@ -258,11 +259,13 @@ class HipOps:
     def semch_agg_blocks(self, F, C_):
         return self.lib.gast_semch_agg_blocks(int(F), int(C_))
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0)):
-        """A_*: [nnz+1][C] (row nnz all zero); deg = (Dr_sym, Dr_con) of the pattern tables selects the unrolled kernels."""
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
+        """A_*: [nnz+1][C] (row nnz all zero); deg = (Dr_sym, Dr_con) of the pattern tables selects the unrolled kernels;
+        center = (bn_1.running_mean, bn_2.running_mean) or Nones: subtracted from the stored outputs."""
         self.launches += 1
         _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), int(deg[0]), _p(A_con),
-                                           _p(pat_con), int(deg[1]), _p(Y), _ld(Y), _p(partials), _stream()), 'gast_semch_agg_fwd')
+                                           _p(pat_con), int(deg[1]), _p(Y), _ld(Y), _p(partials), _p(center[0]), _p(center[1]),
+                                           _stream()), 'gast_semch_agg_fwd')
 
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return self.lib.gast_semch_agg_bwd_ws_floats(int(F), int(C_), int(nnz_sym), int(nnz_con))
@@ -288,15 +291,16 @@ class HipOps:
 
     # -- BatchNorm pieces
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
-                    scale, shift, mean, rstd):
+                    scale, shift, mean, rstd, centered=False):
         self.launches += 1
         _check(self.lib.gast_bn_finalize(_p(partials), nblk, partials.shape[1], col0, N, float(count), _p(gamma), _p(beta),
                                          _p(running_mean), _p(running_var), _p(nbt), momentum, eps, _p(scale), _p(shift),
-                                         _p(mean), _p(rstd), _stream()), 'gast_bn_finalize')
+                                         _p(mean), _p(rstd), int(bool(centered)), _stream()), 'gast_bn_finalize')
 
-    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift):
+    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         self.launches += 1
-        _check(self.lib.gast_bn_eval(_p(gamma), _p(beta), _p(rm), _p(rv), eps, N, _p(scale), _p(shift), _stream()), 'gast_bn_eval')
+        _check(self.lib.gast_bn_eval(_p(gamma), _p(beta), _p(rm), _p(rv), eps, N, _p(scale), _p(shift), int(bool(centered)),
+                                     _stream()), 'gast_bn_eval')
 
     def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc):
         self.launches += 1
@@ -341,10 +345,10 @@ class HipOps:
         self.launches += 1
         _check(self.lib.gast_input_stats(_p(x), rows, F_in, _p(partials), None, _stream()), 'gast_input_stats')
 
-    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials):
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
         self.launches += 1
         _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
-                                        _p(partials), _stream()), 'gast_expand_fwd')
+                                        _p(partials), _p(center), _stream()), 'gast_expand_fwd')
 
     def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
         self.launches += 1

@@ -52,23 +52,31 @@ class BNState:
 class Engine:
     """Executes the plan for one model instance.  `spec` is built by model.gast_net (see `ModelSpec`)."""
 
-    def __init__(self, spec, ops):
+    def __init__(self, spec, ops, centered=False):
         self.spec = spec
         self.ops = ops
+        # centred storage (bf16 activations): every lazily-normalised pre-BN tensor is stored as x - running_mean so that its
+        # bf16 rounding error scales with the spread of the channel, not with |mean| (DESIGN.md section 5)
+        self.centered = bool(centered)
+
+    def _ctr(self, bn):
+        return bn['running_mean'] if self.centered else None
 
     # ------------------------------------------------------------------------------------------ helpers
     def _new(self, rows, cols, dt, dev, zero=False):
         return (torch.zeros if zero else torch.empty)(rows, cols, dtype=dt, device=dev)
 
-    def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0):
+    def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0, centered=False):
         """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n)."""
         ops = self.ops
         sl = slice(off, off + n)
         if training:
             ops.bn_finalize(partials, nblk, col0, n, count, bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'],
-                            bn['num_batches_tracked'], BN_MOMENTUM, BN_EPS, st.scale[sl], st.shift[sl], st.mean[sl], st.rstd[sl])
+                            bn['num_batches_tracked'], BN_MOMENTUM, BN_EPS, st.scale[sl], st.shift[sl], st.mean[sl], st.rstd[sl],
+                            centered=centered)
         else:
-            ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl])
+            ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl],
+                        centered=centered)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, inp, bufs, training, act_dtype, drop):
@@ -102,9 +110,11 @@ class Engine:
         E = self._new(P0, C0, dt, dev)
         nbE = ops.rowwise_blocks(P0, C0)
         partE = torch.empty(nbE, C0, 2, dtype=torch.float32, device=dev)
-        ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE)
+        cen = self.centered
+        ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE,
+                       center=self._ctr(bufs['expand_bn']))
         bnE = BNState(C0, dev, P0)
-        self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training)
+        self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen)
         X = self._new(P0, C0, dt, dev)
         ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
         sv.update(x=x, bn0=bn0, E=E, bnE=bnE, T=T)
@@ -137,15 +147,16 @@ class Engine:
                 part1 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
                 segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
                              scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
-                ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1)
+                ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
+                         bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
                 bn1 = BNState(C, dev, P)
-                self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training)
+                self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
                 part2 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
                 ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
-                         T2, ident(Tn), epi=EPI_STATS, partials=part2)
+                         T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
                 bn2 = BNState(C, dev, P)
-                self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training)
+                self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen)
                 X = self._new(P, C, dt, dev)
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
                                  use_drop, 3 * s, drop, B, Tn, J, C, X)
@@ -190,10 +201,12 @@ class Engine:
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
-        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]))
+        cen = self.centered
+        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
+                          center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
         bnY = BNState(2 * C, dev, P)
-        self._bn_forward(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, training, off=0)
-        self._bn_forward(partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, training, off=C)
+        self._bn_forward(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, training, off=0, centered=cen)
+        self._bn_forward(partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, training, off=C, centered=cen)
         # global attention core
         Ya = self._new(P, C, dt, dev)
         ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
@@ -201,14 +214,15 @@ class Engine:
         Lp = self._new(P, C, dt, dev)
         partL = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
         ops.gemm(dom, C, [dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)], Lp, im,
-                 epi=EPI_STATS, partials=partL)
+                 epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen)
         bnL = BNState(C, dev, P)
-        self._bn_forward(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, training)
+        self._bn_forward(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, training, centered=cen)
         Gp = self._new(P, C, dt, dev)
         partG = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
-        ops.gemm(dom, C, [dict(A=Ya, K=C, map=im, W=Wgc)], Gp, im, epi=EPI_STATS, partials=partG)
+        ops.gemm(dom, C, [dict(A=Ya, K=C, map=im, W=Wgc)], Gp, im, epi=EPI_STATS, partials=partG,
+                 bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)
         bnG = BNState(C, dev, P)
-        self._bn_forward(partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, training)
+        self._bn_forward(partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, training, centered=cen)
         # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised
         pro = PRO_BNRELU_DROP if use_drop else PRO_BNRELU
         O = self._new(P, 2 * C, dt, dev)
@@ -216,9 +230,9 @@ class Engine:
         segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]),
                 dict(A=Lp, K=C, map=im, W=Wbc[:, C:2 * C], pro=pro, scale=bnL.scale, shift=bnL.shift, salt=3 * s + 1),
                 dict(A=Gp, K=C, map=im, W=Wbc[:, 2 * C:3 * C], pro=pro, scale=bnG.scale, shift=bnG.shift, salt=3 * s + 2)]
-        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, drop=drop)
+        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, drop=drop, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
         bnO = BNState(2 * C, dev, P)
-        self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training)
+        self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, Lp=Lp, bnL=bnL, Gp=Gp, bnG=bnG, O=O, bnO=bnO,
                     C=C, Tn=Tn, P=P, pro=pro)
 

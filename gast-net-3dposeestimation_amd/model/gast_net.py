@@ -123,6 +123,7 @@ class _GastFunction(torch.autograd.Function):
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
+        runner.engine.centered = runner.centered
         pred, sv = runner.engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device))
         ctx.runner, ctx.packer, ctx.st, ctx.inp, ctx.sv = runner, packer, st, inp, sv
         return pred
@@ -175,6 +176,14 @@ class _Runner:
         if v in ('bf16', 'bfloat16'):
             return torch.bfloat16
         raise ValueError('GAST_HIP_DTYPE must be fp32 or bf16, got %r' % v)
+
+    @property
+    def centered(self):
+        """Store pre-BN tensors as x - running_mean?  GAST_HIP_CENTER = auto (default: on for bf16 activations) | 0 | 1."""
+        v = os.environ.get('GAST_HIP_CENTER', 'auto').lower()
+        if v == 'auto':
+            return self.act_dtype == torch.bfloat16
+        return v not in ('0', 'off', 'false')
 
     @property
     def engine(self):

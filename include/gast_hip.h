@@ -96,6 +96,7 @@ typedef struct {
     int ldc;
     gast_rowmap cmap;     /* where row m is stored */
     const float* bias;    /* [N] or null */
+    int bias_neg;         /* subtract bias instead of adding it ("centred" storage of a pre-BN tensor: C = acc - running_mean) */
     const void* addend;   /* optional [rows][ldadd], added before the epilogue non-linearity */
     int ldadd;
     gast_rowmap addmap;
@@ -172,7 +173,8 @@ int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t
  * gast_semch_agg_blocks). */
 int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
                        const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con, const int32_t* pat_con,
-                       int deg_con, void* Y, int ldy, float* partials, gast_stream_t stream);   /* deg_* = Dr of the tables */
+                       int deg_con, void* Y, int ldy, float* partials, const float* center_sym, const float* center_con,
+                       gast_stream_t stream);   /* deg_* = Dr of the tables; center_* (nullable, [C]) are subtracted from the outputs */
 int gast_semch_agg_blocks(int F, int C);
 /* Backward: dH columns [0,4C) and dA = [dA_sym (nnz_sym rows) ; dA_con (nnz_con rows)] x C, fully written (no zero-fill
  * needed).  ws: workspace of gast_semch_agg_bwd_ws_floats() floats for the per-block partial rows. */
@@ -197,12 +199,14 @@ int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, co
 /* ---- BatchNorm2d (momentum 0.1, eps 1e-5; gast_net.py:20,58-59,147,149 etc.) as a two-phase scheme ---------
  * Producers emit per-row-block partial sums; `gast_bn_finalize` turns them into the per-channel scale/shift that
  * consumers apply on load, and updates the running statistics exactly as nn.BatchNorm2d does in train mode. */
+/* centered != 0: the statistics belong to a tensor stored as x - running_mean (value of running_mean before this call): the
+ * running mean update becomes running_mean += momentum * mean', scale/shift/mean refer to the stored (centred) values. */
 int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float momentum, float eps,
-                     float* scale, float* shift, float* mean, float* rstd, gast_stream_t stream);
+                     float* scale, float* shift, float* mean, float* rstd, int centered, gast_stream_t stream);
 int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
-                 float eps, int N, float* scale, float* shift, gast_stream_t stream);
+                 float eps, int N, float* scale, float* shift, int centered, gast_stream_t stream);
 /* partials hold {sum dz, sum dz*x}; writes dgamma, dbeta and the per-channel coefficients of
  * dx = ka*dz + kb*x + kc. */
 int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
@@ -233,7 +237,7 @@ int gast_input_stats_blocks(long rows);
 /* E[(b,t,j), c] = sum_{f,tap} W[c][f][tap] * (sc0[f]*x[(b, t*t_stride+tap, j), f] + sh0[f]) + partial sums for expand_bn */
 int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                     const float* W, const float* sc0, const float* sh0, int C,
-                    void* E, int lde, float* partials, gast_stream_t stream);
+                    void* E, int lde, float* partials, const float* center, gast_stream_t stream);   /* center: nullable [C], subtracted */
 /* G[c][f][tap] = sum_m dE[m,c]*xhat[(b,t*ts+tap,j), f],  S[c] = sum_m dE[m,c]   (both fp32, zero-filled here) */
 int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
                     int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,

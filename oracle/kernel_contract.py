@@ -85,7 +85,7 @@ def _ld(a):
 
 # ------------------------------------------------------------------------------------------------ gemm / wgrad
 def gemm(dom, N, segs, C, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-         xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, round_fn=None):
+         xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, round_fn=None, bias_neg=False):
     """segs: list of dicts {A, K, map, W, pro, scale, shift, salt}.  drop = (seed, thresh, inv_keep) or None.
     Writes C (and partials) in place.  round_fn emulates storage rounding (identity for fp32)."""
     B, Tn, J = dom
@@ -97,7 +97,7 @@ def gemm(dom, N, segs, C, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLA
         a = _prologue(a, ok, rows, _ld(s['A']), s['K'], s.get('pro', 0), s.get('scale'), s.get('shift'), s.get('salt', 0), drop)
         acc += a @ np.asarray(s['W'][:N, :s['K']], np.float64).T
     if bias is not None:
-        acc += np.asarray(bias, np.float64)[None, :N]
+        acc += (-1.0 if bias_neg else 1.0) * np.asarray(bias, np.float64)[None, :N]
     crow = map_rows(cmap, B, Tn, J)
     if addend is not None:
         ar = map_rows(addmap, B, Tn, J)
@@ -227,7 +227,7 @@ def semch_agg_blocks(F, C):
     return min((F + fb - 1) // fb, 512)
 
 
-def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round_fn=None):
+def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round_fn=None, center_sym=None, center_con=None):
     Hf = np.asarray(H[:F * J, :4 * C], np.float64).reshape(F, J, 4 * C)
     out = np.zeros((F, J, 2 * C))
     for g, (A, pat) in enumerate(((A_sym, pat_sym), (A_con, pat_con))):
@@ -239,6 +239,9 @@ def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round
             i, j = erow[k], col[k]
             src = h0 if i == j else h1
             out[:, i, g * C:(g + 1) * C] += A[k][None, :] * src[:, j, :]
+    for g, ctr in enumerate((center_sym, center_con)):
+        if ctr is not None:
+            out[:, :, g * C:(g + 1) * C] -= np.asarray(ctr, np.float64)[None, None, :C]
     if round_fn is not None:
         out = round_fn(out)
     Y[:F * J, :2 * C] = out.reshape(F * J, 2 * C)
@@ -321,7 +324,8 @@ def attn_bwd(dY, G, AC, C_k, F, J, C, nheads, dG, dAC, dC_k, round_fn=None, dbia
 
 # ------------------------------------------------------------------------------------------------ BatchNorm pieces
 def bn_finalize(partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,
-                scale, shift, mean, rstd):
+                scale, shift, mean, rstd, centered=False):
+    """centered: the statistics are those of x - running_mean (value before this call); see gast_hip.h."""
     p = np.asarray(partials[:nblk, col0:col0 + N], np.float64)
     s1, s2 = p[:, :, 0].sum(axis=0), p[:, :, 1].sum(axis=0)
     mu = s1 / count
@@ -334,16 +338,16 @@ def bn_finalize(partials, nblk, col0, N, count, gamma, beta, running_mean, runni
     rstd[:N] = r
     if running_mean is not None:
         unb = var * (count / (count - 1.0)) if count > 1 else var
-        running_mean[:N] = (1 - momentum) * running_mean[:N] + momentum * mu
+        running_mean[:N] = (running_mean[:N] + momentum * mu) if centered else ((1 - momentum) * running_mean[:N] + momentum * mu)
         running_var[:N] = (1 - momentum) * running_var[:N] + momentum * unb
     if nbt is not None:
         nbt[...] = nbt + 1
 
 
-def bn_eval(gamma, beta, rm, rv, eps, N, scale, shift):
+def bn_eval(gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
     sc = np.asarray(gamma, np.float64) / np.sqrt(np.asarray(rv, np.float64) + eps)
     scale[:N] = sc
-    shift[:N] = np.asarray(beta, np.float64) - np.asarray(rm, np.float64) * sc
+    shift[:N] = np.asarray(beta, np.float64) - (0.0 if centered else np.asarray(rm, np.float64) * sc)
 
 
 def bn_bwd_finalize(partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc):
@@ -446,11 +450,13 @@ def _expand_taps(x, B, T_in, J, F_in, k0, t_stride):
     return T_out, taps
 
 
-def expand_fwd(x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, partials, round_fn=None):
+def expand_fwd(x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, partials, round_fn=None, center=None):
     T_out, taps = _expand_taps(x, B, T_in, J, F_in, k0, t_stride)
     xn = taps * np.asarray(sc0, np.float64)[None, None, None, :, None] + np.asarray(sh0, np.float64)[None, None, None, :, None]
     w = np.asarray(W, np.float64).reshape(C, F_in, k0)
     e = np.einsum('btjfk,cfk->btjc', xn, w).reshape(B * T_out * J, C)
+    if center is not None:
+        e = e - np.asarray(center, np.float64)[None, :C]
     if round_fn is not None:
         e = round_fn(e)
     rows = B * T_out * J

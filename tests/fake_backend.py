@@ -48,11 +48,11 @@ class OracleOps:
         return kc.gemm_row_blocks(M)
 
     def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, xscale=None,
-             xshift=None, xdrop=False, xsalt=0, drop=None):
+             xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         self.launches += 1
         kc.gemm(dom, N, _segs(segs, 'A'), _np(C_), kc.RowMap(*cmap), _np(bias), _np(addend),
                 kc.RowMap(*addmap) if addmap is not None else None, epi, _np(partials), _np(X), _np(xscale), _np(xshift),
-                xdrop, xsalt, _drop(drop))
+                xdrop, xsalt, _drop(drop), bias_neg=bias_neg)
 
     def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         self.launches += 1
@@ -67,8 +67,9 @@ class OracleOps:
     def semch_agg_blocks(self, F, C_):
         return kc.semch_agg_blocks(F, C_)
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0)):
-        kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials))
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
+        kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials),
+                         center_sym=_np(center[0]), center_con=_np(center[1]))
 
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return 1
@@ -86,12 +87,12 @@ class OracleOps:
         kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k), dbias_ac=_np(dbias_ac))
 
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale,
-                    shift, mean, rstd):
+                    shift, mean, rstd, centered=False):
         kc.bn_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(beta), _np(running_mean), _np(running_var), _np(nbt),
-                       momentum, eps, _np(scale), _np(shift), _np(mean), _np(rstd))
+                       momentum, eps, _np(scale), _np(shift), _np(mean), _np(rstd), centered=centered)
 
-    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift):
-        kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift))
+    def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
+        kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift), centered=centered)
 
     def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc_):
         kc.bn_bwd_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(mean), _np(rstd), _np(dgamma), _np(dbeta), _np(ka),
@@ -122,8 +123,8 @@ class OracleOps:
     def input_stats(self, x, rows, F_in, partials):
         kc.input_stats(_np(x), rows, F_in, _np(partials))
 
-    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials):
-        kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials))
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
+        kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials), center=_np(center))
 
     def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
         kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(G), _np(S))

@@ -93,6 +93,8 @@ GEMM_CASES = [
     ('splitk_stats', (4, 1, 17), 200, [(512, 1, 1, 0, 1), (512, 1, 1, 0, 2)], 1, False, True),
     ('splitk_bwd_taps', (3, 1, 17), 64, [(256, 3, 1, 0, 0), (256, 3, 1, 1, 0), (256, 3, 1, 2, 0)], 2, True, False),
     ('splitk_plain', (2, 2, 19), 36, [(1288, 2, 1, 0, 0)], 0, False, False),
+    ('centred_stats', (3, 5, 17), 136, [(64, 5, 1, 0, 1)], 1, False, 'neg'),
+    ('centred_splitk', (4, 1, 17), 200, [(512, 1, 1, 0, 1), (512, 1, 1, 0, 2)], 1, False, 'neg'),
 ]
 
 
@@ -101,6 +103,8 @@ GEMM_CASES = [
 def test_gemm(ops, case, dt):
     from gast_hip.binding import Dropout, dropout_params
     name, dom, N, segdefs, epi, use_add, use_bias = case
+    bias_neg = use_bias == 'neg'      # centred storage: C = acc - bias
+    use_bias = bool(use_bias)
     gen = torch.Generator().manual_seed(sum(map(ord, name)))
     B, Tn, J = dom
     M = B * Tn * J
@@ -140,10 +144,11 @@ def test_gemm(ops, case, dt):
     ops.gemm(dom, N, segs_d, Cd[:, :N], cmap, bias=bias.cuda() if use_bias else None, addend=add.cuda() if use_add else None,
              addmap=addmap, epi=epi, partials=pd, X=X.cuda() if X is not None else None,
              xscale=xs.cuda() if xs is not None else None, xshift=xh.cuda() if xh is not None else None,
-             xdrop=epi == 2, xsalt=9, drop=Dropout(seed_tensor(seed), thresh, inv_keep))
+             xdrop=epi == 2, xsalt=9, drop=Dropout(seed_tensor(seed), thresh, inv_keep), bias_neg=bias_neg)
     kc.gemm(dom, N, segs_h, Ch[:, :N], cmap, bias=host(bias) if use_bias else None, addend=host(add) if use_add else None,
             addmap=addmap, epi=epi, partials=ph, X=host(X) if X is not None else None, xscale=host(xs) if xs is not None else None,
-            xshift=host(xh) if xh is not None else None, xdrop=epi == 2, xsalt=9, drop=(seed, thresh, inv_keep), round_fn=rnd)
+            xshift=host(xh) if xh is not None else None, xdrop=epi == 2, xsalt=9, drop=(seed, thresh, inv_keep), round_fn=rnd,
+            bias_neg=bias_neg)
     torch.cuda.synchronize()
     got = host(Cd)
     close(got[:, :N], Ch[:, :N], dt, name + ' C')
@@ -242,11 +247,15 @@ def test_semch_agg(ops, J, C, F, dt):
     Y = torch.zeros(P, 2 * C).to(dt).cuda()
     nb = ops.semch_agg_blocks(F, C)
     part = torch.zeros(nb, 2 * C, 2).cuda()
-    ops.semch_agg_fwd(H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), Y, part, deg=deg)
+    # odd C-products exercise the centred storage (outputs minus a per-channel centre), the others the plain one
+    ctr = (rand(gen, C), rand(gen, C)) if (J * C) % 2 == 0 else (None, None)
+    ops.semch_agg_fwd(H.cuda(), F, J, C, As.cuda(), dev(ps), Ac.cuda(), dev(pc), Y, part, deg=deg,
+                      center=tuple(c.cuda() if c is not None else None for c in ctr))
     Yh = np.zeros((P, 2 * C))
     ph = np.zeros((nb, 2 * C, 2))
     rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
-    kc.semch_agg_fwd(host(H), F, J, C, host(As)[:-1], ps, host(Ac)[:-1], pc, Yh, ph, round_fn=rnd)
+    kc.semch_agg_fwd(host(H), F, J, C, host(As)[:-1], ps, host(Ac)[:-1], pc, Yh, ph, round_fn=rnd,
+                     center_sym=host(ctr[0]) if ctr[0] is not None else None, center_con=host(ctr[1]) if ctr[1] is not None else None)
     close(host(Y), Yh, dt, 'agg fwd')
     close(host(part).sum(0), ph.sum(0), dt, 'agg partial totals', fp32=1e-4, bf16=3e-2)
     close(host(part), ph, dt, 'agg partials per block', fp32=1e-4, bf16=3e-2)
@@ -335,8 +344,29 @@ def test_bn_finalize_and_backward(ops):
     bn.train(); bn(x)
     close(host(rmd), host(bn.running_mean), torch.float32, 'running_mean vs torch', fp32=1e-5)
     close(host(rvd), host(bn.running_var), torch.float32, 'running_var vs torch', fp32=1e-5)
+    # centred storage: statistics of (x - running_mean) must produce the same running stats and an equivalent affine map
+    xc = x - rm[None, :]
+    partc = torch.zeros(nblk, ncol, 2)
+    for b, ch in enumerate(torch.chunk(xc, nblk)):
+        partc[b, col0:col0 + N, 0] = ch.sum(0)
+        partc[b, col0:col0 + N, 1] = (ch * ch).sum(0)
+    outc = [torch.zeros(N).cuda() for _ in range(4)]
+    rmc, rvc, nbtc = rm.cuda(), rv.cuda(), nbt.cuda()
+    ops.bn_finalize(partc.cuda(), nblk, col0, N, count, gamma.cuda(), beta.cuda(), rmc, rvc, nbtc, 0.1, 1e-5, *outc, centered=True)
+    hc = [np.zeros(N) for _ in range(4)]
+    rmh2, rvh2, nbth2 = host(rm), host(rv), np.array(4)
+    kc.bn_finalize(host(partc), nblk, col0, N, count, host(gamma), host(beta), rmh2, rvh2, nbth2, 0.1, 1e-5, *hc, centered=True)
+    for a, b, nme in zip(outc, hc, ('scale', 'shift', 'mean', 'rstd')):
+        close(host(a), b, torch.float32, 'centred bn_finalize ' + nme)
+    close(host(rmc), host(bn.running_mean), torch.float32, 'centred running_mean vs torch', fp32=1e-5)
+    close(host(rvc), host(bn.running_var), torch.float32, 'centred running_var vs torch', fp32=1e-5)
+    # scale * (x - rm) + shift_c == scale * x + shift
+    close(host(outc[0]), host(outs[0]), torch.float32, 'centred scale', fp32=1e-5)
+    close(host(outc[1]) - host(outc[0]) * host(rm), host(outs[1]), torch.float32, 'centred shift', fp32=1e-4)
     # eval
     sc, sh = torch.zeros(N).cuda(), torch.zeros(N).cuda()
+    ops.bn_eval(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5, N, sc, sh, centered=True)
+    close(host(sh), host(beta), torch.float32, 'centred bn_eval shift')
     ops.bn_eval(gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda(), 1e-5, N, sc, sh)
     sch, shh = np.zeros(N), np.zeros(N)
     kc.bn_eval(host(gamma), host(beta), host(rm), host(rv), 1e-5, N, sch, shh)
@@ -438,10 +468,12 @@ def test_input_side(ops, B, T, J, k0, ts, C, dt):
     E = torch.zeros(P, C).to(dt).cuda()
     nbe = ops.rowwise_blocks(P, C)
     pe = torch.zeros(nbe, C, 2).cuda()
-    ops.expand_fwd(x.cuda(), B, T, J, F_in, k0, ts, W.cuda(), sc0.cuda(), sh0.cuda(), C, E, pe)
+    ctr = rand(gen, C) if k0 == 3 else None
+    ops.expand_fwd(x.cuda(), B, T, J, F_in, k0, ts, W.cuda(), sc0.cuda(), sh0.cuda(), C, E, pe, center=ctr.cuda() if ctr is not None else None)
     Eh = np.zeros((P, C))
     peh = np.zeros((nbe, C, 2))
-    kc.expand_fwd(host(x), B, T, J, F_in, k0, ts, host(W), host(sc0), host(sh0), C, Eh, peh, round_fn=rnd)
+    kc.expand_fwd(host(x), B, T, J, F_in, k0, ts, host(W), host(sc0), host(sh0), C, Eh, peh, round_fn=rnd,
+                  center=host(ctr) if ctr is not None else None)
     close(host(E), Eh, dt, 'expand_fwd')
     close(host(pe), peh, dt, 'expand_fwd partials', fp32=1e-4, bf16=3e-2)
     dE = rand(gen, P, C).to(dt)

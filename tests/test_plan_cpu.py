@@ -20,8 +20,12 @@ def build(cfg, dropout=0.0):
     return m
 
 
+@pytest.mark.parametrize('centered', ['0', '1'])
 @pytest.mark.parametrize('name', golden_names())
-def test_plan_matches_reference_golden(name):
+def test_plan_matches_reference_golden(name, centered, monkeypatch):
+    """centered=1: the bf16 path's storage convention (pre-BN tensors minus running_mean) run in fp32 arithmetic must be
+    mathematically the same network, including the running-statistic updates."""
+    monkeypatch.setenv('GAST_HIP_CENTER', centered)
     cfg, z, state, grads, post = load_golden(name)
     m = build(cfg)
     assert m.receptive_field() == cfg['receptive_field']
