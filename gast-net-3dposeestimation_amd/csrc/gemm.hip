@@ -589,7 +589,8 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int ntiles = 0;
     for (int s2 = 0; s2 < a.nseg; ++s2) ntiles += (a.seg[s2].K + 8 * epc - 1) / (8 * epc);
     int splitk = 1;
-    if (ws && gridM * gridN <= 160 && ntiles >= 4) {
+    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling/bisecting ablations only
+    if (ws && gridM * gridN <= 160 && ntiles >= 4 && !(dbg & 64)) {
         splitk = 512 / (gridM * gridN);
         if (splitk > 8) splitk = 8;
         if (splitk > ntiles / 2) splitk = ntiles / 2;
@@ -606,7 +607,6 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
     if (a.addend && (a.ldadd % epc || !aligned16(a.addend))) vec_epi = 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
-    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling ablations only
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     else if (a.out_f32)

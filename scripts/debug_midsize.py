@@ -1,0 +1,38 @@
+"""Debug helper (GPU box): the midsize oracle comparison of tests/test_model_gpu.py with per-parameter gradient errors.
+Usage: python scripts/debug_midsize.py [fp32|bf16] [dilated|strided]"""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'gast-net-3dposeestimation_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+mode = sys.argv[1] if len(sys.argv) > 1 else 'fp32'
+variant = sys.argv[2] if len(sys.argv) > 2 else 'strided'
+os.environ['GAST_HIP_DTYPE'] = mode
+from tests_helpers import PARENTS
+from test_plan_cpu import build
+from test_model_gpu import _random_state
+from oracle import gast_oracle as go
+
+J, arc, ch, B, T = (19, (3, 3, 3), 32, 16, 27) if variant == 'strided' else (17, (3, 3, 3), 32, 8, 31)
+cfg = dict(J=J, parents=PARENTS[J], arc=list(arc), channels=ch, causal=False, variant=variant)
+torch.manual_seed(5)
+m = build(cfg)
+gen = torch.Generator().manual_seed(9)
+_random_state(m, gen)
+state = {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+x = torch.rand(B, T, J, 2, generator=gen) * 2 - 1
+om = go.OracleModel(go.adj_from_parents(cfg['parents']), arc, ch, causal=False, variant=variant)
+Tout = T - om.receptive_field() + 1 if variant == 'dilated' else 1
+dy = torch.randn(B, Tout, J, 3, generator=gen)
+y_ref, g_ref, _ = om.output_grads(state, x.numpy(), dy.numpy(), training=True)
+m.cuda().train()
+y = m(x.cuda())
+print('out err %.3e (max %.2f)' % (np.abs(y.detach().cpu().numpy() - y_ref).max(), np.abs(y_ref).max()))
+y.backward(dy.cuda())
+rows = []
+for k, p in m.named_parameters():
+    g = p.grad.cpu().numpy().astype(np.float64)
+    r = g_ref[k]
+    rows.append((np.abs(g - r).max() / (np.abs(r).max() + 1e-12), np.abs(g - r).max(), np.abs(r).max(), k))
+for rel, ab, mx, k in sorted(rows, reverse=True)[:15]:
+    print('%-70s rel %.3e abs %.3e max|ref| %.3e' % (k, rel, ab, mx))
