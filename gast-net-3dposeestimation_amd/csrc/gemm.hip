@@ -615,10 +615,7 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
         hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     GAST_CHECK_LAUNCH();
     if (splitk > 1) {
-        if (a.epi != GAST_EPI_PLAIN) {
-            hipError_t e = hipMemsetAsync(a.partials, 0, (size_t)gridM * a.N * 2 * sizeof(float), st);
-            if (e != hipSuccess) return (int)e;
-        }
+        // the finish kernel accumulates the column statistics with atomics: `partials` arrives zero-filled (gast_hip.h)
         dim3 fgrid(gridN * ((M + 7) / 8));
         if (a.dtype == GAST_F32)
             hipLaunchKernelGGL((splitk_finish_kernel<float, float>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);

@@ -378,20 +378,26 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
 // Accumulators are indexed [f][tap] with compile-time bounds (F_in <= 2 features, k0 <= 8 taps) so they stay in registers and
 // no integer division by the runtime filter width runs per row.
 constexpr int XF = 2, XT = 8;
+// Stage 1: every block reduces its share of the rows into ws[blk][kk][C] (kk = f*k0 + tap for G, kk = F_in*k0 for S): no
+// atomics, two rows in flight per thread.  Stage 2 (expand_bwd_finish_kernel) sums the block rows and applies the
+// parameter-sized epilogue.  (One pass with <=128 long-running blocks ending in (F_in*k0+1)*C atomics took 115 us for
+// 14 MB of dE: 8 bytes in flight per thread.)
 template <typename T>
 __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ dE, int ldde, const float* __restrict__ x, int B, int T_in,
                                                          int J, int F_in, int k0, int t_stride, int T_out,
                                                          const float* __restrict__ mean0, const float* __restrict__ rstd0, int C,
-                                                         float* __restrict__ G, float* __restrict__ S, int TPR, int RB) {
+                                                         float* __restrict__ ws, int TPR, int RB) {
     __shared__ float sred[256][4];
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
     const int C4 = C >> 2;
     const long rows = (long)B * T_out * J;
     const int TJ = T_out * J;
+    const long step = (long)gridDim.x * RB;
     float mu[XF], rs[XF];
 #pragma unroll
     for (int f = 0; f < XF; ++f) { mu[f] = f < F_in ? mean0[f] : 0.f; rs[f] = f < F_in ? rstd0[f] : 0.f; }
+    float* wsb = ws + (long)blockIdx.x * (K0 + 1) * C;
     for (int cg0 = 0; cg0 < C4; cg0 += TPR) {
         const int cg = cg0 + ct;
         const int c = cg * 4;
@@ -401,22 +407,30 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
 #pragma unroll
             for (int tap = 0; tap < XT; ++tap) g[f][tap] = make_float4(0, 0, 0, 0);
         if (slot < RB && cg < C4) {
-            for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
-                int m = (int)r;
-                int b = m / TJ, rem = m - b * TJ;
-                int t = rem / J, j = rem - t * J;
-                const float4 d = ld4(dE + r * ldde + c);
-                gs.x += d.x; gs.y += d.y; gs.z += d.z; gs.w += d.w;
-                const float* xb = x + (((long)b * T_in + t * t_stride) * J + j) * F_in;
+            for (long r0 = (long)blockIdx.x * RB + slot; r0 < rows; r0 += 2 * step) {
+                const long r1 = r0 + step;
+                const bool two = r1 < rows;
+                const float4 d0 = ld4(dE + r0 * ldde + c);
+                const float4 d1 = two ? ld4(dE + r1 * ldde + c) : make_float4(0, 0, 0, 0);
 #pragma unroll
-                for (int tap = 0; tap < XT; ++tap) {
-                    if (tap < k0) {
+                for (int u = 0; u < 2; ++u) {
+                    if (u == 1 && !two) break;
+                    const float4 d = u ? d1 : d0;
+                    const int m = (int)(u ? r1 : r0);
+                    const int b = m / TJ, rem = m - b * TJ;
+                    const int t = rem / J, j = rem - t * J;
+                    gs.x += d.x; gs.y += d.y; gs.z += d.z; gs.w += d.w;
+                    const float* xb = x + (((long)b * T_in + t * t_stride) * J + j) * F_in;
 #pragma unroll
-                        for (int f = 0; f < XF; ++f) {
-                            if (f < F_in) {
-                                const float xh = (xb[(long)tap * J * F_in + f] - mu[f]) * rs[f];
-                                g[f][tap].x = fmaf(d.x, xh, g[f][tap].x); g[f][tap].y = fmaf(d.y, xh, g[f][tap].y);
-                                g[f][tap].z = fmaf(d.z, xh, g[f][tap].z); g[f][tap].w = fmaf(d.w, xh, g[f][tap].w);
+                    for (int tap = 0; tap < XT; ++tap) {
+                        if (tap < k0) {
+#pragma unroll
+                            for (int f = 0; f < XF; ++f) {
+                                if (f < F_in) {
+                                    const float xh = (xb[(long)tap * J * F_in + f] - mu[f]) * rs[f];
+                                    g[f][tap].x = fmaf(d.x, xh, g[f][tap].x); g[f][tap].y = fmaf(d.y, xh, g[f][tap].y);
+                                    g[f][tap].z = fmaf(d.z, xh, g[f][tap].z); g[f][tap].w = fmaf(d.w, xh, g[f][tap].w);
+                                }
                             }
                         }
                     }
@@ -430,20 +444,87 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
                 if (f < F_in && tap < k0) {
                     float4 v[1] = {g[f][tap]};
                     slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
-                    if (slot == 0 && cg < C4) {
-                        const int kk = f * k0 + tap;
-                        atomicAdd(G + (long)(c) * K0 + kk, v[0].x); atomicAdd(G + (long)(c + 1) * K0 + kk, v[0].y);
-                        atomicAdd(G + (long)(c + 2) * K0 + kk, v[0].z); atomicAdd(G + (long)(c + 3) * K0 + kk, v[0].w);
-                    }
+                    if (slot == 0 && cg < C4) *(float4*)(wsb + (long)(f * k0 + tap) * C + c) = v[0];
                 }
             }
         {
             float4 v[1] = {gs};
             slot_reduce<1>(v, sred, tid, slot, ct, TPR, RB);
-            if (slot == 0 && cg < C4) {
-                atomicAdd(S + c, v[0].x); atomicAdd(S + c + 1, v[0].y); atomicAdd(S + c + 2, v[0].z); atomicAdd(S + c + 3, v[0].w);
+            if (slot == 0 && cg < C4) *(float4*)(wsb + (long)K0 * C + c) = v[0];
+        }
+    }
+}
+
+// Stage 2: 256 threads = 32 channels x 8 block-row lanes.  G[c][kk] = sum_blk ws[blk][kk][c], S[c] likewise, then
+//   dW[c][f][tap] = gamma0[f] * G + beta0[f] * S[c]                       (xn = gamma0 * xhat + beta0 feeds the expand conv)
+//   dgamma0[f]   += sum_{c,tap} W[c][f][tap] * G[c][f][tap];   dbeta0[f] += sum_{c,tap} W[c][f][tap] * S[c]   (atomics)
+__global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __restrict__ ws, int nb, int C, int F_in, int k0,
+                                                                const float* __restrict__ W, const float* __restrict__ gamma0,
+                                                                const float* __restrict__ beta0, float* __restrict__ dW,
+                                                                float* __restrict__ dgamma0, float* __restrict__ dbeta0) {
+    __shared__ float sred[8][32][XF * XT + 1];
+    __shared__ float sgb[32][2 * XF];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cx;
+    const int K0 = F_in * k0;
+    float acc[XF * XT + 1];
+#pragma unroll
+    for (int q = 0; q <= XF * XT; ++q) acc[q] = 0.f;
+    if (c < C) {
+        for (int blk = ry; blk < nb; blk += 8) {
+            const float* p = ws + (long)blk * (K0 + 1) * C + c;
+#pragma unroll
+            for (int q = 0; q <= XF * XT; ++q)
+                if (q <= K0) acc[q] += p[(long)q * C];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q <= XF * XT; ++q) sred[ry][cx][q] = acc[q];
+    __syncthreads();
+    float dg[XF], db[XF];
+#pragma unroll
+    for (int f = 0; f < XF; ++f) { dg[f] = 0.f; db[f] = 0.f; }
+    if (ry == 0 && c < C) {
+#pragma unroll
+        for (int q = 0; q <= XF * XT; ++q) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += sred[r][cx][q];
+            acc[q] = v;
+        }
+        float Sc = 0.f;
+#pragma unroll
+        for (int q = 0; q <= XF * XT; ++q) if (q == K0) Sc = acc[q];
+#pragma unroll
+        for (int f = 0; f < XF; ++f) {
+            if (f < F_in) {
+                const float g0 = gamma0[f], b0 = beta0[f];
+#pragma unroll
+                for (int tap = 0; tap < XT; ++tap) {
+                    if (tap < k0) {
+                        float Gv = 0.f;
+#pragma unroll
+                        for (int q = 0; q < XF * XT; ++q) if (q == f * k0 + tap) Gv = acc[q];
+                        const long o = ((long)c * F_in + f) * k0 + tap;
+                        const float w = W[o];
+                        dW[o] = g0 * Gv + b0 * Sc;
+                        dg[f] = fmaf(w, Gv, dg[f]);
+                        db[f] = fmaf(w, Sc, db[f]);
+                    }
+                }
             }
         }
+    }
+    if (ry == 0) {
+#pragma unroll
+        for (int f = 0; f < XF; ++f) { sgb[cx][2 * f] = dg[f]; sgb[cx][2 * f + 1] = db[f]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * F_in) {
+        float v = 0.f;
+        for (int i = 0; i < 32; ++i) v += sgb[i][threadIdx.x];
+        const int f = threadIdx.x >> 1;
+        atomicAdd((threadIdx.x & 1) ? dbeta0 + f : dgamma0 + f, v);
     }
 }
 
@@ -614,28 +695,37 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
     return 0;
 }
 
+static int expand_bwd_blocks(long rows, int C) {
+    int nb = row_blocks(rows, C) / 2;       // two rows in flight per thread
+    if (nb > 512) nb = 512;
+    return nb < 1 ? 1 : nb;
+}
+
+extern "C" long gast_expand_bwd_ws_floats(long rows, int C, int F_in, int k0) {
+    return (long)expand_bwd_blocks(rows, C) * (F_in * k0 + 1) * C;
+}
+
 extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
-                               int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,
-                               gast_stream_t stream) {
-    if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !G || !S) return GAST_EINVAL;
+                               int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
+                               const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !W || !gamma0 || !beta0 || !dW || !dgamma0 || !dbeta0 || !ws)
+        return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in > XF || k0 > XT || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || ldde % 4) return GAST_EALIGN;
     int T_out = conv_t_out(T_in, k0, t_stride);
     long rows = (long)B * T_out * J;
     RowCfg c = row_cfg(C);
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(G, 0, (size_t)C * F_in * k0 * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemsetAsync(S, 0, (size_t)C * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
-    int nb = row_blocks(rows, C);
-    if (nb > 128) nb = 128;     // every block ends with (F_in*k0+1)*C atomics: few, long-running blocks
+    const int nb = expand_bwd_blocks(rows, C);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
-                           T_out, mean0, rstd0, C, G, S, c.TPR, c.RB);
+                           T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
-                           t_stride, T_out, mean0, rstd0, C, G, S, c.TPR, c.RB);
+                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
+                       dgamma0, dbeta0);
     GAST_CHECK_LAUNCH();
     return 0;
 }

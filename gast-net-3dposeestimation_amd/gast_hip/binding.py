@@ -103,7 +103,8 @@ def load_library():
         'gast_input_stats': [vp, cl, ci, vp, vp, vp],
         'gast_input_stats_blocks': [cl],
         'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp],
-        'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp],
+        'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp],
+        'gast_expand_bwd_ws_floats': [cl, ci, ci, ci],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
         'gast_fold': [vp, ci, ci, vp, vp],
@@ -115,6 +116,7 @@ def load_library():
         fn.restype = ci
     lib.gast_semch_agg_bwd_ws_floats.restype = C.c_long
     lib.gast_gemm_splitk_ws_bytes.restype = C.c_long
+    lib.gast_expand_bwd_ws_floats.restype = C.c_long
     lib.gast_version.restype = C.c_char_p
     lib.gast_version.argtypes = []
     _lib = lib
@@ -125,7 +127,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'g
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
-                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
+                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
                     'gast_unfold', 'gast_version']
 
 
@@ -350,10 +352,15 @@ class HipOps:
         _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
                                         _p(partials), _p(center), _stream()), 'gast_expand_fwd')
 
-    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
-        self.launches += 1
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0):
+        """dW written; dgamma0 / dbeta0 accumulated (zero-filled by the caller)."""
+        self.launches += 2
+        T_out = (T_in - k0) // t_stride + 1
+        n = self.lib.gast_expand_bwd_ws_floats(B * T_out * J, C_, F_in, k0)
+        ws = torch.empty(n, dtype=torch.float32, device=dE.device)
         _check(self.lib.gast_expand_bwd(_dt(dE), _p(dE), _ld(dE), _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
-                                        _p(G), _p(S), _stream()), 'gast_expand_bwd')
+                                        _p(W), _p(gamma0), _p(beta0), _p(dW), _p(dgamma0), _p(dbeta0), _p(ws), _stream()),
+               'gast_expand_bwd')
 
     # -- parameter packing / gradient unpacking (gast_hip/packer.py job lists -> device tables, one launch per list)
     @staticmethod

@@ -49,6 +49,42 @@ class BNState:
         self.count = count
 
 
+class ZeroArena:
+    """One zero-filled device buffer per pass, handed out in pieces.
+
+    Split-K GEMMs, split-M weight gradients and column sums accumulate with atomics into zero-initialised destinations; zeroing
+    each of them separately cost ~30 memset nodes (5 us apiece) per step.  The total is learnt on the first pass over a given
+    input shape (individual allocations), afterwards ONE torch.zeros serves every request of the pass."""
+
+    def __init__(self):
+        self.totals = {}
+        self.key = None
+        self.buf = None
+        self.off = 0
+
+    def begin(self, key, dev):
+        self.key, self.dev, self.off = key, dev, 0
+        n = self.totals.get(key)
+        self.buf = torch.zeros(n, dtype=torch.uint8, device=dev) if n else None
+
+    def take(self, shape, dtype=torch.float32):
+        nbytes = 1
+        for d in shape:
+            nbytes *= int(d)
+        nbytes *= torch.empty((), dtype=dtype).element_size()
+        span = (nbytes + 255) // 256 * 256
+        off = self.off
+        self.off += span
+        if self.buf is None or off + span > self.buf.numel():
+            self.buf = None                      # first pass over this shape (or a changed plan): count, allocate separately
+            return torch.zeros(*shape, dtype=dtype, device=self.dev)
+        return self.buf[off:off + nbytes].view(dtype).view(*shape)
+
+    def end(self):
+        self.totals[self.key] = self.off
+        self.buf = None
+
+
 class Engine:
     """Executes the plan for one model instance.  `spec` is built by model.gast_net (see `ModelSpec`)."""
 
@@ -58,6 +94,7 @@ class Engine:
         # centred storage (bf16 activations): every lazily-normalised pre-BN tensor is stored as x - running_mean so that its
         # bf16 rounding error scales with the spread of the channel, not with |mean|
         self.centered = bool(centered)
+        self.za = ZeroArena()
 
     def _ctr(self, bn):
         return bn['running_mean'] if self.centered else None
@@ -89,6 +126,8 @@ class Engine:
         dt = act_dtype
         sv = {'B': B, 'T_in': T_in, 'dt': dt, 'drop': drop, 'training': training}
         use_drop = training and drop is not None and drop.thresh != 0
+        za = self.za
+        za.begin(('fwd', tuple(x.shape), dt, training), dev)
 
         # ---- init_bn statistics + expand conv (gast_net.py:163-164)
         k0 = sp.fw[0]
@@ -144,7 +183,7 @@ class Engine:
                 W1 = inp['l%d.conv1' % s]       # [C][C]
                 nb = ops.gemm_row_blocks(P)
                 T1 = self._new(P, C, dt, dev)
-                part1 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+                part1 = za.take((nb, C, 2))
                 segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
                              scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
                 ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
@@ -152,7 +191,7 @@ class Engine:
                 bn1 = BNState(C, dev, P)
                 self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
-                part2 = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+                part2 = za.take((nb, C, 2))
                 ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
                          T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
                 bn2 = BNState(C, dev, P)
@@ -172,10 +211,11 @@ class Engine:
         ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
                                          scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
         sv.update(stages=stages, levels=levels)
+        za.end()
         return pred.view(B, T[-1], J, 3), sv
 
     def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop):
-        sp, ops = self.spec, self.ops
+        sp, ops, za = self.spec, self.ops, self.za
         dev = X.device
         P = B * Tn * J
         F = B * Tn
@@ -212,13 +252,13 @@ class Engine:
         ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
         # G2 / G3
         Lp = self._new(P, C, dt, dev)
-        partL = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+        partL = za.take((nb, C, 2))
         ops.gemm(dom, C, [dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)], Lp, im,
                  epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen)
         bnL = BNState(C, dev, P)
         self._bn_forward(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, training, centered=cen)
         Gp = self._new(P, C, dt, dev)
-        partG = torch.empty(nb, C, 2, dtype=torch.float32, device=dev)
+        partG = za.take((nb, C, 2))
         ops.gemm(dom, C, [dict(A=Ya, K=C, map=im, W=Wgc)], Gp, im, epi=EPI_STATS, partials=partG,
                  bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)
         bnG = BNState(C, dev, P)
@@ -226,7 +266,7 @@ class Engine:
         # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised
         pro = PRO_BNRELU_DROP if use_drop else PRO_BNRELU
         O = self._new(P, 2 * C, dt, dev)
-        partO = torch.empty(nb, 2 * C, 2, dtype=torch.float32, device=dev)
+        partO = za.take((nb, 2 * C, 2))
         segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]),
                 dict(A=Lp, K=C, map=im, W=Wbc[:, C:2 * C], pro=pro, scale=bnL.scale, shift=bnL.shift, salt=3 * s + 1),
                 dict(A=Gp, K=C, map=im, W=Wbc[:, 2 * C:3 * C], pro=pro, scale=bnG.scale, shift=bnG.shift, salt=3 * s + 2)]
@@ -254,7 +294,8 @@ class Engine:
 
     def backward(self, sv, inp, dpred, gout):
         """dpred: (B,T',J,3) fp32.  Every gradient is written into its destination `gout[key]` (packed fp32 scratch
-        regions for the GEMM operands, views of the flat gradient buffer for directly-held parameters)."""
+        regions for the GEMM operands, views of the flat gradient buffer for directly-held parameters).  The destinations must
+        arrive ZERO-FILLED: split-M weight gradients, column sums and dC_k accumulate into them with atomics."""
         sp, ops = self.spec, self.ops
         dev = dpred.device
         B, dt, drop = sv['B'], sv['dt'], sv['drop']
@@ -265,6 +306,8 @@ class Engine:
         stages, levels = sv['stages'], sv['levels']
         grads = gout
         f32 = torch.float32
+        za = self.za
+        za.begin(('bwd', B, sv['T_in'], dt), dev)
 
         # ---- shrink backward
         last = stages[-1]
@@ -272,14 +315,14 @@ class Engine:
         TL = T[-1]
         PL = B * TL * J
         KP = 8
-        dp = torch.zeros(PL, KP, dtype=dt, device=dev)
+        dp = za.take((PL, KP), dt)
         dp[:, :3] = dpred.reshape(PL, 3).to(dt)
         ops.wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
-                                                        shift=last['bnO'].shift, wcol0=0)], gout['shrink'])
+                                                        shift=last['bnO'].shift, wcol0=0)], gout['shrink'], zero_first=False)
         WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
         dO = self._new(PL, CL, dt, dev)
         nb = ops.gemm_row_blocks(PL)
-        part = torch.empty(nb, CL, 2, dtype=f32, device=dev)
+        part = za.take((nb, CL, 2))
         ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, partials=part,
                  X=last['O'], xscale=last['bnO'].scale, xshift=last['bnO'].shift)
         g = 'g%d.' % (L - 1)
@@ -307,9 +350,9 @@ class Engine:
             self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
             # 1x1 conv
             ops.wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
-                                                            shift=lv['bn1'].shift, wcol0=0)], gout[lk + 'conv1'])
+                                                            shift=lv['bn1'].shift, wcol0=0)], gout[lk + 'conv1'], zero_first=False)
             nbg = ops.gemm_row_blocks(P)
-            part1 = torch.empty(nbg, C, 2, dtype=f32, device=dev)
+            part1 = za.take((nbg, C, 2))
             dT1 = self._new(P, C, dt, dev)
             W1T = inp[lk + 'conv1T']
             ops.gemm((B, Tn, J), C, [dict(A=dT2, K=C, map=ident(Tn), W=W1T)], dT1, ident(Tn), epi=EPI_BNRELU_BWD, partials=part1,
@@ -318,15 +361,15 @@ class Engine:
             # temporal conv: weight gradient (k K-segments) ...
             ops.wgrad((B, Tn, J), dT1, C, ident(Tn),
                       [dict(Q=prev['O'], S=C, map=lv['taps'][tap], pro=PRO_BNRELU, scale=prev['bnO'].scale, shift=prev['bnO'].shift,
-                            wcol0=tap * C) for tap in range(k)], gout[lk + 'conv'])
+                            wcol0=tap * C) for tap in range(k)], gout[lk + 'conv'], zero_first=False)
             # ... and input gradient, fused with the residual branch and the ReLU/BN backward of the previous block's output
             WcT = [inp[lk + 'convT'][tap * C:(tap + 1) * C] for tap in range(k)]     # [tap][cin][cout]
             pg = 'g%d.' % (s - 1)
             if sp.strided:
                 covered = k * Tn == Tp
-                dOp = self._new(Pp, C, dt, dev, zero=not covered)
+                dOp = self._new(Pp, C, dt, dev) if covered else za.take((Pp, C), dt)
                 nbt = ops.gemm_row_blocks(P)
-                partO = torch.zeros(k * nbt, C, 2, dtype=f32, device=dev)
+                partO = za.take((k * nbt, C, 2))
                 res_tap = lv['resmap'].t_off
                 for tap in range(k):
                     ops.gemm((B, Tn, J), C, [dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], dOp, RowMap(Tp, k, tap),
@@ -338,7 +381,7 @@ class Engine:
                 d = sp.dil[s]
                 dOp = self._new(Pp, C, dt, dev)
                 nbo = ops.gemm_row_blocks(Pp)
-                partO = torch.empty(nbo, C, 2, dtype=f32, device=dev)
+                partO = za.take((nbo, C, 2))
                 segs = [dict(A=dT1, K=C, map=RowMap(Tn, 1, -tap * d), W=WcT[tap]) for tap in range(k)]
                 ops.gemm((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
                          epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
@@ -356,20 +399,14 @@ class Engine:
         F_in = x.shape[-1]
         k0 = sp.fw[0]
         s0 = k0 if sp.strided else 1
-        G = torch.empty(C0, F_in, k0, dtype=f32, device=dev)
-        S = torch.empty(C0, dtype=f32, device=dev)
-        ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, G, S)
-        # tiny parameter-sized epilogue (plumbing): xn = gamma0*xhat + beta0
-        g0 = inp['init_bn.weight'].view(1, F_in, 1)
-        b0 = inp['init_bn.bias'].view(1, F_in, 1)
-        W = inp['expand_w'].view(C0, F_in, k0)
-        gout['expand_w'].copy_((g0 * G + b0 * S.view(C0, 1, 1)).view_as(inp['expand_w']))
-        gout['init_bn.weight'].copy_((W * G).sum(dim=(0, 2)))
-        gout['init_bn.bias'].copy_((W * S.view(C0, 1, 1)).sum(dim=(0, 2)))
+        # G / S sums and the parameter-sized epilogue (xn = gamma0*xhat + beta0 feeds the expand conv) in two launches
+        ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, inp['expand_w'],
+                       inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'])
+        za.end()
 
     def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
         """dO: gradient w.r.t. Opre (pre-BN output of the block's cat_conv), (P x 2C).  Returns dX (P x C)."""
-        sp, ops = self.spec, self.ops
+        sp, ops, za = self.spec, self.ops, self.za
         dev = dO.device
         f32 = torch.float32
         C, Tn, P = st['C'], st['Tn'], st['P']
@@ -386,39 +423,38 @@ class Engine:
                   [dict(Q=st['X'], S=C, map=im, wcol0=0),
                    dict(Q=st['Lp'], S=C, map=im, pro=pro, scale=st['bnL'].scale, shift=st['bnL'].shift, salt=3 * s + 1, wcol0=C),
                    dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
-                  grads[g + 'Bbc'], drop=drop)
+                  grads[g + 'Bbc'], drop=drop, zero_first=False)
         WbcT = inp[g + 'BbcT']       # [3C][2C]
         # input gradients of the local / global branches, fused with ReLU + dropout + BN-sum backward
         dL = self._new(P, C, dt, dev)
-        partL = torch.empty(nb, C, 2, dtype=f32, device=dev)
+        partL = za.take((nb, C, 2))
         ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:2 * C])], dL, im, epi=EPI_BNRELU_BWD, partials=partL, X=st['Lp'],
                  xscale=st['bnL'].scale, xshift=st['bnL'].shift, xdrop=xdrop, xsalt=3 * s + 1, drop=drop)
         self._bn_backward(partL, nb, 0, C, st['bnL'], inp[g + 'lcat_bn.weight'], grads, g + 'lcat_bn', dL, st['Lp'], P)
         dG = self._new(P, C, dt, dev)
-        partG = torch.empty(nb, C, 2, dtype=f32, device=dev)
+        partG = za.take((nb, C, 2))
         ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[2 * C:3 * C])], dG, im, epi=EPI_BNRELU_BWD, partials=partG, X=st['Gp'],
                  xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2, drop=drop)
         self._bn_backward(partG, nb, 0, C, st['bnG'], inp[g + 'gcat_bn.weight'], grads, g + 'gcat_bn', dG, st['Gp'], P)
         # local cat conv
         ops.wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
-                                        wcol0=0)], grads[g + 'Blc'])
+                                        wcol0=0)], grads[g + 'Blc'], zero_first=False)
         WlcT = inp[g + 'BlcT']       # [2C][C]
         dY = self._new(P, 2 * C, dt, dev)
-        partY = torch.empty(nb, 2 * C, 2, dtype=f32, device=dev)
+        partY = za.take((nb, 2 * C, 2))
         ops.gemm(dom, 2 * C, [dict(A=dL, K=C, map=im, W=WlcT)], dY, im, epi=EPI_BNRELU_BWD, partials=partY, X=st['Y'],
                  xscale=st['bnY'].scale, xshift=st['bnY'].shift)
         self._bn_backward(partY, nb, 0, C, st['bnY'], inp[g + 'bn_1.weight'], grads, g + 'bn_1', dY, st['Y'], P, off=0, dzcol=0)
         self._bn_backward(partY, nb, C, C, st['bnY'], inp[g + 'bn_2.weight'], grads, g + 'bn_2', dY, st['Y'], P, off=C, dzcol=C)
         # global cat conv
-        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'])
+        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'], zero_first=False)
         WgcT = inp[g + 'BgcT']
         dYa = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dG, K=C, map=im, W=WgcT)], dYa, im)
         # attention core + aggregation backward fill the column blocks of dH
         H = st['H']
         dH = self._new(P, N1, dt, dev)
-        dCk = grads[g + 'C_k']
-        dCk.zero_()
+        dCk = grads[g + 'C_k']          # accumulated with atomics: gradient destinations arrive zeroed (see backward())
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
@@ -428,9 +464,9 @@ class Engine:
         ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym'])
         ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
-        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'])
+        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
         nbias = C + 2 * NHEADS      # bias gradients of g / theta / phi = column sums of their dH columns
-        ops.colsum(dH[:, 4 * C:], P, nbias, grads[g + 'bias1'][4 * C:], zero_first=True)
+        ops.colsum(dH[:, 4 * C:], P, nbias, grads[g + 'bias1'][4 * C:], zero_first=False)
         Wg1T = inp[g + 'Bg1T']       # [C][N1]
         dX = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])], dX, im)

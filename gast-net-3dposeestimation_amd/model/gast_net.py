@@ -133,8 +133,9 @@ class _GastFunction(torch.autograd.Function):
         runner, packer, st = ctx.runner, ctx.packer, ctx.st
         dev = dpred.device
         sink = runner.grad_sink
-        G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
-        Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
+        # gradient destinations are zero-filled once (two fills) instead of once per accumulating kernel (engine.backward)
+        G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
+        Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
         if sink is not None:     # accumulate semantics: directly-written gradients go through a zeroed scratch buffer first
             Gd = torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
             gout = packer.grad_outputs(Gd, Sb)

@@ -101,7 +101,8 @@ typedef struct {
     int ldadd;
     gast_rowmap addmap;
     int epi;              /* GAST_EPI_* */
-    float* partials;      /* epi != PLAIN: [ceil(M/128)][N][2] fp32, fully overwritten */
+    float* partials;      /* epi != PLAIN: [ceil(M/128)][N][2] fp32; fully overwritten by gast_gemm, ACCUMULATED into by the
+                           * split-K path of gast_gemm_ws (pass it zero-filled there) */
     const void* X;        /* epi == BNRELU_BWD: pre-BN tensor addressed with cmap, [rows][ldx] */
     int ldx;
     const float* xscale;  /* [N] */
@@ -238,10 +239,15 @@ int gast_input_stats_blocks(long rows);
 int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                     const float* W, const float* sc0, const float* sh0, int C,
                     void* E, int lde, float* partials, const float* center, gast_stream_t stream);   /* center: nullable [C], subtracted */
-/* G[c][f][tap] = sum_m dE[m,c]*xhat[(b,t*ts+tap,j), f],  S[c] = sum_m dE[m,c]   (both fp32, zero-filled here) */
+/* Backward of init_bn + expand_conv w.r.t. their parameters (reference gast_net.py:163-164; the input needs no gradient).
+ * With G[c][f][tap] = sum_m dE[m,c]*xhat[(b,t*ts+tap,j), f] and S[c] = sum_m dE[m,c]:
+ *   dW[c][f][tap] = gamma0[f]*G + beta0[f]*S[c]      (written)
+ *   dgamma0[f] += sum_{c,tap} W*G,  dbeta0[f] += sum_{c,tap} W*S[c]      (atomics: pass them zero-filled)
+ * ws: gast_expand_bwd_ws_floats(rows = B*T_out*J, C, F_in, k0) floats of scratch. */
 int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
-                    int t_stride, const float* mean0, const float* rstd0, int C, float* G, float* S,
-                    gast_stream_t stream);
+                    int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
+                    const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, gast_stream_t stream);
+long gast_expand_bwd_ws_floats(long rows, int C, int F_in, int k0);
 
 /* out[n] (+)= sum_m X[m, n]   (bias gradients of the g / theta / phi 1x1 convs, global_attention.py:30-35) */
 int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out, int zero_first, gast_stream_t stream);

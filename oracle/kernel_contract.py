@@ -464,9 +464,16 @@ def expand_fwd(x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, partials, r
     _rowwise_partials([e, e * e], rows, C, partials)
 
 
-def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, G, S):
+def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W, gamma0, beta0, dW, dgamma0, dbeta0):
+    """dW written, dgamma0 / dbeta0 accumulated (gast_hip.h)."""
     T_out, taps = _expand_taps(x, B, T_in, J, F_in, k0, t_stride)
     xh = (taps - np.asarray(mean0, np.float64)[None, None, None, :, None]) * np.asarray(rstd0, np.float64)[None, None, None, :, None]
     d = np.asarray(dE[:B * T_out * J, :C], np.float64).reshape(B, T_out, J, C)
-    G[...] = np.einsum('btjc,btjfk->cfk', d, xh).reshape(G.shape)
-    S[:C] = d.sum(axis=(0, 1, 2))
+    G = np.einsum('btjc,btjfk->cfk', d, xh)
+    S = d.sum(axis=(0, 1, 2))
+    w = np.asarray(W, np.float64).reshape(C, F_in, k0)
+    g0 = np.asarray(gamma0, np.float64).reshape(1, F_in, 1)
+    b0 = np.asarray(beta0, np.float64).reshape(1, F_in, 1)
+    dW[...] = (g0 * G + b0 * S.reshape(C, 1, 1)).reshape(dW.shape)
+    dgamma0[...] = dgamma0 + (w * G).sum(axis=(0, 2))
+    dbeta0[...] = dbeta0 + (w * S.reshape(C, 1, 1)).sum(axis=(0, 2))

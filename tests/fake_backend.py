@@ -126,8 +126,9 @@ class OracleOps:
     def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
         kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials), center=_np(center))
 
-    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, G, S):
-        kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(G), _np(S))
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0):
+        kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(W), _np(gamma0), _np(beta0),
+                      _np(dW), _np(dgamma0), _np(dbeta0))
 
 
 def _resolve(ref, bases, R, S):

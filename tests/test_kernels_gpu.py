@@ -478,13 +478,15 @@ def test_input_side(ops, B, T, J, k0, ts, C, dt):
     close(host(pe), peh, dt, 'expand_fwd partials', fp32=1e-4, bf16=3e-2)
     dE = rand(gen, P, C).to(dt)
     mean0, rstd0 = rand(gen, F_in, scale=0.1), torch.rand(F_in, generator=gen) + 1.0
-    G = torch.full((C, F_in, k0), 3.0).cuda()
-    S = torch.full((C,), 3.0).cuda()
-    ops.expand_bwd(dE.cuda(), x.cuda(), B, T, J, F_in, k0, ts, mean0.cuda(), rstd0.cuda(), C, G, S)
-    Gh, Sh = np.zeros((C, F_in, k0)), np.zeros(C)
-    kc.expand_bwd(host(dE), host(x), B, T, J, F_in, k0, ts, host(mean0), host(rstd0), C, Gh, Sh)
-    close(host(G), Gh, dt, 'expand_bwd G', fp32=1e-4, bf16=1e-2)
-    close(host(S), Sh, dt, 'expand_bwd S', fp32=1e-4, bf16=1e-2)
+    g0, b0 = torch.rand(F_in, generator=gen) + 0.5, rand(gen, F_in, scale=0.3)
+    dW = torch.full((C, F_in, k0, 1), 3.0).cuda()
+    dg0, db0 = torch.full((F_in,), 0.25).cuda(), torch.full((F_in,), -0.5).cuda()     # accumulated into
+    ops.expand_bwd(dE.cuda(), x.cuda(), B, T, J, F_in, k0, ts, mean0.cuda(), rstd0.cuda(), C, W.cuda(), g0.cuda(), b0.cuda(), dW, dg0, db0)
+    dWh, dgh, dbh = np.zeros((C, F_in, k0, 1)), np.full(F_in, 0.25), np.full(F_in, -0.5)
+    kc.expand_bwd(host(dE), host(x), B, T, J, F_in, k0, ts, host(mean0), host(rstd0), C, host(W), host(g0), host(b0), dWh, dgh, dbh)
+    close(host(dW), dWh, dt, 'expand_bwd dW', fp32=1e-4, bf16=1e-2)
+    close(host(dg0), dgh, dt, 'expand_bwd dgamma0', fp32=1e-4, bf16=1e-2)
+    close(host(db0), dbh, dt, 'expand_bwd dbeta0', fp32=1e-4, bf16=1e-2)
 
 
 # ------------------------------------------------------------------------------------------------ pack / unpack
