@@ -180,6 +180,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--torch-tail', action='store_true', help='eager mpjpe formula + torch fused Adam instead of the HIP loss/optimizer')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -214,10 +215,13 @@ def main():
     y3d = y3d.to(dev)
     sync = FlatGradAllReduce(model.parameters(), model=model)
     use_graph = not args.no_graph
-    try:      # reference trainval.py:78: Adam(amsgrad=True); fused + capturable so the step can live in a hipGraph
+    if args.torch_tail:   # the eager-formula loss and torch's fused multi-tensor Adam (comparison only)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, fused=True, capturable=use_graph)
-    except Exception:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, capturable=use_graph)
+        loss_fn = lambda p, t: torch.mean(torch.norm(p - t, dim=-1))    # noqa: E731 -- mpjpe, reference common/loss.py:5-11
+    else:                 # reference trainval.py:78 Adam(amsgrad=True) / common/loss.py mpjpe as single HIP launches (row f1)
+        from gast_hip.optim import FlatAdam
+        from gast_hip.loss import mpjpe as loss_fn
+        opt = FlatAdam(model.parameters(), lr=1e-3, amsgrad=True)
 
     timer = None
     if not args.no_kernel_timer and rank == 0:
@@ -226,7 +230,7 @@ def main():
     def step():
         sync.zero_()
         pred = model(x)
-        loss = torch.mean(torch.norm(pred - y3d, dim=-1))    # mpjpe, reference common/loss.py:5-11
+        loss = loss_fn(pred, y3d)
         loss.backward()
         sync.sync()
         opt.step()
@@ -297,8 +301,8 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': 'BASELINE.json configs[1]: SpatioTemporalModel J=17 arc 3,3,3 (RF 27) channels=128, '
-                                   'B=%d/GPU x T=27, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)'
-                                   % (B, '+RCCL grad all-reduce' if world > 1 else ''),
+                                   'B=%d/GPU x T=27, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)%s'
+                                   % (B, '+RCCL grad all-reduce' if world > 1 else '', ' [torch loss/optimizer]' if args.torch_tail else ''),
                        'variant': args.variant, 'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'loss_last': round(float(loss.item()), 6), 'launch': graph_note},
         }

@@ -455,57 +455,50 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
     }
 }
 
-// Stage 2: 256 threads = 32 channels x 8 block-row lanes.  G[c][kk] = sum_blk ws[blk][kk][c], S[c] likewise, then
+// Stage 2: 256 threads = 8 channels x 32 block-row lanes.  G[c][kk] = sum_blk ws[blk][kk][c], S[c] likewise, then
 //   dW[c][f][tap] = gamma0[f] * G + beta0[f] * S[c]                       (xn = gamma0 * xhat + beta0 feeds the expand conv)
 //   dgamma0[f]   += sum_{c,tap} W[c][f][tap] * G[c][f][tap];   dbeta0[f] += sum_{c,tap} W[c][f][tap] * S[c]   (atomics)
+// All per-kk values live in LDS (indexed at run time), never in dynamically indexed registers.
+constexpr int EF_CH = 8, EF_LANES = 32;
 __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __restrict__ ws, int nb, int C, int F_in, int k0,
                                                                 const float* __restrict__ W, const float* __restrict__ gamma0,
                                                                 const float* __restrict__ beta0, float* __restrict__ dW,
                                                                 float* __restrict__ dgamma0, float* __restrict__ dbeta0) {
-    __shared__ float sred[8][32][XF * XT + 1];
-    __shared__ float sgb[32][2 * XF];
-    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int c = blockIdx.x * 32 + cx;
-    const int K0 = F_in * k0;
-    float acc[XF * XT + 1];
-#pragma unroll
-    for (int q = 0; q <= XF * XT; ++q) acc[q] = 0.f;
-    if (c < C) {
-        for (int blk = ry; blk < nb; blk += 8) {
-            const float* p = ws + (long)blk * (K0 + 1) * C + c;
-#pragma unroll
-            for (int q = 0; q <= XF * XT; ++q)
-                if (q <= K0) acc[q] += p[(long)q * C];
-        }
+    __shared__ float sred[EF_LANES][EF_CH][XF * XT + 1];
+    __shared__ float stot[EF_CH][XF * XT + 1];
+    __shared__ float sgb[EF_CH][2 * XF];
+    const int cx = threadIdx.x % EF_CH, ry = threadIdx.x / EF_CH;
+    const int c = blockIdx.x * EF_CH + cx;
+    const int K0 = F_in * k0, K1 = K0 + 1;
+    for (int q = 0; q < K1; ++q) {
+        float a = 0.f;
+        if (c < C)
+            for (int blk = ry; blk < nb; blk += EF_LANES) a += ws[((long)blk * K1 + q) * C + c];
+        sred[ry][cx][q] = a;
     }
-#pragma unroll
-    for (int q = 0; q <= XF * XT; ++q) sred[ry][cx][q] = acc[q];
     __syncthreads();
-    float dg[XF], db[XF];
+    for (int i = threadIdx.x; i < EF_CH * K1; i += 256) {
+        const int ch = i / K1, q = i - ch * K1;
+        float v = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < EF_LANES; ++r) v += sred[r][ch][q];
+        stot[ch][q] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < EF_CH) {
+        const int ch = threadIdx.x, cc = blockIdx.x * EF_CH + ch;
+        float dg[XF], db[XF];
 #pragma unroll
-    for (int f = 0; f < XF; ++f) { dg[f] = 0.f; db[f] = 0.f; }
-    if (ry == 0 && c < C) {
+        for (int f = 0; f < XF; ++f) { dg[f] = 0.f; db[f] = 0.f; }
+        if (cc < C) {
+            const float Sc = stot[ch][K0];
 #pragma unroll
-        for (int q = 0; q <= XF * XT; ++q) {
-            float v = 0.f;
-#pragma unroll
-            for (int r = 0; r < 8; ++r) v += sred[r][cx][q];
-            acc[q] = v;
-        }
-        float Sc = 0.f;
-#pragma unroll
-        for (int q = 0; q <= XF * XT; ++q) if (q == K0) Sc = acc[q];
-#pragma unroll
-        for (int f = 0; f < XF; ++f) {
-            if (f < F_in) {
-                const float g0 = gamma0[f], b0 = beta0[f];
-#pragma unroll
-                for (int tap = 0; tap < XT; ++tap) {
-                    if (tap < k0) {
-                        float Gv = 0.f;
-#pragma unroll
-                        for (int q = 0; q < XF * XT; ++q) if (q == f * k0 + tap) Gv = acc[q];
-                        const long o = ((long)c * F_in + f) * k0 + tap;
+            for (int f = 0; f < XF; ++f) {
+                if (f < F_in) {
+                    const float g0 = gamma0[f], b0 = beta0[f];
+                    for (int tap = 0; tap < k0; ++tap) {
+                        const float Gv = stot[ch][f * k0 + tap];
+                        const long o = ((long)cc * F_in + f) * k0 + tap;
                         const float w = W[o];
                         dW[o] = g0 * Gv + b0 * Sc;
                         dg[f] = fmaf(w, Gv, dg[f]);
@@ -514,15 +507,13 @@ __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __r
                 }
             }
         }
-    }
-    if (ry == 0) {
 #pragma unroll
-        for (int f = 0; f < XF; ++f) { sgb[cx][2 * f] = dg[f]; sgb[cx][2 * f + 1] = db[f]; }
+        for (int f = 0; f < XF; ++f) { sgb[ch][2 * f] = dg[f]; sgb[ch][2 * f + 1] = db[f]; }
     }
     __syncthreads();
     if (threadIdx.x < 2 * F_in) {
         float v = 0.f;
-        for (int i = 0; i < 32; ++i) v += sgb[i][threadIdx.x];
+        for (int i = 0; i < EF_CH; ++i) v += sgb[i][threadIdx.x];
         const int f = threadIdx.x >> 1;
         atomicAdd((threadIdx.x & 1) ? dbeta0 + f : dgamma0 + f, v);
     }
@@ -697,7 +688,7 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
 
 static int expand_bwd_blocks(long rows, int C) {
     int nb = row_blocks(rows, C) / 2;       // two rows in flight per thread
-    if (nb > 512) nb = 512;
+    if (nb > 256) nb = 256;
     return nb < 1 ? 1 : nb;
 }
 
@@ -724,7 +715,7 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
                            t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
-    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + 31) / 32), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
+    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + EF_CH - 1) / EF_CH), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
                        dgamma0, dbeta0);
     GAST_CHECK_LAUNCH();
     return 0;

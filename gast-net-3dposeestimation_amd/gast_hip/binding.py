@@ -109,6 +109,8 @@ def load_library():
         'gast_strided_copy': [vp, vp, ci, vp, vp],
         'gast_fold': [vp, ci, ci, vp, vp],
         'gast_unfold': [vp, ci, ci, vp, vp],
+        'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
+        'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -128,7 +130,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'g
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_version']
 
 
 def _check(rc, what):
@@ -426,6 +428,17 @@ class HipOps:
             t = kw.get(name)
             arr[idx] = t.data_ptr() if t is not None else 0
         return arr
+
+    # -- training-step tail
+    def mpjpe(self, pred, target, loss, dirs):
+        rows, D = pred.numel() // pred.shape[-1], pred.shape[-1]
+        self.launches += 1
+        _check(self.lib.gast_mpjpe(_p(pred), _p(target), rows, D, _p(loss), _p(dirs), _stream()), 'gast_mpjpe')
+
+    def adam_step(self, p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+        self.launches += 2
+        _check(self.lib.gast_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
+                                       weight_decay, grad_scale, _stream()), 'gast_adam_step')
 
     def run_pack(self, packer, st):
         dev = st['Wb'].device

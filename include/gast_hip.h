@@ -268,6 +268,16 @@ int gast_fold(const int64_t* jobs, int njobs, int max_C, const int64_t* bases, g
 int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases, gast_stream_t stream);  /* max_Ci = largest Ci */
 
 /* library identification: returns a static string "gast_hip <version> gfx950" */
+/* ---- training-step tail: loss and optimiser on flat fp32 buffers ------------------------------------ */
+/* mpjpe (reference common/loss.py:5-11): *loss = mean_r ||pred[r,:] - target[r,:]||_2 over `rows` rows of D <= 4 components;
+ * dirs[r,:] = d loss / d pred[r,:] (zero where the difference vanishes).  All fp32, contiguous. */
+int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* loss, float* dirs, gast_stream_t stream);
+/* One Adam / AMSGrad step (torch.optim.Adam semantics, reference trainval.py:78) over flat fp32 buffers of n elements:
+ * p, m, v (and vmax: non-null selects amsgrad) updated in place from g * grad_scale; *step (device int32) is incremented first
+ * and supplies the bias corrections.  16-byte aligned buffers. */
+int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
+
 const char* gast_version(void);
 
 #ifdef __cplusplus
