@@ -51,8 +51,7 @@ __device__ __forceinline__ void rows_for(const gast_wgrad_args& a, const gast_wg
 }
 
 // ------------------------------------------------------------------------------------------------ fp32
-__global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
-                                                        int mchunk) {
+__device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, int tilesS_total, int splitM, int mchunk, int blk) {
     constexpr int BKM = 32;
     __shared__ __attribute__((aligned(16))) float sP[BKM * FSTR];
     __shared__ __attribute__((aligned(16))) float sQ[BKM * FSTR];
@@ -61,7 +60,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x / splitM, sp = blockIdx.x - tile * splitM;
+    const int tile = blk / splitM, sp = blk - tile * splitM;
     const TileCoord tc = decode_tile(a, tile, tilesS_total);
     const gast_wgrad_seg& sg = a.seg[tc.seg];
     const int m_begin = sp * mchunk;
@@ -200,8 +199,8 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&
     }
 }
 
-__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM,
-                                                         int mchunk) {
+__device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M, int tilesS_total, int splitM, int mchunk, int blk,
+                                                int dbg) {
     constexpr int BKM = 64;
     __shared__ __attribute__((aligned(16))) unsigned char sP[BT * LSTR];
     __shared__ __attribute__((aligned(16))) unsigned char sQ[BT * LSTR];
@@ -210,7 +209,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int tile = blockIdx.x / splitM, sp = blockIdx.x - tile * splitM;
+    const int tile = blk / splitM, sp = blk - tile * splitM;
     const TileCoord tc = decode_tile(a, tile, tilesS_total);
     const gast_wgrad_seg& sg = a.seg[tc.seg];
     const int m_begin = sp * mchunk;
@@ -273,7 +272,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
             const bool ok = cin && row >= 0;
             rg[i] = make_uint4(ok ? rl[i].x : 0u, ok ? rl[i].y : 0u, ok ? rl[i].z : 0u, ok ? rl[i].w : 0u);
         }
-        if (pro && cin) {
+        if (pro && cin && !(dbg & 4)) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int row = sRowQ[buf][mb * 8 + i];
@@ -295,7 +294,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
             }
         }
         uint4 tr[8];
-        transpose8x8_bf16(rg, tr);
+        if (dbg & 2) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) tr[q] = rg[q];
+        } else {
+            transpose8x8_bf16(rg, tr);
+        }
 #pragma unroll
         for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
     };
@@ -310,6 +314,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
         __syncthreads();
         if (it + 1 < ntile) load_tile((it + 1) & 1);
         if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+        if (dbg & 1) continue;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             union { uint4 u; s16x8 s; } fa[2], fb[2];
@@ -327,6 +332,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
         }
     }
 
+    if ((dbg & 8) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
@@ -341,18 +347,44 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
     }
 }
 
+__global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
+    wgrad_f32_body(a, M, tilesS_total, splitM, mchunk, blockIdx.x);
+}
+__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk,
+                                                          int dbg) {
+    wgrad_bf16_body(a, M, tilesS_total, splitM, mchunk, blockIdx.x, dbg);
+}
+
+// Several weight gradients in ONE launch (gast_wgrad_multi): the split-M atomics cost 30-60 % of a stand-alone weight-gradient
+// launch because every launch needs >= 768 blocks by itself, i.e. 768 partial 128x128 tiles (50 MB of fp32 atomics) whatever
+// its size.  Sharing the block budget among all the weight gradients of a stage divides that volume by their number and
+// leaves one tail instead of one per launch.
+struct WgBatch {
+    gast_wgrad_args a[GAST_WGRAD_MAX_BATCH];
+    int first[GAST_WGRAD_MAX_BATCH + 1];     // first block of each job
+    int M[GAST_WGRAD_MAX_BATCH], tilesS[GAST_WGRAD_MAX_BATCH], splitM[GAST_WGRAD_MAX_BATCH], mchunk[GAST_WGRAD_MAX_BATCH];
+    int n;
+};
+__global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b) {
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.splitM[d], b.mchunk[d], blockIdx.x - b.first[d]);
+}
+__global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b, int dbg) {
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    wgrad_bf16_body(b.a[d], b.M[d], b.tilesS[d], b.splitM[d], b.mchunk[d], blockIdx.x - b.first[d], dbg);
+}
+
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-}  // namespace
-
-extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
-    if (!args) return GAST_EINVAL;
-    const gast_wgrad_args& a = *args;
+// validation shared by gast_wgrad / gast_wgrad_multi; returns 0 and the tile counts, or an error code
+int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS) {
     if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.P || !a.dW || a.R < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
     const int epc = a.dtype == GAST_F32 ? 4 : 8;
     if (a.R % epc || a.ldp % epc || !aligned16(a.P)) return GAST_EALIGN;
-    int tilesS = 0;
+    tilesS = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_wgrad_seg& g = a.seg[s];
         if (!g.Q || g.S < 1) return GAST_EINVAL;
@@ -362,11 +394,23 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
     }
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
-    const int M = (int)Ml;
+    M = (int)Ml;
+    tilesR = (a.R + BT - 1) / BT;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
+    if (!args) return GAST_EINVAL;
+    const gast_wgrad_args& a = *args;
+    int M, tilesR, tilesS;
+    int rc = wgrad_check(a, M, tilesR, tilesS);
+    if (rc) return rc;
     const int bkm = a.dtype == GAST_F32 ? 32 : 64;
-    const int tilesR = (a.R + BT - 1) / BT;
     const int tiles = tilesR * tilesS;
-    int splitM = 1024 / tiles;
+    static const int tgt = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 768;   // 3 resident blocks per CU
+    int splitM = tgt / tiles;
     int maxsplit = (M + bkm * 4 - 1) / (bkm * 4);
     if (splitM > maxsplit) splitM = maxsplit;
     if (splitM < 1) splitM = 1;
@@ -378,11 +422,54 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
         hipError_t e = hipMemsetAsync(a.dW, 0, (size_t)a.R * a.ldw * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
+    static const int dbg = getenv("GAST_WGRAD_DEBUG") ? atoi(getenv("GAST_WGRAD_DEBUG")) : 0;   // profiling ablations only
     dim3 grid(tiles * splitM), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
     else
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk, dbg);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_t stream) {
+    if (!args || n < 1 || n > GAST_WGRAD_MAX_BATCH) return GAST_EINVAL;
+    WgBatch b;     // 2.4 KB: filled on the host, passed by value (kernel argument)
+    int tilesR[GAST_WGRAD_MAX_BATCH];
+    long tile_rows = 0;
+    int total_tiles = 0;
+    for (int d = 0; d < n; ++d) {
+        if (args[d].dtype != args[0].dtype) return GAST_EINVAL;
+        int rc = wgrad_check(args[d], b.M[d], tilesR[d], b.tilesS[d]);
+        if (rc) return rc;
+        b.a[d] = args[d];
+        total_tiles += tilesR[d] * b.tilesS[d];
+        tile_rows += (long)tilesR[d] * b.tilesS[d] * b.M[d];
+    }
+    const int bkm = args[0].dtype == GAST_F32 ? 32 : 64;
+    static const int tgt = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
+    // one common chunk length (rows of the reduction axis per block) so that every block does the same number of steps
+    long chunk = (tile_rows + tgt - 1) / tgt;
+    chunk = (chunk + bkm - 1) / bkm * bkm;
+    if (chunk < 4 * bkm) chunk = 4 * bkm;
+    hipStream_t st = (hipStream_t)stream;
+    b.n = n;
+    b.first[0] = 0;
+    for (int d = 0; d < n; ++d) {
+        b.mchunk[d] = (int)(chunk < b.M[d] ? chunk : (b.M[d] + bkm - 1) / bkm * bkm);
+        b.splitM[d] = (b.M[d] + b.mchunk[d] - 1) / b.mchunk[d];
+        b.first[d + 1] = b.first[d] + tilesR[d] * b.tilesS[d] * b.splitM[d];
+        if (args[d].zero_first) {
+            hipError_t e = hipMemsetAsync(args[d].dW, 0, (size_t)args[d].R * args[d].ldw * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    static const int dbg = getenv("GAST_WGRAD_DEBUG") ? atoi(getenv("GAST_WGRAD_DEBUG")) : 0;
+    dim3 grid(b.first[n]), block(256);
+    if (args[0].dtype == GAST_F32)
+        hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, block, 0, st, b);
+    else
+        hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, block, 0, st, b, dbg);
     GAST_CHECK_LAUNCH();
     return 0;
 }

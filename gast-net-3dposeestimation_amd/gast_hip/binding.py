@@ -84,6 +84,7 @@ def load_library():
         'gast_gemm_ws': [C.POINTER(_GemmArgs), vp, cl, vp],
         'gast_gemm_splitk_ws_bytes': [cl, ci],
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
+        'gast_wgrad_multi': [C.POINTER(_WgradArgs), ci, vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
         'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp],
@@ -125,7 +126,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
@@ -230,8 +231,7 @@ class HipOps:
         ws = self._splitk_ws(C_.device)
         _check(self.lib.gast_gemm_ws(C.byref(a), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm')
 
-    def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
-        a = _WgradArgs()
+    def _wgrad_args(self, a, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         a.dtype = _dt(P)
         a.B, a.Tn, a.J = (int(v) for v in dom)
         a.P, a.ldp, a.R, a.pmap = _p(P), _ld(P), int(R), _rm(pmap)
@@ -248,8 +248,24 @@ class HipOps:
             raise RuntimeError('gast_hip: dW must be fp32')
         a.dW, a.ldw, a.zero_first = _p(dW), _ld(dW), int(bool(zero_first))
         a.drop = _drop(drop)
+
+    def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
+        a = _WgradArgs()
+        self._wgrad_args(a, dom, P, R, pmap, segs, dW, drop, zero_first)
         self.launches += 1
         _check(self.lib.gast_wgrad(C.byref(a), _stream()), 'gast_wgrad')
+
+    WGRAD_MAX_BATCH = 8
+
+    def wgrad_multi(self, jobs):
+        """jobs: list of dicts with the keyword arguments of wgrad(); launched WGRAD_MAX_BATCH at a time."""
+        for i0 in range(0, len(jobs), self.WGRAD_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.WGRAD_MAX_BATCH]
+            arr = (_WgradArgs * len(chunk))()
+            for a, j in zip(arr, chunk):
+                self._wgrad_args(a, **j)
+            self.launches += 1
+            _check(self.lib.gast_wgrad_multi(arr, len(chunk), _stream()), 'gast_wgrad_multi')
 
     # -- SemCH graph conv
     def semch_adj_fwd(self, e, pat, A_t):

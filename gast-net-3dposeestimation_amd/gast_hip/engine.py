@@ -277,6 +277,17 @@ class Engine:
                     C=C, Tn=Tn, P=P, pro=pro)
 
     # ------------------------------------------------------------------------------------------ backward
+    def _wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=False):
+        """Queue a weight gradient; the queue is flushed once per stage as ONE multi-job launch (ops.wgrad_multi).  Nothing in
+        the backward pass reads a weight gradient, and every operand is in its final state when it is queued (the in-place
+        BatchNorm backward of P runs before)."""
+        self._wq.append(dict(dom=dom, P=P, R=R, pmap=pmap, segs=segs, dW=dW, drop=drop, zero_first=zero_first))
+
+    def _wgrad_flush(self):
+        if self._wq:
+            self.ops.wgrad_multi(self._wq)
+            self._wq = []
+
     def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
         """finalize {sum dz, sum dz*x} -> dgamma/dbeta (written to their destinations) + coefficients, then dz <- dx in place."""
         ops = self.ops
@@ -308,6 +319,7 @@ class Engine:
         f32 = torch.float32
         za = self.za
         za.begin(('bwd', B, sv['T_in'], dt), dev)
+        self._wq = []
 
         # ---- shrink backward
         last = stages[-1]
@@ -317,7 +329,7 @@ class Engine:
         KP = 8
         dp = za.take((PL, KP), dt)
         dp[:, :3] = dpred.reshape(PL, 3).to(dt)
-        ops.wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
+        self._wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
                                                         shift=last['bnO'].shift, wcol0=0)], gout['shrink'], zero_first=False)
         WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
         dO = self._new(PL, CL, dt, dev)
@@ -349,7 +361,7 @@ class Engine:
             lk = 'l%d.' % s
             self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
             # 1x1 conv
-            ops.wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
+            self._wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
                                                             shift=lv['bn1'].shift, wcol0=0)], gout[lk + 'conv1'], zero_first=False)
             nbg = ops.gemm_row_blocks(P)
             part1 = za.take((nbg, C, 2))
@@ -359,7 +371,7 @@ class Engine:
                      X=lv['T1'], xscale=lv['bn1'].scale, xshift=lv['bn1'].shift)
             self._bn_backward(part1, nbg, 0, C, lv['bn1'], inp[lk + 'bn0.weight'], grads, lk + 'bn0', dT1, lv['T1'], P)
             # temporal conv: weight gradient (k K-segments) ...
-            ops.wgrad((B, Tn, J), dT1, C, ident(Tn),
+            self._wgrad((B, Tn, J), dT1, C, ident(Tn),
                       [dict(Q=prev['O'], S=C, map=lv['taps'][tap], pro=PRO_BNRELU, scale=prev['bnO'].scale, shift=prev['bnO'].shift,
                             wcol0=tap * C) for tap in range(k)], gout[lk + 'conv'], zero_first=False)
             # ... and input gradient, fused with the residual branch and the ReLU/BN backward of the previous block's output
@@ -387,6 +399,7 @@ class Engine:
                          epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
             self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
             dO = dOp
+            self._wgrad_flush()
 
         # ---- expand conv + init_bn backward (dX is the gradient w.r.t. relu(expand_bn(E)))
         P0 = B * T[0] * J
@@ -402,6 +415,7 @@ class Engine:
         # G / S sums and the parameter-sized epilogue (xn = gamma0*xhat + beta0 feeds the expand conv) in two launches
         ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, inp['expand_w'],
                        inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'])
+        self._wgrad_flush()
         za.end()
 
     def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
@@ -419,7 +433,7 @@ class Engine:
         pro = st['pro']
         xdrop = pro == PRO_BNRELU_DROP
         # G4 weight gradient: three K segments
-        ops.wgrad(dom, dO, 2 * C, im,
+        self._wgrad(dom, dO, 2 * C, im,
                   [dict(Q=st['X'], S=C, map=im, wcol0=0),
                    dict(Q=st['Lp'], S=C, map=im, pro=pro, scale=st['bnL'].scale, shift=st['bnL'].shift, salt=3 * s + 1, wcol0=C),
                    dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
@@ -437,7 +451,7 @@ class Engine:
                  xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2, drop=drop)
         self._bn_backward(partG, nb, 0, C, st['bnG'], inp[g + 'gcat_bn.weight'], grads, g + 'gcat_bn', dG, st['Gp'], P)
         # local cat conv
-        ops.wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
+        self._wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
                                         wcol0=0)], grads[g + 'Blc'], zero_first=False)
         WlcT = inp[g + 'BlcT']       # [2C][C]
         dY = self._new(P, 2 * C, dt, dev)
@@ -447,7 +461,7 @@ class Engine:
         self._bn_backward(partY, nb, 0, C, st['bnY'], inp[g + 'bn_1.weight'], grads, g + 'bn_1', dY, st['Y'], P, off=0, dzcol=0)
         self._bn_backward(partY, nb, C, C, st['bnY'], inp[g + 'bn_2.weight'], grads, g + 'bn_2', dY, st['Y'], P, off=C, dzcol=C)
         # global cat conv
-        ops.wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'], zero_first=False)
+        self._wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'], zero_first=False)
         WgcT = inp[g + 'BgcT']
         dYa = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dG, K=C, map=im, W=WgcT)], dYa, im)
@@ -464,7 +478,7 @@ class Engine:
         ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym'])
         ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
-        ops.wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
+        self._wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
         nbias = C + 2 * NHEADS      # bias gradients of g / theta / phi = column sums of their dH columns
         ops.colsum(dH[:, 4 * C:], P, nbias, grads[g + 'bias1'][4 * C:], zero_first=False)
         Wg1T = inp[g + 'Bg1T']       # [C][N1]

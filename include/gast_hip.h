@@ -153,6 +153,10 @@ typedef struct {
 } gast_wgrad_args;
 
 int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream);
+/* n <= GAST_WGRAD_MAX_BATCH weight gradients (same dtype) in ONE launch: the block budget, hence the split-M atomic volume and
+ * the launch tail, is shared by all of them.  Same per-job semantics as gast_wgrad. */
+#define GAST_WGRAD_MAX_BATCH 8
+int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_t stream);
 
 /* ---- semantic channel-wise graph convolution (local_attention.py:10-56) ------------------------------------
  * Pattern (device int32 array, built once per skeleton by the host from local_attention.py:92-114):

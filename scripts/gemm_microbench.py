@@ -27,7 +27,7 @@ from gast_hip.binding import Dropout, dropout_params
 th, ik = dropout_params(0.05)
 seed = torch.tensor([5], dtype=torch.int32).cuda()
 out = []
-for name, Tn, N, segs, epi in SHAPES:
+for name, Tn, N, segs, epi in ([] if (len(sys.argv) > 2 and sys.argv[2] == 'wgrad') else SHAPES):
     M = B * Tn * J
     sg = []
     Ktot = 0
@@ -61,3 +61,40 @@ for name, Tn, N, segs, epi in SHAPES:
     fl = 2.0 * M * N * Ktot
     by = abytes + (N * Ktot + M * N) * C.element_size() + (M * N * C.element_size() if epi == 2 else 0)
     print('%-28s M=%6d  %7.1f us  %7.1f TF  %6.2f TB/s (alg)  blocks=%d' % (name, M, us, fl / us / 1e6, by / us / 1e6, ((M + 127) // 128) * ((N + 127) // 128)), flush=True)
+
+# ---- weight gradients: (name, Tn, R, [(S, T_total, t_stride, t_off, pro)])
+WSHAPES = [
+ ('wG4 s1 R512 S768 3seg', 19, 512, [(256, 19, 1, 0, 0), (256, 19, 1, 0, 2), (256, 19, 1, 0, 2)]),
+ ('wG1 s1 R1288 S256', 19, 1288, [(256, 19, 1, 0, 0)]),
+ ('wconv1 R256 S768 taps', 19, 256, [(256, 25, 1, 0, 1), (256, 25, 1, 3, 1), (256, 25, 1, 6, 1)]),
+ ('wG2 s1 R256 S512 pro', 19, 256, [(512, 19, 1, 0, 1)]),
+ ('wG3 s1 R256 S256', 19, 256, [(256, 19, 1, 0, 0)]),
+ ('wG4 s0 R256 S384 3seg', 25, 256, [(128, 25, 1, 0, 0), (128, 25, 1, 0, 2), (128, 25, 1, 0, 2)]),
+ ('wG1 s0 R648 S128', 25, 648, [(128, 25, 1, 0, 0)]),
+ ('wG2 s0 R128 S256 pro', 25, 128, [(256, 25, 1, 0, 1)]),
+]
+if len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
+    for name, Tn, R, segs in WSHAPES:
+        M = B * Tn * J
+        P = torch.randn(M, R, device='cuda').to(dt)
+        sg, Stot, col = [], 0, 0
+        for si, (S, Tt, ts, toff, pro) in enumerate(segs):
+            Q = torch.randn(B * Tt * J, S, device='cuda').to(dt)
+            sg.append(dict(Q=Q, S=S, map=RowMap(Tt, ts, toff), pro=pro, scale=torch.rand(S, device='cuda') + 0.5,
+                           shift=torch.randn(S, device='cuda') * 0.1, salt=si, wcol0=col))
+            col += S
+        if len(segs) == 3 and segs[0][1] != Tn:
+            for s_ in sg[1:]:
+                s_['Q'] = sg[0]['Q']
+        dW = torch.zeros(R, col, device='cuda')
+        for _ in range(3):
+            ops.wgrad((B, Tn, J), P, R, ident(Tn), sg, dW, drop=Dropout(seed, th, ik), zero_first=False)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.wgrad((B, Tn, J), P, R, ident(Tn), sg, dW, drop=Dropout(seed, th, ik), zero_first=False)
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / reps * 1e3
+        fl = 2.0 * M * R * col
+        by = (M * R + M * col) * P.element_size()
+        print('%-28s M=%6d  %7.1f us  %7.1f TF  %6.2f TB/s (alg)' % (name, M, us, fl / us / 1e6, by / us / 1e6), flush=True)

@@ -58,6 +58,10 @@ class OracleOps:
         self.launches += 1
         kc.wgrad(dom, _np(P), R, kc.RowMap(*pmap), _segs(segs, 'Q'), _np(dW), _drop(drop), zero_first)
 
+    def wgrad_multi(self, jobs):
+        for j in jobs:
+            self.wgrad(**j)
+
     def semch_adj_fwd(self, e, pat, A_t):
         kc.semch_adj_fwd(_np(e), _np(pat), _np(A_t))
 

@@ -180,9 +180,8 @@ WGRAD_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
-@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
-def test_wgrad(ops, case, dt):
+def _wgrad_case(case, dt):
+    """device job (keyword arguments of ops.wgrad), host job (for kc.wgrad) and the two dW buffers of one WGRAD_CASES entry"""
     from gast_hip.binding import Dropout, dropout_params
     name, dom, R, segdefs = case
     gen = torch.Generator().manual_seed(sum(map(ord, name)) + 1)
@@ -202,10 +201,33 @@ def test_wgrad(ops, case, dt):
         segs_h.append(dict(Q=hQ[:, :S], S=S, map=kc.RowMap(Tt, ts, toff), pro=pro, scale=host(sc), shift=host(sh), salt=si + 3, wcol0=w0))
     dWd = torch.full((R, ldw), 3.0).cuda()
     dWh = np.full((R, ldw), 3.0)
-    ops.wgrad(dom, P.cuda()[:, :R], R, kc.RowMap(Tn, 1, 0), segs_d, dWd, drop=Dropout(seed_tensor(99), thresh, inv_keep))
-    kc.wgrad(dom, host(P)[:, :R], R, kc.RowMap(Tn, 1, 0), segs_h, dWh, drop=(99, thresh, inv_keep))
+    jd = dict(dom=dom, P=P.cuda()[:, :R], R=R, pmap=kc.RowMap(Tn, 1, 0), segs=segs_d, dW=dWd, drop=Dropout(seed_tensor(99), thresh, inv_keep))
+    jh = dict(dom=dom, P=host(P)[:, :R], R=R, pmap=kc.RowMap(Tn, 1, 0), segs=segs_h, dW=dWh, drop=(99, thresh, inv_keep))
+    return jd, jh
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
+def test_wgrad(ops, case, dt):
+    jd, jh = _wgrad_case(case, dt)
+    ops.wgrad(**jd)
+    kc.wgrad(jh['dom'], jh['P'], jh['R'], jh['pmap'], jh['segs'], jh['dW'], drop=jh['drop'])
     torch.cuda.synchronize()
-    close(host(dWd), dWh, dt, name, fp32=3e-5, bf16=2e-2)
+    close(host(jd['dW']), jh['dW'], dt, case[0], fp32=3e-5, bf16=2e-2)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+def test_wgrad_multi(ops, dt):
+    """All WGRAD_CASES (different domains, segment counts, prologues) as ONE multi-job launch, accumulating into the 3.0 fill
+    (zero_first=False) for the odd jobs and overwriting it for the even ones."""
+    jobs = [_wgrad_case(c, dt) for c in WGRAD_CASES]
+    for i, (jd, jh) in enumerate(jobs):
+        jd['zero_first'] = i % 2 == 0
+    ops.wgrad_multi([jd for jd, _ in jobs])
+    torch.cuda.synchronize()
+    for i, (jd, jh) in enumerate(jobs):
+        kc.wgrad(jh['dom'], jh['P'], jh['R'], jh['pmap'], jh['segs'], jh['dW'], jh['drop'], i % 2 == 0)
+        close(host(jd['dW']), jh['dW'], dt, 'multi ' + WGRAD_CASES[i][0], fp32=3e-5, bf16=2e-2)
 
 
 # ------------------------------------------------------------------------------------------------ SemCH
