@@ -626,6 +626,255 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
     }
 }
 
+// ------------------------------------------------------------------------------------------------ global attention, wave-per-unit
+// One WAVE owns a (frame, head) unit at a time and never meets a block barrier: the J x J tiles and the fp32 copies of the
+// g / dy tiles live in a per-wave LDS region, the phases of a unit are separated by wave-local waits only, and the four waves
+// of a block drift freely against each other.  16-byte (fp32) / 8-byte (bf16) global accesses.  (The block-per-head kernels
+// above -- kept for head widths other than 32/64/128 channels -- spent 83 us on 60 MB: 2-byte loads, ~8 block barriers per
+// 4 frames, 68 of 256 threads busy in the row phases.)
+// A wave keeps ONE head for its whole life (the wave count is a multiple of nheads), so the C_k row of a lane, the dC_k
+// accumulators and the bias-gradient sums stay in registers across units; they leave through a per-wave partial row
+// [C | 2*nheads | nheads*J*J] that attn_bwd_finish_kernel reduces without atomics.
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int CI4> struct AttnW {
+    static constexpr int CI = CI4 * 4, GS = CI + 4, RG = 64 / CI4, NR = (JMAX + RG - 1) / RG;
+    static constexpr int FWD_FLOATS = JMAX * JP + JMAX * GS + 32;
+    static constexpr int BWD_FLOATS = 4 * JMAX * JP + 2 * JMAX * GS + 32;
+};
+
+// rows of att = softmax_j(leaky(a_i + c_j)) + C_k for lane i < J; optionally p and the LeakyReLU slopes
+__device__ __forceinline__ void attn_row(int lane, int J, float a_i, const float* __restrict__ sc, const float* ckrow,
+                                         float (*satt)[JP], float (*sp)[JP], float (*sslope)[JP]) {
+    if (lane < J) {
+        float mx = -3.0e38f;
+        for (int j = 0; j < J; ++j) {
+            float s = a_i + sc[j];
+            s = s > 0.f ? s : 0.2f * s;
+            mx = fmaxf(mx, s);
+        }
+        float sum = 0.f;
+        for (int j = 0; j < J; ++j) {
+            float s = a_i + sc[j];
+            const float sl = s > 0.f ? 1.f : 0.2f;
+            const float ex = expf(s * sl - mx);
+            satt[lane][j] = ex;
+            if (sslope) sslope[lane][j] = sl;
+            sum += ex;
+        }
+        const float inv = 1.f / sum;
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+            if (j < J) {
+                const float pv = satt[lane][j] * inv;
+                if (sp) sp[lane][j] = pv;
+                satt[lane][j] = pv + ckrow[j];
+            }
+        }
+    }
+}
+
+template <typename T, int CI4>
+__global__ void __launch_bounds__(256) attn_fwd_wave_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ AC, int ldac,
+                                                            const float* __restrict__ Ck, int F, int J, int nheads,
+                                                            T* __restrict__ Y, int ldy) {
+    using W = AttnW<CI4>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* base = smem + w * W::FWD_FLOATS;
+    float (*satt)[JP] = (float (*)[JP])base;
+    float* sg = base + JMAX * JP;
+    float* sc = sg + JMAX * W::GS;
+    const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+    const int h = gw % nheads;
+    float ckrow[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) ckrow[j] = (lane < J && j < J) ? Ck[((long)h * J + lane) * J + j] : 0.f;
+    const int rg = lane / CI4, c4 = lane - rg * CI4;
+    for (int u = gw; u < F * nheads; u += nw) {
+        const int f = u / nheads;
+        float a_i = 0.f;
+        if (lane < J) {
+            const T* acp = AC + ((long)f * J + lane) * ldac;
+            a_i = Elem<T>::ld(acp + h);
+            sc[lane] = Elem<T>::ld(acp + nheads + h);
+        }
+        for (int t = lane; t < J * CI4; t += 64) {
+            const int j = t / CI4, cc = t - j * CI4;
+            *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+        }
+        wave_lds_sync();
+        attn_row(lane, J, a_i, sc, ckrow, satt, nullptr, nullptr);
+        wave_lds_sync();
+        float4 acc[W::NR];
+#pragma unroll
+        for (int q = 0; q < W::NR; ++q) acc[q] = make_float4(0, 0, 0, 0);
+        for (int j = 0; j < J; ++j) {
+            const float4 gv = *(const float4*)(sg + j * W::GS + c4 * 4);
+#pragma unroll
+            for (int q = 0; q < W::NR; ++q) {
+                const float a = satt[rg + W::RG * q][j];      // rows >= J: never stored below
+                acc[q].x = fmaf(a, gv.x, acc[q].x); acc[q].y = fmaf(a, gv.y, acc[q].y);
+                acc[q].z = fmaf(a, gv.z, acc[q].z); acc[q].w = fmaf(a, gv.w, acc[q].w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < W::NR; ++q) {
+            const int i = rg + W::RG * q;
+            if (i < J) st4(Y + ((long)f * J + i) * ldy + h * W::CI + c4 * 4, acc[q]);
+        }
+        wave_lds_sync();
+    }
+}
+
+template <typename T, int CI4>
+__global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict__ dY, int lddy, const T* __restrict__ G, int ldg,
+                                                            const T* __restrict__ AC, int ldac, const float* __restrict__ Ck,
+                                                            int F, int J, int nheads, T* __restrict__ dG, int lddg,
+                                                            T* __restrict__ dAC, int lddac, float* __restrict__ ws, int ncol) {
+    using W = AttnW<CI4>;
+    constexpr int NP = (JMAX * JMAX + 63) / 64;      // (i, j) pairs per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float* base = smem + w * W::BWD_FLOATS;
+    float (*satt)[JP] = (float (*)[JP])base;
+    float (*sp)[JP] = (float (*)[JP])(base + JMAX * JP);
+    float (*sds)[JP] = (float (*)[JP])(base + 2 * JMAX * JP);     // LeakyReLU slopes, then ds
+    float (*sdat)[JP] = (float (*)[JP])(base + 3 * JMAX * JP);
+    float* sg = base + 4 * JMAX * JP;
+    float* sdy = sg + JMAX * W::GS;
+    float* sc = sdy + JMAX * W::GS;
+    const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+    const int h = gw % nheads;
+    const int C = nheads * W::CI;
+    float ckrow[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) ckrow[j] = (lane < J && j < J) ? Ck[((long)h * J + lane) * J + j] : 0.f;
+    const int rg = lane / CI4, c4 = lane - rg * CI4;
+    float ckacc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) ckacc[q] = 0.f;
+    float4 gsum = make_float4(0, 0, 0, 0);
+    float da_sum = 0.f, dc_sum = 0.f;
+    for (int u = gw; u < F * nheads; u += nw) {
+        const int f = u / nheads;
+        float a_i = 0.f;
+        if (lane < J) {
+            const T* acp = AC + ((long)f * J + lane) * ldac;
+            a_i = Elem<T>::ld(acp + h);
+            sc[lane] = Elem<T>::ld(acp + nheads + h);
+        }
+        for (int t = lane; t < J * CI4; t += 64) {
+            const int j = t / CI4, cc = t - j * CI4;
+            *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+            *(float4*)(sdy + j * W::GS + cc * 4) = ld4(dY + ((long)f * J + j) * lddy + h * W::CI + cc * 4);
+        }
+        wave_lds_sync();
+        attn_row(lane, J, a_i, sc, ckrow, satt, sp, sds);
+        // datt[i][j] = sum_c dy[i][c] * g[j][c]   (pairs t = lane + 64 q)
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            const int t = lane + 64 * q;
+            if (t < J * J) {
+                const int i = t / J, j = t - i * J;
+                const float* pd = sdy + i * W::GS;
+                const float* pg = sg + j * W::GS;
+                float acc = 0.f;
+#pragma unroll 4
+                for (int cc = 0; cc < CI4; ++cc) {
+                    const float4 x = *(const float4*)(pd + cc * 4);
+                    const float4 y = *(const float4*)(pg + cc * 4);
+                    acc = fmaf(x.x, y.x, acc); acc = fmaf(x.y, y.y, acc); acc = fmaf(x.z, y.z, acc); acc = fmaf(x.w, y.w, acc);
+                }
+                sdat[i][j] = acc;
+                ckacc[q] += acc;
+            }
+        }
+        wave_lds_sync();
+        // softmax + LeakyReLU backward, row i = lane: ds_ij = p_ij (datt_ij - <p_i, datt_i>) slope_ij;  da_i = sum_j ds_ij
+        if (lane < J) {
+            float dot = 0.f;
+            for (int j = 0; j < J; ++j) dot = fmaf(sp[lane][j], sdat[lane][j], dot);
+            float da = 0.f;
+            for (int j = 0; j < J; ++j) {
+                const float ds = sp[lane][j] * (sdat[lane][j] - dot) * sds[lane][j];
+                sds[lane][j] = ds;
+                da += ds;
+            }
+            Elem<T>::st(dAC + ((long)f * J + lane) * lddac + h, da);
+            da_sum += da;
+        }
+        wave_lds_sync();
+        if (lane < J) {
+            float dc = 0.f;
+            for (int i = 0; i < J; ++i) dc += sds[i][lane];
+            Elem<T>::st(dAC + ((long)f * J + lane) * lddac + nheads + h, dc);
+            dc_sum += dc;
+        }
+        // dg[j][c] = sum_i att[i][j] * dy[i][c]
+        float4 acc[W::NR];
+#pragma unroll
+        for (int q = 0; q < W::NR; ++q) acc[q] = make_float4(0, 0, 0, 0);
+        for (int i = 0; i < J; ++i) {
+            const float4 dv = *(const float4*)(sdy + i * W::GS + c4 * 4);
+#pragma unroll
+            for (int q = 0; q < W::NR; ++q) {
+                const int jq = rg + W::RG * q;
+                const float a = satt[i][jq < JMAX ? jq : 0];
+                acc[q].x = fmaf(a, dv.x, acc[q].x); acc[q].y = fmaf(a, dv.y, acc[q].y);
+                acc[q].z = fmaf(a, dv.z, acc[q].z); acc[q].w = fmaf(a, dv.w, acc[q].w);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < W::NR; ++q) {
+            const int j = rg + W::RG * q;
+            if (j < J) {
+                st4(dG + ((long)f * J + j) * lddg + h * W::CI + c4 * 4, acc[q]);
+                gsum.x += acc[q].x; gsum.y += acc[q].y; gsum.z += acc[q].z; gsum.w += acc[q].w;
+            }
+        }
+        wave_lds_sync();
+    }
+    // per-wave partial row: [g bias sums (C) | da sums (nheads) | dc sums (nheads) | dC_k (nheads*J*J)]; a wave writes only the
+    // slices of its head, the nheads waves that share a row index write disjoint slices
+    float* row = ws + (long)(gw / nheads) * ncol;
+    for (int off = CI4; off < 64; off <<= 1) {
+        gsum.x += __shfl_xor(gsum.x, off); gsum.y += __shfl_xor(gsum.y, off);
+        gsum.z += __shfl_xor(gsum.z, off); gsum.w += __shfl_xor(gsum.w, off);
+    }
+    if (rg == 0) *(float4*)(row + h * W::CI + c4 * 4) = gsum;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { da_sum += __shfl_xor(da_sum, off); dc_sum += __shfl_xor(dc_sum, off); }
+    if (lane == 0) { row[C + h] = da_sum; row[C + nheads + h] = dc_sum; }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int t = lane + 64 * q;
+        if (t < J * J) row[C + 2 * nheads + h * J * J + t] = ckacc[q];
+    }
+}
+
+// dbias[n] += sum_r ws[r][n] (n < nb);  dCk[n - nb] += sum_r ws[r][n] (n >= nb)      (256 threads = 32 columns x 8 row lanes)
+__global__ void __launch_bounds__(256) attn_bwd_finish_kernel(const float* __restrict__ ws, int nrow, int ncol, int nb,
+                                                              float* __restrict__ dbias, float* __restrict__ dCk) {
+    __shared__ float sred[8][32];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + cx;
+    float a = 0.f;
+    if (n < ncol) {
+#pragma unroll 4
+        for (int r = ry; r < nrow; r += 8) a += ws[(long)r * ncol + n];
+    }
+    sred[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && n < ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += sred[r][cx];
+        if (n < nb) { if (dbias) dbias[n] += t; }
+        else dCk[n - nb] += t;
+    }
+}
+
 inline int agg_tpf(int C) { int c4 = C / 4; return c4 < 256 ? c4 : 256; }
 
 }  // namespace
@@ -772,11 +1021,72 @@ static int attn_grid(int F, int nheads, int ub) {
     return per_head * nheads;
 }
 
+// wave-per-unit path: head width 32 / 64 / 128 channels, vector-aligned operands, wave count a multiple of nheads
+static int attn_wave_ci4(int dtype, int C, int nheads, int ldg, int ldy, const void* G, const void* Y) {
+    if (C % nheads) return 0;
+    const int Ci = C / nheads;
+    if (Ci != 32 && Ci != 64 && Ci != 128) return 0;
+    if (4 % nheads) return 0;                         // 4 waves per block: every wave keeps one head
+    const int al = dtype == GAST_F32 ? 16 : 8;        // ld4 granularity in bytes
+    const int es = dtype == GAST_F32 ? 4 : 2;
+    if ((ldg * es) % al || (ldy * es) % al || ((uintptr_t)G % al) || ((uintptr_t)Y % al)) return 0;
+    return Ci / 4;
+}
+static int attn_wave_grid(int F, int nheads) {
+    long units = (long)F * nheads;
+    long g = (units + 7) / 8;                          // >= 2 units per wave
+    if (g > 768) g = 768;
+    return g < 1 ? 1 : (int)g;
+}
+
+template <typename T, int CI4>
+static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J, int nheads, void* Y,
+                                int ldy, hipStream_t st) {
+    const size_t smem = (size_t)4 * AttnW<CI4>::FWD_FLOATS * sizeof(float);
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
+                       ldac, C_k, F, J, nheads, (T*)Y, ldy);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+template <typename T, int CI4>
+static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
+                                int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
+                                hipStream_t st) {
+    const size_t smem = (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float);
+    if (smem > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    const int grid = attn_wave_grid(F, nheads);
+    const int C = nheads * CI4 * 4;
+    const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;
+    hipLaunchKernelGGL((attn_bwd_wave_kernel<T, CI4>), dim3(grid), dim3(256), smem, st, (const T*)dY, lddy, (const T*)G, ldg, (const T*)AC,
+                       ldac, C_k, F, J, nheads, (T*)dG, lddg, (T*)dAC, lddac, ws, ncol);
+    GAST_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3((ncol + 31) / 32), dim3(256), 0, st, ws, grid * 4 / nheads, ncol, nb, dbias, dC_k);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
                              int F, int J, int C, int nheads, void* Y, int ldy, gast_stream_t stream) {
     if (!G || !AC || !C_k || !Y) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
+    switch (attn_wave_ci4(dtype, C, nheads, ldg, ldy, G, Y)) {
+#define GAST_FWD_WAVE(CI4_)                                                                                                         \
+        case CI4_: return dtype == GAST_F32                                                                                         \
+            ? launch_attn_fwd_wave<float, CI4_>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, (hipStream_t)stream)                  \
+            : launch_attn_fwd_wave<bf16_t, CI4_>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, (hipStream_t)stream);
+        GAST_FWD_WAVE(8) GAST_FWD_WAVE(16) GAST_FWD_WAVE(32)
+#undef GAST_FWD_WAVE
+        default: break;
+    }
     const int Ci = C / nheads, GS = (Ci + 3) / 4 * 4 + 4;
     int ub = UB;
     size_t smem = 0;
@@ -803,12 +1113,31 @@ extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, 
     return 0;
 }
 
+extern "C" long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads) {
+    if (nheads < 1 || F < 1 || J < 1) return 0;
+    return (long)(attn_wave_grid(F, nheads) * 4 / nheads + 1) * (C + 2 * nheads + nheads * J * J);
+}
+
 extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
                              const float* C_k, int F, int J, int C, int nheads,
-                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias_ac, gast_stream_t stream) {
+                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_stream_t stream) {
     if (!dY || !G || !AC || !C_k || !dG || !dAC || !dC_k) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
+    if (ws && attn_wave_ci4(dtype, C, nheads, ldg, ldy, G, dY) && attn_wave_ci4(dtype, C, nheads, lddg, lddg, dG, dG)) {
+        switch (C / nheads / 4) {
+#define GAST_BWD_WAVE(CI4_)                                                                                                         \
+            case CI4_: return dtype == GAST_F32                                                                                     \
+                ? launch_attn_bwd_wave<float, CI4_>(dY, ldy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, \
+                                                    (hipStream_t)stream)                                                            \
+                : launch_attn_bwd_wave<bf16_t, CI4_>(dY, ldy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, \
+                                                     (hipStream_t)stream);
+            GAST_BWD_WAVE(8) GAST_BWD_WAVE(16) GAST_BWD_WAVE(32)
+#undef GAST_BWD_WAVE
+            default: break;
+        }
+    }
+    float* dbias_ac = dbias ? dbias + C : nullptr;
     const int Ci = C / nheads, GS = (Ci + 3) / 4 * 4 + 4;
     int ub = UB;
     size_t smem = 0;
@@ -832,5 +1161,6 @@ extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, 
         hipLaunchKernelGGL((attn_bwd_kernel<bf16_t>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dY, ldy, (const bf16_t*)G, ldg,
                            (const bf16_t*)AC, ldac, C_k, F, J, C, nheads, (bf16_t*)dG, lddg, (bf16_t*)dAC, lddac, dC_k, dbias_ac, ub);
     GAST_CHECK_LAUNCH();
+    if (dbias) return gast_colsum(dtype, dG, lddg, (long)F * J, C, dbias, 0, stream);      // g-bias part: column sums of dG
     return 0;
 }

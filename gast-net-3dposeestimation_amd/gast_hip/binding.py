@@ -92,7 +92,8 @@ def load_library():
         'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
         'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
-        'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp],
+        'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, vp],
+        'gast_attn_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp],
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -127,7 +128,7 @@ def load_library():
 
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
-                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd',
+                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
@@ -304,10 +305,14 @@ class HipOps:
         _check(self.lib.gast_attn_fwd(_dt(G), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads, _p(Y), _ld(Y), _stream()),
                'gast_attn_fwd')
 
-    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias_ac=None):
-        self.launches += 1
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias=None, generic=False):
+        """dC_k and dbias ([C + 2*nheads]: column sums of [dG | dAC]) are accumulated into (zero-filled by the caller)."""
+        self.launches += 2
+        ws = None
+        if not generic:
+            ws = torch.empty(max(1, self.lib.gast_attn_bwd_ws_floats(F, J, C_, nheads)), dtype=torch.float32, device=G.device)
         _check(self.lib.gast_attn_bwd(_dt(G), _p(dY), _ld(dY), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads,
-                                      _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _p(dbias_ac), _stream()), 'gast_attn_bwd')
+                                      _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _p(dbias), _p(ws), _stream()), 'gast_attn_bwd')
 
     # -- BatchNorm pieces
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps,

@@ -469,7 +469,9 @@ class Engine:
         H = st['H']
         dH = self._new(P, N1, dt, dev)
         dCk = grads[g + 'C_k']          # accumulated with atomics: gradient destinations arrive zeroed (see backward())
-        ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk)
+        # (+ the bias gradients of g / theta / phi = column sums of these dH columns, reduced in the same pass)
+        ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk,
+                     dbias=grads[g + 'bias1'][4 * C:])
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
         ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
@@ -479,8 +481,6 @@ class Engine:
         ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
         self._wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
-        nbias = C + 2 * NHEADS      # bias gradients of g / theta / phi = column sums of their dH columns
-        ops.colsum(dH[:, 4 * C:], P, nbias, grads[g + 'bias1'][4 * C:], zero_first=False)
         Wg1T = inp[g + 'Bg1T']       # [C][N1]
         dX = self._new(P, C, dt, dev)
         ops.gemm(dom, C, [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])], dX, im)

@@ -195,11 +195,13 @@ long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con);
  * att = softmax_j(LeakyReLU_0.2(a_i + c_j)) + C_k[h,i,j];  Y[i, hCi+c] = sum_j att_ij g[j, hCi+c]. */
 int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
                   int F, int J, int C, int nheads, void* Y, int ldy, gast_stream_t stream);
-/* Backward: dG (C cols), dAC (2*nheads cols) written; dC_k[nheads][J][J] and (optional) dbias_ac[2*nheads] = column sums of
- * dAC taken in fp32 before rounding (bias gradients of theta / phi) are accumulated atomically (caller zeroes). */
+/* Backward: dG (C cols), dAC (2*nheads cols) written; dC_k[nheads][J][J] and (optional) dbias[C + 2*nheads] = column sums of
+ * [dG | dAC] over all rows (bias gradients of g / theta / phi, global_attention.py:29-34) are ACCUMULATED (caller zeroes).
+ * ws: gast_attn_bwd_ws_floats() floats of scratch (per-wave partial rows), or null to force the generic kernels. */
 int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
                   const float* C_k, int F, int J, int C, int nheads,
-                  void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias_ac, gast_stream_t stream);
+                  void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_stream_t stream);
+long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads);
 
 /* ---- BatchNorm2d (momentum 0.1, eps 1e-5; gast_net.py:20,58-59,147,149 etc.) as a two-phase scheme ---------
  * Producers emit per-row-block partial sums; `gast_bn_finalize` turns them into the per-channel scale/shift that

@@ -301,8 +301,8 @@ def attn_fwd(G, AC, C_k, F, J, C, nheads, Y, round_fn=None):
     Y[:F * J, :C] = y
 
 
-def attn_bwd(dY, G, AC, C_k, F, J, C, nheads, dG, dAC, dC_k, round_fn=None, dbias_ac=None):
-    """dC_k is accumulated (+=); the caller zeroes it."""
+def attn_bwd(dY, G, AC, C_k, F, J, C, nheads, dG, dAC, dC_k, round_fn=None, dbias=None):
+    """dC_k and dbias ([C + 2*nheads] = column sums of [dG | dAC]) are accumulated (+=); the caller zeroes them."""
     Ci = C // nheads
     p, att, slope = _attn_common(AC, C_k, F, J, nheads)
     g = np.asarray(G[:F * J, :C], np.float64).reshape(F, J, nheads, Ci)
@@ -314,8 +314,9 @@ def attn_bwd(dY, G, AC, C_k, F, J, C, nheads, dG, dAC, dC_k, round_fn=None, dbia
     da = ds.sum(axis=3).transpose(0, 2, 1)              # (F,J,h)
     dc = ds.sum(axis=2).transpose(0, 2, 1)
     dac = np.concatenate([da, dc], axis=2).reshape(F * J, 2 * nheads)
-    if dbias_ac is not None:
-        dbias_ac += dac.sum(axis=0)        # column sums before storage rounding
+    if dbias is not None:
+        dbias[:C] += dg.sum(axis=0)        # column sums before storage rounding
+        dbias[C:C + 2 * nheads] += dac.sum(axis=0)
     if round_fn is not None:
         dg, dac = round_fn(dg), round_fn(dac)
     dG[:F * J, :C] = dg

@@ -87,8 +87,8 @@ class OracleOps:
     def attn_fwd(self, G, AC, C_k, F, J, C_, nheads, Y):
         kc.attn_fwd(_np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(Y))
 
-    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias_ac=None):
-        kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k), dbias_ac=_np(dbias_ac))
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias=None, generic=False):
+        kc.attn_bwd(_np(dY), _np(G), _np(AC), _np(C_k), F, J, C_, nheads, _np(dG), _np(dAC), _np(dC_k), dbias=_np(dbias))
 
     def bn_finalize(self, partials, nblk, col0, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale,
                     shift, mean, rstd, centered=False):

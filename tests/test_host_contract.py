@@ -118,3 +118,18 @@ def test_pattern_tables_match_contract():
         for ours, ref in ((sym, s2), (con, c2)):
             tab, nnz = pattern_table(ours)
             assert np.array_equal(tab.numpy(), kc.build_pattern(ref)) and nnz == int((ref > 0).sum())
+
+
+def test_binding_argument_counts_match_header():
+    """every ctypes signature has as many arguments as the C declaration (a short list silently drops the stream pointer)"""
+    import re
+    from gast_hip import binding
+    lib = binding.load_library()
+    h = open(os.path.join(os.path.dirname(__file__), '..', 'include', 'gast_hip.h')).read()
+    h = re.sub(r'/\*.*?\*/', '', h, flags=re.S)
+    for m in re.finditer(r'\b(?:int|long|const char\*)\s+(gast_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;', h):
+        name, params = m.group(1), m.group(2).strip()
+        n = 0 if params in ('', 'void') else params.count(',') + 1
+        fn = getattr(lib, name)
+        assert fn.argtypes is not None, name
+        assert len(fn.argtypes) == n, (name, len(fn.argtypes), n)

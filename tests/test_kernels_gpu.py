@@ -301,8 +301,11 @@ def test_semch_agg(ops, J, C, F, dt):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
-@pytest.mark.parametrize('J,C,F', [(17, 16, 37), (19, 128, 50), (15, 8, 9), (17, 512, 6), (16, 2048, 3), (17, 256, 2200)])
-def test_attention(ops, J, C, F, dt):
+@pytest.mark.parametrize('J,C,F,generic', [(17, 16, 37, False), (19, 128, 50, False), (15, 8, 9, False), (17, 512, 6, False),
+                                           (16, 2048, 3, False), (17, 256, 2200, False), (17, 128, 301, True), (19, 256, 7, False),
+                                           (15, 128, 1, False)])
+def test_attention(ops, J, C, F, generic, dt):
+    """head widths 32 / 64 / 128 take the wave-per-unit kernels, everything else (and generic=True) the block-per-head ones"""
     gen = torch.Generator().manual_seed(J + C)
     nh = 4
     P = F * J
@@ -322,12 +325,12 @@ def test_attention(ops, J, C, F, dt):
     assert np.all(got[:, C:] == 3.0)
     dY = rand(gen, P, C).to(dt)
     dHd = torch.full((P, ld), 2.0).to(dt).cuda()
-    dCk = torch.zeros(nh, J, J).cuda()
-    dbac = torch.zeros(2 * nh).cuda()
-    ops.attn_bwd(dY.cuda(), G, AC, Ck.cuda(), F, J, C, nh, dHd[:, :C], dHd[:, C:C + 2 * nh], dCk, dbias_ac=dbac)
-    dG, dAC, dCkh, dbach = np.zeros((P, C)), np.zeros((P, 2 * nh)), np.zeros((nh, J, J)), np.zeros(2 * nh)
-    kc.attn_bwd(host(dY), Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, dG, dAC, dCkh, round_fn=rnd, dbias_ac=dbach)
-    assert np.abs(host(dbac) - dbach).max() <= (2e-4 if dt == torch.float32 else 2e-2) * max(1.0, np.abs(dbach).max()), 'attn bwd dbias_ac'
+    dCk = torch.full((nh, J, J), 0.5).cuda()             # accumulated into
+    dbias = torch.full((C + 2 * nh,), -0.25).cuda()
+    ops.attn_bwd(dY.cuda(), G, AC, Ck.cuda(), F, J, C, nh, dHd[:, :C], dHd[:, C:C + 2 * nh], dCk, dbias=dbias, generic=generic)
+    dG, dAC, dCkh, dbh = np.zeros((P, C)), np.zeros((P, 2 * nh)), np.full((nh, J, J), 0.5), np.full(C + 2 * nh, -0.25)
+    kc.attn_bwd(host(dY), Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, dG, dAC, dCkh, round_fn=rnd, dbias=dbh)
+    assert np.abs(host(dbias) - dbh).max() <= (2e-4 if dt == torch.float32 else 2e-2) * max(1.0, np.abs(dbh).max()), 'attn bwd dbias'
     got = host(dHd)
     close(got[:, :C], dG, dt, 'attn bwd dG')
     close(got[:, C:C + 2 * nh], dAC, dt, 'attn bwd dAC', fp32=1e-4, bf16=3e-2)
