@@ -113,6 +113,7 @@ def load_library():
         'gast_unfold': [vp, ci, ci, vp, vp],
         'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
+        'gast_null_launch': [vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -132,7 +133,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'g
                     'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_version']
 
 
 def _check(rc, what):
@@ -460,6 +461,9 @@ class HipOps:
         self.launches += 2
         _check(self.lib.gast_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
                                        weight_decay, grad_scale, _stream()), 'gast_adam_step')
+
+    def null_launch(self):
+        _check(self.lib.gast_null_launch(_stream()), 'gast_null_launch')
 
     def run_pack(self, packer, st):
         dev = st['Wb'].device

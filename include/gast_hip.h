@@ -284,6 +284,8 @@ int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* 
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
 
+/* launches an empty kernel: the fixed dispatch cost an event pair sees around any launch (bench.py calibration) */
+int gast_null_launch(gast_stream_t stream);
 const char* gast_version(void);
 
 #ifdef __cplusplus

@@ -1,0 +1,32 @@
+"""Per-kernel averages of rocprofv3 --pmc counter CSVs (one counter per pass).  Usage:
+python scripts/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json]
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE counts the
+128-byte requests of 16-byte-per-lane coalesced loads at 64 bytes (MI355X_MICROARCH.md, section HBM)."""
+import csv, sys, json, re, collections
+
+def load(path):
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    for r in csv.DictReader(open(path)):
+        n = re.sub(r'\(anonymous namespace\)::', '', r['Kernel_Name'])
+        n = re.sub(r'^void ', '', n)
+        m = re.match(r'([\w:]+)(<[^(]*>)?', n)
+        key = (m.group(1) + (m.group(2) or '')) if m else n[:60]
+        agg[key][0] += 1
+        agg[key][1] += float(r['Counter_Value'])
+    return agg
+
+fetch, write = load(sys.argv[1]), load(sys.argv[2])
+out = {}
+for k in sorted(fetch, key=lambda k: -fetch[k][1]):
+    nf, f = fetch[k]
+    nw, w = write.get(k, (0, 0.0))
+    if nf == 0:
+        continue
+    fkb, wkb = f / nf, (w / nw if nw else 0.0)
+    out[k] = dict(launches=nf, fetch_kib_per_launch=round(fkb, 1), write_kib_per_launch=round(wkb, 1),
+                  hbm_bytes_per_launch=round((2 * fkb + wkb) * 1024))
+for k, v in list(out.items())[:14]:
+    print('%-70s n=%4d fetch %9.1f KiB write %9.1f KiB -> hbm %8.2f MB/launch' % (k[:70], v['launches'], v['fetch_kib_per_launch'],
+                                                                               v['write_kib_per_launch'], v['hbm_bytes_per_launch'] / 1e6))
+if len(sys.argv) > 3:
+    json.dump(out, open(sys.argv[3], 'w'), indent=1)
