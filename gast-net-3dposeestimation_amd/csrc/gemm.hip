@@ -76,7 +76,7 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
 }
 
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws) {
+__device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws, int blk) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -91,8 +91,8 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
     const int lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     // split-K (small-M GEMMs: few output tiles, long K): blockIdx.x = tile * splitk + split
-    const int sp = blockIdx.x % splitk;
-    const int logical = xcd_remap(blockIdx.x / splitk, gridM * gridN);
+    const int sp = blk % splitk;
+    const int logical = xcd_remap(blk / splitk, gridM * gridN);
     const int mt = logical / gridN, nt = logical - mt * gridN;
 
     if (tid < BM) {
@@ -485,6 +485,28 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
 template <typename T, typename TO>
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws) {
+    gemm_body<T, TO>(a, M, gridM, gridN, vec_epi, dbg, splitk, ws, blockIdx.x);
+}
+
+// Several independent GEMMs of one plan step in ONE grid (gast_gemm_multi): the K <= 256 launches of a block (G2 / G3, the two
+// branch input gradients, ...) have 425-646 blocks each -- 1.7-2.5 per CU at an occupancy of 3 -- and end in a tail; launched
+// together they share one tail and one launch.
+struct GemmBatch {
+    gast_gemm_args a[GAST_GEMM_MAX_BATCH];
+    int first[GAST_GEMM_MAX_BATCH + 1];
+    int M[GAST_GEMM_MAX_BATCH], gridM[GAST_GEMM_MAX_BATCH], gridN[GAST_GEMM_MAX_BATCH], vec_epi[GAST_GEMM_MAX_BATCH];
+    int n;
+};
+static_assert(sizeof(GemmBatch) <= 3584, "GemmBatch travels as a kernel argument (4 KB limit)");
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b, int dbg) {
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    gemm_body<T, TO>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], dbg, 1, nullptr, blockIdx.x - b.first[d]);
+}
+
+template <typename T, typename TO>
 __global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args a, int M, int gridN, int splitk, const float* __restrict__ ws) {
     __shared__ float sRed[8][BN][2];
     const int tid = threadIdx.x;
@@ -565,9 +587,9 @@ extern "C" long gast_gemm_splitk_ws_bytes(long M, int N) { return 8L * M * N * (
 extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
 extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) { return gast_gemm_ws(args, nullptr, 0, stream); }
 
-extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream) {
-    if (!args) return GAST_EINVAL;
-    const gast_gemm_args& a = *args;
+namespace {
+// validation + launch geometry shared by gast_gemm_ws / gast_gemm_multi
+int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gridM, int& gridN, int& vec_epi, int& splitk) {
     if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.C || a.N < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
     const int epc = a.dtype == GAST_F32 ? 4 : 8;
@@ -583,12 +605,13 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return GAST_EINVAL;
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
-    const int M = (int)Ml;
-    const int gridM = (M + BM - 1) / BM, gridN = (a.N + BN - 1) / BN;
+    M = (int)Ml;
+    gridM = (M + BM - 1) / BM;
+    gridN = (a.N + BN - 1) / BN;
     // split-K: few output tiles and a long K loop (the M = B*J rows of the last stage): up to 8 K ranges per tile
     int ntiles = 0;
     for (int s2 = 0; s2 < a.nseg; ++s2) ntiles += (a.seg[s2].K + 8 * epc - 1) / (8 * epc);
-    int splitk = 1;
+    splitk = 1;
     static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling/bisecting ablations only
     if (ws && gridM * gridN <= 160 && ntiles >= 4 && !(dbg & 64)) {
         splitk = 512 / (gridM * gridN);
@@ -601,12 +624,23 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
             splitk = (ntiles + tps - 1) / tps;      // no empty K ranges
         }
     }
-    dim3 grid(gridM * gridN * splitk), block(256);
-    hipStream_t st = (hipStream_t)stream;
     // the coalesced (LDS-staged, 16-byte) epilogue needs same-width in/out element types and 16-byte aligned rows
-    int vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
+    vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
     if (a.addend && (a.ldadd % epc || !aligned16(a.addend))) vec_epi = 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
+    return 0;
+}
+}  // namespace
+
+extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream) {
+    if (!args) return GAST_EINVAL;
+    const gast_gemm_args& a = *args;
+    int M, gridM, gridN, vec_epi, splitk;
+    int rc = gemm_plan(a, ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
+    if (rc) return rc;
+    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
     else if (a.out_f32)
@@ -625,5 +659,39 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
             hipLaunchKernelGGL((splitk_finish_kernel<bf16_t, bf16_t>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
         GAST_CHECK_LAUNCH();
     }
+    return 0;
+}
+
+extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream) {
+    if (!args || n < 1 || n > GAST_GEMM_MAX_BATCH) return GAST_EINVAL;
+    GemmBatch b;
+    b.n = 0;
+    b.first[0] = 0;
+    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;
+    for (int d = 0; d < n; ++d) {
+        if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32) return GAST_EINVAL;
+        int M, gridM, gridN, vec_epi, splitk;
+        int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
+        if (rc) return rc;
+        if (splitk > 1) {                       // small-M job: its own split-K launch pair
+            rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
+            if (rc) return rc;
+            continue;
+        }
+        const int k = b.n++;
+        b.a[k] = args[d];
+        b.M[k] = M; b.gridM[k] = gridM; b.gridN[k] = gridN; b.vec_epi[k] = vec_epi;
+        b.first[k + 1] = b.first[k] + gridM * gridN;
+    }
+    if (b.n == 0) return 0;
+    dim3 grid(b.first[b.n]), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (args[0].dtype == GAST_F32)
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b, dbg);
+    else if (args[0].out_f32)
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b, dbg);
+    else
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b, dbg);
+    GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -72,13 +72,19 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
     for (int r = 0; r < FIN_LANES; ++r) { s1 += sred[r][cx][0]; s2 += sred[r][cx][1]; }
 }
 
-__global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
-                                   double count, const float* __restrict__ gamma, const float* __restrict__ beta, float* running_mean,
-                                   float* running_var, int64_t* nbt, float momentum, float eps, float* scale, float* shift,
-                                   float* mean_out, float* rstd_out, int centered) {
+__device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    const float* __restrict__ partials = j.partials;
+    const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N, centered = j.centered;
+    const double count = j.count;
+    const float* __restrict__ gamma = j.gamma;
+    const float* __restrict__ beta = j.beta;
+    float* running_mean = j.running_mean; float* running_var = j.running_var; int64_t* nbt = j.num_batches_tracked;
+    const float momentum = j.momentum, eps = j.eps;
+    float* scale = j.scale; float* shift = j.shift; float* mean_out = j.mean; float* rstd_out = j.rstd;
     const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
     const int n = blockIdx.x * FIN_COLS + cx;
+    if ((int)blockIdx.x * FIN_COLS >= N) return;
     double s1, s2;
     finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
@@ -101,6 +107,10 @@ __global__ void __launch_bounds__(256) bn_finalize_kernel(const float* __restric
     if (n == 0 && nbt) *nbt += 1;
 }
 
+// up to GAST_BN_MAX_BATCH independent finalizes in one launch: blockIdx.y = job
+struct BnFinBatch { gast_bn_fin_job j[GAST_BN_MAX_BATCH]; };
+__global__ void __launch_bounds__(256) bn_finalize_multi_kernel(const BnFinBatch b) { bn_finalize_body(b.j[blockIdx.y]); }
+
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                const float* __restrict__ rv, float eps, int N, float* scale, float* shift, int centered) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -110,12 +120,18 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
     shift[n] = centered ? beta[n] : beta[n] - rm[n] * sc;
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __restrict__ partials, int nblk, int ncol_total, int col0, int N,
-                                       double count, const float* __restrict__ gamma, const float* __restrict__ mean,
-                                       const float* __restrict__ rstd, float* dgamma, float* dbeta, float* ka, float* kb, float* kc) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& j) {
     __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    const float* __restrict__ partials = j.partials;
+    const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N;
+    const double count = j.count;
+    const float* __restrict__ gamma = j.gamma;
+    const float* __restrict__ mean = j.mean;
+    const float* __restrict__ rstd = j.rstd;
+    float* dgamma = j.dgamma; float* dbeta = j.dbeta; float* ka = j.ka; float* kb = j.kb; float* kc = j.kc;
     const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
     const int n = blockIdx.x * FIN_COLS + cx;
+    if ((int)blockIdx.x * FIN_COLS >= N) return;
     double s1, s2;
     finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
@@ -130,6 +146,9 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_kernel(const float* __res
     kb[n] = (float)b;
     kc[n] = (float)(-b * mu - a * db / count);
 }
+
+struct BnBwdFinBatch { gast_bn_bwd_fin_job j[GAST_BN_MAX_BATCH]; };
+__global__ void __launch_bounds__(256) bn_bwd_finalize_multi_kernel(const BnBwdFinBatch b) { bn_bwd_finalize_body(b.j[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ elementwise
 template <typename T>
@@ -524,16 +543,30 @@ __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __r
 
 extern "C" int gast_rowwise_blocks(long rows, int N) { return row_blocks(rows, N); }
 
+extern "C" int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_BN_MAX_BATCH) return GAST_EINVAL;
+    BnFinBatch b;
+    int maxN = 0;
+    for (int d = 0; d < n; ++d) {
+        const gast_bn_fin_job& j = jobs[d];
+        if (!j.partials || !j.gamma || !j.beta || !j.scale || !j.shift || !j.mean || !j.rstd || j.N < 1 || j.nblk < 1 || j.count <= 0)
+            return GAST_EINVAL;
+        if ((j.running_mean == nullptr) != (j.running_var == nullptr)) return GAST_EINVAL;
+        b.j[d] = j;
+        if (j.N > maxN) maxN = j.N;
+    }
+    hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3((maxN + FIN_COLS - 1) / FIN_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
                                 int64_t* num_batches_tracked, float momentum, float eps,
                                 float* scale, float* shift, float* mean, float* rstd, int centered, gast_stream_t stream) {
-    if (!partials || !gamma || !beta || !scale || !shift || !mean || !rstd || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
-    if ((running_mean == nullptr) != (running_var == nullptr)) return GAST_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0, N,
-                       count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale, shift, mean, rstd, centered);
-    GAST_CHECK_LAUNCH();
-    return 0;
+    gast_bn_fin_job j = {partials, nblk, ncol_total, col0, N, count, gamma, beta, running_mean, running_var, num_batches_tracked,
+                         momentum, eps, scale, shift, mean, rstd, centered};
+    return gast_bn_finalize_multi(&j, 1, stream);
 }
 
 extern "C" int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
@@ -545,14 +578,28 @@ extern "C" int gast_bn_eval(const float* gamma, const float* beta, const float* 
     return 0;
 }
 
+extern "C" int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_BN_MAX_BATCH) return GAST_EINVAL;
+    BnBwdFinBatch b;
+    int maxN = 0;
+    for (int d = 0; d < n; ++d) {
+        const gast_bn_bwd_fin_job& j = jobs[d];
+        if (!j.partials || !j.gamma || !j.mean || !j.rstd || !j.dgamma || !j.dbeta || !j.ka || !j.kb || !j.kc || j.N < 1 || j.nblk < 1 ||
+            j.count <= 0)
+            return GAST_EINVAL;
+        b.j[d] = j;
+        if (j.N > maxN) maxN = j.N;
+    }
+    hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3((maxN + FIN_COLS - 1) / FIN_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
                                     const float* gamma, const float* mean, const float* rstd,
                                     float* dgamma, float* dbeta, float* ka, float* kb, float* kc, gast_stream_t stream) {
-    if (!partials || !gamma || !mean || !rstd || !dgamma || !dbeta || !ka || !kb || !kc || N < 1 || nblk < 1 || count <= 0) return GAST_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_COLS - 1) / FIN_COLS), dim3(256), 0, (hipStream_t)stream, partials, nblk, ncol_total, col0,
-                       N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc);
-    GAST_CHECK_LAUNCH();
-    return 0;
+    gast_bn_bwd_fin_job j = {partials, nblk, ncol_total, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc};
+    return gast_bn_bwd_finalize_multi(&j, 1, stream);
 }
 
 static inline bool bad_dtype(int d) { return d != GAST_F32 && d != GAST_BF16; }

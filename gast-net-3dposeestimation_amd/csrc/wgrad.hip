@@ -365,6 +365,7 @@ struct WgBatch {
     int M[GAST_WGRAD_MAX_BATCH], tilesS[GAST_WGRAD_MAX_BATCH], splitM[GAST_WGRAD_MAX_BATCH], mchunk[GAST_WGRAD_MAX_BATCH];
     int n;
 };
+static_assert(sizeof(WgBatch) <= 8192, "WgBatch travels by value in the HSA kernarg segment (4.4 KB; no 4 KB CUDA-style limit on gfx950)");
 __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;

@@ -65,6 +65,19 @@ class _WgradArgs(C.Structure):
                 ('ldw', C.c_int), ('zero_first', C.c_int), ('drop', _Dropout)]
 
 
+class _BnFinJob(C.Structure):
+    _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
+                ('count', C.c_double), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
+                ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p), ('momentum', C.c_float), ('eps', C.c_float),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('centered', C.c_int)]
+
+
+class _BnBwdFinJob(C.Structure):
+    _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
+                ('count', C.c_double), ('gamma', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('dgamma', C.c_void_p),
+                ('dbeta', C.c_void_p), ('ka', C.c_void_p), ('kb', C.c_void_p), ('kc', C.c_void_p)]
+
+
 _lib = None
 
 
@@ -82,6 +95,7 @@ def load_library():
         'gast_gemm': [C.POINTER(_GemmArgs), vp],
         'gast_gemm_row_blocks': [ci],
         'gast_gemm_ws': [C.POINTER(_GemmArgs), vp, cl, vp],
+        'gast_gemm_multi': [C.POINTER(_GemmArgs), ci, vp, cl, vp],
         'gast_gemm_splitk_ws_bytes': [cl, ci],
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
         'gast_wgrad_multi': [C.POINTER(_WgradArgs), ci, vp],
@@ -96,6 +110,8 @@ def load_library():
         'gast_attn_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp],
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
+        'gast_bn_finalize_multi': [C.POINTER(_BnFinJob), ci, vp],
+        'gast_bn_bwd_finalize_multi': [C.POINTER(_BnBwdFinJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, vp],
@@ -128,9 +144,9 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
-                    'gast_bn_finalize', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
+                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_version']
@@ -186,23 +202,24 @@ class HipOps:
     def __init__(self):
         self.lib = load_library()
         self.launches = 0
-        self._ws = {}            # per device: fp32 split-K workspace (allocated once, before any graph capture)
+        self._ws = {}            # per (device, stream): fp32 split-K workspace (allocated once, before any graph capture)
 
     SPLITK_WS_BYTES = 96 << 20
 
     def _splitk_ws(self, dev):
-        ws = self._ws.get(dev)
+        """One workspace per launch stream: the engine runs independent branches of the plan on a side stream."""
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._ws.get(key)
         if ws is None:
-            ws = self._ws[dev] = torch.empty(self.SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
+            ws = self._ws[key] = torch.empty(self.SPLITK_WS_BYTES // 4, dtype=torch.float32, device=dev)
         return ws
 
     # -- GEMM family
     def gemm_row_blocks(self, M):
         return self.lib.gast_gemm_row_blocks(int(M))
 
-    def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-             xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
-        a = _GemmArgs()
+    def _gemm_args(self, a, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
+                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         a.dtype = _dt(segs[0]['A'])
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
         a.B, a.Tn, a.J = (int(v) for v in dom)
@@ -229,9 +246,27 @@ class HipOps:
         a.xscale, a.xshift = _p(xscale), _p(xshift)
         a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
         a.drop = _drop(drop)
+
+    def gemm(self, dom, N, segs, C_, cmap, **kw):
+        a = _GemmArgs()
+        self._gemm_args(a, dom, N, segs, C_, cmap, **kw)
         self.launches += 1
         ws = self._splitk_ws(C_.device)
         _check(self.lib.gast_gemm_ws(C.byref(a), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm')
+
+    GEMM_MAX_BATCH = 4
+
+    def gemm_multi(self, jobs):
+        """jobs: list of dicts with the arguments of gemm() (keys dom, N, segs, C_, cmap + keywords): independent GEMMs of one plan
+        step, launched as one grid (GEMM_MAX_BATCH at a time)."""
+        for i0 in range(0, len(jobs), self.GEMM_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.GEMM_MAX_BATCH]
+            arr = (_GemmArgs * len(chunk))()
+            for a, j in zip(arr, chunk):
+                self._gemm_args(a, **j)
+            self.launches += 1
+            ws = self._splitk_ws(chunk[0]['C_'].device)
+            _check(self.lib.gast_gemm_multi(arr, len(chunk), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm_multi')
 
     def _wgrad_args(self, a, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         a.dtype = _dt(P)
@@ -322,6 +357,37 @@ class HipOps:
         _check(self.lib.gast_bn_finalize(_p(partials), nblk, partials.shape[1], col0, N, float(count), _p(gamma), _p(beta),
                                          _p(running_mean), _p(running_var), _p(nbt), momentum, eps, _p(scale), _p(shift),
                                          _p(mean), _p(rstd), int(bool(centered)), _stream()), 'gast_bn_finalize')
+
+    BN_MAX_BATCH = 4
+
+    def bn_finalize_multi(self, jobs):
+        """jobs: dicts with the arguments of bn_finalize(); BN_MAX_BATCH per launch."""
+        for i0 in range(0, len(jobs), self.BN_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.BN_MAX_BATCH]
+            arr = (_BnFinJob * len(chunk))()
+            for a, j in zip(arr, chunk):
+                pt = j['partials']
+                a.partials, a.nblk, a.ncol_total, a.col0, a.N, a.count = _p(pt), j['nblk'], pt.shape[1], j['col0'], j['N'], float(j['count'])
+                a.gamma, a.beta = _p(j['gamma']), _p(j['beta'])
+                a.running_mean, a.running_var, a.num_batches_tracked = _p(j['running_mean']), _p(j['running_var']), _p(j['nbt'])
+                a.momentum, a.eps = j['momentum'], j['eps']
+                a.scale, a.shift, a.mean, a.rstd = _p(j['scale']), _p(j['shift']), _p(j['mean']), _p(j['rstd'])
+                a.centered = int(bool(j.get('centered', False)))
+            self.launches += 1
+            _check(self.lib.gast_bn_finalize_multi(arr, len(chunk), _stream()), 'gast_bn_finalize_multi')
+
+    def bn_bwd_finalize_multi(self, jobs):
+        """jobs: dicts with the arguments of bn_bwd_finalize(); BN_MAX_BATCH per launch."""
+        for i0 in range(0, len(jobs), self.BN_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.BN_MAX_BATCH]
+            arr = (_BnBwdFinJob * len(chunk))()
+            for a, j in zip(arr, chunk):
+                pt = j['partials']
+                a.partials, a.nblk, a.ncol_total, a.col0, a.N, a.count = _p(pt), j['nblk'], pt.shape[1], j['col0'], j['N'], float(j['count'])
+                a.gamma, a.mean, a.rstd = _p(j['gamma']), _p(j['mean']), _p(j['rstd'])
+                a.dgamma, a.dbeta, a.ka, a.kb, a.kc = _p(j['dgamma']), _p(j['dbeta']), _p(j['ka']), _p(j['kb']), _p(j['kc'])
+            self.launches += 1
+            _check(self.lib.gast_bn_bwd_finalize_multi(arr, len(chunk), _stream()), 'gast_bn_bwd_finalize_multi')
 
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         self.launches += 1

@@ -23,6 +23,9 @@ golden fixtures (tests/fake_backend.py); that mirror lives in tests/ and is neve
 """
 from collections import namedtuple
 
+import contextlib
+import os
+
 import torch
 
 RowMap = namedtuple('RowMap', 'T_total t_stride t_off')
@@ -95,6 +98,8 @@ class Engine:
         # bf16 rounding error scales with the spread of the channel, not with |mean|
         self.centered = bool(centered)
         self.za = ZeroArena()
+        self._side = {}          # device -> side stream for independent branches of the plan
+        self._keep = []          # operands of side-stream launches, kept alive until the join
 
     def _ctr(self, bn):
         return bn['running_mean'] if self.centered else None
@@ -114,6 +119,47 @@ class Engine:
         else:
             ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl],
                         centered=centered)
+
+    def _bn_forward_group(self, items, training, centered=False):
+        """items: (partials, nblk, col0, n, count, bn, st, off) -- independent BatchNorms whose statistics are ready at the same
+        point of the plan (bn_1 + bn_2, lcat_bn + gcat_bn): one multi-job finalize launch in training mode."""
+        if not training:
+            for partials, nblk, col0, n, count, bn, st, off in items:
+                self._bn_forward(partials, nblk, col0, n, count, bn, st, False, off=off, centered=centered)
+            return
+        jobs = []
+        for partials, nblk, col0, n, count, bn, st, off in items:
+            sl = slice(off, off + n)
+            jobs.append(dict(partials=partials, nblk=nblk, col0=col0, N=n, count=count, gamma=bn['weight'], beta=bn['bias'],
+                             running_mean=bn['running_mean'], running_var=bn['running_var'], nbt=bn['num_batches_tracked'],
+                             momentum=BN_MOMENTUM, eps=BN_EPS, scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl],
+                             rstd=st.rstd[sl], centered=centered))
+        self.ops.bn_finalize_multi(jobs)
+
+    # ------------------------------------------------------------------------------------------ side stream
+    # Opt-in (GAST_HIP_SIDE_STREAM=1): independent branches (the attention core of a block in the forward pass, the deferred
+    # weight gradients in the backward pass) on a second stream; inside the captured hipGraph they become parallel branches.
+    # Measured on MI355X: the branches do overlap (rocprofv3 shows concurrent kernels), but concurrent kernels slow each other
+    # and the fork/join nodes add ~130 us of gaps per step: 3.36 ms with, 3.34 ms without -- so it is off by default.
+    # Allocation discipline: every tensor a side-stream kernel touches is allocated on the main stream BEFORE the fork and is
+    # kept alive (self._keep / locals) until AFTER the join, so the caching allocator never sees a cross-stream lifetime.
+    def _fork(self, dev):
+        if dev.type != 'cuda' or os.environ.get('GAST_HIP_SIDE_STREAM', '0') in ('0', ''):
+            return None
+        side = self._side.get(dev)
+        if side is None:
+            side = self._side[dev] = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        return side
+
+    @staticmethod
+    def _on(side):
+        return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
+    @staticmethod
+    def _join(side):
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, x, inp, bufs, training, act_dtype, drop):
@@ -231,38 +277,42 @@ class Engine:
         # G1: everything that reads X in one pass (local_attention.py:37-38, global_attention.py:56-72)
         H = self._new(P, N1, dt, dev)
         ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1)], H, im, bias=inp[g + 'bias1'])
-        # masked-softmax adjacencies (parameters only; local_attention.py:40-42)
+        cen = self.centered
+        # ---- everything both branches touch is allocated here, on the main stream, before the fork
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         A_s = torch.empty(nnz_s + 1, C, dtype=torch.float32, device=dev)    # + the zero row padded edge slots point at
         A_c = torch.empty(nnz_c + 1, C, dtype=torch.float32, device=dev)
-        ops.semch_adj_fwd(inp[g + 'e_sym'], sp.pat_sym(dev), A_s)
-        ops.semch_adj_fwd(inp[g + 'e_con'], sp.pat_con(dev), A_c)
-        # neighbour aggregation + bn_1/bn_2 statistics
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
-        cen = self.centered
-        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
-                          center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
         bnY = BNState(2 * C, dev, P)
-        self._bn_forward(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, training, off=0, centered=cen)
-        self._bn_forward(partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, training, off=C, centered=cen)
-        # global attention core
-        Ya = self._new(P, C, dt, dev)
-        ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
-        # G2 / G3
         Lp = self._new(P, C, dt, dev)
         partL = za.take((nb, C, 2))
-        ops.gemm(dom, C, [dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)], Lp, im,
-                 epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen)
         bnL = BNState(C, dev, P)
-        self._bn_forward(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, training, centered=cen)
+        Ya = self._new(P, C, dt, dev)
         Gp = self._new(P, C, dt, dev)
         partG = za.take((nb, C, 2))
-        ops.gemm(dom, C, [dict(A=Ya, K=C, map=im, W=Wgc)], Gp, im, epi=EPI_STATS, partials=partG,
-                 bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)
         bnG = BNState(C, dev, P)
-        self._bn_forward(partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, training, centered=cen)
+        # ---- global branch (optionally on the side stream): attention core -> G3
+        side = self._fork(dev)
+        with self._on(side):
+            ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
+        # ---- local branch: masked-softmax adjacencies (parameters only; local_attention.py:40-42), neighbour aggregation +
+        # bn_1/bn_2 statistics (one finalize launch for both)
+        ops.semch_adj_fwd(inp[g + 'e_sym'], sp.pat_sym(dev), A_s)
+        ops.semch_adj_fwd(inp[g + 'e_con'], sp.pat_con(dev), A_c)
+        ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
+                          center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
+        self._bn_forward_group([(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
+                                (partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, C)], training, centered=cen)
+        self._join(side)
+        # ---- G2 (local cat conv) and G3 (global cat conv) are independent: one grid, then one finalize for lcat_bn + gcat_bn
+        ops.gemm_multi([dict(dom=dom, N=C, segs=[dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)],
+                             C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen),
+                        dict(dom=dom, N=C, segs=[dict(A=Ya, K=C, map=im, W=Wgc)], C_=Gp, cmap=im, epi=EPI_STATS, partials=partG,
+                             bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)])
+        self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, 0),
+                                (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, 0)], training, centered=cen)
         # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised
         pro = PRO_BNRELU_DROP if use_drop else PRO_BNRELU
         O = self._new(P, 2 * C, dt, dev)
@@ -284,8 +334,14 @@ class Engine:
         self._wq.append(dict(dom=dom, P=P, R=R, pmap=pmap, segs=segs, dW=dW, drop=drop, zero_first=zero_first))
 
     def _wgrad_flush(self):
+        """The queued weight gradients as one multi-job launch on the side stream: the next stage's backward chain (on the main
+        stream) has ~35 launches that fill a handful of CUs each; the weight gradients soak up the rest of the machine."""
         if self._wq:
-            self.ops.wgrad_multi(self._wq)
+            side = self._fork(self._wq[0]['P'].device)
+            with self._on(side):
+                self.ops.wgrad_multi(self._wq)
+            self._keep.append(self._wq)        # operands stay alive until the join at the end of backward()
+            self._wside = side
             self._wq = []
 
     def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
@@ -302,6 +358,35 @@ class Engine:
         d = dz if dzcol is None else dz[:, dzcol:dzcol + n]
         xx = Xpre if dzcol is None else Xpre[:, dzcol:dzcol + n]
         ops.bn_bwd_apply(d, xx, rows, n, ka, kb, kc)
+
+    def _bn_backward_group(self, items, gout, one_apply=None):
+        """items: dicts(partials, nblk, col0, n, st, off, gamma, key, dz, X, rows[, dzcol]) -- BatchNorm backward passes whose
+        column sums are ready together: ONE multi-job finalize launch, then `dz <- dx` in place per item, or a single apply over
+        adjacent column ranges of one tensor (one_apply = (dz, X, rows): bn_1 | bn_2)."""
+        ops = self.ops
+        dev = items[0]['gamma'].device
+        ntot = sum(it['n'] for it in items)
+        ka = torch.empty(ntot, dtype=torch.float32, device=dev)
+        kb = torch.empty(ntot, dtype=torch.float32, device=dev)
+        kc = torch.empty(ntot, dtype=torch.float32, device=dev)
+        jobs, o = [], 0
+        for it in items:
+            n, st, off = it['n'], it['st'], it.get('off', 0)
+            sl = slice(off, off + n)
+            jobs.append(dict(partials=it['partials'], nblk=it['nblk'], col0=it['col0'], N=n, count=st.count, gamma=it['gamma'],
+                             mean=st.mean[sl], rstd=st.rstd[sl], dgamma=gout[it['key'] + '.weight'], dbeta=gout[it['key'] + '.bias'],
+                             ka=ka[o:o + n], kb=kb[o:o + n], kc=kc[o:o + n]))
+            o += n
+        ops.bn_bwd_finalize_multi(jobs)
+        if one_apply is not None:
+            dz, X, rows = one_apply
+            ops.bn_bwd_apply(dz, X, rows, ntot, ka, kb, kc)
+            return
+        o = 0
+        for it in items:
+            n = it['n']
+            ops.bn_bwd_apply(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n])
+            o += n
 
     def backward(self, sv, inp, dpred, gout):
         """dpred: (B,T',J,3) fp32.  Every gradient is written into its destination `gout[key]` (packed fp32 scratch
@@ -320,6 +405,7 @@ class Engine:
         za = self.za
         za.begin(('bwd', B, sv['T_in'], dt), dev)
         self._wq = []
+        self._wside = None
 
         # ---- shrink backward
         last = stages[-1]
@@ -416,6 +502,8 @@ class Engine:
         ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, inp['expand_w'],
                        inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'])
         self._wgrad_flush()
+        self._join(self._wside)
+        self._keep = []
         za.end()
 
     def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
@@ -439,32 +527,38 @@ class Engine:
                    dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
                   grads[g + 'Bbc'], drop=drop, zero_first=False)
         WbcT = inp[g + 'BbcT']       # [3C][2C]
-        # input gradients of the local / global branches, fused with ReLU + dropout + BN-sum backward
+        # input gradients of the local / global branches (independent: one grid), fused with ReLU + dropout + BN-sum backward;
+        # then one finalize launch for lcat_bn + gcat_bn
         dL = self._new(P, C, dt, dev)
         partL = za.take((nb, C, 2))
-        ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:2 * C])], dL, im, epi=EPI_BNRELU_BWD, partials=partL, X=st['Lp'],
-                 xscale=st['bnL'].scale, xshift=st['bnL'].shift, xdrop=xdrop, xsalt=3 * s + 1, drop=drop)
-        self._bn_backward(partL, nb, 0, C, st['bnL'], inp[g + 'lcat_bn.weight'], grads, g + 'lcat_bn', dL, st['Lp'], P)
         dG = self._new(P, C, dt, dev)
         partG = za.take((nb, C, 2))
-        ops.gemm(dom, C, [dict(A=dO, K=2 * C, map=im, W=WbcT[2 * C:3 * C])], dG, im, epi=EPI_BNRELU_BWD, partials=partG, X=st['Gp'],
-                 xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2, drop=drop)
-        self._bn_backward(partG, nb, 0, C, st['bnG'], inp[g + 'gcat_bn.weight'], grads, g + 'gcat_bn', dG, st['Gp'], P)
-        # local cat conv
+        ops.gemm_multi([dict(dom=dom, N=C, segs=[dict(A=dO, K=2 * C, map=im, W=WbcT[C:2 * C])], C_=dL, cmap=im, epi=EPI_BNRELU_BWD,
+                             partials=partL, X=st['Lp'], xscale=st['bnL'].scale, xshift=st['bnL'].shift, xdrop=xdrop, xsalt=3 * s + 1,
+                             drop=drop),
+                        dict(dom=dom, N=C, segs=[dict(A=dO, K=2 * C, map=im, W=WbcT[2 * C:3 * C])], C_=dG, cmap=im, epi=EPI_BNRELU_BWD,
+                             partials=partG, X=st['Gp'], xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2,
+                             drop=drop)])
+        self._bn_backward_group([dict(partials=partL, nblk=nb, col0=0, n=C, st=st['bnL'], gamma=inp[g + 'lcat_bn.weight'],
+                                      key=g + 'lcat_bn', dz=dL, X=st['Lp'], rows=P),
+                                 dict(partials=partG, nblk=nb, col0=0, n=C, st=st['bnG'], gamma=inp[g + 'gcat_bn.weight'],
+                                      key=g + 'gcat_bn', dz=dG, X=st['Gp'], rows=P)], grads)
+        # local / global cat conv: weight gradients (queued) and input gradients (independent: one grid)
         self._wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
-                                        wcol0=0)], grads[g + 'Blc'], zero_first=False)
+                                          wcol0=0)], grads[g + 'Blc'], zero_first=False)
+        self._wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'], zero_first=False)
         WlcT = inp[g + 'BlcT']       # [2C][C]
+        WgcT = inp[g + 'BgcT']
         dY = self._new(P, 2 * C, dt, dev)
         partY = za.take((nb, 2 * C, 2))
-        ops.gemm(dom, 2 * C, [dict(A=dL, K=C, map=im, W=WlcT)], dY, im, epi=EPI_BNRELU_BWD, partials=partY, X=st['Y'],
-                 xscale=st['bnY'].scale, xshift=st['bnY'].shift)
-        self._bn_backward(partY, nb, 0, C, st['bnY'], inp[g + 'bn_1.weight'], grads, g + 'bn_1', dY, st['Y'], P, off=0, dzcol=0)
-        self._bn_backward(partY, nb, C, C, st['bnY'], inp[g + 'bn_2.weight'], grads, g + 'bn_2', dY, st['Y'], P, off=C, dzcol=C)
-        # global cat conv
-        self._wgrad(dom, dG, C, im, [dict(Q=st['Ya'], S=C, map=im, wcol0=0)], grads[g + 'Bgc'], zero_first=False)
-        WgcT = inp[g + 'BgcT']
         dYa = self._new(P, C, dt, dev)
-        ops.gemm(dom, C, [dict(A=dG, K=C, map=im, W=WgcT)], dYa, im)
+        ops.gemm_multi([dict(dom=dom, N=2 * C, segs=[dict(A=dL, K=C, map=im, W=WlcT)], C_=dY, cmap=im, epi=EPI_BNRELU_BWD,
+                             partials=partY, X=st['Y'], xscale=st['bnY'].scale, xshift=st['bnY'].shift),
+                        dict(dom=dom, N=C, segs=[dict(A=dG, K=C, map=im, W=WgcT)], C_=dYa, cmap=im)])
+        self._bn_backward_group([dict(partials=partY, nblk=nb, col0=0, n=C, st=st['bnY'], off=0, gamma=inp[g + 'bn_1.weight'],
+                                      key=g + 'bn_1'),
+                                 dict(partials=partY, nblk=nb, col0=C, n=C, st=st['bnY'], off=C, gamma=inp[g + 'bn_2.weight'],
+                                      key=g + 'bn_2')], grads, one_apply=(dY, st['Y'], P))
         # attention core + aggregation backward fill the column blocks of dH
         H = st['H']
         dH = self._new(P, N1, dt, dev)

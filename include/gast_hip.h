@@ -117,6 +117,10 @@ int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
  * over up to 8 blocks per tile and a finish kernel applies bias / addend / epilogue.  ws_bytes >= gast_gemm_splitk_ws_bytes(M, N)
  * enables every split the heuristic may pick; a smaller or null workspace simply disables splitting. */
 int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
+/* n <= GAST_GEMM_MAX_BATCH independent GEMMs (same dtype / out_f32) in ONE grid: one launch and one tail for the thin GEMMs of a
+ * plan step.  Jobs the split-K heuristic picks (small M, long K) are launched on their own.  Per-job semantics of gast_gemm_ws. */
+#define GAST_GEMM_MAX_BATCH 4
+int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream);
 long gast_gemm_splitk_ws_bytes(long M, int N);
 /* number of row blocks (first dimension of `partials`) gast_gemm uses for a domain of M rows */
 int gast_gemm_row_blocks(int M);
@@ -212,6 +216,20 @@ int gast_bn_finalize(const float* partials, int nblk, int ncol_total, int col0, 
                      const float* gamma, const float* beta, float* running_mean, float* running_var,
                      int64_t* num_batches_tracked, float momentum, float eps,
                      float* scale, float* shift, float* mean, float* rstd, int centered, gast_stream_t stream);
+/* Job forms of the two finalizes and their multi-job launches (n <= GAST_BN_MAX_BATCH jobs, one launch): the plan finalizes
+ * bn_1 + bn_2, lcat_bn + gcat_bn (and their backward twins) together. */
+#define GAST_BN_MAX_BATCH 4
+typedef struct {
+    const float* partials; int nblk, ncol_total, col0, N; double count;
+    const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    float momentum, eps; float* scale; float* shift; float* mean; float* rstd; int centered;
+} gast_bn_fin_job;
+typedef struct {
+    const float* partials; int nblk, ncol_total, col0, N; double count;
+    const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta; float* ka; float* kb; float* kc;
+} gast_bn_bwd_fin_job;
+int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream);
+int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                  float eps, int N, float* scale, float* shift, int centered, gast_stream_t stream);
 /* partials hold {sum dz, sum dz*x}; writes dgamma, dbeta and the per-channel coefficients of

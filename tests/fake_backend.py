@@ -54,6 +54,10 @@ class OracleOps:
                 kc.RowMap(*addmap) if addmap is not None else None, epi, _np(partials), _np(X), _np(xscale), _np(xshift),
                 xdrop, xsalt, _drop(drop), bias_neg=bias_neg)
 
+    def gemm_multi(self, jobs):
+        for j in jobs:
+            self.gemm(**j)
+
     def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         self.launches += 1
         kc.wgrad(dom, _np(P), R, kc.RowMap(*pmap), _segs(segs, 'Q'), _np(dW), _drop(drop), zero_first)
@@ -94,6 +98,16 @@ class OracleOps:
                     shift, mean, rstd, centered=False):
         kc.bn_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(beta), _np(running_mean), _np(running_var), _np(nbt),
                        momentum, eps, _np(scale), _np(shift), _np(mean), _np(rstd), centered=centered)
+
+    def bn_finalize_multi(self, jobs):
+        for j in jobs:
+            self.bn_finalize(**j)
+
+    def bn_bwd_finalize_multi(self, jobs):
+        for j in jobs:
+            j = dict(j)
+            j['kc_'] = j.pop('kc')
+            self.bn_bwd_finalize(**j)
 
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift), centered=centered)

@@ -98,9 +98,8 @@ GEMM_CASES = [
 ]
 
 
-@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
-@pytest.mark.parametrize('case', GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
-def test_gemm(ops, case, dt):
+def _gemm_case(case, dt):
+    """device keyword arguments of ops.gemm / host arguments of kc.gemm and the buffers to compare for one GEMM_CASES entry"""
     from gast_hip.binding import Dropout, dropout_params
     name, dom, N, segdefs, epi, use_add, use_bias = case
     bias_neg = use_bias == 'neg'      # centred storage: C = acc - bias
@@ -134,27 +133,55 @@ def test_gemm(ops, case, dt):
     bias = rand(gen, N) if use_bias else None
     add = rand(gen, B * (Tn + 1) * J, N).to(dt) if use_add else None
     addmap = kc.RowMap(Tn + 1, 1, 0) if use_add else None
-    nb = ops.gemm_row_blocks(M)
+    nb = (M + 127) // 128
     pd = torch.zeros(nb, N, 2).cuda() if epi else None
     ph = np.zeros((nb, N, 2)) if epi else None
     X = rand(gen, B * cT * J, N).to(dt) if epi == 2 else None
     xs = (torch.rand(N, generator=gen) + 0.5) if epi == 2 else None
     xh = rand(gen, N, scale=0.3) if epi == 2 else None
     rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
-    ops.gemm(dom, N, segs_d, Cd[:, :N], cmap, bias=bias.cuda() if use_bias else None, addend=add.cuda() if use_add else None,
-             addmap=addmap, epi=epi, partials=pd, X=X.cuda() if X is not None else None,
-             xscale=xs.cuda() if xs is not None else None, xshift=xh.cuda() if xh is not None else None,
-             xdrop=epi == 2, xsalt=9, drop=Dropout(seed_tensor(seed), thresh, inv_keep), bias_neg=bias_neg)
-    kc.gemm(dom, N, segs_h, Ch[:, :N], cmap, bias=host(bias) if use_bias else None, addend=host(add) if use_add else None,
-            addmap=addmap, epi=epi, partials=ph, X=host(X) if X is not None else None, xscale=host(xs) if xs is not None else None,
-            xshift=host(xh) if xh is not None else None, xdrop=epi == 2, xsalt=9, drop=(seed, thresh, inv_keep), round_fn=rnd,
-            bias_neg=bias_neg)
-    torch.cuda.synchronize()
+    jd = dict(dom=dom, N=N, segs=segs_d, C_=Cd[:, :N], cmap=cmap, bias=bias.cuda() if use_bias else None,
+              addend=add.cuda() if use_add else None, addmap=addmap, epi=epi, partials=pd, X=X.cuda() if X is not None else None,
+              xscale=xs.cuda() if xs is not None else None, xshift=xh.cuda() if xh is not None else None,
+              xdrop=epi == 2, xsalt=9, drop=Dropout(seed_tensor(seed), thresh, inv_keep), bias_neg=bias_neg)
+    jh = dict(dom=dom, N=N, segs=segs_h, C=Ch[:, :N], cmap=cmap, bias=host(bias) if use_bias else None,
+              addend=host(add) if use_add else None, addmap=addmap, epi=epi, partials=ph, X=host(X) if X is not None else None,
+              xscale=host(xs) if xs is not None else None, xshift=host(xh) if xh is not None else None, xdrop=epi == 2, xsalt=9,
+              drop=(seed, thresh, inv_keep), round_fn=rnd, bias_neg=bias_neg)
+    return jd, jh, (Cd, Ch, pd, ph)
+
+
+def _gemm_check(case, dt, bufs):
+    name, N, epi = case[0], case[2], case[4]
+    Cd, Ch, pd, ph = bufs
     got = host(Cd)
     close(got[:, :N], Ch[:, :N], dt, name + ' C')
     assert np.all(got[:, N:] == 7.0), 'wrote outside the N columns'
     if epi:
         close(host(pd).sum(axis=0), ph.sum(axis=0), dt, name + ' partial totals', fp32=1e-4, bf16=3e-2)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('case', GEMM_CASES, ids=[c[0] for c in GEMM_CASES])
+def test_gemm(ops, case, dt):
+    jd, jh, bufs = _gemm_case(case, dt)
+    ops.gemm(**jd)
+    kc.gemm(**jh)
+    torch.cuda.synchronize()
+    _gemm_check(case, dt, bufs)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+def test_gemm_multi(ops, dt):
+    """Independent GEMMs with different domains, segment counts, prologues and epilogues as multi-job launches (4 per grid);
+    the split-K-eligible ones are peeled off into their own launch pair by the library."""
+    cases = [c for c in GEMM_CASES]
+    built = [_gemm_case(c, dt) for c in cases]
+    ops.gemm_multi([jd for jd, _, _ in built])
+    torch.cuda.synchronize()
+    for c, (jd, jh, bufs) in zip(cases, built):
+        kc.gemm(**jh)
+        _gemm_check(c, dt, bufs)
 
 
 def test_gemm_out_f32_from_bf16(ops):
@@ -404,6 +431,56 @@ def test_bn_finalize_and_backward(ops):
     kc.bn_bwd_finalize(host(part), nblk, col0, N, count, host(gamma), host(mean), host(rstd), *bh)
     for a, b, nme in zip(bo, bh, ('dgamma', 'dbeta', 'ka', 'kb', 'kc')):
         close(host(a), b, torch.float32, 'bn_bwd_finalize ' + nme, fp32=1e-4)
+
+
+def test_bn_finalize_multi(ops):
+    """three BatchNorms of different widths (two of them slices of one partial buffer, like bn_1 | bn_2) in one launch, forward
+    and backward finalizes, against the single-job contract"""
+    gen = torch.Generator().manual_seed(11)
+    nblk = 9
+    def partial_sums(rows, ncol):
+        x = rand(gen, rows, ncol) * 2 + 0.5
+        pt = torch.zeros(nblk, ncol, 2)
+        for b, ch in enumerate(torch.chunk(x, nblk)):
+            pt[b, :, 0] = ch.sum(0)
+            pt[b, :, 1] = (ch * ch).sum(0)
+        return pt
+    pA, pB = partial_sums(777, 96), partial_sums(123, 40)
+    specs = [(pA, 0, 64, 777.0), (pA, 64, 32, 777.0), (pB, 4, 36, 123.0)]
+    dev_jobs, host_jobs, bwd_dev, bwd_host = [], [], [], []
+    for pt, col0, N, count in specs:
+        gamma, beta = torch.rand(N, generator=gen) + 0.5, rand(gen, N)
+        rm, rv = rand(gen, N), torch.rand(N, generator=gen) + 0.5
+        d = dict(partials=pt.cuda(), nblk=nblk, col0=col0, N=N, count=count, gamma=gamma.cuda(), beta=beta.cuda(), running_mean=rm.cuda(),
+                 running_var=rv.cuda(), nbt=torch.tensor(2, dtype=torch.int64).cuda(), momentum=0.1, eps=1e-5,
+                 scale=torch.zeros(N).cuda(), shift=torch.zeros(N).cuda(), mean=torch.zeros(N).cuda(), rstd=torch.zeros(N).cuda())
+        h = dict(partials=host(pt), nblk=nblk, col0=col0, N=N, count=count, gamma=host(gamma), beta=host(beta), running_mean=host(rm),
+                 running_var=host(rv), nbt=np.array(2), momentum=0.1, eps=1e-5, scale=np.zeros(N), shift=np.zeros(N), mean=np.zeros(N),
+                 rstd=np.zeros(N))
+        dev_jobs.append(d)
+        host_jobs.append(h)
+    ops.bn_finalize_multi(dev_jobs)
+    for d, h in zip(dev_jobs, host_jobs):
+        kc.bn_finalize(**h)
+        for k in ('scale', 'shift', 'mean', 'rstd', 'running_mean', 'running_var'):
+            close(host(d[k]), h[k], torch.float32, 'bn_finalize_multi ' + k, fp32=1e-5)
+        assert int(d['nbt'].item()) == 3
+        N = d['N']
+        bd = dict(partials=d['partials'], nblk=nblk, col0=d['col0'], N=N, count=d['count'], gamma=d['gamma'], mean=d['mean'], rstd=d['rstd'],
+                  dgamma=torch.zeros(N).cuda(), dbeta=torch.zeros(N).cuda(), ka=torch.zeros(N).cuda(), kb=torch.zeros(N).cuda(),
+                  kc=torch.zeros(N).cuda())
+        bh = dict(partials=h['partials'], nblk=nblk, col0=h['col0'], N=N, count=h['count'], gamma=h['gamma'], mean=h['mean'], rstd=h['rstd'],
+                  dgamma=np.zeros(N), dbeta=np.zeros(N), ka=np.zeros(N), kb=np.zeros(N), kc=np.zeros(N))
+        bwd_dev.append(bd)
+        bwd_host.append(bh)
+    ops.bn_bwd_finalize_multi(bwd_dev)
+    for bd, bh in zip(bwd_dev, bwd_host):
+        kc.bn_bwd_finalize(**bh)
+        for k in ('dgamma', 'dbeta', 'ka', 'kb'):
+            close(host(bd[k]), bh[k], torch.float32, 'bn_bwd_finalize_multi ' + k, fp32=1e-4)
+        # kc = -kb*mean - ka*dbeta/count cancels almost completely on this data: compare against the size of its terms
+        terms = np.abs(bh['kb'] * host(bd['mean'])) + np.abs(bh['ka'] * bh['dbeta'] / bd['count'])
+        assert np.all(np.abs(host(bd['kc']) - bh['kc']) <= 1e-5 * terms + 1e-12)
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
