@@ -32,7 +32,8 @@ __device__ __host__ __forceinline__ Pat make_pat(const int32_t* p, int J, int nn
 
 // ------------------------------------------------------------------------------------------------ adjacency softmax
 // one thread per (channel c, row i): A_t[k][c] = exp(e[c][k] - max) / sum over the edges k of row i
-__global__ void semch_adj_fwd_kernel(const float* __restrict__ e, int C, const int32_t* __restrict__ pat, float* __restrict__ A_t) {
+__device__ __forceinline__ void semch_adj_fwd_body(const float* __restrict__ e, int C, const int32_t* __restrict__ pat,
+                                                   float* __restrict__ A_t) {
     const int J = pat[0], nnz = pat[1];
     const Pat p = make_pat(pat, J, nnz);
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -47,9 +48,18 @@ __global__ void semch_adj_fwd_kernel(const float* __restrict__ e, int C, const i
     for (int k = k0; k < k1; ++k) A_t[(long)k * C + c] = expf(e[(long)c * nnz + k] - mx) * inv;
     if (i == 0) A_t[(long)nnz * C + c] = 0.f;   // the all-zero weight row that padded (ELL) edge slots point at
 }
+__global__ void semch_adj_fwd_kernel(const float* __restrict__ e, int C, const int32_t* __restrict__ pat, float* __restrict__ A_t) {
+    semch_adj_fwd_body(e, C, pat, A_t);
+}
+// all adjacency softmaxes of a pass in one launch (they depend on parameters only): blockIdx.y = job
+struct AdjBatch { gast_adj_job j[GAST_ADJ_MAX_BATCH]; };
+__global__ void semch_adj_fwd_multi_kernel(const AdjBatch b) {
+    const gast_adj_job& j = b.j[blockIdx.y];
+    semch_adj_fwd_body(j.e, j.C, j.pat, j.A_t);
+}
 
-__global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
-                                     const int32_t* __restrict__ pat, float* __restrict__ de) {
+__device__ __forceinline__ void semch_adj_bwd_body(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
+                                                   const int32_t* __restrict__ pat, float* __restrict__ de) {
     const int J = pat[0], nnz = pat[1];
     const Pat p = make_pat(pat, J, nnz);
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -59,6 +69,14 @@ __global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float
     float dot = 0.f;
     for (int k = k0; k < k1; ++k) dot += A_t[(long)k * C + c] * dA_t[(long)k * C + c];
     for (int k = k0; k < k1; ++k) de[(long)c * nnz + k] = A_t[(long)k * C + c] * (dA_t[(long)k * C + c] - dot);
+}
+__global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
+                                     const int32_t* __restrict__ pat, float* __restrict__ de) {
+    semch_adj_bwd_body(dA_t, A_t, C, pat, de);
+}
+__global__ void semch_adj_bwd_multi_kernel(const AdjBatch b) {
+    const gast_adj_job& j = b.j[blockIdx.y];
+    semch_adj_bwd_body(j.dA_t, j.A_t, j.C, j.pat, j.e);     // j.e = de (output) in the backward form
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour aggregation
@@ -892,6 +910,24 @@ extern "C" int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, co
     if (!dA_t || !A_t || !pat || !de || C < 1) return GAST_EINVAL;
     int n = C * JMAX;
     hipLaunchKernelGGL(semch_adj_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, dA_t, A_t, C, pat, de);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backward, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_ADJ_MAX_BATCH) return GAST_EINVAL;
+    AdjBatch b;
+    int maxC = 0;
+    for (int d = 0; d < n; ++d) {
+        if (!jobs[d].e || !jobs[d].pat || !jobs[d].A_t || jobs[d].C < 1 || (backward && !jobs[d].dA_t)) return GAST_EINVAL;
+        b.j[d] = jobs[d];
+        if (jobs[d].C > maxC) maxC = jobs[d].C;
+    }
+    const int nthr = maxC * JMAX;
+    if (backward)
+        hipLaunchKernelGGL(semch_adj_bwd_multi_kernel, dim3((nthr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
+    else
+        hipLaunchKernelGGL(semch_adj_fwd_multi_kernel, dim3((nthr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

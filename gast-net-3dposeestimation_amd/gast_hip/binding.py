@@ -65,6 +65,10 @@ class _WgradArgs(C.Structure):
                 ('ldw', C.c_int), ('zero_first', C.c_int), ('drop', _Dropout)]
 
 
+class _AdjJob(C.Structure):
+    _fields_ = [('e', C.c_void_p), ('C', C.c_int), ('pat', C.c_void_p), ('A_t', C.c_void_p), ('dA_t', C.c_void_p)]
+
+
 class _BnFinJob(C.Structure):
     _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
                 ('count', C.c_double), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
@@ -101,6 +105,7 @@ def load_library():
         'gast_wgrad_multi': [C.POINTER(_WgradArgs), ci, vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
         'gast_semch_adj_bwd': [vp, vp, ci, vp, vp, vp],
+        'gast_semch_adj_multi': [C.POINTER(_AdjJob), ci, ci, vp],
         'gast_semch_agg_fwd': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp, vp, vp],
         'gast_semch_agg_blocks': [ci, ci],
         'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
@@ -144,7 +149,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
@@ -312,6 +317,28 @@ class HipOps:
     def semch_adj_bwd(self, dA_t, A_t, pat, de):
         self.launches += 1
         _check(self.lib.gast_semch_adj_bwd(_p(dA_t), _p(A_t), de.shape[0], _p(pat), _p(de), _stream()), 'gast_semch_adj_bwd')
+
+    ADJ_MAX_BATCH = 8
+
+    def semch_adj_fwd_multi(self, jobs):
+        """jobs: (e, pat, A_t) triples -- every adjacency softmax of the forward pass in one launch."""
+        for i0 in range(0, len(jobs), self.ADJ_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.ADJ_MAX_BATCH]
+            arr = (_AdjJob * len(chunk))()
+            for a, (e, pat, A_t) in zip(arr, chunk):
+                a.e, a.C, a.pat, a.A_t, a.dA_t = _p(e), e.shape[0], _p(pat), _p(A_t), None
+            self.launches += 1
+            _check(self.lib.gast_semch_adj_multi(arr, len(chunk), 0, _stream()), 'gast_semch_adj_multi')
+
+    def semch_adj_bwd_multi(self, jobs):
+        """jobs: (dA_t, A_t, pat, de) tuples -- every adjacency softmax backward of the pass in one launch."""
+        for i0 in range(0, len(jobs), self.ADJ_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.ADJ_MAX_BATCH]
+            arr = (_AdjJob * len(chunk))()
+            for a, (dA_t, A_t, pat, de) in zip(arr, chunk):
+                a.e, a.C, a.pat, a.A_t, a.dA_t = _p(de), de.shape[0], _p(pat), _p(A_t), _p(dA_t)
+            self.launches += 1
+            _check(self.lib.gast_semch_adj_multi(arr, len(chunk), 1, _stream()), 'gast_semch_adj_multi')
 
     def semch_agg_blocks(self, F, C_):
         return self.lib.gast_semch_agg_blocks(int(F), int(C_))

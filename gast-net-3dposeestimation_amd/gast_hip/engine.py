@@ -204,6 +204,16 @@ class Engine:
         ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
         sv.update(x=x, bn0=bn0, E=E, bnE=bnE, T=T)
 
+        # ---- masked-softmax adjacencies of every block (parameters only; local_attention.py:40-42): one launch for all of them
+        adjs, jobs = [], []
+        for s in range(L):
+            Cs = C0 * (2 ** s)
+            A_s = torch.empty(sp.nnz_sym + 1, Cs, dtype=torch.float32, device=dev)    # + the zero row padded edge slots point at
+            A_c = torch.empty(sp.nnz_con + 1, Cs, dtype=torch.float32, device=dev)
+            jobs += [(inp['g%d.e_sym' % s], sp.pat_sym(dev), A_s), (inp['g%d.e_con' % s], sp.pat_con(dev), A_c)]
+            adjs.append((A_s, A_c))
+        ops.semch_adj_fwd_multi(jobs)
+
         stages, levels = [], []
         for s in range(L):
             C = C0 * (2 ** s)
@@ -246,7 +256,7 @@ class Engine:
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
                                  use_drop, 3 * s, drop, B, Tn, J, C, X)
                 levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, k=k))
-            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop))
+            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, adjs[s]))
 
         # ---- shrink (gast_net.py:99)
         last = stages[-1]
@@ -260,7 +270,7 @@ class Engine:
         za.end()
         return pred.view(B, T[-1], J, 3), sv
 
-    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop):
+    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop, adj):
         sp, ops, za = self.spec, self.ops, self.za
         dev = X.device
         P = B * Tn * J
@@ -279,9 +289,7 @@ class Engine:
         ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1)], H, im, bias=inp[g + 'bias1'])
         cen = self.centered
         # ---- everything both branches touch is allocated here, on the main stream, before the fork
-        nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
-        A_s = torch.empty(nnz_s + 1, C, dtype=torch.float32, device=dev)    # + the zero row padded edge slots point at
-        A_c = torch.empty(nnz_c + 1, C, dtype=torch.float32, device=dev)
+        A_s, A_c = adj
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
@@ -297,10 +305,7 @@ class Engine:
         side = self._fork(dev)
         with self._on(side):
             ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
-        # ---- local branch: masked-softmax adjacencies (parameters only; local_attention.py:40-42), neighbour aggregation +
-        # bn_1/bn_2 statistics (one finalize launch for both)
-        ops.semch_adj_fwd(inp[g + 'e_sym'], sp.pat_sym(dev), A_s)
-        ops.semch_adj_fwd(inp[g + 'e_con'], sp.pat_con(dev), A_c)
+        # ---- local branch: neighbour aggregation + bn_1/bn_2 statistics (one finalize launch for both)
         ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
                           center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
         self._bn_forward_group([(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
@@ -406,6 +411,7 @@ class Engine:
         za.begin(('bwd', B, sv['T_in'], dt), dev)
         self._wq = []
         self._wside = None
+        self._adjq = []
 
         # ---- shrink backward
         last = stages[-1]
@@ -502,6 +508,8 @@ class Engine:
         ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, inp['expand_w'],
                        inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'])
         self._wgrad_flush()
+        ops.semch_adj_bwd_multi(self._adjq)
+        self._adjq = []
         self._join(self._wside)
         self._keep = []
         za.end()
@@ -571,8 +579,9 @@ class Engine:
         ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
         ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws,
                           cdeg=(sp.deg_sym[1], sp.deg_con[1]))
-        ops.semch_adj_bwd(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym'])
-        ops.semch_adj_bwd(dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])
+        # softmax backward of the adjacencies: queued, one launch for all blocks at the end of backward()
+        self._adjq += [(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym']),
+                       (dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])]
         # G1 backward: one fat weight-gradient and one fat input-gradient GEMM
         self._wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
         Wg1T = inp[g + 'Bg1T']       # [C][N1]

@@ -175,6 +175,12 @@ int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, ga
 /* de[c][k] = A (dA - sum_row A dA)   (softmax backward) */
 int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t* pat, float* de, gast_stream_t stream);
 
+/* All adjacency softmaxes of a pass in ONE launch (they depend on parameters only): forward jobs {e, C, pat, A_t}, backward jobs
+ * {dA_t, A_t, C, pat, e = de (output)}; n <= GAST_ADJ_MAX_BATCH. */
+#define GAST_ADJ_MAX_BATCH 8
+typedef struct { float* e; int C; const int32_t* pat; float* A_t; const float* dA_t; } gast_adj_job;
+int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backward, gast_stream_t stream);
+
 /* Y[f*J+i, p*C + c] = A_p[c,i,i] h0_p[f*J+i, c] + sum_{j in N_p(i), j != i} A_p[c,i,j] h1_p[f*J+j, c]
  * for the two graphs p = 0 (symmetry) and 1 (connection); H holds [h0_sym | h1_sym | h0_con | h1_con] in columns
  * [0,4C) (local_attention.py:44-48).  Also emits BatchNorm partial sums over the 2C output columns

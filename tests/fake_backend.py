@@ -75,6 +75,14 @@ class OracleOps:
     def semch_agg_blocks(self, F, C_):
         return kc.semch_agg_blocks(F, C_)
 
+    def semch_adj_fwd_multi(self, jobs):
+        for e, pat, A_t in jobs:
+            self.semch_adj_fwd(e, pat, A_t)
+
+    def semch_adj_bwd_multi(self, jobs):
+        for dA_t, A_t, pat, de in jobs:
+            self.semch_adj_bwd(dA_t, A_t, pat, de)
+
     def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
         kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials),
                          center_sym=_np(center[0]), center_con=_np(center[1]))

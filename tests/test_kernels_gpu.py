@@ -278,6 +278,26 @@ def test_semch_adj(ops, J):
         deh = np.zeros((C, nnz))
         kc.semch_adj_bwd(host(dA), Ah[:nnz], pat, deh)
         close(host(de), deh, torch.float32, 'adj bwd')
+    # the multi-job launches: both graphs at three channel widths in one grid, forward then backward
+    fj, bj, refs = [], [], []
+    for C in (8, 40, 136):
+        for pat in (ps, pc):
+            nnz = int(pat[1])
+            e = 1 + rand(gen, C, nnz, scale=0.5)
+            A = torch.full((nnz + 1, C), 7.0).cuda()
+            dA = rand(gen, nnz, C)
+            de = torch.zeros(C, nnz).cuda()
+            fj.append((e.cuda(), dev(pat), A))
+            bj.append((dA.cuda(), A, dev(pat), de))
+            Ah, deh = np.full((nnz + 1, C), 7.0), np.zeros((C, nnz))
+            kc.semch_adj_fwd(host(e), pat, Ah)
+            kc.semch_adj_bwd(host(dA), Ah[:nnz], pat, deh)
+            refs.append((Ah, deh))
+    ops.semch_adj_fwd_multi(fj)
+    ops.semch_adj_bwd_multi(bj)
+    for (_, _, A), (_, _, _, de), (Ah, deh) in zip(fj, bj, refs):
+        close(host(A), Ah, torch.float32, 'adj fwd multi')
+        close(host(de), deh, torch.float32, 'adj bwd multi')
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
