@@ -276,6 +276,8 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--split-graph', action='store_true', help='force the two-graph step (the default for --gpus > 1)')
+    ap.add_argument('--full-graph', action='store_true', help='--gpus > 1: capture the RCCL all-reduce inside one graph')
     ap.add_argument('--torch-tail', action='store_true', help='eager mpjpe formula + torch fused Adam instead of the HIP loss/optimizer')
     args = ap.parse_args()
 
@@ -332,10 +334,21 @@ def main():
         opt.step()
         return loss
 
-    # ---- untimed warm-up (also the side-stream warm-up torch requires before capture), then capture ONE step
-    graph = None
-    graph_note = 'eager'
-    if use_graph:
+    def step_compute():      # everything before the gradient exchange
+        sync.zero_()
+        pred = model(x)
+        loss = loss_fn(pred, y3d)
+        loss.backward()
+        return loss
+
+    # ---- untimed warm-up (also the side-stream warm-up torch requires before capture), then capture the step.
+    # 'full': ONE hipGraph for the whole step (single GPU; with --full-graph also across the RCCL all-reduce).
+    # 'split' (default for N > 1): graph A = zero_grad + forward + loss + backward, the flat-buffer all-reduce launched eagerly on
+    # the same stream, graph B = Adam -- no collective inside a captured graph, two graph launches + one RCCL call per step.
+    mode, graph_note = 'eager', 'eager'
+    graphs, static_loss = [], None
+    want = 'eager' if not use_graph else ('split' if (args.split_graph or (world > 1 and not args.full_graph)) else 'full')
+    if want != 'eager':
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -344,37 +357,52 @@ def main():
                     step()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = step()
-            graph_note = 'hipGraph replay of the whole step (captured through torch.cuda.graph)'
+            if want == 'full':
+                g0 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g0):
+                    static_loss = step()
+                graphs = [g0]
+                graph_note = 'hipGraph replay of the whole step (captured through torch.cuda.graph)'
+            else:
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    static_loss = step_compute()
+                with torch.cuda.graph(gb, pool=ga.pool()):
+                    opt.step()
+                graphs = [ga, gb]
+                graph_note = ('two hipGraphs per step (zero_grad+fwd+loss+bwd | Adam) around an eagerly launched flat-gradient '
+                              'all-reduce')
+            mode = want
         except Exception as e:   # noqa: BLE001 -- report and fall back to eager launches (same kernels)
-            graph = None
+            graphs = []
             graph_note = 'eager (graph capture failed: %s)' % (str(e).splitlines()[0][:120],)
             torch.cuda.synchronize()
-    if graph is None:
-        for _ in range(args.warmup):
-            step()
-    else:
-        for _ in range(args.warmup):
-            graph.replay()
+
+    def run_step():
+        if mode == 'full':
+            graphs[0].replay()
+        elif mode == 'split':
+            graphs[0].replay()
+            sync.sync()
+            graphs[1].replay()
+        else:
+            return step()
+        return static_loss
+
+    for _ in range(args.warmup):
+        run_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        if graph is None:
-            loss = step()
-        else:
-            graph.replay()
+        loss = run_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if graph is not None:
-        loss = static_loss
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

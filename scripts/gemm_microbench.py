@@ -27,7 +27,9 @@ from gast_hip.binding import Dropout, dropout_params
 th, ik = dropout_params(0.05)
 seed = torch.tensor([5], dtype=torch.int32).cuda()
 out = []
-for name, Tn, N, segs, epi in ([] if (len(sys.argv) > 2 and sys.argv[2] == 'wgrad') else SHAPES):
+ONLY = os.environ.get('GAST_MB_ONLY')
+reps = int(os.environ.get('GAST_MB_REPS', reps))
+for name, Tn, N, segs, epi in ([] if (len(sys.argv) > 2 and sys.argv[2] == 'wgrad') else [s_ for s_ in SHAPES if not ONLY or ONLY in s_[0]]):
     M = B * Tn * J
     sg = []
     Ktot = 0
