@@ -413,7 +413,8 @@ def main():
         timer.calibrate()
         timer.enabled = True
         for _ in range(max(1, args.timer_steps)):
-            step()
+            step_compute()       # rank 0 only: no collective in the instrumented pass
+            opt.step()
         torch.cuda.synchronize()
         timer.enabled = False
         gemm_replay_ms = timer.replay_only('gemm')
