@@ -135,6 +135,7 @@ def load_library():
         'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
         'gast_null_launch': [vp],
+        'gast_chunk_gather': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_version']
 
 
 def _check(rc, what):
@@ -554,6 +555,16 @@ class HipOps:
         self.launches += 2
         _check(self.lib.gast_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
                                        weight_decay, grad_scale, _stream()), 'gast_adam_step')
+
+    def chunk_gather(self, poses2d, poses3d, cams, seq_off, pairs, first_pair, B, chunk, pad, causal_shift, perm2d, perm3d, out2d, out3d,
+                     outcam):
+        self.launches += 1 + (poses3d is not None) + (cams is not None)
+        J2, F2 = poses2d.shape[-2], poses2d.shape[-1]
+        J3, F3 = (poses3d.shape[-2], poses3d.shape[-1]) if poses3d is not None else (0, 0)
+        ncam = cams.shape[-1] if cams is not None else 0
+        _check(self.lib.gast_chunk_gather(_p(poses2d), _p(poses3d), _p(cams), _p(seq_off), _p(pairs), int(first_pair), int(B), int(chunk),
+                                          int(pad), int(causal_shift), J2, F2, J3, F3, ncam, _p(perm2d), _p(perm3d), _p(out2d), _p(out3d),
+                                          _p(outcam), _stream()), 'gast_chunk_gather')
 
     def null_launch(self):
         _check(self.lib.gast_null_launch(_stream()), 'gast_null_launch')

@@ -308,6 +308,18 @@ int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* 
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
 
+/* ---- data side: device-resident ChunkedGenerator (reference common/generators.py:93-159) ---------------- */
+/* Builds one training batch from sequences resident in HBM.  poses2d: all sequences concatenated, [sum_len][J2][F2] fp32; seq_off:
+ * nseq+1 frame offsets; pairs: the epoch's (seq, start_3d, end_3d, flip) int32 rows (generators.py:33-42, already shuffled),
+ * the batch being rows [first_pair, first_pair + B).  out2d[i] = the window [start_3d - pad - causal_shift, end_3d + pad -
+ * causal_shift) with edge replication outside the sequence (np.pad "edge", generators.py:100-110); flipped samples get x -> -x and
+ * the joint permutation perm2d (destination joint j reads source joint perm2d[j]; built from kps_left/kps_right,
+ * generators.py:112-115).  poses3d / out3d (chunk frames, perm3d) and cams / outcam (ncam coefficients, 2 and 7 negated when
+ * flipped) are optional (both null or both non-null). */
+int gast_chunk_gather(const float* poses2d, const float* poses3d, const float* cams, const int64_t* seq_off, const int32_t* pairs,
+                      long first_pair, int B, int chunk, int pad, int causal_shift, int J2, int F2, int J3, int F3, int ncam,
+                      const int32_t* perm2d, const int32_t* perm3d, float* out2d, float* out3d, float* outcam, gast_stream_t stream);
+
 /* launches an empty kernel: the fixed dispatch cost an event pair sees around any launch (bench.py calibration) */
 int gast_null_launch(gast_stream_t stream);
 const char* gast_version(void);
