@@ -271,6 +271,45 @@ def test_full_size_properties(mode):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
+@pytest.mark.parametrize('J,arc,B', [(17, (3, 3, 3, 3), 256), (19, (3, 3, 3), 64), (15, (3, 3, 3), 32)])
+def test_other_baseline_configs_properties(J, arc, B, monkeypatch):
+    """BASELINE.json configs[2..4] shapes (arc 3,3,3,3 RF 81 B=256; 19-joint body+foot; HumanEva 15 joints), bf16: dilated == strided
+    on T = RF with shared weights, T' contract, a training step with finite gradients and a loss that matches the fp32 path."""
+    from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
+    from oracle.gast_oracle import adj_from_parents
+    from gast_hip.loss import mpjpe
+    adj = torch.from_numpy(adj_from_parents(PARENTS[J]))
+    torch.manual_seed(0)
+    md = SpatioTemporalModel(adj, J, 2, J, filter_widths=list(arc), channels=128, dropout=0.05)
+    ms = SpatioTemporalModelOptimized1f(adj, J, 2, J, filter_widths=list(arc), channels=128, dropout=0.05)
+    RF = md.receptive_field()
+    assert RF == int(np.prod(arc))
+    gen = torch.Generator().manual_seed(4321)
+    _random_state(md, gen)
+    ms.load_state_dict(md.state_dict(), strict=True)
+    md.cuda().eval(); ms.cuda().eval()
+    x = (torch.rand(B, RF, J, 2, generator=gen) * 2 - 1).cuda()
+    y3d = (torch.randn(B, 1, J, 3, generator=gen) * 0.3).cuda()
+    out = {}
+    for mode in ('fp32', 'bf16'):
+        monkeypatch.setenv('GAST_HIP_DTYPE', mode)
+        with torch.no_grad():
+            yd, ys = md(x), ms(x)
+        assert yd.shape == (B, 1, J, 3)
+        tol = 1e-4 if mode == 'fp32' else 3e-2
+        assert (yd - ys).abs().max().item() < tol * max(1.0, yd.abs().max().item())
+        out[mode] = yd
+    assert (out['fp32'] - out['bf16']).abs().max().item() < 3e-2 * max(1.0, out['fp32'].abs().max().item())
+    with torch.no_grad():
+        assert md((torch.rand(2, RF + 5, J, 2, generator=gen) * 2 - 1).cuda()).shape == (2, 6, J, 3)
+    ms.train()
+    loss = mpjpe(ms(x), y3d)
+    loss.backward()
+    assert torch.isfinite(loss)
+    for k, p in ms.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+
+
 def test_bf16_vs_fp32_full_size(monkeypatch):
     """The bf16 path at the BASELINE size with reference-initialised weights against the fp32 HIP path (itself pinned to the
     reference at 1e-4) on identical inputs: output drift, MPJPE shift (north star: < 0.1 mm) and gradient direction."""
