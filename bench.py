@@ -420,6 +420,33 @@ def main():
         gemm_replay_ms = timer.replay_only('gemm')
         tsteps = max(1, args.timer_steps)
 
+    # ---- forward pass alone (the north star quotes its roofline target on the forward): train-mode forward under no_grad,
+    # captured into its own hipGraph and replayed 20x inside one event pair
+    fwd_ms = None
+    if rank == 0 and world == 1 and use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(3):
+                    model(x)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gf = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gf), torch.no_grad():
+                model(x)
+            for _ in range(3):
+                gf.replay()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                gf.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            fwd_ms = e0.elapsed_time(e1) / 20
+        except Exception:
+            fwd_ms = None
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
@@ -471,6 +498,16 @@ def main():
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)
             tot_roof = sum(v['roof_ms'] for v in agg.values()) / tsteps
             out['path_roofline'] = {'sum_kernel_roofline_ms_per_step': round(tot_roof, 4), 'frac_of_step': round(tot_roof / ms, 4)}
+        if fwd_ms:
+            # 793.4 MB compulsory bf16 traffic (1587 MB fp32) and 160.7 GFLOP per B=128 forward of the dilated model
+            fb = (793.4e6 if args.dtype == 'bf16' else 1586.8e6) * (B / 128.0)
+            ff = 160.7e9 * (B / 128.0)
+            roof = max(fb / (HBM_PEAK_GBS * 1e9), ff / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)) * 1e3
+            out['forward_only'] = {'ms': round(fwd_ms, 4), 'sequences_per_s': round(B / fwd_ms * 1e3, 1), 'roofline_ms': round(roof, 4),
+                                   'frac_of_roofline': round(roof / fwd_ms, 4),
+                                   'note': 'train-mode forward (batch-stat BN, dropout) of the same model and batch, own hipGraph; '
+                                           'roofline = max(HBM, MFMA) of the algorithmic work of SURVEY.md App. C'
+                                           + ('' if args.variant == 'dilated' else ' (dilated-model figure; the strided twin does 0.31x the work)')}
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
