@@ -147,3 +147,67 @@ class ChunkedGenerator:
                 self.state = None
             else:
                 enabled = False
+
+
+class UnchunkedGenerator:
+    """
+    Non-batched data generator, used for testing (device-resident twin of reference common/generators.py:162-235; same arguments
+    + `device`).  Sequences are returned one at a time, un-chunked, edge-padded by `pad` (shifted by `causal_shift`); with
+    `augment` the batch holds the sequence and its mirrored copy (test-time augmentation, reference main.py:313-318).  Yields
+    float32 device tensors built by one `gast_chunk_gather` launch per sequence.
+    """
+
+    def __init__(self, cameras, poses_3d, poses_2d, pad=0, causal_shift=0,
+                 augment=False, kps_left=None, kps_right=None, joints_left=None, joints_right=None, device=None):
+        assert poses_3d is None or len(poses_3d) == len(poses_2d)
+        assert cameras is None or len(cameras) == len(poses_2d)
+        self.augment = augment
+        self.kps_left = kps_left
+        self.kps_right = kps_right
+        self.joints_left = joints_left
+        self.joints_right = joints_right
+        self.pad = pad
+        self.causal_shift = causal_shift
+        if device is None:
+            device = torch.device('cuda', torch.cuda.current_device()) if torch.cuda.is_available() else torch.device('cpu')
+        self.device = torch.device(device)
+        self.lengths = [p.shape[0] for p in poses_2d]
+        f32 = lambda seqs: torch.from_numpy(np.ascontiguousarray(np.concatenate(seqs, axis=0), dtype=np.float32)).to(self.device)  # noqa: E731
+        self.poses_2d = f32(poses_2d)
+        self.poses_3d = f32(poses_3d) if poses_3d else None
+        self.cameras = (torch.from_numpy(np.ascontiguousarray(np.stack(cameras), dtype=np.float32)).to(self.device) if cameras else None)
+        self.seq_off = torch.from_numpy(np.concatenate([[0], np.cumsum(self.lengths)]).astype(np.int64)).to(self.device)
+        self.perm_2d = torch.from_numpy(flip_permutation(self.poses_2d.shape[1], kps_left, kps_right)).to(self.device)
+        self.perm_3d = (torch.from_numpy(flip_permutation(self.poses_3d.shape[1], joints_left, joints_right)).to(self.device)
+                        if self.poses_3d is not None else None)
+        # (seq, start, end, flip) rows: the plain and the mirrored copy of every sequence
+        rows = []
+        for i, n in enumerate(self.lengths):
+            rows += [(i, 0, n, 0), (i, 0, n, 1)]
+        self.table = torch.from_numpy(np.asarray(rows, dtype=np.int32)).to(self.device)
+        self._ops = None
+
+    def num_frames(self):
+        return sum(self.lengths)
+
+    def augment_enabled(self):
+        return self.augment
+
+    def set_augment(self, augment):
+        self.augment = augment
+
+    def next_epoch(self):
+        if self.device.type != 'cuda':
+            raise RuntimeError('UnchunkedGenerator: sequences are on %s; the gather is a HIP kernel (no CPU fallback)' % self.device)
+        if self._ops is None:
+            from gast_hip.binding import HipOps
+            self._ops = HipOps()
+        nb = 2 if self.augment else 1
+        for i, n in enumerate(self.lengths):
+            b2 = torch.empty(nb, n + 2 * self.pad, self.poses_2d.shape[1], self.poses_2d.shape[2], dtype=torch.float32, device=self.device)
+            b3 = (torch.empty(nb, n, self.poses_3d.shape[1], self.poses_3d.shape[2], dtype=torch.float32, device=self.device)
+                  if self.poses_3d is not None else None)
+            cam = (torch.empty(nb, self.cameras.shape[-1], dtype=torch.float32, device=self.device) if self.cameras is not None else None)
+            self._ops.chunk_gather(self.poses_2d, self.poses_3d, self.cameras, self.seq_off, self.table, 2 * i, nb, n, self.pad,
+                                   self.causal_shift, self.perm_2d, self.perm_3d, b2, b3, cam)
+            yield cam, b3, b2

@@ -3,7 +3,7 @@ synthetic sequences.  Run in the build container only (needs /root/reference): p
 import os, sys
 import numpy as np
 sys.path.insert(0, '/root/reference')
-from common.generators import ChunkedGenerator          # noqa: E402
+from common.generators import ChunkedGenerator, UnchunkedGenerator          # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 KPS_LEFT, KPS_RIGHT = [1, 3, 5, 7, 9, 11, 13, 15], [2, 4, 6, 8, 10, 12, 14, 16]      # COCO (reference main.py keypoints_symmetry)
@@ -46,3 +46,22 @@ for name, c in CASES.items():
         nb = 0
     np.savez_compressed(os.path.join(HERE, 'generator_%s.npz' % name), **out)
     print(name, 'pairs', len(gen.pairs), 'batches/epoch', gen.num_batches)
+
+# ---- UnchunkedGenerator (evaluation side, reference common/generators.py:162-235): every sequence, plain + mirrored
+rng = np.random.RandomState(11)
+lengths = [5, 31]
+p2 = [rng.randn(n, 17, 2).astype(np.float32).astype(np.float64) for n in lengths]
+p3 = [rng.randn(n, 17, 3).astype(np.float32).astype(np.float64) for n in lengths]
+cams = [rng.randn(9).astype(np.float32).astype(np.float64) for _ in lengths]
+out = {'lengths': np.array(lengths)}
+for i in range(len(lengths)):
+    out['p2_%d' % i], out['p3_%d' % i], out['cam_%d' % i] = p2[i].astype(np.float32), p3[i].astype(np.float32), cams[i].astype(np.float32)
+for tag, pad, cs, aug in (('sym_aug', 13, 0, True), ('causal_plain', 4, 4, False)):
+    gen = UnchunkedGenerator(cams, p3, p2, pad=pad, causal_shift=cs, augment=aug, kps_left=KPS_LEFT, kps_right=KPS_RIGHT,
+                             joints_left=JOINTS_LEFT, joints_right=JOINTS_RIGHT)
+    for i, (cam, b3, b2) in enumerate(gen.next_epoch()):
+        out['%s_%d_2d' % (tag, i)] = b2.astype(np.float32)
+        out['%s_%d_3d' % (tag, i)] = b3.astype(np.float32)
+        out['%s_%d_cam' % (tag, i)] = cam.astype(np.float32)
+np.savez_compressed(os.path.join(HERE, 'unchunked_generator.npz'), **out)
+print('unchunked ok')

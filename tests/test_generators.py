@@ -108,3 +108,38 @@ def test_device_generator_feeds_the_model():
         assert torch.isfinite(loss)
         n += b2.shape[0]
     assert n == len(gen.pairs) == 2 * 65
+
+
+def _load_unchunked():
+    z = np.load(os.path.join(GOLDEN, 'unchunked_generator.npz'))
+    n = len(z['lengths'])
+    return (z, [z['p2_%d' % i].astype(np.float64) for i in range(n)], [z['p3_%d' % i].astype(np.float64) for i in range(n)],
+            [z['cam_%d' % i].astype(np.float64) for i in range(n)])
+
+
+def test_unchunked_oracle_matches_reference():
+    """the same gather restated in numpy (oracle) reproduces the reference UnchunkedGenerator: a sequence is one chunk of its own
+    length, the mirrored copy is the `flip` row"""
+    from oracle.generators_oracle import build_batch
+    z, p2, p3, cams = _load_unchunked()
+    for tag, pad, cs, aug in (('sym_aug', 13, 0, True), ('causal_plain', 4, 4, False)):
+        for i, n in enumerate(z['lengths']):
+            rows = [(i, 0, n, 0)] + ([(i, 0, n, 1)] if aug else [])
+            cam, b3, b2 = build_batch(rows, p2, p3, cams, int(n), pad, cs, KPS_LEFT, KPS_RIGHT, JOINTS_LEFT, JOINTS_RIGHT)
+            assert np.array_equal(b2.astype(np.float32), z['%s_%d_2d' % (tag, i)])
+            assert np.array_equal(b3.astype(np.float32), z['%s_%d_3d' % (tag, i)])
+            assert np.array_equal(cam.astype(np.float32), z['%s_%d_cam' % (tag, i)])
+
+
+@pytest.mark.gpu
+def test_device_unchunked_generator_bit_exact():
+    from gast_hip.generators import UnchunkedGenerator
+    z, p2, p3, cams = _load_unchunked()
+    for tag, pad, cs, aug in (('sym_aug', 13, 0, True), ('causal_plain', 4, 4, False)):
+        gen = UnchunkedGenerator(cams, p3, p2, pad=pad, causal_shift=cs, augment=aug, kps_left=KPS_LEFT, kps_right=KPS_RIGHT,
+                                 joints_left=JOINTS_LEFT, joints_right=JOINTS_RIGHT, device='cuda')
+        assert gen.num_frames() == int(z['lengths'].sum()) and gen.augment_enabled() == aug
+        for i, (cam, b3, b2) in enumerate(gen.next_epoch()):
+            assert np.array_equal(b2.cpu().numpy(), z['%s_%d_2d' % (tag, i)]), (tag, i)
+            assert np.array_equal(b3.cpu().numpy(), z['%s_%d_3d' % (tag, i)]), (tag, i)
+            assert np.array_equal(cam.cpu().numpy(), z['%s_%d_cam' % (tag, i)]), (tag, i)
