@@ -59,7 +59,7 @@ __global__ void semch_adj_fwd_multi_kernel(const AdjBatch b) {
 }
 
 __device__ __forceinline__ void semch_adj_bwd_body(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
-                                                   const int32_t* __restrict__ pat, float* __restrict__ de) {
+                                                   const int32_t* __restrict__ pat, float* __restrict__ de, int accumulate = 0) {
     const int J = pat[0], nnz = pat[1];
     const Pat p = make_pat(pat, J, nnz);
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -68,15 +68,18 @@ __device__ __forceinline__ void semch_adj_bwd_body(const float* __restrict__ dA_
     int k0 = p.row_ptr[i], k1 = p.row_ptr[i + 1];
     float dot = 0.f;
     for (int k = k0; k < k1; ++k) dot += A_t[(long)k * C + c] * dA_t[(long)k * C + c];
-    for (int k = k0; k < k1; ++k) de[(long)c * nnz + k] = A_t[(long)k * C + c] * (dA_t[(long)k * C + c] - dot);
+    for (int k = k0; k < k1; ++k) {
+        const float v = A_t[(long)k * C + c] * (dA_t[(long)k * C + c] - dot);
+        if (accumulate) de[(long)c * nnz + k] += v; else de[(long)c * nnz + k] = v;
+    }
 }
 __global__ void semch_adj_bwd_kernel(const float* __restrict__ dA_t, const float* __restrict__ A_t, int C,
                                      const int32_t* __restrict__ pat, float* __restrict__ de) {
     semch_adj_bwd_body(dA_t, A_t, C, pat, de);
 }
-__global__ void semch_adj_bwd_multi_kernel(const AdjBatch b) {
+__global__ void semch_adj_bwd_multi_kernel(const AdjBatch b, int accumulate) {
     const gast_adj_job& j = b.j[blockIdx.y];
-    semch_adj_bwd_body(j.dA_t, j.A_t, j.C, j.pat, j.e);     // j.e = de (output) in the backward form
+    semch_adj_bwd_body(j.dA_t, j.A_t, j.C, j.pat, j.e, accumulate);     // j.e = de (output) in the backward form
 }
 
 // ------------------------------------------------------------------------------------------------ neighbour aggregation
@@ -925,7 +928,7 @@ extern "C" int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backwar
     }
     const int nthr = maxC * JMAX;
     if (backward)
-        hipLaunchKernelGGL(semch_adj_bwd_multi_kernel, dim3((nthr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
+        hipLaunchKernelGGL(semch_adj_bwd_multi_kernel, dim3((nthr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b, backward == 2);
     else
         hipLaunchKernelGGL(semch_adj_fwd_multi_kernel, dim3((nthr + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
     GAST_CHECK_LAUNCH();

@@ -129,6 +129,7 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& 
     const float* __restrict__ mean = j.mean;
     const float* __restrict__ rstd = j.rstd;
     float* dgamma = j.dgamma; float* dbeta = j.dbeta; float* ka = j.ka; float* kb = j.kb; float* kc = j.kc;
+    const int accumulate = j.accumulate;
     const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
     const int n = blockIdx.x * FIN_COLS + cx;
     if ((int)blockIdx.x * FIN_COLS >= N) return;
@@ -138,8 +139,8 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& 
     double mu = mean[n], r = rstd[n], g = gamma[n];
     double dg = r * (s2 - mu * s1);   // sum dz * xhat
     double db = s1;
-    dgamma[n] = (float)dg;
-    dbeta[n] = (float)db;
+    if (accumulate) { dgamma[n] += (float)dg; dbeta[n] += (float)db; }      // gradient destinations: plain read-modify-write, one owner per element
+    else { dgamma[n] = (float)dg; dbeta[n] = (float)db; }
     double a = g * r;
     double b = -g * r * r * dg / count;
     ka[n] = (float)a;
@@ -482,7 +483,7 @@ constexpr int EF_CH = 8, EF_LANES = 32;
 __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __restrict__ ws, int nb, int C, int F_in, int k0,
                                                                 const float* __restrict__ W, const float* __restrict__ gamma0,
                                                                 const float* __restrict__ beta0, float* __restrict__ dW,
-                                                                float* __restrict__ dgamma0, float* __restrict__ dbeta0) {
+                                                                float* __restrict__ dgamma0, float* __restrict__ dbeta0, int accumulate) {
     __shared__ float sred[EF_LANES][EF_CH][XF * XT + 1];
     __shared__ float stot[EF_CH][XF * XT + 1];
     __shared__ float sgb[EF_CH][2 * XF];
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __r
                         const float Gv = stot[ch][f * k0 + tap];
                         const long o = ((long)cc * F_in + f) * k0 + tap;
                         const float w = W[o];
-                        dW[o] = g0 * Gv + b0 * Sc;
+                        if (accumulate) dW[o] += g0 * Gv + b0 * Sc; else dW[o] = g0 * Gv + b0 * Sc;
                         dg[f] = fmaf(w, Gv, dg[f]);
                         db[f] = fmaf(w, Sc, db[f]);
                     }
@@ -598,7 +599,7 @@ extern "C" int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n
 extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int col0, int N, double count,
                                     const float* gamma, const float* mean, const float* rstd,
                                     float* dgamma, float* dbeta, float* ka, float* kb, float* kc, gast_stream_t stream) {
-    gast_bn_bwd_fin_job j = {partials, nblk, ncol_total, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc};
+    gast_bn_bwd_fin_job j = {partials, nblk, ncol_total, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc, 0};
     return gast_bn_bwd_finalize_multi(&j, 1, stream);
 }
 
@@ -745,7 +746,8 @@ extern "C" long gast_expand_bwd_ws_floats(long rows, int C, int F_in, int k0) {
 
 extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
                                int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
-                               const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, gast_stream_t stream) {
+                               const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate,
+                               gast_stream_t stream) {
     if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !W || !gamma0 || !beta0 || !dW || !dgamma0 || !dbeta0 || !ws)
         return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in > XF || k0 > XT || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
@@ -763,7 +765,7 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
                            t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + EF_CH - 1) / EF_CH), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
-                       dgamma0, dbeta0);
+                       dgamma0, dbeta0, accumulate);
     GAST_CHECK_LAUNCH();
     return 0;
 }

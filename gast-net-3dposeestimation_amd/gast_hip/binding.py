@@ -79,7 +79,7 @@ class _BnFinJob(C.Structure):
 class _BnBwdFinJob(C.Structure):
     _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
                 ('count', C.c_double), ('gamma', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('dgamma', C.c_void_p),
-                ('dbeta', C.c_void_p), ('ka', C.c_void_p), ('kb', C.c_void_p), ('kc', C.c_void_p)]
+                ('dbeta', C.c_void_p), ('ka', C.c_void_p), ('kb', C.c_void_p), ('kc', C.c_void_p), ('accumulate', C.c_int)]
 
 
 _lib = None
@@ -126,7 +126,7 @@ def load_library():
         'gast_input_stats': [vp, cl, ci, vp, vp, vp],
         'gast_input_stats_blocks': [cl],
         'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp],
-        'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp],
+        'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp],
         'gast_expand_bwd_ws_floats': [cl, ci, ci, ci],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
@@ -331,15 +331,15 @@ class HipOps:
             self.launches += 1
             _check(self.lib.gast_semch_adj_multi(arr, len(chunk), 0, _stream()), 'gast_semch_adj_multi')
 
-    def semch_adj_bwd_multi(self, jobs):
-        """jobs: (dA_t, A_t, pat, de) tuples -- every adjacency softmax backward of the pass in one launch."""
+    def semch_adj_bwd_multi(self, jobs, accumulate=False):
+        """jobs: (dA_t, A_t, pat, de) tuples -- every adjacency softmax backward of the pass in one launch (de written, or +=)."""
         for i0 in range(0, len(jobs), self.ADJ_MAX_BATCH):
             chunk = jobs[i0:i0 + self.ADJ_MAX_BATCH]
             arr = (_AdjJob * len(chunk))()
             for a, (dA_t, A_t, pat, de) in zip(arr, chunk):
                 a.e, a.C, a.pat, a.A_t, a.dA_t = _p(de), de.shape[0], _p(pat), _p(A_t), _p(dA_t)
             self.launches += 1
-            _check(self.lib.gast_semch_adj_multi(arr, len(chunk), 1, _stream()), 'gast_semch_adj_multi')
+            _check(self.lib.gast_semch_adj_multi(arr, len(chunk), 2 if accumulate else 1, _stream()), 'gast_semch_adj_multi')
 
     def semch_agg_blocks(self, F, C_):
         return self.lib.gast_semch_agg_blocks(int(F), int(C_))
@@ -414,6 +414,7 @@ class HipOps:
                 a.partials, a.nblk, a.ncol_total, a.col0, a.N, a.count = _p(pt), j['nblk'], pt.shape[1], j['col0'], j['N'], float(j['count'])
                 a.gamma, a.mean, a.rstd = _p(j['gamma']), _p(j['mean']), _p(j['rstd'])
                 a.dgamma, a.dbeta, a.ka, a.kb, a.kc = _p(j['dgamma']), _p(j['dbeta']), _p(j['ka']), _p(j['kb']), _p(j['kc'])
+                a.accumulate = int(bool(j.get('accumulate', False)))
             self.launches += 1
             _check(self.lib.gast_bn_bwd_finalize_multi(arr, len(chunk), _stream()), 'gast_bn_bwd_finalize_multi')
 
@@ -470,14 +471,14 @@ class HipOps:
         _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
                                         _p(partials), _p(center), _stream()), 'gast_expand_fwd')
 
-    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0):
-        """dW written; dgamma0 / dbeta0 accumulated (zero-filled by the caller)."""
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0, accumulate=False):
+        """dW written (or += with accumulate); dgamma0 / dbeta0 always accumulated (zero-filled by the caller)."""
         self.launches += 2
         T_out = (T_in - k0) // t_stride + 1
         n = self.lib.gast_expand_bwd_ws_floats(B * T_out * J, C_, F_in, k0)
         ws = torch.empty(n, dtype=torch.float32, device=dE.device)
         _check(self.lib.gast_expand_bwd(_dt(dE), _p(dE), _ld(dE), _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
-                                        _p(W), _p(gamma0), _p(beta0), _p(dW), _p(dgamma0), _p(dbeta0), _p(ws), _stream()),
+                                        _p(W), _p(gamma0), _p(beta0), _p(dW), _p(dgamma0), _p(dbeta0), _p(ws), int(bool(accumulate)), _stream()),
                'gast_expand_bwd')
 
     # -- parameter packing / gradient unpacking (gast_hip/packer.py job lists -> device tables, one launch per list)

@@ -350,19 +350,12 @@ class Engine:
             self._wq = []
 
     def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
-        """finalize {sum dz, sum dz*x} -> dgamma/dbeta (written to their destinations) + coefficients, then dz <- dx in place."""
-        ops = self.ops
-        dev = gamma.device
-        dg = gout[key + '.weight']
-        db = gout[key + '.bias']
-        ka = torch.empty(n, dtype=torch.float32, device=dev)
-        kb = torch.empty(n, dtype=torch.float32, device=dev)
-        kc = torch.empty(n, dtype=torch.float32, device=dev)
-        sl = slice(off, off + n)
-        ops.bn_bwd_finalize(partials, nblk, col0, n, st.count, gamma, st.mean[sl], st.rstd[sl], dg, db, ka, kb, kc)
+        """finalize {sum dz, sum dz*x} -> dgamma/dbeta (ACCUMULATED into their destinations: the gradient buffers arrive zeroed or
+        hold a running sum) + coefficients, then dz <- dx in place."""
         d = dz if dzcol is None else dz[:, dzcol:dzcol + n]
         xx = Xpre if dzcol is None else Xpre[:, dzcol:dzcol + n]
-        ops.bn_bwd_apply(d, xx, rows, n, ka, kb, kc)
+        self._bn_backward_group([dict(partials=partials, nblk=nblk, col0=col0, n=n, st=st, off=off, gamma=gamma, key=key, dz=d, X=xx,
+                                      rows=rows)], gout)
 
     def _bn_backward_group(self, items, gout, one_apply=None):
         """items: dicts(partials, nblk, col0, n, st, off, gamma, key, dz, X, rows[, dzcol]) -- BatchNorm backward passes whose
@@ -380,7 +373,7 @@ class Engine:
             sl = slice(off, off + n)
             jobs.append(dict(partials=it['partials'], nblk=it['nblk'], col0=it['col0'], N=n, count=st.count, gamma=it['gamma'],
                              mean=st.mean[sl], rstd=st.rstd[sl], dgamma=gout[it['key'] + '.weight'], dbeta=gout[it['key'] + '.bias'],
-                             ka=ka[o:o + n], kb=kb[o:o + n], kc=kc[o:o + n]))
+                             ka=ka[o:o + n], kb=kb[o:o + n], kc=kc[o:o + n], accumulate=True))
             o += n
         ops.bn_bwd_finalize_multi(jobs)
         if one_apply is not None:
@@ -506,9 +499,10 @@ class Engine:
         s0 = k0 if sp.strided else 1
         # G / S sums and the parameter-sized epilogue (xn = gamma0*xhat + beta0 feeds the expand conv) in two launches
         ops.expand_bwd(dE, x, B, sv['T_in'], J, F_in, k0, s0, sv['bn0'].mean, sv['bn0'].rstd, C0, inp['expand_w'],
-                       inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'])
+                       inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'],
+                       accumulate=True)
         self._wgrad_flush()
-        ops.semch_adj_bwd_multi(self._adjq)
+        ops.semch_adj_bwd_multi(self._adjq, accumulate=True)
         self._adjq = []
         self._join(self._wside)
         self._keep = []

@@ -133,21 +133,17 @@ class _GastFunction(torch.autograd.Function):
         runner, packer, st = ctx.runner, ctx.packer, ctx.st
         dev = dpred.device
         sink = runner.grad_sink
-        # gradient destinations are zero-filled once (two fills) instead of once per accumulating kernel (engine.backward)
+        # Every gradient kernel ACCUMULATES into its destination (split-M atomics, += for the directly written BatchNorm / e /
+        # expand gradients, accumulate-mode unpack): G is either a fresh zero buffer or the caller's flat gradient buffer
+        # (FlatGradAllReduce / FlatAdam), which then sums over backward calls like autograd's .grad does.
         G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
         Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
-        if sink is not None:     # accumulate semantics: directly-written gradients go through a zeroed scratch buffer first
-            Gd = torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
-            gout = packer.grad_outputs(Gd, Sb)
-        else:
-            gout = packer.grad_outputs(G, Sb)
+        gout = packer.grad_outputs(G, Sb)
         runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
         ctx.sv = None
+        runner.engine.ops.run_unpack(packer, st, Sb, G, True)
         if sink is not None:
-            G.add_(Gd)                                                     # one fused add for all directly-written gradients
-            runner.engine.ops.run_unpack(packer, st, Sb, G, True)
             return (None,) * 6 + (None,) * len(packer.params)
-        runner.engine.ops.run_unpack(packer, st, Sb, G, False)
         return (None,) * 6 + tuple(packer.grad_views(G))
 
 

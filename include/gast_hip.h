@@ -176,7 +176,8 @@ int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, ga
 int gast_semch_adj_bwd(const float* dA_t, const float* A_t, int C, const int32_t* pat, float* de, gast_stream_t stream);
 
 /* All adjacency softmaxes of a pass in ONE launch (they depend on parameters only): forward jobs {e, C, pat, A_t}, backward jobs
- * {dA_t, A_t, C, pat, e = de (output)}; n <= GAST_ADJ_MAX_BATCH. */
+ * {dA_t, A_t, C, pat, e = de (output)}; n <= GAST_ADJ_MAX_BATCH.  backward: 0 = forward, 1 = backward (de written), 2 = backward
+ * accumulating into de. */
 #define GAST_ADJ_MAX_BATCH 8
 typedef struct { float* e; int C; const int32_t* pat; float* A_t; const float* dA_t; } gast_adj_job;
 int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backward, gast_stream_t stream);
@@ -233,6 +234,7 @@ typedef struct {
 typedef struct {
     const float* partials; int nblk, ncol_total, col0, N; double count;
     const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta; float* ka; float* kb; float* kc;
+    int accumulate;      /* dgamma / dbeta: += instead of = (gradient buffers that already hold a sum) */
 } gast_bn_bwd_fin_job;
 int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream);
@@ -271,12 +273,12 @@ int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in,
                     void* E, int lde, float* partials, const float* center, gast_stream_t stream);   /* center: nullable [C], subtracted */
 /* Backward of init_bn + expand_conv w.r.t. their parameters (reference gast_net.py:163-164; the input needs no gradient).
  * With G[c][f][tap] = sum_m dE[m,c]*xhat[(b,t*ts+tap,j), f] and S[c] = sum_m dE[m,c]:
- *   dW[c][f][tap] = gamma0[f]*G + beta0[f]*S[c]      (written)
+ *   dW[c][f][tap] = gamma0[f]*G + beta0[f]*S[c]      (written, or += when accumulate != 0)
  *   dgamma0[f] += sum_{c,tap} W*G,  dbeta0[f] += sum_{c,tap} W*S[c]      (atomics: pass them zero-filled)
  * ws: gast_expand_bwd_ws_floats(rows = B*T_out*J, C, F_in, k0) floats of scratch. */
 int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, int T_in, int J, int F_in, int k0,
                     int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
-                    const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, gast_stream_t stream);
+                    const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate, gast_stream_t stream);
 long gast_expand_bwd_ws_floats(long rows, int C, int F_in, int k0);
 
 /* out[n] (+)= sum_m X[m, n]   (bias gradients of the g / theta / phi 1x1 convs, global_attention.py:30-35) */

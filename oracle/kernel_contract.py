@@ -211,14 +211,15 @@ def semch_adj_fwd(e, pat, A_t):
         A_t[nnz:, :] = 0      # the zero weight row the padded (ELL) edge slots point at
 
 
-def semch_adj_bwd(dA_t, A_t, pat, de):
+def semch_adj_bwd(dA_t, A_t, pat, de, accumulate=False):
     J, nnz, row_ptr, *_ = parse_pattern(pat)
     A = np.asarray(A_t, np.float64)
     dA = np.asarray(dA_t, np.float64)
     for i in range(J):
         ks = slice(row_ptr[i], row_ptr[i + 1])
         dot = (A[ks] * dA[ks]).sum(axis=0, keepdims=True)
-        de[:, ks] = (A[ks] * (dA[ks] - dot)).T
+        v = (A[ks] * (dA[ks] - dot)).T
+        de[:, ks] = de[:, ks] + v if accumulate else v
 
 
 def semch_agg_blocks(F, C):
@@ -351,14 +352,18 @@ def bn_eval(gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
     shift[:N] = np.asarray(beta, np.float64) - (0.0 if centered else np.asarray(rm, np.float64) * sc)
 
 
-def bn_bwd_finalize(partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc):
+def bn_bwd_finalize(partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc, accumulate=False):
     p = np.asarray(partials[:nblk, col0:col0 + N], np.float64)
     s1, s2 = p[:, :, 0].sum(axis=0), p[:, :, 1].sum(axis=0)
     mu, r, g = (np.asarray(v, np.float64)[:N] for v in (mean, rstd, gamma))
     dg = r * (s2 - mu * s1)
     db = s1
-    dgamma[:N] = dg
-    dbeta[:N] = db
+    if accumulate:
+        dgamma[:N] += dg
+        dbeta[:N] += db
+    else:
+        dgamma[:N] = dg
+        dbeta[:N] = db
     a = g * r
     b = -g * r * r * dg / count
     ka[:N] = a
@@ -465,8 +470,8 @@ def expand_fwd(x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, partials, r
     _rowwise_partials([e, e * e], rows, C, partials)
 
 
-def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W, gamma0, beta0, dW, dgamma0, dbeta0):
-    """dW written, dgamma0 / dbeta0 accumulated (gast_hip.h)."""
+def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W, gamma0, beta0, dW, dgamma0, dbeta0, accumulate=False):
+    """dW written (+= with accumulate), dgamma0 / dbeta0 accumulated (gast_hip.h)."""
     T_out, taps = _expand_taps(x, B, T_in, J, F_in, k0, t_stride)
     xh = (taps - np.asarray(mean0, np.float64)[None, None, None, :, None]) * np.asarray(rstd0, np.float64)[None, None, None, :, None]
     d = np.asarray(dE[:B * T_out * J, :C], np.float64).reshape(B, T_out, J, C)
@@ -475,6 +480,7 @@ def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W, gamma0
     w = np.asarray(W, np.float64).reshape(C, F_in, k0)
     g0 = np.asarray(gamma0, np.float64).reshape(1, F_in, 1)
     b0 = np.asarray(beta0, np.float64).reshape(1, F_in, 1)
-    dW[...] = (g0 * G + b0 * S.reshape(C, 1, 1)).reshape(dW.shape)
+    dWv = (g0 * G + b0 * S.reshape(C, 1, 1)).reshape(dW.shape)
+    dW[...] = dW + dWv if accumulate else dWv
     dgamma0[...] = dgamma0 + (w * G).sum(axis=(0, 2))
     dbeta0[...] = dbeta0 + (w * S.reshape(C, 1, 1)).sum(axis=(0, 2))

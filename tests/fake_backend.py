@@ -79,9 +79,9 @@ class OracleOps:
         for e, pat, A_t in jobs:
             self.semch_adj_fwd(e, pat, A_t)
 
-    def semch_adj_bwd_multi(self, jobs):
+    def semch_adj_bwd_multi(self, jobs, accumulate=False):
         for dA_t, A_t, pat, de in jobs:
-            self.semch_adj_bwd(dA_t, A_t, pat, de)
+            kc.semch_adj_bwd(_np(dA_t), _np(A_t), _np(pat), _np(de), accumulate=accumulate)
 
     def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
         kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials),
@@ -120,9 +120,9 @@ class OracleOps:
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift), centered=centered)
 
-    def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc_):
+    def bn_bwd_finalize(self, partials, nblk, col0, N, count, gamma, mean, rstd, dgamma, dbeta, ka, kb, kc_, accumulate=False):
         kc.bn_bwd_finalize(_np(partials), nblk, col0, N, count, _np(gamma), _np(mean), _np(rstd), _np(dgamma), _np(dbeta), _np(ka),
-                           _np(kb), _np(kc_))
+                           _np(kb), _np(kc_), accumulate=accumulate)
 
     def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc_):
         kc.bn_bwd_apply(_np(dz), _np(X), rows, N, _np(ka), _np(kb), _np(kc_))
@@ -152,9 +152,9 @@ class OracleOps:
     def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
         kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials), center=_np(center))
 
-    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0):
+    def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0, accumulate=False):
         kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(W), _np(gamma0), _np(beta0),
-                      _np(dW), _np(dgamma0), _np(dbeta0))
+                      _np(dW), _np(dgamma0), _np(dbeta0), accumulate=accumulate)
 
 
 def _resolve(ref, bases, R, S):

@@ -430,3 +430,30 @@ def test_training_trajectory_matches_reference():
     assert worst < 2.0, per_step
     assert err_final < 1e-2, err_final               # eval prediction after 12 Adam steps (outputs of magnitude ~1)
     assert all(v < 1.2e-2 for v in perr.values()), perr      # at most lr per step and parameter
+
+
+def test_flat_gradient_buffer_accumulates_like_autograd():
+    """With a flat gradient sink (FlatGradAllReduce / FlatAdam) every gradient kernel adds into the caller's buffer: two backward
+    passes without zeroing give twice the gradient of one, and equal the sink-less autograd result."""
+    from gast_hip.dist import FlatGradAllReduce
+    os.environ['GAST_HIP_DTYPE'] = 'fp32'
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    torch.manual_seed(3)
+    m = build(cfg).cuda().train()
+    gen = torch.Generator().manual_seed(5)
+    _random_state(m, gen)
+    x = (torch.rand(6, 11, 17, 2, generator=gen) * 2 - 1).cuda()
+    dy = torch.randn(6, 3, 17, 3, generator=gen).cuda()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m(x).backward(dy)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.load_state_dict(sd)
+    m.zero_grad(set_to_none=True)
+    sync = FlatGradAllReduce(m.parameters(), model=m)
+    for _ in range(2):
+        m.load_state_dict(sd)          # same BatchNorm buffers for both passes
+        m(x).backward(dy)
+    for k, p in m.named_parameters():
+        assert p.grad.data_ptr() >= sync.flat.data_ptr()
+        scale = float(ref[k].abs().max()) + 1e-6
+        assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 2e-5, k
