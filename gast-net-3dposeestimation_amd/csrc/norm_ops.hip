@@ -173,6 +173,57 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, i
     }
 }
 
+// BatchNorm backward for SHORT tensors (the M = B*J rows of the last stage, small models): finalize and apply in ONE launch.
+// A block owns 32 columns of one job: it reduces the partial column sums (as bn_bwd_finalize), keeps the three coefficients in
+// LDS and rewrites FUSED_ROWS rows of its columns (dz <- ka*dz + kb*x + kc; grid.z walks the rows, every split redoes the cheap
+// reduction).  256 threads = 8 column quads x 32 row lanes.
+constexpr int FUSED_ROWS = 256;      // rows per block of the fused kernel (grid.z splits the rows)
+struct BnBwdFusedBatch { gast_bn_bwd_job j[GAST_BN_MAX_BATCH]; };
+template <typename T>
+__global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const BnBwdFusedBatch b) {
+    __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    __shared__ float scoef[3][FIN_COLS];
+    const gast_bn_bwd_job& j = b.j[blockIdx.y];
+    const int N = j.f.N;
+    if ((int)blockIdx.x * FIN_COLS >= N) return;
+    {
+        const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
+        const int n = blockIdx.x * FIN_COLS + cx;
+        double s1, s2;
+        finalize_sums(j.f.partials, j.f.nblk, j.f.ncol_total, j.f.col0 + n, n < N, sred, cx, ry, s1, s2);
+        if (ry == 0) {
+            float a = 0.f, bb = 0.f, c = 0.f;
+            if (n < N) {
+                const double mu = j.f.mean[n], r = j.f.rstd[n], g = j.f.gamma[n];
+                const double dg = r * (s2 - mu * s1), db = s1;
+                if (blockIdx.z == 0) {          // every row split recomputes the coefficients, one writes the parameter gradients
+                    if (j.f.accumulate) { j.f.dgamma[n] += (float)dg; j.f.dbeta[n] += (float)db; }
+                    else { j.f.dgamma[n] = (float)dg; j.f.dbeta[n] = (float)db; }
+                }
+                const double ad = g * r, bd = -g * r * r * dg / j.f.count;
+                a = (float)ad; bb = (float)bd; c = (float)(-bd * mu - ad * db / j.f.count);
+            }
+            scoef[0][cx] = a; scoef[1][cx] = bb; scoef[2][cx] = c;
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, rl = threadIdx.x >> 3;          // column quad, row lane
+    const int c = blockIdx.x * FIN_COLS + q * 4;
+    if (c >= N) return;
+    const float4 a = *(const float4*)&scoef[0][q * 4], kb = *(const float4*)&scoef[1][q * 4], kc = *(const float4*)&scoef[2][q * 4];
+    T* dz = (T*)j.dz;
+    const T* X = (const T*)j.X;
+    const long r_end = min(j.rows, (long)(blockIdx.z + 1) * FUSED_ROWS);
+    for (long r = (long)blockIdx.z * FUSED_ROWS + rl; r < r_end; r += 32) {
+        float4 d = ld4(dz + r * j.lddz + c), x = ld4(X + r * j.ldx + c);
+        d.x = fmaf(a.x, d.x, fmaf(kb.x, x.x, kc.x));
+        d.y = fmaf(a.y, d.y, fmaf(kb.y, x.y, kc.y));
+        d.z = fmaf(a.z, d.z, fmaf(kb.z, x.z, kc.z));
+        d.w = fmaf(a.w, d.w, fmaf(kb.w, x.w, kc.w));
+        st4(dz + r * j.lddz + c, d);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
@@ -592,6 +643,28 @@ extern "C" int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n
         if (j.N > maxN) maxN = j.N;
     }
     hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3((maxN + FIN_COLS - 1) / FIN_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bn_bwd_fused_multi(int dtype, const gast_bn_bwd_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_BN_MAX_BATCH || (dtype != GAST_F32 && dtype != GAST_BF16)) return GAST_EINVAL;
+    BnBwdFusedBatch b;
+    int maxN = 0;
+    long maxRows = 0;
+    for (int d = 0; d < n; ++d) {
+        const gast_bn_bwd_job& j = jobs[d];
+        if (j.rows > maxRows) maxRows = j.rows;
+        if (!j.f.partials || !j.f.gamma || !j.f.mean || !j.f.rstd || !j.f.dgamma || !j.f.dbeta || !j.dz || !j.X || j.f.N < 1 ||
+            j.f.nblk < 1 || j.f.count <= 0 || j.rows < 1)
+            return GAST_EINVAL;
+        if (j.f.N % 4 || j.lddz % 4 || j.ldx % 4) return GAST_EALIGN;
+        b.j[d] = j;
+        if (j.f.N > maxN) maxN = j.f.N;
+    }
+    dim3 grid((maxN + FIN_COLS - 1) / FIN_COLS, n, (unsigned)((maxRows + FUSED_ROWS - 1) / FUSED_ROWS));
+    if (dtype == GAST_F32) hipLaunchKernelGGL((bn_bwd_fused_kernel<float>), grid, dim3(256), 0, (hipStream_t)stream, b);
+    else hipLaunchKernelGGL((bn_bwd_fused_kernel<bf16_t>), grid, dim3(256), 0, (hipStream_t)stream, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

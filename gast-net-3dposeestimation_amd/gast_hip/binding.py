@@ -82,6 +82,10 @@ class _BnBwdFinJob(C.Structure):
                 ('dbeta', C.c_void_p), ('ka', C.c_void_p), ('kb', C.c_void_p), ('kc', C.c_void_p), ('accumulate', C.c_int)]
 
 
+class _BnBwdJob(C.Structure):
+    _fields_ = [('f', _BnBwdFinJob), ('dz', C.c_void_p), ('lddz', C.c_int), ('X', C.c_void_p), ('ldx', C.c_int), ('rows', C.c_long)]
+
+
 _lib = None
 
 
@@ -117,6 +121,7 @@ def load_library():
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         'gast_bn_finalize_multi': [C.POINTER(_BnFinJob), ci, vp],
         'gast_bn_bwd_finalize_multi': [C.POINTER(_BnBwdFinJob), ci, vp],
+        'gast_bn_bwd_fused_multi': [ci, C.POINTER(_BnBwdJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, vp],
@@ -152,7 +157,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
-                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
+                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_version']
@@ -417,6 +422,27 @@ class HipOps:
                 a.accumulate = int(bool(j.get('accumulate', False)))
             self.launches += 1
             _check(self.lib.gast_bn_bwd_finalize_multi(arr, len(chunk), _stream()), 'gast_bn_bwd_finalize_multi')
+
+    @staticmethod
+    def _fill_bwd_fin(a, j):
+        pt = j['partials']
+        a.partials, a.nblk, a.ncol_total, a.col0, a.N, a.count = _p(pt), j['nblk'], pt.shape[1], j['col0'], j['N'], float(j['count'])
+        a.gamma, a.mean, a.rstd = _p(j['gamma']), _p(j['mean']), _p(j['rstd'])
+        a.dgamma, a.dbeta = _p(j['dgamma']), _p(j['dbeta'])
+        a.ka, a.kb, a.kc = _p(j.get('ka')), _p(j.get('kb')), _p(j.get('kc'))
+        a.accumulate = int(bool(j.get('accumulate', False)))
+
+    def bn_bwd_fused_multi(self, jobs):
+        """jobs: dicts of bn_bwd_finalize() arguments (without ka/kb/kc) + dz, X, rows: finalize and in-place apply in one launch per
+        BN_MAX_BATCH jobs -- for short tensors."""
+        for i0 in range(0, len(jobs), self.BN_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.BN_MAX_BATCH]
+            arr = (_BnBwdJob * len(chunk))()
+            for a, j in zip(arr, chunk):
+                self._fill_bwd_fin(a.f, j)
+                a.dz, a.lddz, a.X, a.ldx, a.rows = _p(j['dz']), _ld(j['dz']), _p(j['X']), _ld(j['X']), int(j['rows'])
+            self.launches += 1
+            _check(self.lib.gast_bn_bwd_fused_multi(_dt(chunk[0]['dz']), arr, len(chunk), _stream()), 'gast_bn_bwd_fused_multi')
 
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         self.launches += 1

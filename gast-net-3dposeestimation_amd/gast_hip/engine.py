@@ -36,6 +36,9 @@ BN_EPS = 1e-5
 NHEADS = 4
 
 
+FUSED_BN_BWD_ROWS = 8192      # BatchNorm backward: finalize + apply in one launch up to this many rows
+
+
 def ident(T):
     return RowMap(T, 1, 0)
 
@@ -364,6 +367,23 @@ class Engine:
         ops = self.ops
         dev = items[0]['gamma'].device
         ntot = sum(it['n'] for it in items)
+        rows_max = one_apply[2] if one_apply is not None else max(it['rows'] for it in items)
+        if rows_max <= FUSED_BN_BWD_ROWS:
+            # short tensors (the M = B*J stage, small models): finalize + apply in ONE launch for the whole group
+            jobs, o = [], 0
+            for it in items:
+                n, st, off = it['n'], it['st'], it.get('off', 0)
+                sl = slice(off, off + n)
+                if one_apply is not None:
+                    dz, X, rows = one_apply[0][:, o:o + n], one_apply[1][:, o:o + n], one_apply[2]
+                else:
+                    dz, X, rows = it['dz'], it['X'], it['rows']
+                jobs.append(dict(partials=it['partials'], nblk=it['nblk'], col0=it['col0'], N=n, count=st.count, gamma=it['gamma'],
+                                 mean=st.mean[sl], rstd=st.rstd[sl], dgamma=gout[it['key'] + '.weight'],
+                                 dbeta=gout[it['key'] + '.bias'], accumulate=True, dz=dz, X=X, rows=rows))
+                o += n
+            ops.bn_bwd_fused_multi(jobs)
+            return
         ka = torch.empty(ntot, dtype=torch.float32, device=dev)
         kb = torch.empty(ntot, dtype=torch.float32, device=dev)
         kc = torch.empty(ntot, dtype=torch.float32, device=dev)

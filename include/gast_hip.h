@@ -236,6 +236,10 @@ typedef struct {
     const float* gamma; const float* mean; const float* rstd; float* dgamma; float* dbeta; float* ka; float* kb; float* kc;
     int accumulate;      /* dgamma / dbeta: += instead of = (gradient buffers that already hold a sum) */
 } gast_bn_bwd_fin_job;
+/* finalize + in-place apply (dz <- ka*dz + kb*x + kc) in ONE launch, for short tensors (a block streams all rows of its 32
+ * columns): f.ka / f.kb / f.kc are not written. */
+typedef struct { gast_bn_bwd_fin_job f; void* dz; int lddz; const void* X; int ldx; long rows; } gast_bn_bwd_job;
+int gast_bn_bwd_fused_multi(int dtype, const gast_bn_bwd_job* jobs, int n, gast_stream_t stream);
 int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

@@ -117,6 +117,15 @@ class OracleOps:
             j['kc_'] = j.pop('kc')
             self.bn_bwd_finalize(**j)
 
+    def bn_bwd_fused_multi(self, jobs):
+        import numpy as np
+        for j in jobs:
+            N = j['N']
+            ka, kb, kc_ = np.zeros(N), np.zeros(N), np.zeros(N)
+            kc.bn_bwd_finalize(_np(j['partials']), j['nblk'], j['col0'], N, j['count'], _np(j['gamma']), _np(j['mean']), _np(j['rstd']),
+                               _np(j['dgamma']), _np(j['dbeta']), ka, kb, kc_, accumulate=j.get('accumulate', False))
+            kc.bn_bwd_apply(_np(j['dz']), _np(j['X']), j['rows'], N, ka, kb, kc_)
+
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift), centered=centered)
 

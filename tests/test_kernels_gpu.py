@@ -501,6 +501,30 @@ def test_bn_finalize_multi(ops):
         # kc = -kb*mean - ka*dbeta/count cancels almost completely on this data: compare against the size of its terms
         terms = np.abs(bh['kb'] * host(bd['mean'])) + np.abs(bh['ka'] * bh['dbeta'] / bd['count'])
         assert np.all(np.abs(host(bd['kc']) - bh['kc']) <= 1e-5 * terms + 1e-12)
+    # fused finalize + apply (short tensors): same jobs, dgamma / dbeta accumulated onto a fill, dz rewritten in place
+    for dt in DTYPES:
+        rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+        fj, refs = [], []
+        for bd, bh in zip(bwd_dev, bwd_host):
+            N, rows = bd['N'], 301
+            dz, X = rand(gen, rows, N + 8).to(dt), rand(gen, rows, N + 4).to(dt)
+            dzd = dz.cuda()
+            j = dict(bd)
+            j.update(dgamma=torch.full((N,), 0.5).cuda(), dbeta=torch.full((N,), -1.0).cuda(), accumulate=True, dz=dzd[:, :N],
+                     X=X.cuda()[:, :N], rows=rows)
+            for k in ('ka', 'kb', 'kc'):
+                j.pop(k)
+            fj.append(j)
+            dzh = host(dz).copy()
+            kc.bn_bwd_apply(dzh, host(X), rows, N, bh['ka'], bh['kb'], bh['kc'], round_fn=rnd)
+            refs.append((dzd, dzh, bh))
+        ops.bn_bwd_fused_multi(fj)
+        for j, (dzd, dzh, bh) in zip(fj, refs):
+            N = j['N']
+            close(host(dzd)[:, :N], dzh[:, :N], dt, 'bn_bwd_fused dz')
+            assert np.array_equal(host(dzd)[:, N:], dzh[:, N:]), 'wrote outside the N columns'
+            close(host(j['dgamma']) - 0.5, bh['dgamma'], torch.float32, 'bn_bwd_fused dgamma', fp32=1e-4)
+            close(host(j['dbeta']) + 1.0, bh['dbeta'], torch.float32, 'bn_bwd_fused dbeta', fp32=1e-4)
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
