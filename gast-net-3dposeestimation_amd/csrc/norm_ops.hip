@@ -227,10 +227,13 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const BnBwdFusedBatch
 template <typename T>
 __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
-                                                           T* __restrict__ Y, int ldy, int TPR, int RB) {
+                                                           T* __restrict__ Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop,
+                                                           int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
+    const bool dr = use_drop && drop.thresh != 0;
+    const uint32_t key = dr ? drop_key(drop, salt) : 0u;
     for (int cg = ct; cg < N4; cg += TPR) {
         const int c = cg * 4;
         const float4 s = *(const float4*)(scale + c), h = *(const float4*)(shift + c);
@@ -240,6 +243,13 @@ __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__
             x.y = fmaxf(fmaf(x.y, s.y, h.y), 0.f);
             x.z = fmaxf(fmaf(x.z, s.z, h.z), 0.f);
             x.w = fmaxf(fmaf(x.w, s.w, h.w), 0.f);
+            if (dr) {       // the dropout stream is indexed by the element offset in the SOURCE tensor X
+                const uint32_t e0 = (uint32_t)(r * ldx + c);
+                x.x *= drop_mul(key, drop.thresh, drop.inv_keep, e0);
+                x.y *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 1);
+                x.z *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 2);
+                x.w *= drop_mul(key, drop.thresh, drop.inv_keep, e0 + 3);
+            }
             st4(Y + r * ldy + c, x);
         }
     }
@@ -695,17 +705,17 @@ extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, i
 }
 
 extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                                 void* Y, int ldy, gast_stream_t stream) {
+                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
     if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1) return GAST_EINVAL;
     if (N % 4 || ldx % 4 || ldy % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bnrelu_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)X, ldx, rows, N, scale,
-                           shift, (float*)Y, ldy, c.TPR, c.RB);
+                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
-                           shift, (bf16_t*)Y, ldy, c.TPR, c.RB);
+                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
 }

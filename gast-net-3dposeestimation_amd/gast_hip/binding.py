@@ -124,7 +124,7 @@ def load_library():
         'gast_bn_bwd_fused_multi': [ci, C.POINTER(_BnBwdJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
-        'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, vp],
+        'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, cu, _Dropout, vp],
         'gast_bnrelu_bwd_mask': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
         'gast_rowwise_blocks': [cl, ci],
         'gast_residual_fwd': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp],
@@ -460,10 +460,11 @@ class HipOps:
         _check(self.lib.gast_bn_bwd_apply(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _stream()),
                'gast_bn_bwd_apply')
 
-    def bnrelu_apply(self, X, rows, N, scale, shift, Y):
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
+        """Y = drop(relu(scale*X + shift)); the dropout stream `salt` is indexed by the element offset in X."""
         self.launches += 1
-        _check(self.lib.gast_bnrelu_apply(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), _stream()),
-               'gast_bnrelu_apply')
+        _check(self.lib.gast_bnrelu_apply(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), int(bool(use_drop)),
+                                          int(salt), _drop(drop), _stream()), 'gast_bnrelu_apply')
 
     def rowwise_blocks(self, rows, N):
         return self.lib.gast_rowwise_blocks(int(rows), int(N))

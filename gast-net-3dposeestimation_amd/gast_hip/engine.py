@@ -297,13 +297,16 @@ class Engine:
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
         bnY = BNState(2 * C, dev, P)
-        Lp = self._new(P, C, dt, dev)
+        # the local and the global branch write the two column halves of ONE tensor LG = [Lpre | Gpre] (and one BNState): their
+        # post-activation drop(relu(bn(.))) is materialised once as ZLG, so the G4 GEMM / its weight gradient read a plain operand
+        # (the dropout hash in their load prologues was 3/4 of the VALU stream of those kernels, 250 of 345 instructions per K tile)
+        LG = self._new(P, 2 * C, dt, dev)
+        Lp, Gp = LG[:, :C], LG[:, C:]
         partL = za.take((nb, C, 2))
-        bnL = BNState(C, dev, P)
-        Ya = self._new(P, C, dt, dev)
-        Gp = self._new(P, C, dt, dev)
         partG = za.take((nb, C, 2))
-        bnG = BNState(C, dev, P)
+        bnLG = BNState(2 * C, dev, P)
+        Ya = self._new(P, C, dt, dev)
+        ZLG = self._new(P, 2 * C, dt, dev)
         # ---- global branch (optionally on the side stream): attention core -> G3
         side = self._fork(dev)
         with self._on(side):
@@ -319,20 +322,18 @@ class Engine:
                              C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen),
                         dict(dom=dom, N=C, segs=[dict(A=Ya, K=C, map=im, W=Wgc)], C_=Gp, cmap=im, epi=EPI_STATS, partials=partG,
                              bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)])
-        self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnL, 0),
-                                (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnG, 0)], training, centered=cen)
-        # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised
-        pro = PRO_BNRELU_DROP if use_drop else PRO_BNRELU
+        self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnLG, 0),
+                                (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnLG, C)], training, centered=cen)
+        ops.bnrelu_apply(LG, P, 2 * C, bnLG.scale, bnLG.shift, ZLG, use_drop=use_drop, salt=3 * s + 1, drop=drop)
+        # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised: two K segments
         O = self._new(P, 2 * C, dt, dev)
         partO = za.take((nb, 2 * C, 2))
-        segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]),
-                dict(A=Lp, K=C, map=im, W=Wbc[:, C:2 * C], pro=pro, scale=bnL.scale, shift=bnL.shift, salt=3 * s + 1),
-                dict(A=Gp, K=C, map=im, W=Wbc[:, 2 * C:3 * C], pro=pro, scale=bnG.scale, shift=bnG.shift, salt=3 * s + 2)]
-        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, drop=drop, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
+        segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]), dict(A=ZLG, K=2 * C, map=im, W=Wbc[:, C:3 * C])]
+        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
         bnO = BNState(2 * C, dev, P)
         self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
-        return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, Lp=Lp, bnL=bnL, Gp=Gp, bnG=bnG, O=O, bnO=bnO,
-                    C=C, Tn=Tn, P=P, pro=pro)
+        return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
+                    C=C, Tn=Tn, P=P, use_drop=use_drop)
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=False):
@@ -540,31 +541,24 @@ class Engine:
         dom = (B, Tn, J)
         im = ident(Tn)
         nb = ops.gemm_row_blocks(P)
-        pro = st['pro']
-        xdrop = pro == PRO_BNRELU_DROP
-        # G4 weight gradient: three K segments
-        self._wgrad(dom, dO, 2 * C, im,
-                  [dict(Q=st['X'], S=C, map=im, wcol0=0),
-                   dict(Q=st['Lp'], S=C, map=im, pro=pro, scale=st['bnL'].scale, shift=st['bnL'].shift, salt=3 * s + 1, wcol0=C),
-                   dict(Q=st['Gp'], S=C, map=im, pro=pro, scale=st['bnG'].scale, shift=st['bnG'].shift, salt=3 * s + 2, wcol0=2 * C)],
-                  grads[g + 'Bbc'], drop=drop, zero_first=False)
+        xdrop = st['use_drop']
+        # G4 weight gradient: two K segments (X | ZLG), plain operands
+        self._wgrad(dom, dO, 2 * C, im, [dict(Q=st['X'], S=C, map=im, wcol0=0), dict(Q=st['ZLG'], S=2 * C, map=im, wcol0=C)],
+                    grads[g + 'Bbc'], zero_first=False)
         WbcT = inp[g + 'BbcT']       # [3C][2C]
-        # input gradients of the local / global branches (independent: one grid), fused with ReLU + dropout + BN-sum backward;
-        # then one finalize launch for lcat_bn + gcat_bn
-        dL = self._new(P, C, dt, dev)
-        partL = za.take((nb, C, 2))
-        dG = self._new(P, C, dt, dev)
-        partG = za.take((nb, C, 2))
-        ops.gemm_multi([dict(dom=dom, N=C, segs=[dict(A=dO, K=2 * C, map=im, W=WbcT[C:2 * C])], C_=dL, cmap=im, epi=EPI_BNRELU_BWD,
-                             partials=partL, X=st['Lp'], xscale=st['bnL'].scale, xshift=st['bnL'].shift, xdrop=xdrop, xsalt=3 * s + 1,
-                             drop=drop),
-                        dict(dom=dom, N=C, segs=[dict(A=dO, K=2 * C, map=im, W=WbcT[2 * C:3 * C])], C_=dG, cmap=im, epi=EPI_BNRELU_BWD,
-                             partials=partG, X=st['Gp'], xscale=st['bnG'].scale, xshift=st['bnG'].shift, xdrop=xdrop, xsalt=3 * s + 2,
-                             drop=drop)])
-        self._bn_backward_group([dict(partials=partL, nblk=nb, col0=0, n=C, st=st['bnL'], gamma=inp[g + 'lcat_bn.weight'],
-                                      key=g + 'lcat_bn', dz=dL, X=st['Lp'], rows=P),
-                                 dict(partials=partG, nblk=nb, col0=0, n=C, st=st['bnG'], gamma=inp[g + 'gcat_bn.weight'],
-                                      key=g + 'gcat_bn', dz=dG, X=st['Gp'], rows=P)], grads)
+        # input gradient of the local | global branches: ONE GEMM onto the column halves of dLG, fused with ReLU + dropout (the
+        # mask is re-derived from the pre-BN tensor LG and the dropout stream of the forward) + the BN-sum backward; one finalize
+        # launch for lcat_bn + gcat_bn and one in-place apply over both halves
+        dLG = self._new(P, 2 * C, dt, dev)
+        dL, dG = dLG[:, :C], dLG[:, C:]
+        partLG = za.take((nb, 2 * C, 2))
+        bnLG = st['bnLG']
+        ops.gemm(dom, 2 * C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:3 * C])], dLG, im, epi=EPI_BNRELU_BWD, partials=partLG, X=st['LG'],
+                 xscale=bnLG.scale, xshift=bnLG.shift, xdrop=xdrop, xsalt=3 * s + 1, drop=drop)
+        self._bn_backward_group([dict(partials=partLG, nblk=nb, col0=0, n=C, st=bnLG, off=0, gamma=inp[g + 'lcat_bn.weight'],
+                                      key=g + 'lcat_bn'),
+                                 dict(partials=partLG, nblk=nb, col0=C, n=C, st=bnLG, off=C, gamma=inp[g + 'gcat_bn.weight'],
+                                      key=g + 'gcat_bn')], grads, one_apply=(dLG, st['LG'], P))
         # local / global cat conv: weight gradients (queued) and input gradients (independent: one grid)
         self._wgrad(dom, dL, C, im, [dict(Q=st['Y'], S=2 * C, map=im, pro=PRO_BNRELU, scale=st['bnY'].scale, shift=st['bnY'].shift,
                                           wcol0=0)], grads[g + 'Blc'], zero_first=False)

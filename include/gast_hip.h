@@ -252,9 +252,11 @@ int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int co
 /* dz <- ka*dz + kb*x + kc (in place) */
 int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
                       const float* ka, const float* kb, const float* kc, gast_stream_t stream);
-/* Y = relu(scale*X + shift) */
+/* Y = drop(relu(scale*X + shift)); dropout (use_drop != 0) uses stream `salt` indexed by the element offset in X.  Materialises
+ * the post-activation of the local / global branch (gast_net.py:24-27) once, so that the G4 GEMM, its weight gradient and the
+ * branch input gradients need neither the BatchNorm prologue nor the dropout hash (mask = [Y > 0], see epi_scale). */
 int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                      void* Y, int ldy, gast_stream_t stream);
+                      void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream);
 /* dz = dY * [scale*X+shift > 0] * keep/(1-p)  + partial sums {sum dz, sum dz*x}: partials[nblk][N][2] */
 int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
                          const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,

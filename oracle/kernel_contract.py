@@ -376,8 +376,13 @@ def bn_bwd_apply(dz, X, rows, N, ka, kb, kc, round_fn=None):
     dz[:rows, :N] = round_fn(v) if round_fn else v
 
 
-def bnrelu_apply(X, rows, N, scale, shift, Y, round_fn=None):
+def bnrelu_apply(X, rows, N, scale, shift, Y, round_fn=None, use_drop=False, salt=0, drop=None):
+    """drop = (seed, thresh, inv_keep); the stream is indexed by the element offset in X (row * ld(X) + col)."""
     v = np.maximum(np.asarray(X[:rows, :N], np.float64) * np.asarray(scale, np.float64)[:N] + np.asarray(shift, np.float64)[:N], 0)
+    if use_drop and drop is not None and drop[1] != 0:
+        seed, thresh, inv_keep = drop
+        e = np.arange(rows, dtype=np.int64)[:, None] * _ld(X) + np.arange(N)[None, :]
+        v = v * drop_mul(drop_key(seed, salt), thresh, inv_keep, e)
     Y[:rows, :N] = round_fn(v) if round_fn else v
 
 

@@ -1,0 +1,38 @@
+"""Debug helper (GPU box): finite-difference check of parameter gradients with the dropout seed pinned, for several eps and p."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'gast-net-3dposeestimation_amd'), os.path.join(ROOT, 'tests')):
+    sys.path.insert(0, p)
+os.environ['GAST_HIP_DTYPE'] = 'fp32'
+from tests_helpers import PARENTS
+from test_plan_cpu import build
+from test_model_gpu import _random_state
+cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+for pdrop in (0.0, 0.25):
+    torch.manual_seed(11)
+    m = build(cfg, dropout=pdrop).cuda().train()
+    gen = torch.Generator().manual_seed(6)
+    _random_state(m, gen)
+    x = (torch.rand(8, 13, 17, 2, generator=gen) * 2 - 1).cuda()
+    y3d = (torch.randn(8, 5, 17, 3, generator=gen) * 0.3).cuda()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    key = str(x.device)
+    def loss_at(sdc):
+        m.load_state_dict(sdc)
+        if pdrop > 0:
+            m._runner._seeds[key] = torch.tensor([4242], dtype=torch.int32, device=x.device)
+        return torch.mean(torch.norm(m(x).double() - y3d.double(), dim=-1))
+    loss = loss_at(sd); loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    for name in ['expand_conv.weight', 'layers_graph_conv.0.cat_conv.weight', 'layers_graph_conv.1.local_graph_layer.cat_conv.weight', 'layers_conv.0.weight', 'shrink.weight']:
+        v = torch.randn(sd[name].shape, generator=gen).cuda(); v = v / v.norm() * sd[name].norm()
+        an = float((grads[name] * v).sum())
+        out = []
+        for eps in (4e-3, 1e-3, 2.5e-4):
+            vals = []
+            for sgn in (1, -1):
+                sdc = dict(sd); sdc[name] = sd[name] + sgn * eps * v
+                with torch.no_grad(): vals.append(loss_at(sdc).item())
+            out.append((vals[0] - vals[1]) / (2 * eps))
+        print('p=%.2f %-62s analytic % .6f  fd %s' % (pdrop, name, an, ' '.join('% .6f' % o for o in out)))

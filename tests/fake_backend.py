@@ -136,8 +136,8 @@ class OracleOps:
     def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc_):
         kc.bn_bwd_apply(_np(dz), _np(X), rows, N, _np(ka), _np(kb), _np(kc_))
 
-    def bnrelu_apply(self, X, rows, N, scale, shift, Y):
-        kc.bnrelu_apply(_np(X), rows, N, _np(scale), _np(shift), _np(Y))
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
+        kc.bnrelu_apply(_np(X), rows, N, _np(scale), _np(shift), _np(Y), use_drop=use_drop, salt=salt, drop=_drop(drop))
 
     def rowwise_blocks(self, rows, N):
         return kc.rowwise_blocks(rows, N)

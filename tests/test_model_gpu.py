@@ -457,3 +457,46 @@ def test_flat_gradient_buffer_accumulates_like_autograd():
         assert p.grad.data_ptr() >= sync.flat.data_ptr()
         scale = float(ref[k].abs().max()) + 1e-6
         assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 2e-5, k
+
+
+def test_dropout_gradients_by_finite_differences():
+    """With dropout active the backward pass must use exactly the masks of its forward pass (they are regenerated from the counter
+    stream at four places: the materialised local|global post-activation, the branch input-gradient epilogue, the temporal
+    residual and its backward).  Independent check: central finite differences of the loss along random parameter directions
+    with the dropout seed pinned, fp32."""
+    os.environ['GAST_HIP_DTYPE'] = 'fp32'
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    torch.manual_seed(11)
+    m = build(cfg, dropout=0.25).cuda().train()
+    gen = torch.Generator().manual_seed(6)
+    _random_state(m, gen)
+    x = (torch.rand(8, 13, 17, 2, generator=gen) * 2 - 1).cuda()
+    y3d = (torch.randn(8, 5, 17, 3, generator=gen) * 0.3).cuda()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    key = str(x.device)
+
+    def loss_at():
+        m.load_state_dict(sd_cur)
+        m._runner._seeds[key] = torch.tensor([4242], dtype=torch.int32, device=x.device)     # same masks for every evaluation
+        return torch.mean(torch.norm(m(x).double() - y3d.double(), dim=-1))
+
+    sd_cur = sd
+    loss = loss_at()
+    loss.backward()
+    grads = {k: p.grad.clone() for k, p in m.named_parameters()}
+    names = ['expand_conv.weight', 'layers_graph_conv.0.cat_conv.weight', 'layers_graph_conv.1.local_graph_layer.cat_conv.weight',
+             'layers_conv.0.weight', 'layers_graph_conv.0.global_graph_layer.cat_conv.weight']
+    for name in names:
+        v = torch.randn(sd[name].shape, generator=gen).cuda()
+        v = v / v.norm() * sd[name].norm()
+        eps = 2.5e-4       # the central difference converges to the analytic value as eps -> 0 (scripts/debug_fd.py: kinks of ReLU)
+        vals = []
+        for sgn in (+1, -1):
+            sd_cur = dict(sd)
+            sd_cur[name] = sd[name] + sgn * eps * v
+            with torch.no_grad():
+                vals.append(loss_at().item())
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        an = float((grads[name] * v).sum())
+        _log(test='dropout_fd', param=name, fd=fd, analytic=an)
+        assert abs(fd - an) < 6e-2 * max(abs(an), abs(fd)) + 2e-4, (name, fd, an)
