@@ -766,7 +766,7 @@ extern "C" int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, 
     }
     RowCfg c = row_cfg(N);
     int nb = row_blocks(rows, N);
-    if (nb > 256) nb = 256;
+    if (nb > 1024) nb = 1024;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)X, ldx, rows, N, out, c.TPR, c.RB);
     else
@@ -819,7 +819,7 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
 
 static int expand_bwd_blocks(long rows, int C) {
     int nb = row_blocks(rows, C) / 2;       // two rows in flight per thread
-    if (nb > 256) nb = 256;
+    if (nb > 1024) nb = 1024;
     return nb < 1 ? 1 : nb;
 }
 
