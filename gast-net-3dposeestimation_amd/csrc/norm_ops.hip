@@ -536,67 +536,56 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
     }
 }
 
-// Stage 2: 256 threads = 8 channels x 32 block-row lanes.  G[c][kk] = sum_blk ws[blk][kk][c], S[c] likewise, then
-//   dW[c][f][tap] = gamma0[f] * G + beta0[f] * S[c]                       (xn = gamma0 * xhat + beta0 feeds the expand conv)
-//   dgamma0[f]   += sum_{c,tap} W[c][f][tap] * G[c][f][tap];   dbeta0[f] += sum_{c,tap} W[c][f][tap] * S[c]   (atomics)
-// All per-kk values live in LDS (indexed at run time), never in dynamically indexed registers.
+// Stage 2: grid = (channel groups of 8, F_in*k0).  Block (cg, kk) sums G[c][kk] = sum_blk ws[blk][kk][c] and S[c] (column K0) over
+// the block rows with 256 threads = 8 channels x 32 block-row lanes, then
+//   dW[c][f][tap] (+)= gamma0[f] * G + beta0[f] * S[c]                    (xn = gamma0 * xhat + beta0 feeds the expand conv)
+//   dgamma0[f]   += sum_c W[c][f][tap] * G[c][kk];   dbeta0[f] += sum_c W[c][f][tap] * S[c]          (atomics, kk = f*k0 + tap)
 constexpr int EF_CH = 8, EF_LANES = 32;
 __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __restrict__ ws, int nb, int C, int F_in, int k0,
                                                                 const float* __restrict__ W, const float* __restrict__ gamma0,
                                                                 const float* __restrict__ beta0, float* __restrict__ dW,
                                                                 float* __restrict__ dgamma0, float* __restrict__ dbeta0, int accumulate) {
-    __shared__ float sred[EF_LANES][EF_CH][XF * XT + 1];
-    __shared__ float stot[EF_CH][XF * XT + 1];
-    __shared__ float sgb[EF_CH][2 * XF];
+    __shared__ float sred[EF_LANES][EF_CH][2];
+    __shared__ float sgb[EF_CH][2];
     const int cx = threadIdx.x % EF_CH, ry = threadIdx.x / EF_CH;
     const int c = blockIdx.x * EF_CH + cx;
+    const int kk = blockIdx.y;
     const int K0 = F_in * k0, K1 = K0 + 1;
-    for (int q = 0; q < K1; ++q) {
-        float a = 0.f;
-        if (c < C)
-            for (int blk = ry; blk < nb; blk += EF_LANES) a += ws[((long)blk * K1 + q) * C + c];
-        sred[ry][cx][q] = a;
+    const int f = kk / k0, tap = kk - f * k0;
+    float g = 0.f, sv = 0.f;
+    if (c < C) {
+#pragma unroll 4
+        for (int blk = ry; blk < nb; blk += EF_LANES) {
+            const float* p = ws + (long)blk * K1 * C + c;
+            g += p[(long)kk * C];
+            sv += p[(long)K0 * C];
+        }
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < EF_CH * K1; i += 256) {
-        const int ch = i / K1, q = i - ch * K1;
-        float v = 0.f;
-#pragma unroll 8
-        for (int r = 0; r < EF_LANES; ++r) v += sred[r][ch][q];
-        stot[ch][q] = v;
-    }
+    sred[ry][cx][0] = g;
+    sred[ry][cx][1] = sv;
     __syncthreads();
     if (threadIdx.x < EF_CH) {
         const int ch = threadIdx.x, cc = blockIdx.x * EF_CH + ch;
-        float dg[XF], db[XF];
-#pragma unroll
-        for (int f = 0; f < XF; ++f) { dg[f] = 0.f; db[f] = 0.f; }
+        float Gv = 0.f, Sc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < EF_LANES; ++r) { Gv += sred[r][ch][0]; Sc += sred[r][ch][1]; }
+        float dg = 0.f, db = 0.f;
         if (cc < C) {
-            const float Sc = stot[ch][K0];
-#pragma unroll
-            for (int f = 0; f < XF; ++f) {
-                if (f < F_in) {
-                    const float g0 = gamma0[f], b0 = beta0[f];
-                    for (int tap = 0; tap < k0; ++tap) {
-                        const float Gv = stot[ch][f * k0 + tap];
-                        const long o = ((long)cc * F_in + f) * k0 + tap;
-                        const float w = W[o];
-                        if (accumulate) dW[o] += g0 * Gv + b0 * Sc; else dW[o] = g0 * Gv + b0 * Sc;
-                        dg[f] = fmaf(w, Gv, dg[f]);
-                        db[f] = fmaf(w, Sc, db[f]);
-                    }
-                }
-            }
+            const long o = ((long)cc * F_in + f) * k0 + tap;
+            const float w = W[o];
+            const float v = gamma0[f] * Gv + beta0[f] * Sc;
+            if (accumulate) dW[o] += v; else dW[o] = v;
+            dg = w * Gv;
+            db = w * Sc;
         }
-#pragma unroll
-        for (int f = 0; f < XF; ++f) { sgb[ch][2 * f] = dg[f]; sgb[ch][2 * f + 1] = db[f]; }
+        sgb[ch][0] = dg;
+        sgb[ch][1] = db;
     }
     __syncthreads();
-    if (threadIdx.x < 2 * F_in) {
+    if (threadIdx.x < 2) {
         float v = 0.f;
         for (int i = 0; i < EF_CH; ++i) v += sgb[i][threadIdx.x];
-        const int f = threadIdx.x >> 1;
-        atomicAdd((threadIdx.x & 1) ? dbeta0 + f : dgamma0 + f, v);
+        atomicAdd(threadIdx.x ? dbeta0 + f : dgamma0 + f, v);
     }
 }
 
@@ -847,7 +836,7 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
                            t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
-    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + EF_CH - 1) / EF_CH), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
+    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + EF_CH - 1) / EF_CH, F_in * k0), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
                        dgamma0, dbeta0, accumulate);
     GAST_CHECK_LAUNCH();
     return 0;
