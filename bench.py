@@ -57,9 +57,10 @@ class KernelTimer:
         self.enabled = False
         self.overhead_ms = 0.0
         self.calls = []        # (name, fn, args, kwargs, raw_ms filled in by summary) of the instrumented pass
-        for name in ('gemm', 'wgrad', 'wgrad_multi', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bn_bwd_apply',
+        for name in ('gemm', 'gemm_multi', 'wgrad', 'wgrad_multi', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bn_bwd_apply',
                      'bnrelu_apply', 'bnrelu_bwd_mask', 'residual_fwd', 'expand_fwd', 'expand_bwd', 'colsum', 'bn_finalize',
-                     'bn_bwd_finalize', 'semch_adj_fwd', 'semch_adj_bwd', 'input_stats', 'adam_step', 'run_pack', 'run_unpack'):
+                     'bn_finalize_multi', 'bn_bwd_finalize', 'bn_bwd_finalize_multi', 'bn_bwd_fused_multi', 'semch_adj_fwd_multi',
+                     'semch_adj_bwd_multi', 'input_stats', 'adam_step', 'run_pack', 'run_unpack'):
             self._wrap(name)
 
     def calibrate(self, n=200):
@@ -125,8 +126,8 @@ class KernelTimer:
             r = orig(*a, **k)
             e1.record()
             self.records.append((name, e0, e1, fl, by))
-            if name == 'gemm':
-                self.calls.append([name, orig, a, k, e0, e1])
+            if name in ('gemm', 'gemm_multi'):
+                self.calls.append(['gemm', orig, a, k, e0, e1])
             return r
         setattr(self.ops, name, wrapped)
 
@@ -156,6 +157,18 @@ class KernelTimer:
         if addend is not None:
             by += min(M, B * addmap.T_total * J) * N * es
         return flops, by
+
+    def cost_gemm_multi(self, jobs):
+        fl = by = 0.0
+        for j in jobs:
+            j = dict(j)
+            f, b = self.cost_gemm(j.pop('dom'), j.pop('N'), j.pop('segs'), j.pop('C_'), j.pop('cmap'), **j)
+            fl += f
+            by += b
+        return fl, by
+
+    def cost_bn_bwd_fused_multi(self, jobs):
+        return (sum(4.0 * j['rows'] * j['N'] for j in jobs), sum(3.0 * j['rows'] * j['N'] * self._es(j['dz']) for j in jobs))
 
     def cost_wgrad(self, dom, P, R, pmap, segs, dW, **kw):
         B, Tn, J = dom
@@ -196,7 +209,7 @@ class KernelTimer:
     def cost_bn_bwd_apply(self, dz, X, rows, N, *a):
         return 4.0 * rows * N, 3.0 * rows * N * self._es(dz)
 
-    def cost_bnrelu_apply(self, X, rows, N, scale, shift, Y):
+    def cost_bnrelu_apply(self, X, rows, N, scale, shift, Y, **k):
         return 2.0 * rows * N, 2.0 * rows * N * self._es(X)
 
     def cost_bnrelu_bwd_mask(self, dY, X, rows, N, *a, **k):
@@ -209,7 +222,7 @@ class KernelTimer:
         rows = E.shape[0]
         return 2.0 * rows * C_ * F_in * k0, rows * C_ * self._es(E) + x.numel() * 4.0
 
-    def cost_expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, *a):
+    def cost_expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, *a, **k):
         rows = dE.shape[0]
         return 2.0 * rows * C_ * (F_in * k0 + 1), rows * C_ * self._es(dE) + x.numel() * 4.0
 
@@ -468,6 +481,8 @@ def main():
                 a['roof_mfma_ms'] = a['flops'] / (peak_tf * 1e12) * 1e3
                 a['roof_ms'] = max(a['roof_hbm_ms'], a['roof_mfma_ms'])
             gm = agg.get('gemm')
+            if gm and 'gemm_multi' in agg:      # the paired thin GEMMs run as one grid: same kernel family
+                gm = {k: gm[k] + agg['gemm_multi'][k] for k in gm}
             if gm and gm['ms'] > 0:
                 bound = 'hbm' if gm['roof_hbm_ms'] >= gm['roof_mfma_ms'] else 'mfma'
                 eager_avg_ms = gm['ms'] / gm['launches']
@@ -481,12 +496,16 @@ def main():
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_bytes.json')))
-                    key = 'gemm_kernel<unsigned short, unsigned short>' if args.dtype == 'bf16' else 'gemm_kernel<float, float>'
-                    traffic = pmc[key]['hbm_bytes_per_launch']
-                    tsrc = 'profiles/r01_pmc_hbm_bytes.json: (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, rocprofv3 --pmc, %d launches' % pmc[key]['launches']
+                    tname = 'unsigned short' if args.dtype == 'bf16' else 'float'
+                    fam = [v for k, v in pmc.items() if k.startswith(('gemm_kernel<' + tname, 'gemm_multi_kernel<' + tname,
+                                                                       'splitk_finish_kernel<' + tname))]
+                    calls = sum(v['launches'] for k, v in pmc.items() if k.startswith(('gemm_kernel<' + tname, 'gemm_multi_kernel<' + tname)))
+                    traffic = round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in fam) / calls)
+                    tsrc = ('profiles/r01_pmc_hbm_bytes.json: sum of (2*FETCH_SIZE + WRITE_SIZE) KiB over the gemm / gemm_multi / splitk_finish '
+                            'kernels / %d gemm launches, rocprofv3 --pmc' % calls)
                 except Exception:
                     pass
-                out['roofline'] = {'kernel': 'gemm_kernel<%s> (gast_gemm)' % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
+                out['roofline'] = {'kernel': 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)' % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
                                    'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': tsrc,
                                    'launches_per_step': gm['launches'] / tsteps, 'avg_launch_us': round(avg_ms * 1e3, 2),
                                    'avg_launch_us_method': ('hipGraph replay of the step\'s gast_gemm launches alone, one HIP-event pair around 20 replays' if gemm_replay_ms else 'eager HIP-event pairs'),
