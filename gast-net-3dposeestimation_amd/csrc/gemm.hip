@@ -76,7 +76,7 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
 }
 
 template <typename T, typename TO>
-__device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws, int blk) {
+__device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws, int blk) {
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -276,7 +276,6 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     }
 
     // ------------------------------------------------------------------ epilogue
-    if (dbg & 1) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     const int epi = a.epi;
     const bool xdrop = epi == GAST_EPI_BNRELU_BWD && a.xdrop && thresh != 0;
     uint32_t xkey = 0;
@@ -485,8 +484,8 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int dbg, int splitk, float* __restrict__ ws) {
-    gemm_body<T, TO>(a, M, gridM, gridN, vec_epi, dbg, splitk, ws, blockIdx.x);
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
+    gemm_body<T, TO>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
 
 // Several independent GEMMs of one plan step in ONE grid (gast_gemm_multi): the K <= 256 launches of a block (G2 / G3, the two
@@ -500,10 +499,10 @@ struct GemmBatch {
 };
 static_assert(sizeof(GemmBatch) <= 3584, "GemmBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b, int dbg) {
+__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    gemm_body<T, TO>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], dbg, 1, nullptr, blockIdx.x - b.first[d]);
+    gemm_body<T, TO>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
 }
 
 template <typename T, typename TO>
@@ -612,8 +611,8 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     int ntiles = 0;
     for (int s2 = 0; s2 < a.nseg; ++s2) ntiles += (a.seg[s2].K + 8 * epc - 1) / (8 * epc);
     splitk = 1;
-    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;   // profiling/bisecting ablations only
-    if (ws && gridM * gridN <= 160 && ntiles >= 4 && !(dbg & 64)) {
+    static const int allow_splitk = getenv("GAST_GEMM_SPLITK") ? atoi(getenv("GAST_GEMM_SPLITK")) : 1;   // 0: bisecting aid
+    if (ws && gridM * gridN <= 160 && ntiles >= 4 && allow_splitk) {
         splitk = 512 / (gridM * gridN);
         if (splitk > 8) splitk = 8;
         if (splitk > ntiles / 2) splitk = ntiles / 2;
@@ -638,15 +637,14 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int M, gridM, gridN, vec_epi, splitk;
     int rc = gemm_plan(a, ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
     if (rc) return rc;
-    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, dbg, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     GAST_CHECK_LAUNCH();
     if (splitk > 1) {
         // the finish kernel accumulates the column statistics with atomics: `partials` arrives zero-filled (gast_hip.h)
@@ -667,7 +665,6 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     GemmBatch b;
     b.n = 0;
     b.first[0] = 0;
-    static const int dbg = getenv("GAST_GEMM_DEBUG") ? atoi(getenv("GAST_GEMM_DEBUG")) : 0;
     for (int d = 0; d < n; ++d) {
         if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32) return GAST_EINVAL;
         int M, gridM, gridN, vec_epi, splitk;
@@ -687,11 +684,11 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     dim3 grid(b.first[b.n]), block(256);
     hipStream_t st = (hipStream_t)stream;
     if (args[0].dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b, dbg);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
     else if (args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b, dbg);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
     else
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b, dbg);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -198,8 +198,7 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&
     }
 }
 
-__device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp,
-                                                int dbg) {
+__device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
     constexpr int BKM = 64;
     __shared__ __attribute__((aligned(16))) unsigned char sP[BT * LSTR];
     __shared__ __attribute__((aligned(16))) unsigned char sQ[BT * LSTR];
@@ -270,7 +269,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
             const bool ok = cin && row >= 0;
             rg[i] = make_uint4(ok ? rl[i].x : 0u, ok ? rl[i].y : 0u, ok ? rl[i].z : 0u, ok ? rl[i].w : 0u);
         }
-        if (pro && cin && !(dbg & 4)) {
+        if (pro && cin) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int row = sRowQ[buf][mb * 8 + i];
@@ -292,12 +291,7 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
             }
         }
         uint4 tr[8];
-        if (dbg & 2) {
-#pragma unroll
-            for (int q = 0; q < 8; ++q) tr[q] = rg[q];
-        } else {
-            transpose8x8_bf16(rg, tr);
-        }
+        transpose8x8_bf16(rg, tr);
 #pragma unroll
         for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
     };
@@ -312,7 +306,6 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
         __syncthreads();
         if (it + 1 < ntile) load_tile((it + 1) & 1);
         if (it + 2 < ntile) compute_rows(it + 2, it & 1);
-        if (dbg & 1) continue;
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             union { uint4 u; s16x8 s; } fa[2], fb[2];
@@ -330,7 +323,6 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
         }
     }
 
-    if ((dbg & 8) && acc[0][0][0] != 12345.678f) return;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
         const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
@@ -349,10 +341,9 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
     const int tile = blockIdx.x / splitM;
     wgrad_f32_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
-__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk,
-                                                          int dbg) {
+__global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
     const int tile = blockIdx.x / splitM;
-    wgrad_bf16_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM, dbg);
+    wgrad_bf16_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 
 // Several weight gradients in ONE launch (gast_wgrad_multi): the split-M atomics cost 30-60 % of a stand-alone weight-gradient
@@ -394,10 +385,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
-__global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b, int dbg) {
+__global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_bf16_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp, dbg);
+    wgrad_bf16_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -446,12 +437,11 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
         hipError_t e = hipMemsetAsync(a.dW, 0, (size_t)a.R * a.ldw * sizeof(float), st);
         if (e != hipSuccess) return (int)e;
     }
-    static const int dbg = getenv("GAST_WGRAD_DEBUG") ? atoi(getenv("GAST_WGRAD_DEBUG")) : 0;   // profiling ablations only
     dim3 grid(tiles * splitM), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
     else
-        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk, dbg);
+        hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -494,12 +484,11 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
             if (e != hipSuccess) return (int)e;
         }
     }
-    static const int dbg = getenv("GAST_WGRAD_DEBUG") ? atoi(getenv("GAST_WGRAD_DEBUG")) : 0;
     dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]), block(256);
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, block, 0, st, b);
     else
-        hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, block, 0, st, b, dbg);
+        hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, block, 0, st, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

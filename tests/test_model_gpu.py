@@ -16,10 +16,10 @@ pytestmark = pytest.mark.gpu
 #   removed by expand_bn) and only carry fp32 round-off.
 # bf16: activations/weights rounded to bf16 (fp32 accumulate / statistics / softmax).  The reference's own CPU autocast-bf16
 #   run drifts 1.8 % of the output magnitude from its fp32 run; tiny-batch BatchNorm (goldens use B=2..5)
-#   amplifies rounding further, so goldens get a looser bound and the north-star 1e-2 is asserted at the BASELINE size in
-#   test_bf16_vs_fp32_full_size.
-#   Gradient tolerance 5e-3 (not 1e-4): with B=2..5 a single ReLU decision at the kink (|z| ~ 3e-8, seen on
-#   j17_a333_c16_dil_causal; scripts/debug_compare.py) flips between MKL-DNN's and our BN rounding and moves a weight gradient by 1/rows ~ 0.3 %.
+#   amplifies rounding further, so goldens get a looser output bound; the drift at the BASELINE size is measured and bounded in
+#   test_bf16_vs_fp32_full_size (DESIGN.md section 5).
+# Gradients: fp32 -> _check_fp32_grads (2e-4 of max|ref|, undecidable ReLU ties evaluated both ways by the oracle);
+#   bf16 -> _grad_cosines (direction and scale).  TOL['grad'/'gabs'] below are only used by the bf16 skip logic of _grad_errors.
 TOL = {'fp32': dict(out=1e-4, out_eval=1e-4, grad=5e-3, gabs=5e-5, out_rel=1e-4),
        'bf16': dict(out=8e-2, out_eval=1e-2, grad=6e-1, gabs=3e-2, out_rel=3e-2)}
 ZERO_GRADS = ('init_bn.bias',)   # mathematically zero (expand_bn removes a constant input shift): pure round-off in any precision
