@@ -111,6 +111,17 @@ __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
 struct BnFinBatch { gast_bn_fin_job j[GAST_BN_MAX_BATCH]; };
 __global__ void __launch_bounds__(256) bn_finalize_multi_kernel(const BnFinBatch b) { bn_finalize_body(b.j[blockIdx.y]); }
 
+// every eval-mode BatchNorm of the model in ONE launch (they depend on parameters and buffers only): blockIdx.y = job
+struct BnEvalBatch { gast_bn_eval_job j[GAST_BN_EVAL_MAX_BATCH]; };
+__global__ void bn_eval_multi_kernel(const BnEvalBatch b, float eps) {
+    const gast_bn_eval_job& j = b.j[blockIdx.y];
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= j.N) return;
+    const float sc = j.gamma[n] / sqrtf(j.running_var[n] + eps);
+    j.scale[n] = sc;
+    j.shift[n] = j.centered ? j.beta[n] : j.beta[n] - j.running_mean[n] * sc;
+}
+
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ rm,
                                const float* __restrict__ rv, float eps, int N, float* scale, float* shift, int centered) {
     int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -618,6 +629,22 @@ extern "C" int gast_bn_finalize(const float* partials, int nblk, int ncol_total,
     gast_bn_fin_job j = {partials, nblk, ncol_total, col0, N, count, gamma, beta, running_mean, running_var, num_batches_tracked,
                          momentum, eps, scale, shift, mean, rstd, centered};
     return gast_bn_finalize_multi(&j, 1, stream);
+}
+
+extern "C" int gast_bn_eval_multi(const gast_bn_eval_job* jobs, int n, float eps, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_BN_EVAL_MAX_BATCH) return GAST_EINVAL;
+    BnEvalBatch b;
+    int maxN = 0;
+    for (int d = 0; d < n; ++d) {
+        if (!jobs[d].gamma || !jobs[d].beta || !jobs[d].running_mean || !jobs[d].running_var || !jobs[d].scale || !jobs[d].shift ||
+            jobs[d].N < 1)
+            return GAST_EINVAL;
+        b.j[d] = jobs[d];
+        if (jobs[d].N > maxN) maxN = jobs[d].N;
+    }
+    hipLaunchKernelGGL(bn_eval_multi_kernel, dim3((maxN + 127) / 128, n), dim3(128), 0, (hipStream_t)stream, b, eps);
+    GAST_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

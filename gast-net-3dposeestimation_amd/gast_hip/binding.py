@@ -69,6 +69,11 @@ class _AdjJob(C.Structure):
     _fields_ = [('e', C.c_void_p), ('C', C.c_int), ('pat', C.c_void_p), ('A_t', C.c_void_p), ('dA_t', C.c_void_p)]
 
 
+class _BnEvalJob(C.Structure):
+    _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('N', C.c_int),
+                ('scale', C.c_void_p), ('shift', C.c_void_p), ('centered', C.c_int)]
+
+
 class _BnFinJob(C.Structure):
     _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
                 ('count', C.c_double), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p),
@@ -120,6 +125,7 @@ def load_library():
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp],
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         'gast_bn_finalize_multi': [C.POINTER(_BnFinJob), ci, vp],
+        'gast_bn_eval_multi': [C.POINTER(_BnEvalJob), ci, cf, vp],
         'gast_bn_bwd_finalize_multi': [C.POINTER(_BnBwdFinJob), ci, vp],
         'gast_bn_bwd_fused_multi': [ci, C.POINTER(_BnBwdJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -157,7 +163,7 @@ def load_library():
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
-                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
+                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_version']
@@ -443,6 +449,20 @@ class HipOps:
                 a.dz, a.lddz, a.X, a.ldx, a.rows = _p(j['dz']), _ld(j['dz']), _p(j['X']), _ld(j['X']), int(j['rows'])
             self.launches += 1
             _check(self.lib.gast_bn_bwd_fused_multi(_dt(chunk[0]['dz']), arr, len(chunk), _stream()), 'gast_bn_bwd_fused_multi')
+
+    BN_EVAL_MAX_BATCH = 32
+
+    def bn_eval_multi(self, jobs, eps):
+        """jobs: (gamma, beta, running_mean, running_var, scale, shift, centered) tuples: every eval-mode BatchNorm of the model in one
+        launch."""
+        for i0 in range(0, len(jobs), self.BN_EVAL_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.BN_EVAL_MAX_BATCH]
+            arr = (_BnEvalJob * len(chunk))()
+            for a, (gamma, beta, rm, rv, scale, shift, centered) in zip(arr, chunk):
+                a.gamma, a.beta, a.running_mean, a.running_var, a.N = _p(gamma), _p(beta), _p(rm), _p(rv), gamma.numel()
+                a.scale, a.shift, a.centered = _p(scale), _p(shift), int(bool(centered))
+            self.launches += 1
+            _check(self.lib.gast_bn_eval_multi(arr, len(chunk), eps, _stream()), 'gast_bn_eval_multi')
 
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         self.launches += 1

@@ -47,9 +47,10 @@ class BNState:
     """scale/shift (+ mean/rstd in training) of one BatchNorm2d for the current batch."""
     __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
-    def __init__(self, n, dev, count):
-        self.scale = torch.empty(n, dtype=torch.float32, device=dev)
-        self.shift = torch.empty(n, dtype=torch.float32, device=dev)
+    def __init__(self, n, dev, count, pre=None):
+        """pre = (scale, shift) views of the eval-mode table (already filled): nothing to compute for this state."""
+        self.scale = pre[0] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
+        self.shift = pre[1] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
         self.mean = torch.empty(n, dtype=torch.float32, device=dev)
         self.rstd = torch.empty(n, dtype=torch.float32, device=dev)
         self.count = count
@@ -101,6 +102,7 @@ class Engine:
         # bf16 rounding error scales with the spread of the channel, not with |mean|
         self.centered = bool(centered)
         self.za = ZeroArena()
+        self._pre = {}           # eval mode: pre-filled (scale, shift) views per BNState name
         self._side = {}          # device -> side stream for independent branches of the plan
         self._keep = []          # operands of side-stream launches, kept alive until the join
 
@@ -119,9 +121,36 @@ class Engine:
             ops.bn_finalize(partials, nblk, col0, n, count, bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'],
                             bn['num_batches_tracked'], BN_MOMENTUM, BN_EPS, st.scale[sl], st.shift[sl], st.mean[sl], st.rstd[sl],
                             centered=centered)
-        else:
+        elif not self._pre:       # (eval states are normally pre-filled by _eval_table)
             ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl],
                         centered=centered)
+
+    def _eval_table(self, inp, bufs, dev):
+        """Eval mode: scale/shift of EVERY BatchNorm in one launch (they depend on parameters and running statistics only).
+        Returns {state name: (scale, shift)} views into one table; a state that spans two BatchNorms (bn_1|bn_2, lcat|gcat) gets
+        their concatenation."""
+        sp = self.spec
+        L = len(sp.fw)
+        groups = [('bn0', ['init_bn']), ('bnE', ['expand_bn'])]
+        for s in range(L):
+            g = 'g%d.' % s
+            if s > 0:
+                groups += [('l%d.bn1' % s, ['l%d.bn0' % s]), ('l%d.bn2' % s, ['l%d.bn1' % s])]
+            groups += [(g + 'bnY', [g + 'bn_1', g + 'bn_2']), (g + 'bnLG', [g + 'lcat_bn', g + 'gcat_bn']), (g + 'bnO', [g + 'cat_bn'])]
+        total = sum((sum(inp[k + '.weight'].numel() for k in keys) + 3) // 4 * 4 for _, keys in groups)
+        table = torch.empty(2, total, dtype=torch.float32, device=dev)
+        jobs, out, o = [], {}, 0
+        for name, keys in groups:
+            o = (o + 3) // 4 * 4              # consumers load scale/shift with 16-byte accesses
+            o0 = o
+            for k in keys:
+                n = inp[k + '.weight'].numel()
+                jobs.append((inp[k + '.weight'], inp[k + '.bias'], bufs[k]['running_mean'], bufs[k]['running_var'], table[0, o:o + n],
+                             table[1, o:o + n], self.centered and k != 'init_bn'))      # the network input is never stored centred
+                o += n
+            out[name] = (table[0, o0:o], table[1, o0:o])
+        self.ops.bn_eval_multi(jobs, BN_EPS)
+        return out
 
     def _bn_forward_group(self, items, training, centered=False):
         """items: (partials, nblk, col0, n, count, bn, st, off) -- independent BatchNorms whose statistics are ready at the same
@@ -177,6 +206,8 @@ class Engine:
         use_drop = training and drop is not None and drop.thresh != 0
         za = self.za
         za.begin(('fwd', tuple(x.shape), dt, training), dev)
+        self._pre = {} if training else self._eval_table(inp, bufs, dev)
+        pre = self._pre.get
 
         # ---- init_bn statistics + expand conv (gast_net.py:163-164)
         k0 = sp.fw[0]
@@ -185,7 +216,7 @@ class Engine:
             raise RuntimeError('input has %d frames, receptive field needs at least %d' % (T_in, sp.receptive_field))
         T = [(T_in - k0) // s0 + 1]
         rows_in = B * T_in * J
-        bn0 = BNState(F_in, dev, rows_in)
+        bn0 = BNState(F_in, dev, rows_in, pre('bn0'))
         if training:
             nb = ops.input_stats_blocks(rows_in)
             part = torch.empty(nb, F_in, 2, dtype=torch.float32, device=dev)
@@ -201,7 +232,7 @@ class Engine:
         cen = self.centered
         ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE,
                        center=self._ctr(bufs['expand_bn']))
-        bnE = BNState(C0, dev, P0)
+        bnE = BNState(C0, dev, P0, pre('bnE'))
         self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen)
         X = self._new(P0, C0, dt, dev)
         ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
@@ -247,13 +278,13 @@ class Engine:
                              scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
                 ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
                          bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
-                bn1 = BNState(C, dev, P)
+                bn1 = BNState(C, dev, P, pre('l%d.bn1' % s))
                 self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
                 part2 = za.take((nb, C, 2))
                 ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
                          T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
-                bn2 = BNState(C, dev, P)
+                bn2 = BNState(C, dev, P, pre('l%d.bn2' % s))
                 self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen)
                 X = self._new(P, C, dt, dev)
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
@@ -296,7 +327,7 @@ class Engine:
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
         partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
-        bnY = BNState(2 * C, dev, P)
+        bnY = BNState(2 * C, dev, P, self._pre.get(g + 'bnY'))
         # the local and the global branch write the two column halves of ONE tensor LG = [Lpre | Gpre] (and one BNState): their
         # post-activation drop(relu(bn(.))) is materialised once as ZLG, so the G4 GEMM / its weight gradient read a plain operand
         # (the dropout hash in their load prologues was 3/4 of the VALU stream of those kernels, 250 of 345 instructions per K tile)
@@ -304,7 +335,7 @@ class Engine:
         Lp, Gp = LG[:, :C], LG[:, C:]
         partL = za.take((nb, C, 2))
         partG = za.take((nb, C, 2))
-        bnLG = BNState(2 * C, dev, P)
+        bnLG = BNState(2 * C, dev, P, self._pre.get(g + 'bnLG'))
         Ya = self._new(P, C, dt, dev)
         ZLG = self._new(P, 2 * C, dt, dev)
         # ---- global branch (optionally on the side stream): attention core -> G3
@@ -330,7 +361,7 @@ class Engine:
         partO = za.take((nb, 2 * C, 2))
         segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]), dict(A=ZLG, K=2 * C, map=im, W=Wbc[:, C:3 * C])]
         ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
-        bnO = BNState(2 * C, dev, P)
+        bnO = BNState(2 * C, dev, P, self._pre.get(g + 'bnO'))
         self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
                     C=C, Tn=Tn, P=P, use_drop=use_drop)

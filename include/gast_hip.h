@@ -240,6 +240,10 @@ typedef struct {
  * columns): f.ka / f.kb / f.kc are not written. */
 typedef struct { gast_bn_bwd_fin_job f; void* dz; int lddz; const void* X; int ldx; long rows; } gast_bn_bwd_job;
 int gast_bn_bwd_fused_multi(int dtype, const gast_bn_bwd_job* jobs, int n, gast_stream_t stream);
+/* all eval-mode BatchNorms of a model in one launch (scale/shift from the running statistics; inference path, row f4) */
+#define GAST_BN_EVAL_MAX_BATCH 32
+typedef struct { const float* gamma; const float* beta; const float* running_mean; const float* running_var; int N; float* scale; float* shift; int centered; } gast_bn_eval_job;
+int gast_bn_eval_multi(const gast_bn_eval_job* jobs, int n, float eps, gast_stream_t stream);
 int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

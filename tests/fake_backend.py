@@ -126,6 +126,10 @@ class OracleOps:
                                _np(j['dgamma']), _np(j['dbeta']), ka, kb, kc_, accumulate=j.get('accumulate', False))
             kc.bn_bwd_apply(_np(j['dz']), _np(j['X']), j['rows'], N, ka, kb, kc_)
 
+    def bn_eval_multi(self, jobs, eps):
+        for gamma, beta, rm, rv, scale, shift, centered in jobs:
+            self.bn_eval(gamma, beta, rm, rv, eps, gamma.numel(), scale, shift, centered=centered)
+
     def bn_eval(self, gamma, beta, rm, rv, eps, N, scale, shift, centered=False):
         kc.bn_eval(_np(gamma), _np(beta), _np(rm), _np(rv), eps, N, _np(scale), _np(shift), centered=centered)
 
