@@ -1073,7 +1073,7 @@ static int attn_wave_ci4(int dtype, int C, int nheads, int ldg, int ldy, const v
 }
 static int attn_wave_grid(int F, int nheads) {
     long units = (long)F * nheads;
-    long g = (units + 7) / 8;                          // >= 2 units per wave
+    long g = (units + 3) / 4;                          // one unit per wave until the grid cap (a unit is a ~15 us dependent chain)
     if (g > 768) g = 768;
     return g < 1 ? 1 : (int)g;
 }
