@@ -240,8 +240,8 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
 template <typename T, int D>
 __device__ __forceinline__ void agg_cols_ell(const T* __restrict__ dYf, int ldy, T* __restrict__ dHf, int lddh, int J, int C,
                                              const float* __restrict__ A, const int32_t* __restrict__ ell_i,
-                                             const int32_t* __restrict__ ell_k, int c, int h0c, int h1c, int yc) {
-    for (int j = 0; j < J; ++j) {
+                                             const int32_t* __restrict__ ell_k, int c, int h0c, int h1c, int yc, int j0, int jstep) {
+    for (int j = j0; j < J; j += jstep) {
         int ii[D], kk[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { ii[d] = ell_i[j * D + d]; kk[d] = ell_k[j * D + d]; }
@@ -271,6 +271,9 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
                                                                 T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb,
                                                                 int nchunk, int CC, int TPF, int FB) {
+    // gridDim.y = joint split (few frames: the per-thread chains over 17 joints / 82 edges are the critical path, so the joints
+    // of phase A and the edges of phase B are dealt to gridDim.y blocks)
+    const int jpart = blockIdx.y, jsplit = gridDim.y;
     __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
     const int tid = threadIdx.x;
     const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
@@ -288,8 +291,8 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
         for (int f = fb * FB + slot; f < F; f += nfb * FB) {
             const T* dYf = dY + (long)f * J * ldy;
             T* dHf = dH + (long)f * J * lddh;
-            agg_cols_ell<T, DS>(dYf, ldy, dHf, lddh, J, C, A_sym, ps.ell_ci, ps.ell_ck, c, c, C + c, c);
-            agg_cols_ell<T, DC>(dYf, ldy, dHf, lddh, J, C, A_con, pc.ell_ci, pc.ell_ck, c, 2 * C + c, 3 * C + c, C + c);
+            agg_cols_ell<T, DS>(dYf, ldy, dHf, lddh, J, C, A_sym, ps.ell_ci, ps.ell_ck, c, c, C + c, c, jpart, jsplit);
+            agg_cols_ell<T, DC>(dYf, ldy, dHf, lddh, J, C, A_con, pc.ell_ci, pc.ell_ck, c, 2 * C + c, 3 * C + c, C + c, jpart, jsplit);
         }
     }
     __syncthreads();
@@ -298,7 +301,7 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
     for (int pidx = tid; pidx < nnz_t * CC4; pidx += 256) {
         const int k = pidx / CC4, c4 = pidx - k * CC4;
         const int cg = ch * CC + c4 * 4;
-        if (cg >= C) continue;
+        if (cg >= C || (k % jsplit) != jpart) continue;
         const int g = k < nnz_s ? 0 : 1;
         const int i = s_ei[k], j = s_ej[k];
         const int yc = g * C + cg;
@@ -1006,18 +1009,20 @@ extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void
     size_t smem = 0;   // the fixed-degree kernel needs no dynamic LDS
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.nfb * c.nchunk);
+    // few frames (the M = B*J stage): split the joints / edges over 4 blocks so that the launch covers the chip
+    dim3 grid_ell(c.nfb * c.nchunk, c.nfb * c.nchunk <= 128 ? 4 : 1);
 #define AGG_BWD_ELL(DS, DC)                                                                                                   \
     do {                                                                                                                      \
         if (dtype == GAST_F32) {                                                                                              \
             if (smem > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_ell_kernel<float, DS, DC>,                  \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
-            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<float, DS, DC>), grid, dim3(256), smem, st, (const float*)dY, ldy,   \
+            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<float, DS, DC>), grid_ell, dim3(256), smem, st, (const float*)dY, ldy, \
                                (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb,    \
                                c.nchunk, c.CC, c.TPF, c.FB);                                                                  \
         } else {                                                                                                              \
             if (smem > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_ell_kernel<bf16_t, DS, DC>,                 \
                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                 \
-            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<bf16_t, DS, DC>), grid, dim3(256), smem, st, (const bf16_t*)dY, ldy, \
+            hipLaunchKernelGGL((semch_agg_bwd_ell_kernel<bf16_t, DS, DC>), grid_ell, dim3(256), smem, st, (const bf16_t*)dY, ldy, \
                                (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb,  \
                                c.nchunk, c.CC, c.TPF, c.FB);                                                                  \
         }                                                                                                                     \
