@@ -164,8 +164,8 @@ template <typename T, int D>
 __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, T* __restrict__ Yf, int ldy, int J, int C,
                                              const float* __restrict__ A, const int32_t* __restrict__ ell_j,
                                              const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2,
-                                             float4 ctr) {
-    for (int i = 0; i < J; ++i) {
+                                             float4 ctr, int i0, int istep) {
+    for (int i = i0; i < J; i += istep) {
         int jj[D], kk[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) { jj[d] = ell_j[i * D + d]; kk[d] = ell_k[i * D + d]; }
@@ -209,10 +209,11 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
                 const T* Hf = H + (long)f * J * ldh;
                 T* Yf = Y + (long)f * J * ldy;
                 const float4 z4 = make_float4(0, 0, 0, 0);
+                // gridDim.y = joint split (few frames: the rows i = blockIdx.y, blockIdx.y + gridDim.y, ... of every frame)
                 agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, A_sym, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0],
-                                    ctr_s ? *(const float4*)(ctr_s + c) : z4);
+                                    ctr_s ? *(const float4*)(ctr_s + c) : z4, blockIdx.y, gridDim.y);
                 agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, A_con, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1],
-                                    ctr_c ? *(const float4*)(ctr_c + c) : z4);
+                                    ctr_c ? *(const float4*)(ctr_c + c) : z4, blockIdx.y, gridDim.y);
             }
         }
 #pragma unroll
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
                 for (int sl = 0; sl < FB; ++sl)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
-                float* pp = partials + ((long)blockIdx.x * 2 * C + g * C + c) * 2;
+                float* pp = partials + (((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + g * C + c) * 2;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
             }
@@ -938,11 +939,15 @@ extern "C" int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backwar
     return 0;
 }
 
-extern "C" int gast_semch_agg_blocks(int F, int C) {
+static int agg_fwd_frame_blocks(int F, int C) {
     int TPF = agg_tpf(C), FB = 256 / TPF;
     int nb = (F + FB - 1) / FB;
     return nb < 512 ? nb : 512;
 }
+// few frames (the M = B*J stage): the rows of a frame are dealt to 4 blocks so that the launch covers the chip; the partial-sum
+// rows are then [joint part][frame block]
+static int agg_fwd_joint_split(int F, int C) { return agg_fwd_frame_blocks(F, C) <= 128 ? 4 : 1; }
+extern "C" int gast_semch_agg_blocks(int F, int C) { return agg_fwd_frame_blocks(F, C) * agg_fwd_joint_split(F, C); }
 
 extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
                                   const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
@@ -952,27 +957,35 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
     int TPF = agg_tpf(C), FB = 256 / TPF;
-    int nb = gast_semch_agg_blocks(F, C);
+    const int nb = agg_fwd_frame_blocks(F, C), jsplit = agg_fwd_joint_split(F, C);
+    const dim3 grid_ell(nb, jsplit);
     hipStream_t st = (hipStream_t)stream;
 #define AGG_FWD_ELL(DS, DC)                                                                                                  \
     do {                                                                                                                     \
         if (dtype == GAST_F32)                                                                                               \
-            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), grid_ell, dim3(256), 0, st, (const float*)H, ldh, F, J, C, \
                                A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);   \
         else                                                                                                                 \
-            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), grid_ell, dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, \
                                C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con); \
     } while (0)
     // the fixed-degree kernels walk exactly DS / DC padded slots per row: the pattern tables must have been built with
     // these degrees, which is the case for deg_sym == 2 (every supported skeleton) and deg_con in {5, 6}
     if (deg_sym == 2 && deg_con == 5) AGG_FWD_ELL(2, 5);
     else if (deg_sym == 2 && deg_con == 6) AGG_FWD_ELL(2, 6);
-    else if (dtype == GAST_F32)
-        hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
-                           A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);
-    else
-        hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym,
-                           A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con);
+    else {
+        // generic CSR kernel: it fills the first nb partial rows only; the joint-split rows stay zero
+        if (jsplit > 1) {
+            hipError_t e = hipMemsetAsync(partials + (size_t)nb * 2 * C * 2, 0, (size_t)nb * (jsplit - 1) * 2 * C * 2 * sizeof(float), st);
+            if (e != hipSuccess) return (int)e;
+        }
+        if (dtype == GAST_F32)
+            hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
+                               A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);
+        else
+            hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym,
+                               pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con);
+    }
 #undef AGG_FWD_ELL
     GAST_CHECK_LAUNCH();
     return 0;

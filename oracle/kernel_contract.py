@@ -222,10 +222,19 @@ def semch_adj_bwd(dA_t, A_t, pat, de, accumulate=False):
         de[:, ks] = de[:, ks] + v if accumulate else v
 
 
-def semch_agg_blocks(F, C):
+def _agg_frame_blocks(F, C):
     tpf = min(C // 4, 256)
     fb = 256 // tpf
     return min((F + fb - 1) // fb, 512)
+
+
+def _agg_joint_split(F, C):
+    """few frames: the rows (joints) of a frame are dealt to 4 blocks; partial rows are then [joint part][frame block]"""
+    return 4 if _agg_frame_blocks(F, C) <= 128 else 1
+
+
+def semch_agg_blocks(F, C):
+    return _agg_frame_blocks(F, C) * _agg_joint_split(F, C)
 
 
 def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round_fn=None, center_sym=None, center_con=None):
@@ -246,16 +255,17 @@ def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round
     if round_fn is not None:
         out = round_fn(out)
     Y[:F * J, :2 * C] = out.reshape(F * J, 2 * C)
-    # partial sums: frames are dealt round-robin to (block, slot): f = (it*nblk + blk)*FB + slot
-    nblk = semch_agg_blocks(F, C)
+    # partial sums: frames are dealt round-robin to (block, slot): f = (it*nfb + blk)*FB + slot; joints i = part, part + split, ...
+    nfb, split = _agg_frame_blocks(F, C), _agg_joint_split(F, C)
     tpf = min(C // 4, 256)
     fb = 256 // tpf
-    partials[:nblk] = 0
-    blk_of_frame = (np.arange(F) // fb) % nblk
-    for b in range(nblk):
-        sel = out[blk_of_frame == b]
-        partials[b, :2 * C, 0] = sel.sum(axis=(0, 1))
-        partials[b, :2 * C, 1] = (sel * sel).sum(axis=(0, 1))
+    partials[:nfb * split] = 0
+    blk_of_frame = (np.arange(F) // fb) % nfb
+    for part in range(split):
+        for b in range(nfb):
+            sel = out[blk_of_frame == b][:, part::split]
+            partials[part * nfb + b, :2 * C, 0] = sel.sum(axis=(0, 1))
+            partials[part * nfb + b, :2 * C, 1] = (sel * sel).sum(axis=(0, 1))
 
 
 def semch_agg_bwd(dY, H, F, J, C, A_sym, pat_sym, A_con, pat_con, dH, dA_sym, dA_con, round_fn=None):

@@ -6,6 +6,8 @@ import numpy as np
 import pytest
 import torch
 
+from parity_helpers import (ZERO_GRADS, BF16_NOISY, FP32_GRAD_TOL, _grad_errors, _grad_cosines, _tie_budget,  # noqa: F401
+                            _check_fp32_grads)
 from conftest import golden_names, load_golden
 from tests_helpers import PARENTS
 
@@ -22,98 +24,8 @@ pytestmark = pytest.mark.gpu
 #   bf16 -> _grad_cosines (direction and scale).  TOL['grad'/'gabs'] below are only used by the bf16 skip logic of _grad_errors.
 TOL = {'fp32': dict(out=1e-4, out_eval=1e-4, grad=5e-3, gabs=5e-5, out_rel=1e-4),
        'bf16': dict(out=8e-2, out_eval=1e-2, grad=6e-1, gabs=3e-2, out_rel=3e-2)}
-ZERO_GRADS = ('init_bn.bias',)   # mathematically zero (expand_bn removes a constant input shift): pure round-off in any precision
-# bf16 only: gradients that are sums of heavily cancelling softmax-backward terms (p*(datt - <p,datt>)) over all positions; with
-# bf16-stored g / dy the centred quantity keeps ~1 significant digit (the reference under autocast-bf16 behaves the same way)
-BF16_NOISY = ('theta.bias', 'phi.bias', 'theta.weight', 'phi.weight', 'concat_project.0.weight')
 METRICS = []
 BF16_COS, BF16_RATIO = 0.85, 0.7     # per-parameter cosine / norm ratio of bf16 gradients vs the fp32 truth (see _grad_cosines)
-
-
-def _grad_errors(m, ref, tol, budget=None):
-    """Worst score (<= 1 passes) of max|g - ref| against tol['grad'] * max|ref| + tol['gabs'], per parameter.  `budget[k]`
-    (optional, elementwise >= 0) is subtracted from the error first: the spread between the two decisions of the oracle's
-    undecidable ReLU inputs (see _tie_budget)."""
-    worst = ('', 0.0)
-    gmax = max(float(np.abs(v).max()) for v in ref.values())
-    for k, p in m.named_parameters():
-        if tol['gabs'] > 1e-3 and k.endswith(BF16_NOISY):
-            continue
-        r = ref[k]
-        e = np.abs(p.grad.float().cpu().numpy() - r)
-        if k in ZERO_GRADS:     # pure round-off around an exact zero: bounded against the largest gradient of the model
-            score = float(e.max()) / (1e-4 * gmax + tol['gabs'])
-            if score > worst[1]:
-                worst = (k, score)
-            continue
-        if budget is not None:
-            e = np.maximum(e - 1.25 * budget[k], 0.0)
-        score = float(e.max()) / (tol['grad'] * float(np.abs(r).max()) + tol['gabs'])
-        if score > worst[1]:
-            worst = (k, score)
-    return worst
-
-
-def _grad_cosines(m, ref, min_numel=64):
-    """bf16 gradient check.  bf16 storage perturbs pre-activations by ~1e-2, which flips the ReLU decision of ~0.4 % of the
-    elements per layer; each flip changes the gradient by that element's whole contribution, so after ~15 ReLU layers the
-    elementwise difference to the fp32 gradient is tens of percent of max|g| BY CONSTRUCTION (it is the exact gradient of a
-    slightly different piecewise-linear function, which is what any bf16 training run optimises).  What must hold is that
-    the direction and the scale agree: cosine and norm ratio per parameter tensor."""
-    worst_cos, worst_ratio = ('', 1.0), ('', 1.0)
-    for k, p in m.named_parameters():
-        r = ref[k].astype(np.float64).ravel()
-        if k in ZERO_GRADS or k.endswith(BF16_NOISY) or r.size < min_numel:
-            continue
-        g = p.grad.float().cpu().numpy().astype(np.float64).ravel()
-        nr, ng = np.linalg.norm(r), np.linalg.norm(g)
-        if nr < 1e-9:
-            continue
-        c = float(g @ r / (nr * ng + 1e-300))
-        if c < worst_cos[1]:
-            worst_cos = (k, c)
-        ratio = min(ng / nr, nr / max(ng, 1e-300))
-        if ratio < worst_ratio[1]:
-            worst_ratio = (k, float(ratio))
-    return worst_cos, worst_ratio
-
-
-FP32_GRAD_TOL = dict(grad=2e-4, gabs=2e-5)
-
-
-def _check_fp32_grads(m, ref, run_oracle):
-    """fp32 gradients against the float64 oracle / the reference golden: 2e-4 of max|ref| (+2e-5) per parameter.  When that
-    fails, ReLU inputs within eps of zero are evaluated both ways by the oracle (at most 32 of them, eps <= 1e-5: the fp32
-    round-off of a pre-activation of magnitude ~1-10) and only the part of the error their decisions cannot explain counts."""
-    worst = _grad_errors(m, ref, FP32_GRAD_TOL)
-    info = dict(strict_score=worst[1], strict_worst=worst[0], eps=0.0, ties=0)
-    if worst[1] > 1.0:
-        for eps in (1e-6, 1e-5):
-            n, budget = _tie_budget(run_oracle, eps)
-            info.update(eps=eps, ties=n)
-            if n > 32:
-                break
-            w = _grad_errors(m, ref, FP32_GRAD_TOL, budget)
-            if w[1] < worst[1]:
-                worst = w
-            if w[1] <= 1.0:
-                break
-    return worst, info
-
-
-def _tie_budget(run_oracle, eps):
-    """Evaluate the oracle with every ReLU/LeakyReLU input |v| < eps decided as positive, then as negative.
-    Returns (number of such inputs, {param: |g_on - g_off|})."""
-    from oracle import np_autograd as ag
-    out = {}
-    try:
-        for side in ('on', 'off'):
-            ag.TIES.update(eps=eps, side=side, count=0)
-            out[side] = run_oracle()
-            n = ag.TIES['count']
-    finally:
-        ag.TIES.update(eps=0.0, side='on', count=0)
-    return n, {k: np.abs(out['on'][k] - out['off'][k]) for k in out['on']}
 
 
 def _log(**kw):

@@ -45,11 +45,13 @@ def test_plan_matches_reference_golden(name, centered, monkeypatch):
     loss = torch.mean(torch.norm(y - y3d, dim=-1))
     assert abs(loss.item() - float(z['loss'])) < 1e-5
     loss.backward()
-    for k, p in m.named_parameters():
-        ref = grads[k]
-        scale = max(1e-3, float(np.abs(ref).max()))
-        err = float(np.abs(p.grad.numpy() - ref).max()) / scale
-        assert err < 2e-3, (k, err)
+    # gradients: 2e-4 of max|ref| per parameter; ReLU inputs within 1e-6 of zero are undecidable between two fp32 summation orders
+    # (the golden j17_a333_c16_dil_causal has one at |z| ~ 3e-8) and are evaluated both ways by the oracle (parity_helpers)
+    from oracle import gast_oracle as go
+    from parity_helpers import _check_fp32_grads
+    om = go.OracleModel(go.adj_from_parents(cfg['parents']), cfg['arc'], cfg['channels'], causal=cfg['causal'], variant=cfg['variant'])
+    worst, info = _check_fp32_grads(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2])
+    assert worst[1] <= 1.0, (worst, info)
     for k, b in m.named_buffers():
         if k.endswith('num_batches_tracked'):
             assert int(b) == int(post[k]), k
