@@ -291,14 +291,19 @@ def main():
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--split-graph', action='store_true', help='force the two-graph step (the default for --gpus > 1)')
     ap.add_argument('--full-graph', action='store_true', help='--gpus > 1: capture the RCCL all-reduce inside one graph')
+    ap.add_argument('--force-collective', action='store_true',
+                    help='single process: still create the RCCL process group and run the all-reduce / barriers of the N > 1 path '
+                         '(exercises that code path on a 1-GPU box)')
     ap.add_argument('--torch-tail', action='store_true', help='eager mpjpe formula + torch fused Adam instead of the HIP loss/optimizer')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
@@ -325,6 +330,7 @@ def main():
     y3d[:, :, 0] = 0                                     # reference main.py:225
     y3d = y3d.to(dev)
     sync = FlatGradAllReduce(model.parameters(), model=model)
+    sync.force = args.force_collective
     use_graph = not args.no_graph
     if args.torch_tail:   # the eager-formula loss and torch's fused multi-tensor Adam (comparison only)
         opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, fused=True, capturable=use_graph)
@@ -360,7 +366,7 @@ def main():
     # the same stream, graph B = Adam -- no collective inside a captured graph, two graph launches + one RCCL call per step.
     mode, graph_note = 'eager', 'eager'
     graphs, static_loss = [], None
-    want = 'eager' if not use_graph else ('split' if (args.split_graph or (world > 1 and not args.full_graph)) else 'full')
+    want = 'eager' if not use_graph else ('split' if (args.split_graph or (collective and not args.full_graph)) else 'full')
     if want != 'eager':
         try:
             side = torch.cuda.Stream()
@@ -405,18 +411,18 @@ def main():
     for _ in range(args.warmup):
         run_step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if collective:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    if collective:
+        dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if collective:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -530,7 +536,7 @@ def main():
         if cpu is not None:
             out['cpu_baseline'] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if collective:
         dist.destroy_process_group()
 
 

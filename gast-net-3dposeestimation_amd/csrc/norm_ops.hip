@@ -51,14 +51,19 @@ __device__ __forceinline__ void slot_reduce(float4 (&v)[NV], float (*sred)[4 * N
 // 256 threads = 32 columns x 8 partial-row lanes; each lane sums every 8th partial row (independent loads, unrolled),
 // then the 8 lanes are combined in LDS in double precision.  (One thread per column walking all row blocks serially
 // exposed one L2 latency per row block: 80 us for 425 blocks.)
-constexpr int FIN_COLS = 32, FIN_LANES = 8;
+constexpr int FIN_COLS = 32, FIN_LANES = 8;          // the fused short-tensor kernel (its apply half wants 32 columns)
+// The stand-alone finalizes run on 4..16 blocks, so their time is the serial chain of partial-row loads of one lane:
+// 16 columns x 16 lanes (a 128-byte row segment per load wave) and 8 loads in flight halve that chain again
+// (425 row blocks: 15 us -> 8 us).
+constexpr int FINS_COLS = 16, FINS_LANES = 16;
 
+template <int COLS, int LANES>
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
-                                              double (*sred)[FIN_COLS][2], int cx, int ry, double& s1, double& s2) {
+                                              double (*sred)[COLS][2], int cx, int ry, double& s1, double& s2) {
     double a1 = 0.0, a2 = 0.0;
     if (valid) {
-#pragma unroll 4
-        for (int b = ry; b < nblk; b += FIN_LANES) {
+#pragma unroll 8
+        for (int b = ry; b < nblk; b += LANES) {
             const float2 p = *(const float2*)(partials + ((long)b * ncol_total + col) * 2);
             a1 += (double)p.x;
             a2 += (double)p.y;
@@ -69,11 +74,11 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
     __syncthreads();
     s1 = 0.0; s2 = 0.0;
 #pragma unroll
-    for (int r = 0; r < FIN_LANES; ++r) { s1 += sred[r][cx][0]; s2 += sred[r][cx][1]; }
+    for (int r = 0; r < LANES; ++r) { s1 += sred[r][cx][0]; s2 += sred[r][cx][1]; }
 }
 
 __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
-    __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    __shared__ double sred[FINS_LANES][FINS_COLS][2];
     const float* __restrict__ partials = j.partials;
     const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N, centered = j.centered;
     const double count = j.count;
@@ -82,11 +87,11 @@ __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     float* running_mean = j.running_mean; float* running_var = j.running_var; int64_t* nbt = j.num_batches_tracked;
     const float momentum = j.momentum, eps = j.eps;
     float* scale = j.scale; float* shift = j.shift; float* mean_out = j.mean; float* rstd_out = j.rstd;
-    const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
-    const int n = blockIdx.x * FIN_COLS + cx;
-    if ((int)blockIdx.x * FIN_COLS >= N) return;
+    const int cx = threadIdx.x & (FINS_COLS - 1), ry = threadIdx.x / FINS_COLS;
+    const int n = blockIdx.x * FINS_COLS + cx;
+    if ((int)blockIdx.x * FINS_COLS >= N) return;
     double s1, s2;
-    finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    finalize_sums<FINS_COLS, FINS_LANES>(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -132,7 +137,7 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
 }
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& j) {
-    __shared__ double sred[FIN_LANES][FIN_COLS][2];
+    __shared__ double sred[FINS_LANES][FINS_COLS][2];
     const float* __restrict__ partials = j.partials;
     const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N;
     const double count = j.count;
@@ -141,11 +146,11 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& 
     const float* __restrict__ rstd = j.rstd;
     float* dgamma = j.dgamma; float* dbeta = j.dbeta; float* ka = j.ka; float* kb = j.kb; float* kc = j.kc;
     const int accumulate = j.accumulate;
-    const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
-    const int n = blockIdx.x * FIN_COLS + cx;
-    if ((int)blockIdx.x * FIN_COLS >= N) return;
+    const int cx = threadIdx.x & (FINS_COLS - 1), ry = threadIdx.x / FINS_COLS;
+    const int n = blockIdx.x * FINS_COLS + cx;
+    if ((int)blockIdx.x * FINS_COLS >= N) return;
     double s1, s2;
-    finalize_sums(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    finalize_sums<FINS_COLS, FINS_LANES>(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
     double mu = mean[n], r = rstd[n], g = gamma[n];
     double dg = r * (s2 - mu * s1);   // sum dz * xhat
@@ -201,7 +206,7 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const BnBwdFusedBatch
         const int cx = threadIdx.x & (FIN_COLS - 1), ry = threadIdx.x / FIN_COLS;
         const int n = blockIdx.x * FIN_COLS + cx;
         double s1, s2;
-        finalize_sums(j.f.partials, j.f.nblk, j.f.ncol_total, j.f.col0 + n, n < N, sred, cx, ry, s1, s2);
+        finalize_sums<FIN_COLS, FIN_LANES>(j.f.partials, j.f.nblk, j.f.ncol_total, j.f.col0 + n, n < N, sred, cx, ry, s1, s2);
         if (ry == 0) {
             float a = 0.f, bb = 0.f, c = 0.f;
             if (n < N) {
@@ -383,7 +388,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 }
 
 // ------------------------------------------------------------------------------------------------ input side
-constexpr int IN_ROWS_PER_BLOCK = 4096;
+constexpr int IN_ROWS_PER_BLOCK = 1024;      // 4 rows per thread: 58 blocks on the B=128 window batch (15 blocks of 4096 rows took 12 us)
 
 __global__ void __launch_bounds__(256) input_stats_kernel(const float* __restrict__ x, long rows, int F_in, float* __restrict__ partials) {
     // partials[blk][f][2]; F_in <= 8
@@ -617,7 +622,7 @@ extern "C" int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_s
         b.j[d] = j;
         if (j.N > maxN) maxN = j.N;
     }
-    hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3((maxN + FIN_COLS - 1) / FIN_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(bn_finalize_multi_kernel, dim3((maxN + FINS_COLS - 1) / FINS_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -668,7 +673,7 @@ extern "C" int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n
         b.j[d] = j;
         if (j.N > maxN) maxN = j.N;
     }
-    hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3((maxN + FIN_COLS - 1) / FIN_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
+    hipLaunchKernelGGL(bn_bwd_finalize_multi_kernel, dim3((maxN + FINS_COLS - 1) / FINS_COLS, n), dim3(256), 0, (hipStream_t)stream, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

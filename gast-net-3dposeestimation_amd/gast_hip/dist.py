@@ -32,13 +32,14 @@ class FlatGradAllReduce:
             model._runner.grad_sink = self.flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.force = False          # True: issue the collective even for a single rank (bench.py --force-collective)
 
     def zero_(self):
         self.flat.zero_()
 
     def sync(self):
         """sum over ranks / world size, in place; no-op for a single process."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
             self.flat.mul_(1.0 / self.world)
 

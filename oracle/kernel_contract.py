@@ -449,7 +449,7 @@ def colsum(X, rows, N, out, zero_first=True):
 
 
 # ------------------------------------------------------------------------------------------------ input side
-IN_ROWS_PER_BLOCK = 4096
+IN_ROWS_PER_BLOCK = 1024
 
 
 def input_stats_blocks(rows):
