@@ -84,6 +84,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     __shared__ int sCrow[BM];
     __shared__ int sAddRow[BM];
     __shared__ float sRed[4][BN][2];
+    __shared__ int sBadSeg[GAST_MAX_SEG];      // does the segment map a row of this tile that must read as zero?
     unsigned char* const sA = smem;
     unsigned char* const sB = smem + BM * LSTR;
 
@@ -95,6 +96,8 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     const int logical = xcd_remap(blk / splitk, gridM * gridN);
     const int mt = logical / gridN, nt = logical - mt * gridN;
 
+    if (tid < GAST_MAX_SEG) sBadSeg[tid] = 0;
+    __syncthreads();
     if (tid < BM) {
         int m = mt * BM + tid;
         int crow = -1, arow = -1;
@@ -102,7 +105,11 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             int TJ = a.Tn * a.J;
             int b = m / TJ, rem = m - b * TJ;
             int t = rem / a.J, j = rem - t * a.J;
-            for (int s = 0; s < a.nseg; ++s) sRow[s][tid] = (int)map_row(a.seg[s].map, b, t, j, a.J);
+            for (int s = 0; s < a.nseg; ++s) {
+                const int r = (int)map_row(a.seg[s].map, b, t, j, a.J);
+                sRow[s][tid] = r;
+                if (r < 0) sBadSeg[s] = 1;       // an out-of-range tap inside the tile (rows past M are never stored: no zeroing needed)
+            }
             crow = (int)map_row(a.cmap, b, t, j, a.J);
             if (a.addend) arow = (int)map_row(a.addmap, b, t, j, a.J);
         } else {
@@ -136,6 +143,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     struct SegRegs {
         const T* A; const T* W; const float* scale; const float* shift;
         int lda, ldw, K, pro; uint32_t key; bool drop;
+        bool fix;        // block-uniform: the tile needs zeroed rows (out-of-range taps) or a zeroed K tail
         int row[4];      // source rows of this thread's 4 tile rows (-1 = zero row)
     };
     auto fetch_seg = [&](int s, SegRegs& R) {
@@ -147,6 +155,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
         R.lda = sg.lda; R.ldw = sg.ldw; R.K = sg.K;
         R.drop = sg.pro == GAST_PRO_BNRELU_DROP && thresh != 0;
         R.key = seedv * 0x9E3779B9u + sg.salt * 0x85EBCA6Bu;
+        R.fix = __builtin_amdgcn_readfirstlane(sBadSeg[s]) != 0 || (sg.K % BK) != 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) R.row[i] = sRow[s][rbase + 32 * i];
     };
@@ -200,10 +209,15 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             uint4 v = make_uint4(R.a[i].x, R.a[i].y, R.a[i].z, R.a[i].w);
             if (S.pro != GAST_PRO_NONE)
                 v = prologue<T>(v, sc, sh, S.drop, S.key, thresh, inv_keep, (uint32_t)((long)(row < 0 ? 0 : row) * S.lda + k));
-            const bool oka = kin && row >= 0;      // zero rows / K tail stay zero (relu(shift) must not leak in)
-            const bool okb = kin && nrow[i] >= 0;
-            v = make_uint4(oka ? v.x : 0u, oka ? v.y : 0u, oka ? v.z : 0u, oka ? v.w : 0u);
-            const uint4 wv = make_uint4(okb ? R.b[i].x : 0u, okb ? R.b[i].y : 0u, okb ? R.b[i].z : 0u, okb ? R.b[i].w : 0u);
+            uint4 wv = make_uint4(R.b[i].x, R.b[i].y, R.b[i].z, R.b[i].w);
+            // Zero rows (out-of-range taps) and the K tail must read as zero (relu(shift) must not leak in); a block-uniform
+            // branch, taken by few tiles, instead of 32 v_cndmask per K tile.  Rows past M / W rows past N are clamped to row 0 and
+            // only reach outputs that are never stored.
+            if (S.fix) {
+                const bool oka = kin && row >= 0;
+                v = make_uint4(oka ? v.x : 0u, oka ? v.y : 0u, oka ? v.z : 0u, oka ? v.w : 0u);
+                wv = make_uint4(kin ? wv.x : 0u, kin ? wv.y : 0u, kin ? wv.z : 0u, kin ? wv.w : 0u);
+            }
             *(uint4*)(sA + r * LSTR + chunk * 16) = v;
             *(uint4*)(sB + r * LSTR + chunk * 16) = wv;
         }

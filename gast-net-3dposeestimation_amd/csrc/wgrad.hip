@@ -23,13 +23,13 @@ constexpr int FSTR = 132;    // fp32: LDS row stride in floats
 
 struct TileCoord { int rt, seg, st; };
 
-__device__ __forceinline__ TileCoord decode_tile(const gast_wgrad_args& a, int tile, int tilesS_total) {
+__device__ __forceinline__ TileCoord decode_tile(const gast_wgrad_args& a, int tile, int tilesS_total, int bt = BT) {
     TileCoord c;
     c.rt = tile / tilesS_total;
     int rem = tile - c.rt * tilesS_total;
     c.seg = 0;
     for (int s = 0; s < a.nseg; ++s) {
-        int ts = (a.seg[s].S + BT - 1) / BT;
+        int ts = (a.seg[s].S + bt - 1) / bt;
         if (rem < ts) { c.seg = s; break; }
         rem -= ts;
     }
@@ -181,8 +181,9 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
 }
 
 // ------------------------------------------------------------------------------------------------ bf16
-__device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&out)[8]) {
-    // in[i] = row i (8 bf16: cols 0..7 packed in 4 u32); out[q] = col q (8 bf16: rows 0..7)
+__device__ __forceinline__ void transpose8x8_bf16(const u32x4 (&in)[8], uint4 (&out)[8]) {
+    // in[i] = row i (8 bf16: cols 0..7 packed in 4 u32); out[q] = col q (8 bf16: rows 0..7).  One v_perm_b32 per output word
+    // (the shift/mask form costs two VALU instructions per word, and this kernel is VALU-bound in its staging pass).
     uint32_t w[8][4];
 #pragma unroll
     for (int i = 0; i < 8; ++i) { w[i][0] = in[i].x; w[i][1] = in[i].y; w[i][2] = in[i].z; w[i][3] = in[i].w; }
@@ -192,34 +193,47 @@ __device__ __forceinline__ void transpose8x8_bf16(const uint4 (&in)[8], uint4 (&
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             uint32_t lo = w[2 * p][q >> 1], hi = w[2 * p + 1][q >> 1];
-            o[p] = (q & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+            // (q odd) high halves: (lo >> 16) | (hi & 0xffff0000); (q even) low halves: (lo & 0xffff) | (hi << 16)
+            o[p] = __builtin_amdgcn_perm(hi, lo, (q & 1) ? 0x07060302u : 0x05040100u);
         }
         out[q] = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
-__device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
-    constexpr int BKM = 64;
-    __shared__ __attribute__((aligned(16))) unsigned char sP[BT * LSTR];
-    __shared__ __attribute__((aligned(16))) unsigned char sQ[BT * LSTR];
-    __shared__ int sRowP[2][BKM];
-    __shared__ int sRowQ[2][BKM];
+// TILE = edge of the square dW tile: 128 (4 waves as 2x2 of 64x64, three blocks per CU) or 256 (8 waves as 2x4 of 128x64, one
+// block per CU: half the operand bytes per FLOP -- the 128x128 blocks are bound by their global loads).  2*TILE threads: the
+// first TILE stage P, the others Q, one 8(m) x 8(col) block each per 64-row step.
+constexpr int WG_BKM = 64;
+constexpr int wgrad_bf16_lds_bytes(int tile) { return 2 * tile * LSTR + 4 * WG_BKM * (int)sizeof(int) + 16; }
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+template <int TILE>
+__device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem, const gast_wgrad_args& a, int M, int tilesS_total,
+                                                int mchunk, int tile, int sp) {
+    constexpr int BKM = WG_BKM;
+    constexpr int WGC = TILE / 64;            // wave columns (each wave: TILE/2 rows x 64 columns of the dW tile)
+    constexpr int WROWS = TILE / 2;
+    constexpr int MI = WROWS / 32;
+    unsigned char* const sP = smem;
+    unsigned char* const sQ = smem + TILE * LSTR;
+    int (*sRowP)[BKM] = (int (*)[BKM])(smem + 2 * TILE * LSTR);
+    int (*sRowQ)[BKM] = sRowP + 2;
+    int* const sBad = (int*)(sRowQ + 2);      // [2]: does the 64-row step hold a row that must read as zero?
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w / WGC, wc = w - wr * WGC;
     const int li = lane & 31, lh = lane >> 5;
-    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const TileCoord tc = decode_tile(a, tile, tilesS_total, TILE);
     const gast_wgrad_seg& sg = a.seg[tc.seg];
     const int m_begin = sp * mchunk;
     const int m_end = min(M, m_begin + mchunk);
     if (m_begin >= m_end) return;
     const int ntile = (m_end - m_begin + BKM - 1) / BKM;
 
-    // staging role: waves 0-1 stage P, waves 2-3 stage Q; each thread owns an 8(m) x 8(col) block
-    const int op = tid >> 7, task = tid & 127;
+    // staging role: the first TILE threads stage P, the others Q; each thread owns an 8(m) x 8(col) block
+    const int op = tid / TILE, task = tid - op * TILE;
     const int mb = task & 7, rc = task >> 3;
     const bf16_t* base = op == 0 ? (const bf16_t*)a.P : (const bf16_t*)sg.Q;
     const int ld = op == 0 ? a.ldp : sg.ldq;
-    const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 8;
+    const int col = (op == 0 ? tc.rt : tc.st) * TILE + rc * 8;
     const bool cin = col < (op == 0 ? a.R : sg.S);
     const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
     const bool drop = op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
@@ -233,9 +247,9 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
     }
     unsigned char* sdst = op == 0 ? sP : sQ;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -248,33 +262,40 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
             rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
             sRowP[buf][tid] = pr;
             sRowQ[buf][tid] = qr;
+            const unsigned long long bad = __ballot(pr < 0);      // tid < 64 is exactly wave 0
+            if (tid == 0) sBad[buf] = bad != 0ull;
         }
     };
 
-    u32x4 rl[8];
-    uint4 rg[8];
+    u32x4 rl[8];      // the staged 8(m) x 8(col) block: loaded, fixed up in place, transposed into LDS
     const int colc = cin ? col : 0;
     auto load_tile = [&](int buf) {
+        // the 8 source rows of this thread's block in two 16-byte LDS reads (one read + wait per row in front of every load
+        // serialised eight LDS round trips ahead of the MFMAs)
+        const int4* rp = (const int4*)((op == 0 ? sRowP[buf] : sRowQ[buf]) + mb * 8);
+        const int4 r0 = rp[0], r1 = rp[1];
+        const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
-            gload16(rl[i], base + (long)(row < 0 ? 0 : row) * ld + colc);
-        }
+        for (int i = 0; i < 8; ++i) gload16(rl[i], base + (long)(rows[i] < 0 ? 0 : rows[i]) * ld + colc);
     };
     auto store_tile = [&](int buf) {
         gload_wait_n<0>();
+        // Rows outside the chunk / the row map must read as zero (they are summed into valid outputs): only the last step of a
+        // chunk or an out-of-range tap has any -- a block-uniform branch instead of 32 v_cndmask per step.  Columns beyond R / S
+        // need no zeroing: they only reach dW rows / columns that are never written.
+        if (__builtin_amdgcn_readfirstlane(sBad[buf])) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
-            const bool ok = cin && row >= 0;
-            rg[i] = make_uint4(ok ? rl[i].x : 0u, ok ? rl[i].y : 0u, ok ? rl[i].z : 0u, ok ? rl[i].w : 0u);
+            for (int i = 0; i < 8; ++i) {
+                const int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
+                if (row < 0) rl[i] = u32x4{0u, 0u, 0u, 0u};
+            }
         }
         if (pro && cin) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 int row = sRowQ[buf][mb * 8 + i];
                 if (row < 0) continue;
-                uint32_t wv[4] = {rg[i].x, rg[i].y, rg[i].z, rg[i].w};
+                uint32_t wv[4] = {rl[i].x, rl[i].y, rl[i].z, rl[i].w};
                 uint32_t e0 = (uint32_t)((long)row * ld + col);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
@@ -287,11 +308,11 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
                     }
                     wv[p] = pack_bf16x2(lo, hi);
                 }
-                rg[i] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                rl[i] = u32x4{wv[0], wv[1], wv[2], wv[3]};
             }
         }
         uint4 tr[8];
-        transpose8x8_bf16(rg, tr);
+        transpose8x8_bf16(rl, tr);
 #pragma unroll
         for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
     };
@@ -308,15 +329,15 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
         if (it + 2 < ntile) compute_rows(it + 2, it & 1);
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
-            union { uint4 u; s16x8 s; } fa[2], fb[2];
+            union { uint4 u; s16x8 s; } fa[MI], fb[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-                fa[mi].u = *(const uint4*)(sP + (wr * 64 + mi * 32 + li) * LSTR + (kc * 2 + lh) * 16);
+            for (int mi = 0; mi < MI; ++mi)
+                fa[mi].u = *(const uint4*)(sP + (wr * WROWS + mi * 32 + li) * LSTR + (kc * 2 + lh) * 16);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
                 fb[ni].u = *(const uint4*)(sQ + (wc * 64 + ni * 32 + li) * LSTR + (kc * 2 + lh) * 16);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi].s, fb[ni].s, acc[mi][ni], 0, 0, 0);
@@ -325,13 +346,13 @@ __device__ __forceinline__ void wgrad_bf16_body(const gast_wgrad_args& a, int M,
 
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        const int scol = tc.st * TILE + wc * 64 + ni * 32 + li;
         if (scol >= sg.S) continue;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int rrow = tc.rt * TILE + wr * WROWS + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
             }
     }
@@ -342,8 +363,9 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
     wgrad_f32_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
     const int tile = blockIdx.x / splitM;
-    wgrad_bf16_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
+    wgrad_bf16_body<128>(smem, a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 
 // Several weight gradients in ONE launch (gast_wgrad_multi): the split-M atomics cost 30-60 % of a stand-alone weight-gradient
@@ -386,15 +408,23 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b
     wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_bf16_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_bf16_body<128>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+}
+// 256x256 tiles: 512 threads, 74.8 KB of dynamic LDS, one block per CU (two waves per SIMD: 256 registers each)
+__global__ void __launch_bounds__(512, 2) wgrad_bf16_multi256_kernel(const WgBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem[];
+    int d, tile, sp;
+    if (!wg_decode(b, d, tile, sp)) return;
+    wgrad_bf16_body<256>(dsmem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // validation shared by gast_wgrad / gast_wgrad_multi; returns 0 and the tile counts, or an error code
-int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS) {
+int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS, int bt = BT) {
     if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.P || !a.dW || a.R < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
     const int epc = a.dtype == GAST_F32 ? 4 : 8;
@@ -405,12 +435,12 @@ int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS) {
         if (!g.Q || g.S < 1) return GAST_EINVAL;
         if (g.S % epc || g.ldq % epc || !aligned16(g.Q)) return GAST_EALIGN;
         if (g.pro != GAST_PRO_NONE && (!g.scale || !g.shift || !aligned16(g.scale) || !aligned16(g.shift))) return GAST_EINVAL;
-        tilesS += (g.S + BT - 1) / BT;
+        tilesS += (g.S + bt - 1) / bt;
     }
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
     M = (int)Ml;
-    tilesR = (a.R + BT - 1) / BT;
+    tilesR = (a.R + bt - 1) / bt;
     return 0;
 }
 
@@ -450,18 +480,28 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     if (!args || n < 1 || n > GAST_WGRAD_MAX_BATCH) return GAST_EINVAL;
     WgBatch b;     // 2.4 KB: filled on the host, passed by value (kernel argument)
     int tilesR[GAST_WGRAD_MAX_BATCH];
+    for (int d = 0; d < n; ++d)
+        if (args[d].dtype != args[0].dtype) return GAST_EINVAL;
+    // tile edge (bf16): 128, or 256 with GAST_WGRAD_TILE=256.  Measured on the B=128 step (scripts/wgrad_multi_bench.py): the
+    // 256x256 variant halves the operand bytes per FLOP but runs one 8-wave block per CU with a single register set in flight,
+    // and its wait -> transpose -> LDS write -> barrier -> issue -> MFMA -> barrier round is then fully exposed: 275 us vs 264 us
+    // on the C=256 stage (19 vs 74 tiles), 111 vs 86 us on the C=512 stage, 124 vs 105 us on the C=128 stage.  Kept for the
+    // next step (a second LDS stage / loader waves), not selected by default.
+    static const int tile_env = getenv("GAST_WGRAD_TILE") ? atoi(getenv("GAST_WGRAD_TILE")) : 128;
+    const int bt = (args[0].dtype == GAST_BF16 && tile_env == 256) ? 256 : BT;
     long tile_rows = 0;
     int total_tiles = 0;
     for (int d = 0; d < n; ++d) {
-        if (args[d].dtype != args[0].dtype) return GAST_EINVAL;
-        int rc = wgrad_check(args[d], b.M[d], tilesR[d], b.tilesS[d]);
+        int rc = wgrad_check(args[d], b.M[d], tilesR[d], b.tilesS[d], bt);
         if (rc) return rc;
         b.a[d] = args[d];
         total_tiles += tilesR[d] * b.tilesS[d];
         tile_rows += (long)tilesR[d] * b.tilesS[d] * b.M[d];
     }
     const int bkm = args[0].dtype == GAST_F32 ? 32 : 64;
-    static const int tgt = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
+    static const int tgt128 = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
+    static const int tgt256 = getenv("GAST_WGRAD_BLOCKS256") ? atoi(getenv("GAST_WGRAD_BLOCKS256")) : 512;   // one resident block per CU
+    const int tgt = bt == 256 ? tgt256 : tgt128;
     // one common chunk length (rows of the reduction axis per block) so that every block does the same number of steps
     long chunk = (tile_rows + tgt - 1) / tgt;
     chunk = (chunk + bkm - 1) / bkm * bkm;
@@ -484,11 +524,16 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
             if (e != hipSuccess) return (int)e;
         }
     }
-    dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]), block(256);
+    dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]);
     if (args[0].dtype == GAST_F32)
-        hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, block, 0, st, b);
-    else
-        hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, block, 0, st, b);
+        hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, dim3(256), 0, st, b);
+    else if (bt == 256) {
+        constexpr int lds = wgrad_bf16_lds_bytes(256);
+        static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_bf16_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL(wgrad_bf16_multi256_kernel, grid, dim3(512), lds, st, b);
+    } else
+        hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, dim3(256), 0, st, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -257,6 +257,18 @@ def test_wgrad_multi(ops, dt):
         close(host(jd['dW']), jh['dW'], dt, 'multi ' + WGRAD_CASES[i][0], fp32=3e-5, bf16=2e-2)
 
 
+def test_wgrad_multi_tile256_variant():
+    """The opt-in 256x256-tile weight-gradient kernel (GAST_WGRAD_TILE=256, read once per process by the library): the same
+    multi-job parity cases in a child process."""
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, GAST_WGRAD_TILE='256')
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
+                        '-k', 'test_wgrad_multi and bf16 and not tile256'], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 # ------------------------------------------------------------------------------------------------ SemCH
 @pytest.mark.parametrize('J', [15, 16, 17, 19])
 def test_semch_adj(ops, J):
