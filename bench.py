@@ -242,38 +242,70 @@ class KernelTimer:
 
 
 # --------------------------------------------------------------------------------------------------------- cpu baseline
-def cpu_baseline(seconds_budget=20.0):
-    """The numpy oracle on this host's cores, fwd+bwd of the same model, bounded sample."""
+def _stock_steps(device, autocast_bf16, B, budget_s, max_steps, warm_B=None):
+    """Training steps (reference main.py:227-239: zero_grad, forward, mpjpe, backward, Adam amsgrad) of the oracle's
+    restatement of the model on STOCK PyTorch operators (oracle/torch_ops.py: F.conv2d / F.batch_norm / matmul / softmax / cat,
+    torch autograd) -- the operator sequence the reference issues -- on `device`.  Returns (steps, seconds)."""
     from oracle import gast_oracle as go
+    from oracle import torch_ops
     from model.gast_net import SpatioTemporalModel
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get('num_threads', 1) for p in threadpool_info() if p.get('user_api') == 'blas'] or [1])
-    except Exception:
-        threads = 1
     adj = adj_from_parents(PARENTS17)
     torch.manual_seed(0)
     m = SpatioTemporalModel(adj, 17, 2, 17, filter_widths=[3, 3, 3], channels=128, dropout=0.05)
-    state = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
-    om = go.OracleModel(adj.numpy(), [3, 3, 3], 128, dropout=0.0, dtype=np.float32)
-    rng = np.random.default_rng(1234)
-    Bs = 8
-    x = (rng.random((Bs, 27, 17, 2)) * 2 - 1).astype(np.float32)
-    y = (rng.standard_normal((Bs, 1, 17, 3)) * 0.3).astype(np.float32)
-    om.loss_and_grads(state, x[:2], y[:2])          # warm-up (BLAS threads, page faults)
-    t0 = time.time()
-    reps = 0
-    while True:
-        om.loss_and_grads(state, x, y)
-        reps += 1
-        if time.time() - t0 > seconds_budget or reps >= 3:
-            break
-    dt = time.time() - t0
-    return dict(value=round(Bs * reps / dt, 3), unit='sequences/s', cores=int(threads), kind='port',
+    state = {k: v.detach().to(device) for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    x = (torch.rand(B, 27, 17, 2, generator=g) * 2 - 1).to(device)
+    y = (torch.randn(B, 1, 17, 3, generator=g) * 0.3).to(device)
+    y[:, :, 0] = 0
+    sync = torch.cuda.synchronize if device != 'cpu' else (lambda: None)
+    with go.use_backend(torch_ops):
+        om = go.OracleModel(adj.numpy(), [3, 3, 3], 128, dropout=0.05, dtype=torch.float32)
+        P = go._P(state, torch.float32)
+        opt = torch.optim.Adam([v.v for v in P.leaves.values()], lr=1e-3, amsgrad=True)
+
+        def step(xb, yb):
+            opt.zero_grad(set_to_none=True)
+            with torch.autocast('cuda', dtype=torch.bfloat16, enabled=bool(autocast_bf16)):
+                pred, _ = om.forward(None, xb, training=True, P=P)
+            loss = torch.mean(torch.norm(pred.v.float() - yb, dim=-1))
+            loss.backward()
+            opt.step()
+        wb = warm_B or B
+        step(x[:wb], y[:wb])          # warm-up (thread pools / MIOpen find / page faults)
+        sync()
+        t0 = time.time()
+        n = 0
+        while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
+            step(x, y)
+            n += 1
+        sync()
+        return n, time.time() - t0
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The reference's CPU path restated on the same stock PyTorch CPU operators (ATen / oneDNN), all host cores, bounded sample."""
+    B = 128
+    threads = torch.get_num_threads()
+    n, dt = _stock_steps('cpu', False, B, seconds_budget, 3, warm_B=8)
+    return dict(value=round(B * n / dt, 3), unit='sequences/s', cores=int(threads), kind='port',
                 host_cpus=os.cpu_count(),
-                sample='numpy fp32 oracle (oracle/gast_oracle.py), fwd+bwd of %d x %d of the 128 sequences (B=%d per pass), '
-                       'J=17 T=27 C=128; the reference itself (PyTorch CPU) cannot travel to this box -- it measured 13.6 seq/s '
-                       'fwd+bwd+Adam on 8 Xeon cores in the build container (BASELINE.md section 2)' % (reps, Bs, Bs))
+                sample='%d full training step(s) (zero_grad+fwd+mpjpe+bwd+Adam amsgrad, fp32, B=128 T=27 J=17 C=128, dropout 0.05) of '
+                       'the oracle restatement on stock PyTorch CPU operators (oracle/torch_ops.py: the ATen operator sequence the '
+                       'reference issues; pinned to the reference fixtures by tests/test_oracle_golden.py), %d torch threads; the '
+                       'reference itself cannot travel to this box -- it measured 13.6 seq/s on 8 Xeon cores in the build '
+                       'container (BASELINE.md section 2)' % (n, threads))
+
+
+def stock_gpu_baseline():
+    """SURVEY.md section 8(d) "extra comparator": the same model through stock PyTorch-ROCm operators on this GPU (what
+    `model.cuda()` of the reference gives a user): eager launches, fp32 and autocast-bf16."""
+    out = {}
+    for tag, ac in (('fp32', False), ('autocast_bf16', True)):
+        n, dt = _stock_steps('cuda', ac, 128, 10.0, 10)
+        out[tag] = dict(ms_per_step=round(dt / n * 1e3, 2), sequences_per_s=round(128 * n / dt, 1), steps=n)
+    out['note'] = ('oracle restatement on stock ATen/MIOpen/rocBLAS operators (oracle/torch_ops.py), eager, '
+                   'zero_grad+fwd+mpjpe+bwd+Adam(amsgrad), B=128 T=27 J=17 C=128, dropout 0.05')
+    return out
 
 
 # --------------------------------------------------------------------------------------------------------- main
@@ -286,6 +318,8 @@ def main():
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--stock-baseline', action='store_true',
+                    help='also time the same model through stock PyTorch-ROCm operators on this GPU (SURVEY 8d comparator)')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -535,6 +569,10 @@ def main():
                                            + ('' if args.variant == 'dilated' else ' (dilated-model figure; the strided twin does 0.31x the work)')}
         if cpu is not None:
             out['cpu_baseline'] = cpu
+        if args.stock_baseline and world == 1:
+            del model, opt, sync, graphs
+            torch.cuda.empty_cache()
+            out['stock_pytorch_rocm'] = stock_gpu_baseline()
         print(json.dumps(out), flush=True)
     if collective:
         dist.destroy_process_group()

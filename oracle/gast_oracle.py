@@ -8,13 +8,30 @@ follows.  It is pinned against fixtures produced by running the reference itself
 tests/golden/*.npz; checked by tests/test_oracle_golden.py).  The reference has no golden vectors of its own
 (SURVEY.md section 8c).
 
-Only tests/, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg import this module.  The product never does.
+The primitives come from a backend module: `np_autograd` (default: numpy, float64, the pinned oracle) or, inside
+`with use_backend(torch_ops):`, stock PyTorch operators on any device -- the same restatement then is the "stock
+PyTorch-ROCm" comparator of SURVEY.md section 8(d) and a GPU-side second reference (see oracle/torch_ops.py).
+
+Only tests/, `__graft_entry__.smoke()` and `bench.py`'s baseline legs import this module.  The product never does.
 """
+import contextlib
+
 import numpy as np
 
 from . import np_autograd as ag
 
 NEG_FILL = -9e15  # local_attention.py:40
+
+
+@contextlib.contextmanager
+def use_backend(mod):
+    """Run the restatement on another primitive set (oracle.torch_ops) for the duration of the block."""
+    global ag
+    old, ag = ag, mod
+    try:
+        yield
+    finally:
+        ag = old
 
 
 # ------------------------------------------------------------------------------------------------ skeleton / patterns
@@ -75,11 +92,11 @@ class _P:
         self.buf = {}
         for k, v in state.items():
             if k.endswith('running_mean') or k.endswith('running_var'):
-                self.buf[k] = np.array(v, dtype=dtype)
+                self.buf[k] = ag.asarray(v, dtype)
             elif k.endswith('num_batches_tracked'):
-                self.buf[k] = np.array(v)
+                self.buf[k] = ag.asarray(v, None)
             else:
-                self.leaves[k] = ag.leaf(np.array(v, dtype=dtype))
+                self.leaves[k] = ag.leaf(ag.asarray(v, dtype))
 
     def p(self, name):
         return self.leaves[name]
@@ -94,7 +111,11 @@ def _bn(P, prefix, x, training):
 
 
 def _dropout(x, p, rng):
-    if p <= 0 or rng is None:
+    if p <= 0:
+        return x
+    if hasattr(ag, 'dropout'):       # stock backend: its own RNG stream
+        return ag.dropout(x, p)
+    if rng is None:
         return x
     keep = (rng.random(x.v.shape) >= p).astype(x.v.dtype) / (1.0 - p)
     return ag.dropout_mask(x, keep)
@@ -112,7 +133,7 @@ def sem_ch_graph_conv(P, prefix, x, adj_pattern):
     h1 = ag.permute(ag.reshape(h1, h1.shape + (1,)), (0, 1, 3, 2, 4))
     m = np.broadcast_to(adj_pattern > 0, (Cout, J, J))                    # :23-24
     adj = ag.softmax(ag.masked_fill_from(e, m, NEG_FILL), axis=2)         # :40-42
-    E = np.eye(J, dtype=x.v.dtype)[None]                                  # :44-45
+    E = ag.eye(J, x)                                                      # :44-45
     out = ag.add(ag.matmul(ag.mul_const(adj, E), h0), ag.matmul(ag.mul_const(adj, 1 - E), h1))  # :47
     out = ag.reshape(ag.permute(out, (0, 1, 3, 2, 4)), out.shape[:2] + (J, Cout))               # :48
     return out
@@ -207,12 +228,14 @@ class OracleModel:
     def receptive_field(self):
         return 1 + 2 * sum(self.pad)                                     # gast_net.py:62-69
 
-    def forward(self, state, x, training=False, rng=None):
+    def forward(self, state, x, training=False, rng=None, P=None):
         """state: name->ndarray (reference state_dict layout); x: (B,T,J,2).  Returns (y Var (B,T',J,3), P).
-        With training=True the BatchNorm buffers inside P.buf are updated as the reference would."""
-        P = _P(state, self.dtype)
+        With training=True the BatchNorm buffers inside P.buf are updated as the reference would.  P: reuse a parameter store
+        built earlier (`_P(state, dtype)`) instead of copying `state` again -- a training loop over persistent leaves."""
+        if P is None:
+            P = _P(state, self.dtype)
         p_drop = self.dropout if training else 0.0
-        xv = ag.const(np.asarray(x, dtype=self.dtype))
+        xv = ag.const(ag.asarray(x, self.dtype))
         assert xv.v.ndim == 4                                                              # gast_net.py:93-95
         h = ag.permute(xv, (0, 3, 1, 2))                                                   # :162
         h = _bn(P, 'init_bn', h, training)                                                 # :163
@@ -242,16 +265,17 @@ class OracleModel:
     def loss_and_grads(self, state, x, y3d, training=True, rng=None):
         """mpjpe(model(x), y3d) (main.py:230-237) and its gradient w.r.t. every parameter."""
         y, P = self.forward(state, x, training=training, rng=rng)
-        loss = ag.mpjpe(y, np.asarray(y3d, dtype=self.dtype))
+        loss = ag.mpjpe(y, ag.asarray(y3d, self.dtype))
         ag.backward(loss)
-        grads = {k: (v.g if v.g is not None else np.zeros_like(v.v)) for k, v in P.leaves.items()}
-        return float(loss.v), y.v, grads, P.buf
+        grads = {k: (v.g if v.g is not None else v.v * 0) for k, v in P.leaves.items()}
+        lv = loss.v.detach() if hasattr(loss.v, 'detach') else loss.v
+        return float(lv), y.v, grads, P.buf
 
     def output_grads(self, state, x, dy, training=True):
         """Gradients of sum(y * dy) for an arbitrary upstream gradient dy (used for at-size GPU parity)."""
         y, P = self.forward(state, x, training=training)
-        ag.backward(y, seed=np.asarray(dy, dtype=self.dtype))
-        grads = {k: (v.g if v.g is not None else np.zeros_like(v.v)) for k, v in P.leaves.items()}
+        ag.backward(y, seed=ag.asarray(dy, self.dtype))
+        grads = {k: (v.g if v.g is not None else v.v * 0) for k, v in P.leaves.items()}
         return y.v, grads, P.buf
 
 

@@ -44,6 +44,15 @@ def const(v):
     return Var(np.asarray(v), (), None, False)
 
 
+def asarray(v, dtype, like=None):
+    """A private copy of `v` as an ndarray of `dtype` (None: keep).  (Backend hook: oracle/torch_ops.py has the tensor twin.)"""
+    return np.array(v) if dtype is None else np.array(v, dtype=dtype)
+
+
+def eye(J, like):
+    return np.eye(J, dtype=like.v.dtype)[None]
+
+
 def backward(root, seed=None):
     order, seen = [], set()
 

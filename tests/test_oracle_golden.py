@@ -57,3 +57,29 @@ def test_train_forward_backward_matches_reference(name):
             assert int(buf[k]) == int(post[k])
         else:
             np.testing.assert_allclose(buf[k], post[k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize('name', golden_names())
+def test_stock_torch_backend_matches_reference_and_numpy_oracle(name):
+    """The same restatement on oracle.torch_ops (stock ATen operators, torch autograd; float64 on CPU here): pinned to the
+    reference fixtures and to the numpy oracle, so it can serve as the GPU-side second reference / stock comparator."""
+    import torch
+    from oracle import torch_ops
+    cfg, z, state, grads, post = load_golden(name)
+    m = _model(cfg)
+    loss_np, y_np, g_np, buf_np = m.loss_and_grads(state, z['x'], z['y3d'], training=True)
+    tstate = {k: torch.from_numpy(np.array(v)) for k, v in state.items()}
+    with go.use_backend(torch_ops):
+        mt = _model(cfg, dtype=torch.float64)
+        y_eval, _ = mt.forward(tstate, torch.from_numpy(z['x']), training=False)
+        loss, y, g, buf = mt.loss_and_grads(tstate, torch.from_numpy(z['x']), torch.from_numpy(z['y3d']), training=True)
+    np.testing.assert_allclose(y_eval.v.detach().numpy(), z['y_eval'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(y.detach().numpy(), y_np, rtol=0, atol=1e-9)
+    assert abs(loss - loss_np) < 1e-10
+    assert set(g) == set(g_np)
+    for k in g_np:
+        scale = max(1e-3, float(np.abs(g_np[k]).max()))
+        assert float(np.abs(g[k].numpy() - g_np[k]).max()) / scale < 1e-8, k
+    for k in post:
+        np.testing.assert_allclose(np.asarray(buf[k]), buf_np[k], rtol=1e-10, atol=1e-12, err_msg=k)
+    assert go.ag.__name__.endswith('np_autograd')      # the context manager restored the default backend
