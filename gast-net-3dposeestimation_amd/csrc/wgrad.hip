@@ -204,9 +204,12 @@ __device__ __forceinline__ void transpose8x8_bf16(const u32x4 (&in)[8], uint4 (&
 // block per CU: half the operand bytes per FLOP -- the 128x128 blocks are bound by their global loads).  2*TILE threads: the
 // first TILE stage P, the others Q, one 8(m) x 8(col) block each per 64-row step.
 constexpr int WG_BKM = 64;
-constexpr int wgrad_bf16_lds_bytes(int tile) { return 2 * tile * LSTR + 4 * WG_BKM * (int)sizeof(int) + 16; }
+constexpr int wgrad_bf16_lds_bytes(int tile, int ring = 1) { return 2 * tile * LSTR + 4 * ring * WG_BKM * (int)sizeof(int) + 16 * ring; }
 
-template <int TILE>
+// RING = register sets in flight: 1 (the tile of step t+1 is loaded while step t multiplies; 168 VGPRs, three blocks per CU) or
+// 2 (tiles t+1 AND t+2 in flight, the wait before the LDS write is a counted vmcnt(8): the window a load has to land in grows
+// from the MFMA phase to a whole step; 2 x 32 more VGPRs, two blocks per CU).  Row-map buffers: 2 * RING.
+template <int TILE, int RING = 1>
 __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem, const gast_wgrad_args& a, int M, int tilesS_total,
                                                 int mchunk, int tile, int sp) {
     constexpr int BKM = WG_BKM;
@@ -216,8 +219,9 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
     unsigned char* const sP = smem;
     unsigned char* const sQ = smem + TILE * LSTR;
     int (*sRowP)[BKM] = (int (*)[BKM])(smem + 2 * TILE * LSTR);
-    int (*sRowQ)[BKM] = sRowP + 2;
-    int* const sBad = (int*)(sRowQ + 2);      // [2]: does the 64-row step hold a row that must read as zero?
+    constexpr int NRB = 2 * RING;             // row-map buffers
+    int (*sRowQ)[BKM] = sRowP + NRB;
+    int* const sBad = (int*)(sRowQ + NRB);    // [NRB]: does the 64-row step hold a row that must read as zero?
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w / WGC, wc = w - wr * WGC;
     const int li = lane & 31, lh = lane >> 5;
@@ -268,8 +272,9 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
     };
 
     u32x4 rl[8];      // the staged 8(m) x 8(col) block: loaded, fixed up in place, transposed into LDS
+    u32x4 rl2[8];     // second register set (RING == 2; dead otherwise)
     const int colc = cin ? col : 0;
-    auto load_tile = [&](int buf) {
+    auto load_tile = [&](u32x4 (&rl)[8], int buf) {
         // the 8 source rows of this thread's block in two 16-byte LDS reads (one read + wait per row in front of every load
         // serialised eight LDS round trips ahead of the MFMAs)
         const int4* rp = (const int4*)((op == 0 ? sRowP[buf] : sRowQ[buf]) + mb * 8);
@@ -278,8 +283,7 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
 #pragma unroll
         for (int i = 0; i < 8; ++i) gload16(rl[i], base + (long)(rows[i] < 0 ? 0 : rows[i]) * ld + colc);
     };
-    auto store_tile = [&](int buf) {
-        gload_wait_n<0>();
+    auto store_tile = [&](u32x4 (&rl)[8], int buf) {
         // Rows outside the chunk / the row map must read as zero (they are summed into valid outputs): only the last step of a
         // chunk or an out-of-range tap has any -- a block-uniform branch instead of 32 v_cndmask per step.  Columns beyond R / S
         // need no zeroing: they only reach dW rows / columns that are never written.
@@ -317,16 +321,7 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
         for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
     };
 
-    compute_rows(0, 0);
-    __syncthreads();
-    load_tile(0);
-    if (ntile > 1) compute_rows(1, 1);
-    for (int it = 0; it < ntile; ++it) {
-        __syncthreads();
-        store_tile(it & 1);
-        __syncthreads();
-        if (it + 1 < ntile) load_tile((it + 1) & 1);
-        if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+    auto mfma_tile = [&]() {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             union { uint4 u; s16x8 s; } fa[MI], fb[2];
@@ -341,6 +336,43 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi].s, fb[ni].s, acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    if constexpr (RING == 1) {
+        compute_rows(0, 0);
+        __syncthreads();
+        load_tile(rl, 0);
+        if (ntile > 1) compute_rows(1, 1);
+        for (int it = 0; it < ntile; ++it) {
+            __syncthreads();
+            gload_wait_n<0>();
+            store_tile(rl, it & 1);
+            __syncthreads();
+            if (it + 1 < ntile) load_tile(rl, (it + 1) & 1);
+            if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+            mfma_tile();
+        }
+    } else {
+        // step t: tile t sits in set t & 1; its reload (tile t + 2) is issued right after its LDS write; row maps three steps ahead
+        auto step = [&](u32x4 (&set)[8], int it) {
+            __syncthreads();                                   // every wave is done with the previous LDS tile
+            if (it + 1 < ntile) gload_wait_n<8>(); else gload_wait_n<0>();     // the other set's 8 loads stay in flight
+            store_tile(set, it & 3);
+            __syncthreads();
+            if (it + 2 < ntile) load_tile(set, (it + 2) & 3);
+            if (it + 3 < ntile) compute_rows(it + 3, (it + 3) & 3);
+            mfma_tile();
+        };
+        compute_rows(0, 0);
+        if (ntile > 1) compute_rows(1, 1);
+        if (ntile > 2) compute_rows(2, 2);
+        __syncthreads();
+        load_tile(rl, 0);
+        if (ntile > 1) load_tile(rl2, 1);
+        for (int it = 0; it < ntile; it += 2) {
+            step(rl, it);
+            if (it + 1 < ntile) step(rl2, it + 1);
         }
     }
 
@@ -412,6 +444,13 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch 
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_bf16_body<128>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+}
+// two register sets in flight (GAST_WGRAD_RING=2): 200 VGPRs, two blocks per CU
+__global__ void __launch_bounds__(256, 2) wgrad_bf16_multi_ring2_kernel(const WgBatch b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128, 2)];
+    int d, tile, sp;
+    if (!wg_decode(b, d, tile, sp)) return;
+    wgrad_bf16_body<128, 2>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 // 256x256 tiles: 512 threads, 74.8 KB of dynamic LDS, one block per CU (two waves per SIMD: 256 registers each)
 __global__ void __launch_bounds__(512, 2) wgrad_bf16_multi256_kernel(const WgBatch b) {
@@ -501,6 +540,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     const int bkm = args[0].dtype == GAST_F32 ? 32 : 64;
     static const int tgt128 = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
     static const int tgt256 = getenv("GAST_WGRAD_BLOCKS256") ? atoi(getenv("GAST_WGRAD_BLOCKS256")) : 512;   // one resident block per CU
+    static const int ring = getenv("GAST_WGRAD_RING") ? atoi(getenv("GAST_WGRAD_RING")) : 1;
     const int tgt = bt == 256 ? tgt256 : tgt128;
     // one common chunk length (rows of the reduction axis per block) so that every block does the same number of steps
     long chunk = (tile_rows + tgt - 1) / tgt;
@@ -532,7 +572,9 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_bf16_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return (int)attr;
         hipLaunchKernelGGL(wgrad_bf16_multi256_kernel, grid, dim3(512), lds, st, b);
-    } else
+    } else if (ring == 2)
+        hipLaunchKernelGGL(wgrad_bf16_multi_ring2_kernel, grid, dim3(256), 0, st, b);
+    else
         hipLaunchKernelGGL(wgrad_bf16_multi_kernel, grid, dim3(256), 0, st, b);
     GAST_CHECK_LAUNCH();
     return 0;

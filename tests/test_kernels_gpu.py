@@ -257,15 +257,17 @@ def test_wgrad_multi(ops, dt):
         close(host(jd['dW']), jh['dW'], dt, 'multi ' + WGRAD_CASES[i][0], fp32=3e-5, bf16=2e-2)
 
 
-def test_wgrad_multi_tile256_variant():
-    """The opt-in 256x256-tile weight-gradient kernel (GAST_WGRAD_TILE=256, read once per process by the library): the same
-    multi-job parity cases in a child process."""
+@pytest.mark.parametrize('knob', ['GAST_WGRAD_TILE=256', 'GAST_WGRAD_RING=2', 'GAST_WGRAD_ORDER=1'])
+def test_wgrad_multi_optin_variants(knob):
+    """The opt-in weight-gradient kernels / block orders (read once per process by the library): 256x256 tiles, two register
+    sets in flight, chunk-major order -- the same multi-job parity cases in a child process."""
     import os
     import subprocess
     import sys
-    env = dict(os.environ, GAST_WGRAD_TILE='256')
+    k, v = knob.split('=')
+    env = dict(os.environ, **{k: v})
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '-k', 'test_wgrad_multi and bf16 and not tile256'], env=env, capture_output=True, text=True, timeout=600)
+                        '-k', 'test_wgrad_multi and bf16 and not optin'], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
