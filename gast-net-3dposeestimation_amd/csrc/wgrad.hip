@@ -546,6 +546,30 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     long chunk = (tile_rows + tgt - 1) / tgt;
     chunk = (chunk + bkm - 1) / bkm * bkm;
     if (chunk < 4 * bkm) chunk = 4 * bkm;
+    const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS");
+    if (ring2) {
+        // two blocks per CU: the block count is quantised against 512 slots (518 blocks run 1.33x slower than 444), so pick
+        // the shortest chunk whose launch fits ONE round; if that leaves a quarter of the slots idle (the B*J-row stage: 300 or
+        // 600 blocks), the shortest chunk that fits one round and a half.
+        auto blocks_for = [&](long c) {
+            long nb = 0;
+            for (int d = 0; d < n; ++d) nb += (long)tilesR[d] * b.tilesS[d] * ((b.M[d] + c - 1) / c);
+            return nb;
+        };
+        long maxM = 0;
+        for (int d = 0; d < n; ++d) if (b.M[d] > maxM) maxM = b.M[d];
+        const long cmax = (maxM + bkm - 1) / bkm * bkm;
+        auto shortest = [&](long slots) {
+            long c = 4 * bkm;
+            while (c < cmax && blocks_for(c) > slots) c += bkm;
+            return c;
+        };
+        chunk = shortest(512);
+        if (blocks_for(chunk) < 384) {
+            const long c2 = shortest(768);
+            if (blocks_for(c2) > blocks_for(chunk)) chunk = c2;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     b.n = n;
     b.first[0] = 0;
