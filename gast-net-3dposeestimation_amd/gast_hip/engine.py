@@ -29,6 +29,7 @@ import os
 import torch
 
 RowMap = namedtuple('RowMap', 'T_total t_stride t_off')
+MAX_SEG = 8     # K segments per gast_gemm / gast_wgrad launch (GAST_MAX_SEG, include/gast_hip.h; checked by tests/test_host_contract.py)
 PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
 EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
 BN_MOMENTUM = 0.1
@@ -254,14 +255,14 @@ class Engine:
             if s > 0:
                 # ---- temporal level s (gast_net.py:167-174 / :242-247): input = previous block's Opre (lazy BN+ReLU)
                 prev = stages[-1]
-                k = sp.fw[s]
+                k = sp.kw[s]                    # taps: fw[s] (dilated / strided) or 2*pad+1 (dense=True ablation)
                 Tp = T[-1]
                 if sp.strided:
                     Tn = (Tp - k) // k + 1
                     taps = [RowMap(Tp, k, tap) for tap in range(k)]
                     resmap = RowMap(Tp, k, sp.causal_shift[s] + k // 2)
                 else:
-                    d = sp.dil[s]
+                    d = sp.tapstep[s]
                     Tn = Tp - (k - 1) * d
                     taps = [RowMap(Tp, 1, tap * d) for tap in range(k)]
                     resmap = RowMap(Tp, 1, sp.pad[s] + sp.causal_shift[s])
@@ -276,8 +277,8 @@ class Engine:
                 part1 = za.take((nb, C, 2))
                 segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
                              scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
-                ops.gemm((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
-                         bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
+                self._gemm_chunked((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
+                                   bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
                 bn1 = BNState(C, dev, P, pre('l%d.bn1' % s))
                 self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
@@ -366,12 +367,26 @@ class Engine:
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
                     C=C, Tn=Tn, P=P, use_drop=use_drop)
 
+    def _gemm_chunked(self, dom, N, segs, out, cmap, addend=None, addmap=None, **epilogue):
+        """ops.gemm for any number of K segments (the 7- and 19-tap convolutions of the dense=True ablation exceed the MAX_SEG
+        segments of one launch): MAX_SEG segments per launch, each launch adding the previous partial result (`out` itself as
+        the addend: every element is read and rewritten by the same thread), the caller's addend in the first and its epilogue
+        (bias, statistics, ReLU/BN backward) in the last."""
+        if len(segs) <= MAX_SEG:
+            return self.ops.gemm(dom, N, segs, out, cmap, addend=addend, addmap=addmap, **epilogue)
+        chunks = [segs[i:i + MAX_SEG] for i in range(0, len(segs), MAX_SEG)]
+        for ci, ch in enumerate(chunks):
+            a, am = (addend, addmap) if ci == 0 else (out, cmap)
+            self.ops.gemm(dom, N, ch, out, cmap, addend=a, addmap=am, **(epilogue if ci == len(chunks) - 1 else {}))
+
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=False):
         """Queue a weight gradient; the queue is flushed once per stage as ONE multi-job launch (ops.wgrad_multi).  Nothing in
         the backward pass reads a weight gradient, and every operand is in its final state when it is queued (the in-place
-        BatchNorm backward of P runs before)."""
-        self._wq.append(dict(dom=dom, P=P, R=R, pmap=pmap, segs=segs, dW=dW, drop=drop, zero_first=zero_first))
+        BatchNorm backward of P runs before).  More than MAX_SEG segments (dense=True taps) become several jobs."""
+        for i in range(0, len(segs), MAX_SEG):
+            self._wq.append(dict(dom=dom, P=P, R=R, pmap=pmap, segs=segs[i:i + MAX_SEG], dW=dW, drop=drop,
+                                 zero_first=zero_first and i == 0))
 
     def _wgrad_flush(self):
         """The queued weight gradients as one multi-job launch on the side stream: the next stage's backward chain (on the main
@@ -527,13 +542,14 @@ class Engine:
                              xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
                 nbo = k * nbt
             else:
-                d = sp.dil[s]
+                d = sp.tapstep[s]
                 dOp = self._new(Pp, C, dt, dev)
                 nbo = ops.gemm_row_blocks(Pp)
                 partO = za.take((nbo, C, 2))
                 segs = [dict(A=dT1, K=C, map=RowMap(Tn, 1, -tap * d), W=WcT[tap]) for tap in range(k)]
-                ops.gemm((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
-                         epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+                self._gemm_chunked((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
+                                   epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale,
+                                   xshift=prev['bnO'].shift)
             self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
             dO = dOp
             self._wgrad_flush()

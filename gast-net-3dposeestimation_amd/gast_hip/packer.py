@@ -137,7 +137,7 @@ class Packer:
         for i in range(1, L):
             lk = 'l%d.' % i
             C = C0 * 2 ** i
-            k = sp.fw[i]
+            k = sp.kw[i]
             conv, conv1 = m.layers_conv[2 * i - 2], m.layers_conv[2 * i - 1]
             self.W.add(lk + 'conv', C, k * C)
             self.W.add(lk + 'convT', k * C, C)

@@ -47,12 +47,13 @@ class GraphAttentionBlock(nn.Module):
 class ModelSpec:
     """Static description of one model instance for the engine."""
 
-    def __init__(self, adj, filter_widths, channels, causal, strided, in_features):
+    def __init__(self, adj, filter_widths, channels, causal, strided, in_features, dense=False):
         self.J = int(adj.shape[0])
         self.fw = list(filter_widths)
         self.channels = int(channels)
         self.causal = bool(causal)
         self.strided = bool(strided)
+        self.dense = bool(dense)
         self.in_features = int(in_features)
         # reference gast_net.py:57,139-143 (dilated) / :215-220 (strided)
         self.pad = [self.fw[0] // 2]
@@ -68,6 +69,10 @@ class ModelSpec:
             self.dil.append(nd)
             nd *= self.fw[i]
         self.receptive_field = 1 + 2 * sum(self.pad)
+        # taps of level s's temporal convolution and the frame step between them: fw[s] taps `dil[s]` apart (dilated), fw[s]
+        # adjacent taps under a stride of fw[s] (strided), or 2*pad[s]+1 adjacent taps (dense=True ablation, gast_net.py:145-146)
+        self.kw = [self.fw[0]] + [2 * self.pad[i] + 1 if self.dense else self.fw[i] for i in range(1, len(self.fw))]
+        self.tapstep = [1] + [1 if (self.dense or self.strided) else self.dil[i] for i in range(1, len(self.fw))]
         sym, con = skeleton_patterns(adj)
         self._tab_sym, self.nnz_sym = pattern_table(sym)
         self._tab_con, self.nnz_con = pattern_table(con)
@@ -228,7 +233,7 @@ class SpatioTemporalModelBase(nn.Module):
         self.expand_bn = nn.BatchNorm2d(channels, momentum=0.1)
         self.shrink = nn.Conv2d(2 ** len(self.filter_widths) * channels, 3, 1, bias=False)
 
-    def _finish_init(self, adj, filter_widths, causal, dropout, channels, strided):
+    def _finish_init(self, adj, filter_widths, causal, dropout, channels, strided, dense=False):
         """Common tail of both variants' constructors: temporal stack + engine spec (reference :133-157 / :210-233)."""
         layers_conv, layers_graph_conv, layers_bn = [], [], []
         layers_graph_conv.append(GraphAttentionBlock(adj, channels, channels, p_dropout=dropout))
@@ -242,7 +247,8 @@ class SpatioTemporalModelBase(nn.Module):
                 conv = nn.Conv2d(width, width, (filter_widths[i], 1), stride=(filter_widths[i], 1), bias=False)
             else:
                 self.causal_shift.append((filter_widths[i] // 2 * next_dilation) if causal else 0)
-                conv = nn.Conv2d(width, width, (filter_widths[i], 1), dilation=(next_dilation, 1), bias=False)
+                conv = nn.Conv2d(width, width, (filter_widths[i], 1) if not dense else (2 * self.pad[-1] + 1, 1),
+                                 dilation=(next_dilation, 1) if not dense else (1, 1), bias=False)
             layers_conv.append(conv)
             layers_bn.append(nn.BatchNorm2d(width, momentum=0.1))
             layers_conv.append(nn.Conv2d(width, width, 1, dilation=1, bias=False))
@@ -254,7 +260,7 @@ class SpatioTemporalModelBase(nn.Module):
         self.layers_graph_conv = nn.ModuleList(layers_graph_conv)
         if channels % 4 != 0:
             raise ValueError('channels must be a multiple of 4 (4 attention heads, reference gast_net.py:16)')
-        spec = ModelSpec(adj, filter_widths, channels, causal, strided, self.in_features)
+        spec = ModelSpec(adj, filter_widths, channels, causal, strided, self.in_features, dense=dense)
         # kept out of nn.Module's registries (no parameters / buffers of its own -> state_dict is untouched)
         object.__setattr__(self, '_runner', _Runner(spec, dropout))
 
@@ -318,11 +324,9 @@ class SpatioTemporalModel(SpatioTemporalModelBase):
         dense -- use regular dense convolutions instead of dilated convolutions (ablation experiment)
         """
         super().__init__(adj, num_joints_in, in_features, num_joints_out, filter_widths, causal, dropout, channels)
-        if dense:
-            raise NotImplementedError('dense=True (ablation, reference gast_net.py:145-146) is not on the accelerated path yet')
         self.expand_conv = nn.Conv2d(in_features, channels, (filter_widths[0], 1), bias=False)
         nn.init.kaiming_normal_(self.expand_conv.weight)
-        self._finish_init(adj, filter_widths, causal, dropout, channels, strided=False)
+        self._finish_init(adj, filter_widths, causal, dropout, channels, strided=False, dense=dense)
 
 
 class SpatioTemporalModelOptimized1f(SpatioTemporalModelBase):

@@ -198,8 +198,9 @@ def graph_attention_block(P, prefix, x, adj, training, p_drop, rng):
 
 
 class OracleModel:
-    """Restatement of SpatioTemporalModel (`variant='dilated'`, gast_net.py:107-177) and
-    SpatioTemporalModelOptimized1f (`variant='strided'`, gast_net.py:180-251)."""
+    """Restatement of SpatioTemporalModel (`variant='dilated'`, gast_net.py:107-177; `variant='dense'`: its `dense=True`
+    ablation, :145-146 -- temporal kernels of width 2*pad+1 with dilation 1) and SpatioTemporalModelOptimized1f
+    (`variant='strided'`, gast_net.py:180-251)."""
 
     def __init__(self, adj, filter_widths, channels, causal=False, dropout=0.0, variant='dilated', dtype=np.float64):
         for fw in filter_widths:
@@ -218,7 +219,7 @@ class OracleModel:
         self.dil = [1]
         for i in range(1, len(self.fw)):
             self.pad.append((self.fw[i] - 1) * nd // 2)
-            if variant == 'dilated':
+            if variant != 'strided':
                 self.causal_shift.append((self.fw[i] // 2 * nd) if causal else 0)
             else:
                 self.causal_shift.append((self.fw[i] // 2) if causal else 0)
@@ -252,7 +253,8 @@ class OracleModel:
             else:
                 pad, shift = self.pad[i + 1], self.causal_shift[i + 1]
                 res = ag.getitem(h, (slice(None), slice(None), slice(pad + shift, h.shape[2] - pad + shift)))  # :170
-                c = ag.conv2d_k1(h, P.p('layers_conv.%d.weight' % (2 * i)), dilation=self.dil[i + 1])  # :173
+                dilation = 1 if self.variant == 'dense' else self.dil[i + 1]                   # :145-146
+                c = ag.conv2d_k1(h, P.p('layers_conv.%d.weight' % (2 * i)), dilation=dilation)  # :173
             c = ag.relu(_bn(P, 'layers_bn.%d' % (2 * i), c, training))
             c = ag.conv2d_k1(c, P.p('layers_conv.%d.weight' % (2 * i + 1)))                # :174
             c = _dropout(ag.relu(_bn(P, 'layers_bn.%d' % (2 * i + 1), c, training)), p_drop, rng)

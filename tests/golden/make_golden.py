@@ -49,6 +49,9 @@ CONFIGS = [
     ('j16_a33_c16_str', 16, (3, 3), 16, False, 'strided', 4, 9),
     ('j17_a53_c16_dil', 17, (5, 3), 16, False, 'dilated', 2, 17),
     ('j17_a3333_c8_dil', 17, (3, 3, 3, 3), 8, False, 'dilated', 2, 83),
+    # variant 'dense' = SpatioTemporalModel(dense=True), the ablation of gast_net.py:145-146 (temporal kernels 7 and 19 wide)
+    ('j17_a333_c16_dense', 17, (3, 3, 3), 16, False, 'dense', 3, 29),
+    ('j19_a33_c32_dense_causal', 19, (3, 3), 32, True, 'dense', 2, 12),
 ]
 
 
@@ -89,14 +92,22 @@ def perturb(model, gen):
 def main():
     gast_net, Skeleton, adj_mx_from_skeleton, mpjpe = import_reference()
     torch.set_num_threads(4)
+    only = set(sys.argv[1:])          # optional: regenerate only these fixtures (the others keep their files and index entries)
+    old_index = json.load(open(os.path.join(HERE, 'index.json'))) if only else {}
     index = {}
     for (name, J, arc, ch, causal, variant, B, T) in CONFIGS:
         torch.manual_seed(1000 + len(index))
         gen = torch.Generator().manual_seed(4321 + len(index))
         skel = Skeleton(parents=list(PARENTS[J]), joints_left=[], joints_right=[])
         adj = adj_mx_from_skeleton(skel)
-        cls = gast_net.SpatioTemporalModel if variant == 'dilated' else gast_net.SpatioTemporalModelOptimized1f
-        model = cls(adj, J, 2, J, filter_widths=list(arc), causal=causal, dropout=0.0, channels=ch)
+        if only and name not in only:
+            index[name] = old_index[name]          # keeps the position-dependent seeds of the later entries
+            continue
+        if variant == 'strided':
+            model = gast_net.SpatioTemporalModelOptimized1f(adj, J, 2, J, filter_widths=list(arc), causal=causal, dropout=0.0, channels=ch)
+        else:
+            model = gast_net.SpatioTemporalModel(adj, J, 2, J, filter_widths=list(arc), causal=causal, dropout=0.0, channels=ch,
+                                                 dense=(variant == 'dense'))
         perturb(model, gen)
         x = torch.rand(B, T, J, 2, generator=gen) * 2 - 1
 
@@ -131,7 +142,7 @@ def main():
 
     # known-answer numbers the reference prints/relies on: parameter counts of the shipped shapes
     counts = {}
-    for J in (17, 19, 15):
+    for J in (() if only else (17, 19, 15)):
         skel = Skeleton(parents=list(PARENTS[J]), joints_left=[], joints_right=[])
         adj = adj_mx_from_skeleton(skel)
         m = gast_net.SpatioTemporalModel(adj, J, 2, J, filter_widths=[3, 3, 3], channels=128)
@@ -142,7 +153,7 @@ def main():
                 json.dump(keys, f, indent=0)
             # adjacency known answer
             np.save(os.path.join(HERE, 'adj_j17.npy'), adj.numpy())
-    index['_param_counts'] = counts
+    index['_param_counts'] = old_index.get('_param_counts', counts) if only else counts
     with open(os.path.join(HERE, 'index.json'), 'w') as f:
         json.dump(index, f, indent=1)
     print(counts)

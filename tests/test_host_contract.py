@@ -133,3 +133,12 @@ def test_binding_argument_counts_match_header():
         fn = getattr(lib, name)
         assert fn.argtypes is not None, name
         assert len(fn.argtypes) == n, (name, len(fn.argtypes), n)
+
+
+def test_segment_limit_is_the_same_everywhere():
+    """The engine chunks K segments (dense=True taps) by MAX_SEG: it must equal the ABI's GAST_MAX_SEG and the binding's array size."""
+    import re
+    from gast_hip import engine, binding
+    hdr = open(os.path.join(ROOT, 'include', 'gast_hip.h')).read()
+    n = int(re.search(r'#define\s+GAST_MAX_SEG\s+(\d+)', hdr).group(1))
+    assert engine.MAX_SEG == binding.MAX_SEG == n

@@ -43,8 +43,11 @@ def build(cfg, dropout=0.0):
     from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
     from oracle.gast_oracle import adj_from_parents
     adj = torch.from_numpy(adj_from_parents(cfg['parents']))
-    cls = SpatioTemporalModel if cfg['variant'] == 'dilated' else SpatioTemporalModelOptimized1f
-    return cls(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'], dropout=dropout, channels=cfg['channels'])
+    if cfg['variant'] == 'strided':
+        return SpatioTemporalModelOptimized1f(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'],
+                                              dropout=dropout, channels=cfg['channels'])
+    return SpatioTemporalModel(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'], dropout=dropout,
+                               channels=cfg['channels'], dense=cfg.get('variant') == 'dense')
 
 
 @pytest.fixture(params=['fp32', 'bf16'])
@@ -185,7 +188,7 @@ def test_full_size_properties(mode):
 
 @pytest.mark.parametrize('J,arc,ch,B,variant', [(17, (3, 3, 3), 128, 128, 'dilated'), (17, (3, 3, 3), 128, 128, 'strided'),
                                                 (17, (3, 3, 3, 3), 64, 32, 'dilated'), (19, (3, 3, 3), 128, 64, 'dilated'),
-                                                (15, (3, 3, 3), 128, 32, 'dilated')])
+                                                (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense')])
 def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, monkeypatch):
     """VALUES at the BASELINE.json sizes (configs[1]: B=128, T=27, J=17, C=128; and the shapes of configs[2..4]): the HIP path
     in fp32 against the oracle restatement running on stock PyTorch-ROCm operators on the same GPU (oracle/torch_ops.py, pinned

@@ -15,9 +15,11 @@ def build(cfg, dropout=0.0):
     from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
     from oracle.gast_oracle import adj_from_parents
     adj = torch.from_numpy(adj_from_parents(cfg['parents']))
-    cls = SpatioTemporalModel if cfg['variant'] == 'dilated' else SpatioTemporalModelOptimized1f
-    m = cls(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'], dropout=dropout, channels=cfg['channels'])
-    return m
+    if cfg['variant'] == 'strided':
+        return SpatioTemporalModelOptimized1f(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'],
+                                              dropout=dropout, channels=cfg['channels'])
+    return SpatioTemporalModel(adj, cfg['J'], 2, cfg['J'], filter_widths=cfg['arc'], causal=cfg['causal'], dropout=dropout,
+                               channels=cfg['channels'], dense=cfg.get('variant') == 'dense')
 
 
 @pytest.mark.parametrize('centered', ['0', '1'])
