@@ -48,3 +48,12 @@ def test_kernel_timer_cost_models_cover_the_engine_calls(monkeypatch):
                  'bn_finalize_multi', 'expand_bwd'):
         assert name in agg and agg[name]['launches'] > 0, name
     assert agg['gemm']['bytes'] > 0 and agg['gemm_multi']['flops'] > 0 and agg['wgrad_multi']['bytes'] > 0
+
+
+def test_stock_operator_baseline_leg_runs_on_cpu():
+    """bench.py's cpu_baseline / --stock-baseline legs (the oracle restatement on stock PyTorch operators): one tiny training step
+    on CPU, so that a signature drift in oracle/ cannot break the default `python bench.py` on the GPU box."""
+    sys.path.insert(0, ROOT)
+    import bench
+    n, dt = bench._stock_steps('cpu', False, 4, 0.0, 1, warm_B=2)
+    assert n == 1 and dt > 0
