@@ -878,6 +878,266 @@ __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict_
     }
 }
 
+// ------------------------------------------------------------------------------------------------ bf16 attention on MFMA
+// Same decomposition (one (frame, head) unit per wave, no block barriers), but the three J x J x Ci products run on
+// v_mfma_f32_32x32x16_bf16 with J padded to 32:
+//   forward   y[i][c]   = sum_j att[i][j] g[j][c]       A = att   (rows i, k = j)   B = g^T  (cols c, k = j)
+//   backward  datt[i][j] = sum_c dy[i][c] g[j][c]       A = dy    (rows i, k = c)   B = g    (cols j, k = c)   straight from global
+//             dg[j][c]   = sum_i att[i][j] dy[i][c]     A = att^T (rows j, k = i)   B = dy^T (cols c, k = i)
+// The row tiles of g / dy are loaded in MFMA-fragment shape (lane = (row, 8-channel half of a 16-channel step)) and the
+// operands whose reduction index is the joint are written transposed to LDS with 2-byte stores; the padding rows / columns of
+// the LDS tiles are zeroed once and never written.  The VALU versions above spend ~340 (forward) / ~900 (backward) FMA-class
+// instructions per lane and unit on these products; att is rounded to bf16 here (the operands of the other two already are).
+template <int CI> struct AttnM {
+    static constexpr int KS = CI / 16, NT = CI / 32;
+    static constexpr int T_BYTES = CI * 64;                                              // transposed operand tile [CI][32] bf16
+    static constexpr int FWD_BYTES = T_BYTES + 32 * 64 + 128;                             // g^T | att [32][32] | c_j
+    static constexpr int BWD_BYTES = T_BYTES + 32 * 64 + 3 * JMAX * JP * 4 + 128;         // dy^T | att^T | p | slope/ds | datt | c_j
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
+    union { uint4 u; s16x8 s; } ua, ub;
+    ua.u = a; ub.u = b;
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.s, ub.s, c, 0, 0, 0);
+}
+// 8 bf16 of a fragment register -> column `col` of rows c0 .. c0+7 of a [*][32] bf16 tile
+__device__ __forceinline__ void scatter8_bf16(bf16_t* __restrict__ tile, int c0, int col, const uint4& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        tile[(c0 + 2 * e) * 32 + col] = (bf16_t)(w[e] & 0xffffu);
+        tile[(c0 + 2 * e + 1) * 32 + col] = (bf16_t)(w[e] >> 16);
+    }
+}
+
+template <int CI>
+__global__ void __launch_bounds__(256) attn_fwd_mfma_kernel(const bf16_t* __restrict__ G, int ldg, const bf16_t* __restrict__ AC, int ldac,
+                                                            const float* __restrict__ Ck, int F, int J, int nheads,
+                                                            bf16_t* __restrict__ Y, int ldy) {
+    using M = AttnM<CI>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned char* base = smemb + w * M::FWD_BYTES;
+    bf16_t* sgT = (bf16_t*)base;                       // [CI][32]: g^T, columns j >= J stay zero
+    bf16_t* satb = (bf16_t*)(base + M::T_BYTES);       // [32][32]: att[i][j], rows / columns >= J stay zero
+    float* sc = (float*)(base + M::T_BYTES + 2048);
+    for (int t = lane; t < (M::T_BYTES + 2048) / 16; t += 64) ((uint4*)base)[t] = make_uint4(0u, 0u, 0u, 0u);
+    const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+    const int h = gw % nheads;
+    float ckrow[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) ckrow[j] = (lane < J && j < J) ? Ck[((long)h * J + lane) * J + j] : 0.f;
+    const int jr = li < J ? li : J - 1;                // source row of this lane's fragments (clamped: rows >= J are never used)
+    wave_lds_sync();
+    for (int u = gw; u < F * nheads; u += nw) {
+        const int f = u / nheads;
+        float a_i = 0.f;
+        if (lane < J) {
+            const bf16_t* acp = AC + ((long)f * J + lane) * ldac;
+            a_i = bf2f(acp[h]);
+            sc[lane] = bf2f(acp[nheads + h]);
+        }
+        uint4 gfr[M::KS];
+#pragma unroll
+        for (int ks = 0; ks < M::KS; ++ks) gfr[ks] = *(const uint4*)(G + ((long)f * J + jr) * ldg + h * CI + ks * 16 + lh * 8);
+        if (li < J) {
+#pragma unroll
+            for (int ks = 0; ks < M::KS; ++ks) scatter8_bf16(sgT, ks * 16 + lh * 8, li, gfr[ks]);
+        }
+        wave_lds_sync();
+        if (lane < J) {        // att row i = lane (same arithmetic as attn_row)
+            float mx = -3.0e38f;
+            for (int j = 0; j < J; ++j) {
+                float sv = a_i + sc[j];
+                sv = sv > 0.f ? sv : 0.2f * sv;
+                mx = fmaxf(mx, sv);
+            }
+            float ex[JMAX];
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                ex[j] = 0.f;
+                if (j < J) {
+                    const float sv = a_i + sc[j];
+                    const float sl = sv > 0.f ? 1.f : 0.2f;
+                    ex[j] = expf(sv * sl - mx);
+                    sum += ex[j];
+                }
+            }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j)
+                if (j < J) satb[lane * 32 + j] = f2bf(ex[j] * inv + ckrow[j]);
+        }
+        wave_lds_sync();
+#pragma unroll
+        for (int nt = 0; nt < M::NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+                acc = mfma_bf16(*(const uint4*)(satb + li * 32 + k2 * 16 + lh * 8), *(const uint4*)(sgT + (nt * 32 + li) * 32 + k2 * 16 + lh * 8), acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (i < J) Y[((long)f * J + i) * ldy + h * CI + nt * 32 + li] = f2bf(acc[r]);
+            }
+        }
+        wave_lds_sync();
+    }
+}
+
+template <int CI>
+__global__ void __launch_bounds__(256) attn_bwd_mfma_kernel(const bf16_t* __restrict__ dY, int lddy, const bf16_t* __restrict__ G, int ldg,
+                                                            const bf16_t* __restrict__ AC, int ldac, const float* __restrict__ Ck,
+                                                            int F, int J, int nheads, bf16_t* __restrict__ dG, int lddg,
+                                                            bf16_t* __restrict__ dAC, int lddac, float* __restrict__ ws, int ncol) {
+    using M = AttnM<CI>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemb[];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+    unsigned char* base = smemb + w * M::BWD_BYTES;
+    bf16_t* sdyT = (bf16_t*)base;                         // [CI][32]: dy^T, columns i >= J stay zero
+    bf16_t* sattT = (bf16_t*)(base + M::T_BYTES);         // [32][32]: att^T[j][i], rows / columns >= J stay zero
+    float (*sp)[JP] = (float (*)[JP])(base + M::T_BYTES + 2048);
+    float (*sds)[JP] = sp + JMAX;                         // LeakyReLU slopes, then ds
+    float (*sdat)[JP] = sds + JMAX;
+    float* sc = (float*)(sdat + JMAX);
+    for (int t = lane; t < (M::T_BYTES + 2048) / 16; t += 64) ((uint4*)base)[t] = make_uint4(0u, 0u, 0u, 0u);
+    const int gw = blockIdx.x * 4 + w, nw = gridDim.x * 4;
+    const int h = gw % nheads;
+    const int C = nheads * CI;
+    float ckrow[JMAX];
+#pragma unroll
+    for (int j = 0; j < JMAX; ++j) ckrow[j] = (lane < J && j < J) ? Ck[((long)h * J + lane) * J + j] : 0.f;
+    const int jr = li < J ? li : J - 1;
+    f32x16 ckacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ckacc[r] = 0.f;
+    float gsum[M::NT];
+#pragma unroll
+    for (int nt = 0; nt < M::NT; ++nt) gsum[nt] = 0.f;
+    float da_sum = 0.f, dc_sum = 0.f;
+    wave_lds_sync();
+    for (int u = gw; u < F * nheads; u += nw) {
+        const int f = u / nheads;
+        float a_i = 0.f;
+        if (lane < J) {
+            const bf16_t* acp = AC + ((long)f * J + lane) * ldac;
+            a_i = bf2f(acp[h]);
+            sc[lane] = bf2f(acp[nheads + h]);
+        }
+        uint4 dfr[M::KS], gfr[M::KS];
+#pragma unroll
+        for (int ks = 0; ks < M::KS; ++ks) {
+            dfr[ks] = *(const uint4*)(dY + ((long)f * J + jr) * lddy + h * CI + ks * 16 + lh * 8);
+            gfr[ks] = *(const uint4*)(G + ((long)f * J + jr) * ldg + h * CI + ks * 16 + lh * 8);
+        }
+        if (li < J) {
+#pragma unroll
+            for (int ks = 0; ks < M::KS; ++ks) scatter8_bf16(sdyT, ks * 16 + lh * 8, li, dfr[ks]);
+        }
+        wave_lds_sync();
+        if (lane < J) {        // row i = lane: p, LeakyReLU slopes, att^T (same arithmetic as attn_row)
+            float mx = -3.0e38f;
+            for (int j = 0; j < J; ++j) {
+                float sv = a_i + sc[j];
+                sv = sv > 0.f ? sv : 0.2f * sv;
+                mx = fmaxf(mx, sv);
+            }
+            float ex[JMAX];
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                ex[j] = 0.f;
+                if (j < J) {
+                    const float sv = a_i + sc[j];
+                    const float sl = sv > 0.f ? 1.f : 0.2f;
+                    ex[j] = expf(sv * sl - mx);
+                    sds[lane][j] = sl;
+                    sum += ex[j];
+                }
+            }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int j = 0; j < JMAX; ++j) {
+                if (j < J) {
+                    const float pv = ex[j] * inv;
+                    sp[lane][j] = pv;
+                    sattT[j * 32 + lane] = f2bf(pv + ckrow[j]);
+                }
+            }
+        }
+        // datt[i][j] = sum_c dy[i][c] g[j][c]: fragments straight from the registers
+        f32x16 d;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < M::KS; ++ks) d = mfma_bf16(dfr[ks], gfr[ks], d);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            ckacc[r] += d[r];                         // (entries with i or j >= J hold finite junk that is never written out)
+            const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (i < J && li < J) sdat[i][li] = d[r];
+        }
+        wave_lds_sync();
+        // softmax + LeakyReLU backward, row i = lane
+        if (lane < J) {
+            float dot = 0.f;
+            for (int j = 0; j < J; ++j) dot = fmaf(sp[lane][j], sdat[lane][j], dot);
+            float da = 0.f;
+            for (int j = 0; j < J; ++j) {
+                const float ds = sp[lane][j] * (sdat[lane][j] - dot) * sds[lane][j];
+                sds[lane][j] = ds;
+                da += ds;
+            }
+            dAC[((long)f * J + lane) * lddac + h] = f2bf(da);
+            da_sum += da;
+        }
+        wave_lds_sync();
+        if (lane < J) {
+            float dc = 0.f;
+            for (int i = 0; i < J; ++i) dc += sds[i][lane];
+            dAC[((long)f * J + lane) * lddac + nheads + h] = f2bf(dc);
+            dc_sum += dc;
+        }
+        // dg[j][c] = sum_i att[i][j] dy[i][c]
+#pragma unroll
+        for (int nt = 0; nt < M::NT; ++nt) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)
+                acc = mfma_bf16(*(const uint4*)(sattT + li * 32 + k2 * 16 + lh * 8), *(const uint4*)(sdyT + (nt * 32 + li) * 32 + k2 * 16 + lh * 8), acc);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (j < J) {
+                    dG[((long)f * J + j) * lddg + h * CI + nt * 32 + li] = f2bf(acc[r]);
+                    gsum[nt] += acc[r];
+                }
+            }
+        }
+        wave_lds_sync();
+    }
+    // per-wave partial row (layout of attn_bwd_wave_kernel): [g bias sums (C) | da sums | dc sums | dC_k (nheads*J*J)]
+    float* row = ws + (long)(gw / nheads) * ncol;
+#pragma unroll
+    for (int nt = 0; nt < M::NT; ++nt) {
+        const float t = gsum[nt] + __shfl_xor(gsum[nt], 32);
+        if (lh == 0) row[h * CI + nt * 32 + li] = t;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { da_sum += __shfl_xor(da_sum, off); dc_sum += __shfl_xor(dc_sum, off); }
+    if (lane == 0) { row[C + h] = da_sum; row[C + nheads + h] = dc_sum; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (i < J && li < J) row[C + 2 * nheads + h * J * J + i * J + li] = ckacc[r];
+    }
+}
+
 // dbias[n] += sum_r ws[r][n] (n < nb);  dCk[n - nb] += sum_r ws[r][n] (n >= nb)      (256 threads = 32 columns x 8 row lanes)
 __global__ void __launch_bounds__(256) attn_bwd_finish_kernel(const float* __restrict__ ws, int nrow, int ncol, int nb,
                                                               float* __restrict__ dbias, float* __restrict__ dCk) {
@@ -1096,9 +1356,29 @@ static int attn_wave_grid(int F, int nheads) {
     return g < 1 ? 1 : (int)g;
 }
 
+// bf16 + 16-byte aligned row tiles: the MFMA kernels (GAST_ATTN_MFMA=0 keeps the VALU wave kernels)
+static bool attn_mfma_ok(int ld_a, const void* a, int ld_b, const void* b) {
+    static const bool on = getenv("GAST_ATTN_MFMA") ? atoi(getenv("GAST_ATTN_MFMA")) != 0 : true;
+    return on && ld_a % 8 == 0 && ld_b % 8 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
+}
+
 template <typename T, int CI4>
 static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J, int nheads, void* Y,
                                 int ldy, hipStream_t st) {
+    if constexpr (sizeof(T) == 2) {
+        if (attn_mfma_ok(ldg, G, ldg, G)) {
+            constexpr int CI = CI4 * 4;
+            const size_t smem = (size_t)4 * AttnM<CI>::FWD_BYTES;
+            if (smem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_mfma_kernel<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL((attn_fwd_mfma_kernel<CI>), dim3(attn_wave_grid(F, nheads)), dim3(256), smem, st, (const bf16_t*)G, ldg,
+                               (const bf16_t*)AC, ldac, C_k, F, J, nheads, (bf16_t*)Y, ldy);
+            GAST_CHECK_LAUNCH();
+            return 0;
+        }
+    }
     const size_t smem = (size_t)4 * AttnW<CI4>::FWD_FLOATS * sizeof(float);
     if (smem > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -1114,16 +1394,32 @@ template <typename T, int CI4>
 static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                 int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
                                 hipStream_t st) {
-    const size_t smem = (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float);
-    if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
     const int grid = attn_wave_grid(F, nheads);
     const int C = nheads * CI4 * 4;
     const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;
-    hipLaunchKernelGGL((attn_bwd_wave_kernel<T, CI4>), dim3(grid), dim3(256), smem, st, (const T*)dY, lddy, (const T*)G, ldg, (const T*)AC,
-                       ldac, C_k, F, J, nheads, (T*)dG, lddg, (T*)dAC, lddac, ws, ncol);
+    bool mfma = false;
+    // (32-channel heads: the transposed staging costs more than the two 2-step products save -- 63 vs 48 us at B=128)
+    if constexpr (sizeof(T) == 2) mfma = CI4 * 4 >= 64 && attn_mfma_ok(lddy, dY, ldg, G);
+    if (mfma) {
+        if constexpr (sizeof(T) == 2) {
+            constexpr int CI = CI4 * 4;
+            const size_t smem = (size_t)4 * AttnM<CI>::BWD_BYTES;
+            if (smem > 48 * 1024) {
+                hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_mfma_kernel<CI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+                if (e != hipSuccess) return (int)e;
+            }
+            hipLaunchKernelGGL((attn_bwd_mfma_kernel<CI>), dim3(grid), dim3(256), smem, st, (const bf16_t*)dY, lddy, (const bf16_t*)G, ldg,
+                               (const bf16_t*)AC, ldac, C_k, F, J, nheads, (bf16_t*)dG, lddg, (bf16_t*)dAC, lddac, ws, ncol);
+        }
+    } else {
+        const size_t smem = (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float);
+        if (smem > 48 * 1024) {
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((attn_bwd_wave_kernel<T, CI4>), dim3(grid), dim3(256), smem, st, (const T*)dY, lddy, (const T*)G, ldg, (const T*)AC,
+                           ldac, C_k, F, J, nheads, (T*)dG, lddg, (T*)dAC, lddac, ws, ncol);
+    }
     GAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3((ncol + 31) / 32), dim3(256), 0, st, ws, grid * 4 / nheads, ncol, nb, dbias, dC_k);
     GAST_CHECK_LAUNCH();

@@ -257,18 +257,23 @@ def test_wgrad_multi(ops, dt):
         close(host(jd['dW']), jh['dW'], dt, 'multi ' + WGRAD_CASES[i][0], fp32=3e-5, bf16=2e-2)
 
 
-@pytest.mark.parametrize('knob', ['GAST_WGRAD_TILE=256', 'GAST_WGRAD_RING=2', 'GAST_WGRAD_ORDER=1'])
-def test_wgrad_multi_optin_variants(knob):
-    """The opt-in weight-gradient kernels / block orders (read once per process by the library): 256x256 tiles, two register
-    sets in flight, chunk-major order -- the same multi-job parity cases in a child process."""
+@pytest.mark.parametrize('knob,select,npass', [('GAST_WGRAD_TILE=256', 'test_wgrad_multi and bf16', 1),
+                                               ('GAST_WGRAD_RING=2', 'test_wgrad_multi and bf16', 1),
+                                               ('GAST_WGRAD_ORDER=1', 'test_wgrad_multi and bf16', 1),
+                                               ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
+def test_optin_kernel_variants(knob, select, npass):
+    """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles, two
+    register sets in flight, chunk-major block order, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
+    in a child process."""
     import os
     import subprocess
     import sys
     k, v = knob.split('=')
     env = dict(os.environ, **{k: v})
     r = subprocess.run([sys.executable, '-m', 'pytest', os.path.abspath(__file__), '-q', '-x', '-m', 'gpu', '-p', 'no:cacheprovider',
-                        '-k', 'test_wgrad_multi and bf16 and not optin'], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0 and '1 passed' in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+                        '-k', '(%s) and not optin' % select], env=env, capture_output=True, text=True, timeout=600)
+    ok = r.returncode == 0 and (' passed' in r.stdout) and ('%d passed' % npass in r.stdout if npass else True)
+    assert ok, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 # ------------------------------------------------------------------------------------------------ SemCH
