@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
 // issued back to back (the CSR version exposes one scalar-load + one vector-load latency per edge).
 template <typename T, int D>
 __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, T* __restrict__ Yf, int ldy, int J, int C,
-                                             const float* __restrict__ A, const int32_t* __restrict__ ell_j,
+                                             const float* __restrict__ A, int lda, int acol, const int32_t* __restrict__ ell_j,
                                              const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2,
                                              float4 ctr, int i0, int istep) {
     for (int i = i0; i < J; i += istep) {
@@ -172,7 +172,7 @@ __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, 
         float4 av[D], hv[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            av[d] = *(const float4*)(A + (long)kk[d] * C + (h0c % C));
+            av[d] = *(const float4*)(A + kk[d] * lda + acol);
             hv[d] = ld4(Hf + (long)jj[d] * ldh + (jj[d] == i ? h0c : h1c));
         }
         float4 acc = make_float4(0, 0, 0, 0);
@@ -186,53 +186,66 @@ __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, 
     }
 }
 
+// Block = (frame block fb, chunk of CC <= 64 channels): the softmax coefficients of the chunk ([nnz + 1][CC] fp32 per pattern)
+// are staged in LDS once per block -- read from global per (frame, joint, slot) they were 2/3 of the kernel's L2 traffic
+// (136 padded slots x C x 4 bytes per frame against 136 x C x 2 bytes of features).  Thread = (frame slot, 4 channels).
 template <typename T, int DS, int DC>
 __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restrict__ H, int ldh, int F, int J, int C,
                                                                 const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
                                                                 T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB,
-                                                                const float* __restrict__ ctr_s, const float* __restrict__ ctr_c) {
+                                                                const float* __restrict__ ctr_s, const float* __restrict__ ctr_c,
+                                                                int nchunk, int CC) {
+    extern __shared__ __attribute__((aligned(16))) float sAgg[];      // [nnz_s + 1][CC] | [nnz_c + 1][CC]
     __shared__ float sred[256][8];
     const int tid = threadIdx.x;
     const int slot = tid / TPF, ct = tid - slot * TPF;
-    const int C4 = C >> 2;
-    const bool active = slot < FB;
+    const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk, nfb = gridDim.x / nchunk;
     const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
-    for (int cg0 = 0; cg0 < C4; cg0 += TPF) {
-        const int cg = cg0 + ct;
-        const bool cin = active && cg < C4;
-        const int c = cg * 4;
-        float4 s1[2], s2[2];
-        s1[0] = s1[1] = s2[0] = s2[1] = make_float4(0, 0, 0, 0);
-        if (cin) {
-            for (int f = blockIdx.x * FB + slot; f < F; f += gridDim.x * FB) {
-                const T* Hf = H + (long)f * J * ldh;
-                T* Yf = Y + (long)f * J * ldy;
-                const float4 z4 = make_float4(0, 0, 0, 0);
-                // gridDim.y = joint split (few frames: the rows i = blockIdx.y, blockIdx.y + gridDim.y, ... of every frame)
-                agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, A_sym, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0],
-                                    ctr_s ? *(const float4*)(ctr_s + c) : z4, blockIdx.y, gridDim.y);
-                agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, A_con, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1],
-                                    ctr_c ? *(const float4*)(ctr_c + c) : z4, blockIdx.y, gridDim.y);
-            }
+    float* sAs = sAgg;
+    float* sAc = sAgg + (ps.nnz + 1) * CC;
+    const int CC4 = CC >> 2;
+    for (int t = tid; t < (ps.nnz + 1) * CC4; t += 256) {
+        const int k = t / CC4, q = t - k * CC4;
+        *(float4*)(sAs + k * CC + q * 4) = *(const float4*)(A_sym + (long)k * C + ch * CC + q * 4);
+    }
+    for (int t = tid; t < (pc.nnz + 1) * CC4; t += 256) {
+        const int k = t / CC4, q = t - k * CC4;
+        *(float4*)(sAc + k * CC + q * 4) = *(const float4*)(A_con + (long)k * C + ch * CC + q * 4);
+    }
+    __syncthreads();
+    const int cl = ct * 4, c = ch * CC + cl;
+    const bool cin = slot < FB && cl < CC && c < C;
+    float4 s1[2], s2[2];
+    s1[0] = s1[1] = s2[0] = s2[1] = make_float4(0, 0, 0, 0);
+    if (cin) {
+        for (int f = fb * FB + slot; f < F; f += nfb * FB) {
+            const T* Hf = H + (long)f * J * ldh;
+            T* Yf = Y + (long)f * J * ldy;
+            const float4 z4 = make_float4(0, 0, 0, 0);
+            // gridDim.y = joint split (few frames: the rows i = blockIdx.y, blockIdx.y + gridDim.y, ... of every frame)
+            agg_rows_ell<T, DS>(Hf, ldh, Yf, ldy, J, C, sAs, CC, cl, ps.ell_rj, ps.ell_rk, c, C + c, c, s1[0], s2[0],
+                                ctr_s ? *(const float4*)(ctr_s + c) : z4, blockIdx.y, gridDim.y);
+            agg_rows_ell<T, DC>(Hf, ldh, Yf, ldy, J, C, sAc, CC, cl, pc.ell_rj, pc.ell_rk, 2 * C + c, 3 * C + c, C + c, s1[1], s2[1],
+                                ctr_c ? *(const float4*)(ctr_c + c) : z4, blockIdx.y, gridDim.y);
         }
+    }
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            __syncthreads();
-            sred[tid][0] = s1[g].x; sred[tid][1] = s1[g].y; sred[tid][2] = s1[g].z; sred[tid][3] = s1[g].w;
-            sred[tid][4] = s2[g].x; sred[tid][5] = s2[g].y; sred[tid][6] = s2[g].z; sred[tid][7] = s2[g].w;
-            __syncthreads();
-            if (slot == 0 && cg < C4) {
-                float t[8];
+    for (int g = 0; g < 2; ++g) {
+        __syncthreads();
+        sred[tid][0] = s1[g].x; sred[tid][1] = s1[g].y; sred[tid][2] = s1[g].z; sred[tid][3] = s1[g].w;
+        sred[tid][4] = s2[g].x; sred[tid][5] = s2[g].y; sred[tid][6] = s2[g].z; sred[tid][7] = s2[g].w;
+        __syncthreads();
+        if (slot == 0 && cl < CC && c < C) {
+            float t[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) t[q] = 0.f;
-                for (int sl = 0; sl < FB; ++sl)
+            for (int q = 0; q < 8; ++q) t[q] = 0.f;
+            for (int sl = 0; sl < FB; ++sl)
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
-                float* pp = partials + (((long)blockIdx.y * gridDim.x + blockIdx.x) * 2 * C + g * C + c) * 2;
+                for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
+            float* pp = partials + (((long)blockIdx.y * nfb + fb) * 2 * C + g * C + c) * 2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
-            }
+            for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
         }
     }
 }
@@ -240,8 +253,8 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
 // backward, fixed-degree column view: for column j the slots (i, k) give dh0 / dh1
 template <typename T, int D>
 __device__ __forceinline__ void agg_cols_ell(const T* __restrict__ dYf, int ldy, T* __restrict__ dHf, int lddh, int J, int C,
-                                             const float* __restrict__ A, const int32_t* __restrict__ ell_i,
-                                             const int32_t* __restrict__ ell_k, int c, int h0c, int h1c, int yc, int j0, int jstep) {
+                                             const float* __restrict__ A, int lda, int acol, const int32_t* __restrict__ ell_i,
+                                             const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, int j0, int jstep) {
     for (int j = j0; j < J; j += jstep) {
         int ii[D], kk[D];
 #pragma unroll
@@ -249,7 +262,7 @@ __device__ __forceinline__ void agg_cols_ell(const T* __restrict__ dYf, int ldy,
         float4 av[D], dv[D];
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            av[d] = *(const float4*)(A + (long)kk[d] * C + c);
+            av[d] = *(const float4*)(A + kk[d] * lda + acol);
             dv[d] = ld4(dYf + (long)ii[d] * ldy + yc);
         }
         float4 d0 = make_float4(0, 0, 0, 0), d1 = make_float4(0, 0, 0, 0);
@@ -276,11 +289,23 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
     // of phase A and the edges of phase B are dealt to gridDim.y blocks)
     const int jpart = blockIdx.y, jsplit = gridDim.y;
     __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
+    extern __shared__ __attribute__((aligned(16))) float sAgg[];     // coefficient slices [nnz_s + 1][CC] | [nnz_c + 1][CC] (as forward)
     const int tid = threadIdx.x;
     const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
     const int slot = tid / TPF, ct = tid - slot * TPF;
     const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
     const int nnz_s = ps.nnz, nnz_c = pc.nnz, nnz_t = nnz_s + nnz_c;
+    float* sAs = sAgg;
+    float* sAc = sAgg + (nnz_s + 1) * CC;
+    for (int t = tid; t < (nnz_s + 1) * (CC >> 2); t += 256) {
+        const int k = t / (CC >> 2), q = t - k * (CC >> 2);
+        *(float4*)(sAs + k * CC + q * 4) = *(const float4*)(A_sym + (long)k * C + ch * CC + q * 4);
+    }
+    for (int t = tid; t < (nnz_c + 1) * (CC >> 2); t += 256) {
+        const int k = t / (CC >> 2), q = t - k * (CC >> 2);
+        *(float4*)(sAc + k * CC + q * 4) = *(const float4*)(A_con + (long)k * C + ch * CC + q * 4);
+    }
+    __syncthreads();
     for (int t = tid; t < 2 * J; t += 256) {
         const Pat& p = t < J ? ps : pc;
         const int i = t < J ? t : t - J, base = t < J ? 0 : nnz_s;
@@ -292,8 +317,8 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
         for (int f = fb * FB + slot; f < F; f += nfb * FB) {
             const T* dYf = dY + (long)f * J * ldy;
             T* dHf = dH + (long)f * J * lddh;
-            agg_cols_ell<T, DS>(dYf, ldy, dHf, lddh, J, C, A_sym, ps.ell_ci, ps.ell_ck, c, c, C + c, c, jpart, jsplit);
-            agg_cols_ell<T, DC>(dYf, ldy, dHf, lddh, J, C, A_con, pc.ell_ci, pc.ell_ck, c, 2 * C + c, 3 * C + c, C + c, jpart, jsplit);
+            agg_cols_ell<T, DS>(dYf, ldy, dHf, lddh, J, C, sAs, CC, cl, ps.ell_ci, ps.ell_ck, c, C + c, c, jpart, jsplit);
+            agg_cols_ell<T, DC>(dYf, ldy, dHf, lddh, J, C, sAc, CC, cl, pc.ell_ci, pc.ell_ck, 2 * C + c, 3 * C + c, C + c, jpart, jsplit);
         }
     }
     __syncthreads();
@@ -1160,7 +1185,6 @@ __global__ void __launch_bounds__(256) attn_bwd_finish_kernel(const float* __res
     }
 }
 
-inline int agg_tpf(int C) { int c4 = C / 4; return c4 < 256 ? c4 : 256; }
 
 }  // namespace
 
@@ -1199,14 +1223,22 @@ extern "C" int gast_semch_adj_multi(const gast_adj_job* jobs, int n, int backwar
     return 0;
 }
 
+// forward aggregation: blocks of (FB frames) x (a chunk of CC <= 64 channels); TPF = CC / 4 threads per frame
+static int agg_fwd_cc(int C) { return C < 64 ? C : 64; }
+static int agg_fwd_tpf(int C) { return agg_fwd_cc(C) / 4; }
 static int agg_fwd_frame_blocks(int F, int C) {
-    int TPF = agg_tpf(C), FB = 256 / TPF;
-    int nb = (F + FB - 1) / FB;
-    return nb < 512 ? nb : 512;
+    const int CC = agg_fwd_cc(C), nchunk = (C + CC - 1) / CC;
+    int FB = 256 / agg_fwd_tpf(C);
+    int nb = (F + FB - 1) / FB, cap = 1024 / nchunk;
+    if (cap < 1) cap = 1;
+    return nb < cap ? nb : cap;
 }
 // few frames (the M = B*J stage): the rows of a frame are dealt to 4 blocks so that the launch covers the chip; the partial-sum
 // rows are then [joint part][frame block]
-static int agg_fwd_joint_split(int F, int C) { return agg_fwd_frame_blocks(F, C) <= 128 ? 4 : 1; }
+static int agg_fwd_joint_split(int F, int C) {
+    const int CC = agg_fwd_cc(C);
+    return agg_fwd_frame_blocks(F, C) * ((C + CC - 1) / CC) <= 128 ? 4 : 1;
+}
 extern "C" int gast_semch_agg_blocks(int F, int C) { return agg_fwd_frame_blocks(F, C) * agg_fwd_joint_split(F, C); }
 
 extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
@@ -1216,18 +1248,21 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || !partials) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
-    int TPF = agg_tpf(C), FB = 256 / TPF;
+    const int CC = agg_fwd_cc(C), nchunk = (C + CC - 1) / CC;
+    int TPF = agg_fwd_tpf(C), FB = 256 / TPF;
     const int nb = agg_fwd_frame_blocks(F, C), jsplit = agg_fwd_joint_split(F, C);
-    const dim3 grid_ell(nb, jsplit);
+    const dim3 grid_ell(nb * nchunk, jsplit);
+    // LDS for the coefficient slices: at most J * deg + 1 rows per pattern (the tables are padded to the fixed degree)
+    const size_t smem = (size_t)(J * deg_sym + 1 + J * deg_con + 1) * CC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
 #define AGG_FWD_ELL(DS, DC)                                                                                                  \
     do {                                                                                                                     \
         if (dtype == GAST_F32)                                                                                               \
-            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), grid_ell, dim3(256), 0, st, (const float*)H, ldh, F, J, C, \
-                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);   \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), grid_ell, dim3(256), smem, st, (const float*)H, ldh, F, J, C, \
+                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC); \
         else                                                                                                                 \
-            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), grid_ell, dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, \
-                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con); \
+            hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), grid_ell, dim3(256), smem, st, (const bf16_t*)H, ldh, F, J, \
+                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC); \
     } while (0)
     // the fixed-degree kernels walk exactly DS / DC padded slots per row: the pattern tables must have been built with
     // these degrees, which is the case for deg_sym == 2 (every supported skeleton) and deg_con in {5, 6}
@@ -1254,7 +1289,7 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
 struct AggBwdCfg { int CC, nchunk, TPF, FB, nfb; };
 static AggBwdCfg agg_bwd_cfg(int F, int C) {
     AggBwdCfg c;
-    c.CC = C < 128 ? C : 128;
+    c.CC = C < 64 ? C : 64;           // channel chunk of a block (its coefficient slices live in LDS)
     c.nchunk = (C + c.CC - 1) / c.CC;
     c.TPF = c.CC / 4;
     c.FB = 256 / c.TPF;
@@ -1279,7 +1314,8 @@ extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void
     if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
     AggBwdCfg c = agg_bwd_cfg(F, C);
     const int nnz_t = nnz_sym + nnz_con;
-    size_t smem = 0;   // the fixed-degree kernel needs no dynamic LDS
+    // fixed-degree kernel: LDS for the coefficient slices, at most J * deg + 1 rows per pattern
+    size_t smem = (size_t)(J * cdeg_sym + 1 + J * cdeg_con + 1) * c.CC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.nfb * c.nchunk);
     // few frames (the M = B*J stage): split the joints / edges over 4 blocks so that the launch covers the chip

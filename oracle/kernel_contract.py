@@ -222,15 +222,23 @@ def semch_adj_bwd(dA_t, A_t, pat, de, accumulate=False):
         de[:, ks] = de[:, ks] + v if accumulate else v
 
 
+def _agg_cfg(F, C):
+    """(frames per block pass, frame blocks, channel chunks) of the forward aggregation: blocks of FB frames x 64 channels"""
+    cc = min(C, 64)
+    nchunk = (C + cc - 1) // cc
+    fb = 256 // (cc // 4)
+    nfb = min((F + fb - 1) // fb, max(1, 1024 // nchunk))
+    return fb, nfb, nchunk
+
+
 def _agg_frame_blocks(F, C):
-    tpf = min(C // 4, 256)
-    fb = 256 // tpf
-    return min((F + fb - 1) // fb, 512)
+    return _agg_cfg(F, C)[1]
 
 
 def _agg_joint_split(F, C):
     """few frames: the rows (joints) of a frame are dealt to 4 blocks; partial rows are then [joint part][frame block]"""
-    return 4 if _agg_frame_blocks(F, C) <= 128 else 1
+    _, nfb, nchunk = _agg_cfg(F, C)
+    return 4 if nfb * nchunk <= 128 else 1
 
 
 def semch_agg_blocks(F, C):
@@ -257,8 +265,7 @@ def semch_agg_fwd(H, F, J, C, A_sym, pat_sym, A_con, pat_con, Y, partials, round
     Y[:F * J, :2 * C] = out.reshape(F * J, 2 * C)
     # partial sums: frames are dealt round-robin to (block, slot): f = (it*nfb + blk)*FB + slot; joints i = part, part + split, ...
     nfb, split = _agg_frame_blocks(F, C), _agg_joint_split(F, C)
-    tpf = min(C // 4, 256)
-    fb = 256 // tpf
+    fb = _agg_cfg(F, C)[0]
     partials[:nfb * split] = 0
     blk_of_frame = (np.arange(F) // fb) % nfb
     for part in range(split):
