@@ -165,6 +165,7 @@ __device__ __forceinline__ void agg_rows_ell(const T* __restrict__ Hf, int ldh, 
                                              const float* __restrict__ A, int lda, int acol, const int32_t* __restrict__ ell_j,
                                              const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, float4& s1, float4& s2,
                                              float4 ctr, int i0, int istep) {
+#pragma unroll 4
     for (int i = i0; i < J; i += istep) {
         int jj[D], kk[D];
 #pragma unroll
@@ -255,6 +256,7 @@ template <typename T, int D>
 __device__ __forceinline__ void agg_cols_ell(const T* __restrict__ dYf, int ldy, T* __restrict__ dHf, int lddh, int J, int C,
                                              const float* __restrict__ A, int lda, int acol, const int32_t* __restrict__ ell_i,
                                              const int32_t* __restrict__ ell_k, int h0c, int h1c, int yc, int j0, int jstep) {
+#pragma unroll 4
     for (int j = j0; j < J; j += jstep) {
         int ii[D], kk[D];
 #pragma unroll
@@ -1293,7 +1295,8 @@ static AggBwdCfg agg_bwd_cfg(int F, int C) {
     c.nchunk = (C + c.CC - 1) / c.CC;
     c.TPF = c.CC / 4;
     c.FB = 256 / c.TPF;
-    int want = 512 / c.nchunk;
+    static const int want_env = getenv("GAST_AGG_BWD_BLOCKS") ? atoi(getenv("GAST_AGG_BWD_BLOCKS")) : 1024;   // 512: 58 us avg at B=128, 1024: 51, 2048: 51
+    int want = want_env / c.nchunk;
     if (want < 1) want = 1;
     int maxfb = (F + c.FB - 1) / c.FB;
     c.nfb = want < maxfb ? want : maxfb;
