@@ -1239,7 +1239,8 @@ static int agg_fwd_frame_blocks(int F, int C) {
 // rows are then [joint part][frame block]
 static int agg_fwd_joint_split(int F, int C) {
     const int CC = agg_fwd_cc(C);
-    return agg_fwd_frame_blocks(F, C) * ((C + CC - 1) / CC) <= 128 ? 4 : 1;
+    const int nblk = agg_fwd_frame_blocks(F, C) * ((C + CC - 1) / CC);
+    return nblk <= 128 ? 4 : nblk <= 512 ? 2 : 1;
 }
 extern "C" int gast_semch_agg_blocks(int F, int C) { return agg_fwd_frame_blocks(F, C) * agg_fwd_joint_split(F, C); }
 

@@ -236,9 +236,9 @@ def _agg_frame_blocks(F, C):
 
 
 def _agg_joint_split(F, C):
-    """few frames: the rows (joints) of a frame are dealt to 4 blocks; partial rows are then [joint part][frame block]"""
+    """few frames: the rows (joints) of a frame are dealt to 4 (2) blocks; partial rows are then [joint part][frame block]"""
     _, nfb, nchunk = _agg_cfg(F, C)
-    return 4 if nfb * nchunk <= 128 else 1
+    return 4 if nfb * nchunk <= 128 else 2 if nfb * nchunk <= 512 else 1
 
 
 def semch_agg_blocks(F, C):
