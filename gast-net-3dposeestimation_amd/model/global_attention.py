@@ -5,6 +5,10 @@ Same constructor signatures, parameter names/shapes and initialisers as the refe
 (gast_hip/engine.py: G1 + ATT + G3): g/theta/phi are columns of one GEMM, the additive score
 f_ij = LeakyReLU(w_theta.theta_i + w_phi.phi_j) is rank-1 so theta/phi fold into two C-vectors per head, and the
 (BT, 2Ci, J, J) concat tensor of the reference is never built.
+
+Only what the `state_dict` contract and the seed-for-seed initialisation test (tests/test_host_contract.py) need is kept:
+the registration ORDER of the sub-modules (it fixes both the key order and the order of the RNG draws) and their
+initialisers.  Activation helper modules of the reference (parameter-free) are not re-created.
 """
 from __future__ import absolute_import, division
 
@@ -12,56 +16,59 @@ import torch
 from torch import nn
 
 
-class GlobalGraph(nn.Module):
-    """Global graph attention layer (one head)."""
+def _pointwise(c_in, c_out):
+    """1x1 Conv1d with bias (reference global_attention.py:30-35)."""
+    return nn.Conv1d(c_in, c_out, kernel_size=1, stride=1, padding=0)
+
+
+class _FusedOnly(nn.Module):
+    """Parameter holder whose arithmetic lives in the fused plan of SpatioTemporalModel."""
+
+    def forward(self, x):
+        raise NotImplementedError('%s holds parameters only: it runs inside the fused HIP plan of SpatioTemporalModel'
+                                  % type(self).__name__)
+
+
+class GlobalGraph(_FusedOnly):
+    """One attention head: g / theta / phi projections, the learnable (J, J) offset C_k and the 2Ci -> 1 score projection."""
 
     def __init__(self, adj, in_channels, inter_channels=None):
-        super(GlobalGraph, self).__init__()
-        self.adj = adj
-        self.in_channels = in_channels
-        self.inter_channels = inter_channels
-        self.softmax = nn.Softmax(dim=-1)
-        self.relu = nn.ReLU(inplace=True)
-        self.leakyrelu = nn.LeakyReLU(0.2)
-        self.g_channels = self.in_channels if self.inter_channels == self.in_channels // 2 else self.inter_channels
-        assert self.inter_channels > 0
-        self.g = nn.Conv1d(self.in_channels, self.g_channels, kernel_size=1, stride=1, padding=0)
-        self.theta = nn.Conv1d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
-        self.phi = nn.Conv1d(self.in_channels, self.inter_channels, kernel_size=1, stride=1, padding=0)
-        self.C_k = nn.Parameter(torch.zeros(self.adj.shape, dtype=torch.float))
-        self.concat_project = nn.Sequential(nn.Conv2d(self.inter_channels * 2, 1, 1, 1, 0, bias=False))
+        super().__init__()
+        assert inter_channels is not None and inter_channels > 0
+        self.adj, self.in_channels, self.inter_channels = adj, in_channels, inter_channels
+        # the value projection keeps the full width when the head is half as wide as its input (reference :25-28)
+        self.g_channels = in_channels if inter_channels == in_channels // 2 else inter_channels
+        # registration order = state_dict order = RNG order: g, theta, phi, C_k, concat_project
+        for name, width in (('g', self.g_channels), ('theta', inter_channels), ('phi', inter_channels)):
+            setattr(self, name, _pointwise(in_channels, width))
+        self.C_k = nn.Parameter(torch.zeros(adj.shape, dtype=torch.float))
+        self.concat_project = nn.Sequential(nn.Conv2d(2 * inter_channels, 1, 1, 1, 0, bias=False))
+        # initialisers (reference :44-50): score projection first, then g, theta, phi (Kaiming weights, zero biases)
         nn.init.kaiming_normal_(self.concat_project[0].weight)
-        for conv in (self.g, self.theta, self.phi):
-            nn.init.kaiming_normal_(conv.weight)
-            nn.init.constant_(conv.bias, 0)
-
-    def forward(self, x):
-        raise NotImplementedError('GlobalGraph runs inside the fused HIP plan of SpatioTemporalModel')
+        for proj in (self.g, self.theta, self.phi):
+            nn.init.kaiming_normal_(proj.weight)
+            nn.init.constant_(proj.bias, 0)
 
 
-class MultiGlobalGraph(nn.Module):
+class MultiGlobalGraph(_FusedOnly):
+    """in_channels // inter_channels heads + the C -> C mixing convolution with its BatchNorm (reference :86-101)."""
+
     def __init__(self, adj, in_channels, inter_channels, dropout=None):
-        super(MultiGlobalGraph, self).__init__()
+        super().__init__()
         self.num_non_local = in_channels // inter_channels
-        self.attentions = nn.ModuleList([GlobalGraph(adj, in_channels, inter_channels) for _ in range(self.num_non_local)])
+        heads = [GlobalGraph(adj, in_channels, inter_channels) for _ in range(self.num_non_local)]
+        self.attentions = nn.ModuleList(heads)
         self.cat_conv = nn.Conv2d(in_channels, in_channels, 1, bias=False)
         self.cat_bn = nn.BatchNorm2d(in_channels, momentum=0.1)
-        self.relu = nn.ReLU(inplace=True)
-        self.dropout = nn.Dropout(dropout) if dropout is not None else None
-
-    def forward(self, x):
-        raise NotImplementedError('MultiGlobalGraph runs inside the fused HIP plan of SpatioTemporalModel')
+        self.dropout = None if dropout is None else nn.Dropout(dropout)
 
 
-class SingleGlobalGraph(nn.Module):
-    """Present in the reference's namespace (global_attention.py:133-173) but unused by gast_net.py (:17 is commented out)."""
+class SingleGlobalGraph(_FusedOnly):
+    """Present in the reference's namespace (global_attention.py:133-173) but unreachable from gast_net.py (:17 is commented
+    out there): constructor only."""
 
     def __init__(self, adj, in_channels, output_channels, dropout=None):
-        super(SingleGlobalGraph, self).__init__()
+        super().__init__()
         self.attentions = GlobalGraph(adj, in_channels, output_channels // 2)
         self.bn = nn.BatchNorm2d(in_channels, momentum=0.1)
-        self.relu = nn.ReLU(inplace=True)
-        self.dropout = nn.Dropout(dropout) if dropout is not None else None
-
-    def forward(self, x):
-        raise NotImplementedError('SingleGlobalGraph is not on the accelerated path (unused by the reference model)')
+        self.dropout = None if dropout is None else nn.Dropout(dropout)
