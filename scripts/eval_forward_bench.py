@@ -4,8 +4,8 @@ import torch
 os.environ['GAST_HIP_DTYPE'] = 'bf16'
 from tests_helpers import PARENTS
 from model.gast_net import SpatioTemporalModel
-from oracle.gast_oracle import adj_from_parents
-m = SpatioTemporalModel(torch.from_numpy(adj_from_parents(PARENTS[17])), 17, 2, 17, filter_widths=[3,3,3], channels=128, dropout=0.05).cuda().eval()
+from bench import adj_from_parents      # (the product's callers build adj themselves; nothing under oracle/ is used here)
+m = SpatioTemporalModel(adj_from_parents(PARENTS[17]), 17, 2, 17, filter_widths=[3,3,3], channels=128, dropout=0.05).cuda().eval()
 for shape in [(128, 27, 17, 2), (2, 2026, 17, 2)]:
     x = (torch.rand(*shape) * 2 - 1).cuda()
     with torch.no_grad():

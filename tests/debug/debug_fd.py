@@ -1,7 +1,7 @@
 """Debug helper (GPU box): finite-difference check of parameter gradients with the dropout seed pinned, for several eps and p."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'gast-net-3dposeestimation_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 os.environ['GAST_HIP_DTYPE'] = 'fp32'

@@ -1,8 +1,8 @@
 """Debug helper (GPU box): the midsize oracle comparison of tests/test_model_gpu.py with per-parameter gradient errors.
-Usage: python scripts/debug_midsize.py [fp32|bf16] [dilated|strided]"""
+Usage: python tests/debug/debug_midsize.py [fp32|bf16] [dilated|strided]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, 'gast-net-3dposeestimation_amd'), os.path.join(ROOT, 'tests')):
     sys.path.insert(0, p)
 mode = sys.argv[1] if len(sys.argv) > 1 else 'fp32'

@@ -516,7 +516,7 @@ def test_dropout_gradients_by_finite_differences():
     for name in names:
         v = torch.randn(sd[name].shape, generator=gen).cuda()
         v = v / v.norm() * sd[name].norm()
-        eps = 2.5e-4       # the central difference converges to the analytic value as eps -> 0 (scripts/debug_fd.py: kinks of ReLU)
+        eps = 2.5e-4       # the central difference converges to the analytic value as eps -> 0 (tests/debug/debug_fd.py: kinks of ReLU)
         vals = []
         for sgn in (+1, -1):
             sd_cur = dict(sd)
