@@ -62,6 +62,5 @@ for s, (a, b) in enumerate(zip(sa['stages'], sb['stages'])):
     print('S%d.H          diff %.3e (rms %.2f)' % (s, (f(a['H']) - f(b['H'])).abs().max().item(), f(a['H']).pow(2).mean().sqrt().item()))
     report('S%d.Y' % s, a['Y'], a['bnY'], b['Y'], b['bnY'])
     print('S%d.Ya         diff %.3e (rms %.2f)' % (s, (f(a['Ya']) - f(b['Ya'])).abs().max().item(), f(a['Ya']).pow(2).mean().sqrt().item()))
-    report('S%d.Lp' % s, a['Lp'], a['bnL'], b['Lp'], b['bnL'])
-    report('S%d.Gp' % s, a['Gp'], a['bnG'], b['Gp'], b['bnG'])
+    report('S%d.LG' % s, a['LG'], a['bnLG'], b['LG'], b['bnLG'])      # [local | global] pre-BN tensor, one BN state for both halves
     report('S%d.O' % s, a['O'], a['bnO'], b['O'], b['bnO'])
