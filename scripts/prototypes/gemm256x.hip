@@ -245,16 +245,27 @@ __global__ void __launch_bounds__(512, 2) gemm256x_kernel(const Args a, int M, i
     for (int ni = 0; ni < 2; ++ni) {
         const int col = wc * 64 + ni * 32 + li;
         const float bias = (a.bias && n0 + col < N) ? a.bias[n0 + col] : 0.f;
+        float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                sC[row * BN + col] = f2bf(acc[mi][ni][r] + bias);
+                const bf16_t yb = f2bf(acc[mi][ni][r] + bias);
+                sC[row * BN + col] = yb;
+                if (a.stats == 2 && m0 + row < M) { const float y = bf2f(yb); s1 += y; s2 = fmaf(y, y, s2); }
             }
+        if (a.stats == 2) {      // statistics straight from the accumulators: a wave's 128 rows are exactly one statistics block
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            if (lh == 0 && n0 + col < N && m0 + wr * 128 < M) {
+                float* pp = a.partials + ((long)(mt * 2 + wr) * N + n0 + col) * 2;
+                pp[0] = s1; pp[1] = s2;
+            }
+        }
     }
     __syncthreads();
-    if (a.stats) {       // thread = (column, 128-row half): sums of the ROUNDED outputs over the valid rows
+    if (a.stats == 1) {  // thread = (column, 128-row half): sums of the ROUNDED outputs over the valid rows
         const int col = tid & 255, half = tid >> 8;
         if (n0 + col < N && m0 + half * 128 < M) {
             float s1 = 0.f, s2 = 0.f;
@@ -309,7 +320,7 @@ template <typename T> static T* to_dev(const std::vector<T>& h) {
 
 struct SegSpec { int K, T_total, t_stride, t_off, pro, share; };     // share >= 0: reuse the A tensor of that earlier segment
 
-static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec> segs, bool bias, bool stats, bool check) {
+static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec> segs, bool bias, int stats, bool check) {
     const int M = B * Tn * J;
     Args a; memset(&a, 0, sizeof a);
     a.B = B; a.Tn = Tn; a.J = J; a.N = N; a.nseg = (int)segs.size();
@@ -335,7 +346,7 @@ static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec
     if (bias) { std::vector<float> hb(N); for (int n = 0; n < N; ++n) hb[n] = ((n % 9) - 4) * 0.1f; a.bias = to_dev(hb); }
     const int nb128 = (M + 127) / 128;
     float* dP = nullptr;
-    if (stats) { hipMalloc(&dP, (size_t)nb128 * N * 2 * 4); hipMemset(dP, 0, (size_t)nb128 * N * 2 * 4); a.stats = 1; a.partials = dP; }
+    if (stats) { hipMalloc(&dP, (size_t)nb128 * N * 2 * 4); hipMemset(dP, 0, (size_t)nb128 * N * 2 * 4); a.stats = stats; a.partials = dP; }
     const int lds = LDS_TILES + 2 * ktab * 4;
     hipFuncSetAttribute((const void*)gemm256x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -389,17 +400,27 @@ static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec
 int main() {
     int rc = 0;
     // small self-checks (naive reference): taps + prologue + statistics + bias; concat of plain segments; zero-row taps; N tail
-    rc |= run("conv taps pro stats", 8, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, true, true);
-    rc |= run("concat plain stats", 10, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, true, true);
-    rc |= run("dgrad taps zero rows", 6, 25, 17, 256, {{256, 19, 1, 0, 0, -1}, {256, 19, 1, -3, 0, 0}, {256, 19, 1, -6, 0, 0}}, false, false, true);
-    rc |= run("N tail 648 bias", 9, 25, 17, 648, {{128, 25, 1, 0, 0, -1}}, true, false, true);
-    rc |= run("mixed pro|plain stats", 7, 19, 17, 256, {{256, 19, 1, 0, 1, -1}, {256, 19, 1, 0, 0, -1}}, false, true, true);
+    rc |= run("conv taps pro stats", 8, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 1, true);
+    rc |= run("concat plain stats", 10, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 1, true);
+    rc |= run("dgrad taps zero rows", 6, 25, 17, 256, {{256, 19, 1, 0, 0, -1}, {256, 19, 1, -3, 0, 0}, {256, 19, 1, -6, 0, 0}}, false, 0, true);
+    rc |= run("N tail 648 bias", 9, 25, 17, 648, {{128, 25, 1, 0, 0, -1}}, true, 0, true);
+    rc |= run("mixed pro|plain stats", 7, 19, 17, 256, {{256, 19, 1, 0, 1, -1}, {256, 19, 1, 0, 0, -1}}, false, 1, true);
+    rc |= run("conv taps pro stats(acc)", 8, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 2, true);
+    rc |= run("concat plain stats(acc)", 10, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, true);
     if (rc) { printf("SELF-CHECK FAILED\n"); return 1; }
     // the step's shapes (B = 128)
-    run("G4 s1 [X|ZLG] stats", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, true, false);
-    run("conv1 taps pro stats", 128, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, true, false);
-    run("G1 s1 N=1288 bias", 128, 19, 17, 1288, {{256, 19, 1, 0, 0, -1}}, true, false, false);
-    run("G1 s0 N=648 bias", 128, 25, 17, 648, {{128, 25, 1, 0, 0, -1}}, true, false, false);
-    run("1x1 s1 pro stats", 128, 19, 17, 256, {{256, 19, 1, 0, 1, -1}}, true, true, false);
+    run("G4 s1 [X|ZLG] stats", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 1, false);
+    run("conv1 taps pro stats", 128, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 1, false);
+    run("G1 s1 N=1288 bias", 128, 19, 17, 1288, {{256, 19, 1, 0, 0, -1}}, true, 0, false);
+    run("G1 s0 N=648 bias", 128, 25, 17, 648, {{128, 25, 1, 0, 0, -1}}, true, 0, false);
+    run("1x1 s1 pro stats", 128, 19, 17, 256, {{256, 19, 1, 0, 1, -1}}, true, 1, false);
+    // statistics from the accumulators instead of a second pass over the staged tile
+    run("G4 s1 stats(acc)", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, false);
+    run("G4 s1 no stats", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 0, false);
+    run("conv1 taps pro stats(acc)", 128, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 2, false);
+    // tile-count quantisation: the same GEMM with M = 32768 (256 tiles: one round), 65536 (512: two rounds), 49152 (384: 1.5 rounds)
+    run("G4-like M=32768 (256 tiles)", 128, 16, 16, 512, {{256, 16, 1, 0, 0, -1}, {512, 16, 1, 0, 0, -1}}, false, 2, false);
+    run("G4-like M=49152 (384 tiles)", 192, 16, 16, 512, {{256, 16, 1, 0, 0, -1}, {512, 16, 1, 0, 0, -1}}, false, 2, false);
+    run("G4-like M=65536 (512 tiles)", 256, 16, 16, 512, {{256, 16, 1, 0, 0, -1}, {512, 16, 1, 0, 0, -1}}, false, 2, false);
     return 0;
 }
