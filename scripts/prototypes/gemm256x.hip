@@ -37,6 +37,9 @@ struct Args {
     bf16_t* C; int ldc;
     const float* bias;
     int stats; float* partials;      // [ceil(M/128)][N][2]
+    // tail split: the tiles past `full_tiles` are cut into `tsplit` K ranges; partial accumulators meet in `slabs`
+    // ([tail tile][part][256*256] fp32), the last arriver (ticket in `tickets[tail tile]`, zeroed before the launch) reduces
+    int full_tiles, tsplit; float* slabs; unsigned* tickets;
 };
 
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
@@ -56,7 +59,9 @@ __global__ void __launch_bounds__(512, 2) gemm256x_kernel(const Args a, int M, i
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int N = a.N;
     const int tilesN = (N + BN - 1) / BN, tilesM = (M + BM - 1) / BM;
-    const int lb = xcd_remap(blockIdx.x, tilesM * tilesN);
+    int lb, part = 0, nparts = 1;
+    if ((int)blockIdx.x < a.full_tiles || a.tsplit <= 1) lb = (int)blockIdx.x < tilesM * tilesN ? xcd_remap(blockIdx.x, min(a.full_tiles, tilesM * tilesN)) : 0;
+    else { const int q = blockIdx.x - a.full_tiles; lb = a.full_tiles + q / a.tsplit; part = q - (q / a.tsplit) * a.tsplit; nparts = a.tsplit; }
     const int mt = lb / tilesN, nt = lb - mt * tilesN;
     const int m0 = mt * BM, n0 = nt * BN;
 
@@ -123,8 +128,10 @@ __global__ void __launch_bounds__(512, 2) gemm256x_kernel(const Args a, int M, i
             k_l = 0; ++seg_l;
         }
     };
-    int ntile = 0;
-    for (int s = 0; s < a.nseg; ++s) ntile += a.seg[s].K / BK;
+    int ntile_all = 0;
+    for (int s = 0; s < a.nseg; ++s) ntile_all += a.seg[s].K / BK;
+    const int t_begin = part * ntile_all / nparts, t_end = (part + 1) * ntile_all / nparts;
+    const int ntile = t_end - t_begin;
 
     u32x4 ra[4];
     bool rz[4];                                        // zero-row flags of the rows held in ra
@@ -191,6 +198,7 @@ __global__ void __launch_bounds__(512, 2) gemm256x_kernel(const Args a, int M, i
     Tile cur, nxt, nn;                                 // tiles t, t+1, t+2
     int cur_seg_entered = -1;
     auto ensure_seg = [&](int s) { if (s != cur_seg_entered) { enter_seg(s); cur_seg_entered = s; } };
+    for (int sk = 0; sk < t_begin; ++sk) next_tile(cur);       // (a K-range block starts in the middle of the tile list)
     next_tile(cur);
     ensure_seg(cur.seg);
     dma_w(cur, 0);
@@ -237,6 +245,41 @@ __global__ void __launch_bounds__(512, 2) gemm256x_kernel(const Args a, int M, i
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi].s, fb[ni].s, acc[mi][ni], 0, 0, 0);
         }
         cur = nxt; nxt = nn; have_nxt = have_nn; have_nn = false;
+    }
+    // ---- tail split: fp32 partial tiles meet in global slabs; the last arriver of a tile adds the others to its registers
+    if (nparts > 1) {
+        __shared__ int s_last;
+        const int tt = lb - a.full_tiles;
+        float* mine = a.slabs + ((long)tt * nparts + part) * (BM * BN);
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mine[(wr * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * 64 + ni * 32 + li] = acc[mi][ni][r];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const unsigned ticket = __hip_atomic_fetch_add(a.tickets + tt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = ticket == (unsigned)(nparts - 1);
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+        if (!s_last) return;
+        for (int p = 0; p < nparts; ++p) {
+            if (p == part) continue;
+            const float* other = a.slabs + ((long)tt * nparts + p) * (BM * BN);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[mi][ni][r] += __builtin_nontemporal_load(other + (wr * 128 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh) * BN + wc * 64 + ni * 32 + li);
+        }
     }
     // ---- epilogue: acc (+ bias) -> bf16 tile in LDS -> statistics, 16-byte stores
     __syncthreads();
@@ -320,7 +363,7 @@ template <typename T> static T* to_dev(const std::vector<T>& h) {
 
 struct SegSpec { int K, T_total, t_stride, t_off, pro, share; };     // share >= 0: reuse the A tensor of that earlier segment
 
-static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec> segs, bool bias, int stats, bool check) {
+static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec> segs, bool bias, int stats, bool check, int tsplit = 1) {
     const int M = B * Tn * J;
     Args a; memset(&a, 0, sizeof a);
     a.B = B; a.Tn = Tn; a.J = J; a.N = N; a.nseg = (int)segs.size();
@@ -349,8 +392,21 @@ static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec
     if (stats) { hipMalloc(&dP, (size_t)nb128 * N * 2 * 4); hipMemset(dP, 0, (size_t)nb128 * N * 2 * 4); a.stats = stats; a.partials = dP; }
     const int lds = LDS_TILES + 2 * ktab * 4;
     hipFuncSetAttribute((const void*)gemm256x_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    const int grid = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    hipLaunchKernelGGL(gemm256x_kernel, dim3(grid), dim3(512), lds, 0, a, M, ktab);
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    a.full_tiles = tiles; a.tsplit = 1;
+    int grid = tiles;
+    if (tsplit > 1 && tiles > 256 && tiles % 256) {      // full rounds as they are, the tiles of the last partial round cut in tsplit K ranges
+        a.full_tiles = tiles / 256 * 256; a.tsplit = tsplit;
+        const int tail = tiles - a.full_tiles;
+        grid = a.full_tiles + tail * tsplit;
+        hipMalloc(&a.slabs, (size_t)tail * tsplit * BM * BN * 4);
+        hipMalloc(&a.tickets, tail * 4);
+    }
+    auto launch = [&]() {
+        if (a.tsplit > 1) hipMemsetAsync(a.tickets, 0, (tiles - a.full_tiles) * 4, 0);
+        hipLaunchKernelGGL(gemm256x_kernel, dim3(grid), dim3(512), lds, 0, a, M, ktab);
+    };
+    launch();
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("%s: launch failed: %s\n", tag, hipGetErrorString(e)); return 1; }
     int rc = 0;
@@ -389,7 +445,7 @@ static int run(const char* tag, int B, int Tn, int J, int N, std::vector<SegSpec
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int reps = 20;
     hipEventRecord(e0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(gemm256x_kernel, dim3(grid), dim3(512), lds, 0, a, M, ktab);
+    for (int i = 0; i < reps; ++i) launch();
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / reps;
@@ -407,6 +463,8 @@ int main() {
     rc |= run("mixed pro|plain stats", 7, 19, 17, 256, {{256, 19, 1, 0, 1, -1}, {256, 19, 1, 0, 0, -1}}, false, 1, true);
     rc |= run("conv taps pro stats(acc)", 8, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 2, true);
     rc |= run("concat plain stats(acc)", 10, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, true);
+    rc |= run("tail split x3 (check)", 18, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 1, -1}}, true, 2, true, 3);      // 23 x 2 = 46 tiles: no split (<= 256)
+    rc |= run("tail split x4 (check)", 104, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 1, -1}}, true, 2, true, 4);     // 132 x 2 = 264 tiles: 8 tail tiles x 4
     if (rc) { printf("SELF-CHECK FAILED\n"); return 1; }
     // the step's shapes (B = 128)
     run("G4 s1 [X|ZLG] stats", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 1, false);
@@ -418,6 +476,9 @@ int main() {
     run("G4 s1 stats(acc)", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, false);
     run("G4 s1 no stats", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 0, false);
     run("conv1 taps pro stats(acc)", 128, 19, 17, 256, {{256, 25, 1, 0, 1, -1}, {256, 25, 1, 3, 1, 0}, {256, 25, 1, 6, 1, 0}}, true, 2, false);
+    run("G4 s1 stats(acc) tail x2", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, false, 2);
+    run("G4 s1 stats(acc) tail x3", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, false, 3);
+    run("G4 s1 stats(acc) tail x4", 128, 19, 17, 512, {{256, 19, 1, 0, 0, -1}, {512, 19, 1, 0, 0, -1}}, false, 2, false, 4);
     // tile-count quantisation: the same GEMM with M = 32768 (256 tiles: one round), 65536 (512: two rounds), 49152 (384: 1.5 rounds)
     run("G4-like M=32768 (256 tiles)", 128, 16, 16, 512, {{256, 16, 1, 0, 0, -1}, {512, 16, 1, 0, 0, -1}}, false, 2, false);
     run("G4-like M=49152 (384 tiles)", 192, 16, 16, 512, {{256, 16, 1, 0, 0, -1}, {512, 16, 1, 0, 0, -1}}, false, 2, false);
