@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 PARENTS17 = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]   # reference reconstruction.py:95
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}   # dense peaks
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3}   # dense peaks (bf16x3: three bf16 products per FLOP pair)
 
 
 def adj_from_parents(parents):
@@ -314,7 +314,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16'), choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16'), choices=['bf16', 'bf16x3', 'fp32'])
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--no-cpu-baseline', action='store_true')

@@ -41,6 +41,17 @@ template <> struct Mma<bf16_t> {
     }
 };
 
+// fp32 storage, split-bf16 arithmetic (GAST_F32X3): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (the difference is exact in
+// fp32), and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped
+// a_lo*b_lo term and the rounding of lo are ~2^-17 relative, i.e. fp32-class products at 3/16 of the fp32 MFMA cost.
+__device__ __forceinline__ void split_bf16x4(const uint4& v, uint2& hi, uint2& lo) {
+    const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
+    hi.x = pack_bf16x2(x0, x1);
+    hi.y = pack_bf16x2(x2, x3);
+    lo.x = pack_bf16x2(x0 - __uint_as_float(hi.x << 16), x1 - __uint_as_float(hi.x & 0xffff0000u));
+    lo.y = pack_bf16x2(x2 - __uint_as_float(hi.y << 16), x3 - __uint_as_float(hi.y & 0xffff0000u));
+}
+
 // apply BN+ReLU(+dropout) to one 16-byte chunk of A held in registers
 template <typename T>
 __device__ __forceinline__ uint4 prologue(uint4 v, const float* sc, const float* sh, bool drop, uint32_t key,
@@ -75,8 +86,9 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <typename T, typename TO>
+template <typename T, typename TO, bool X3 = false>
 __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws, int blk) {
+    static_assert(!X3 || sizeof(T) == 4, "the split-bf16 mode stores fp32");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -218,12 +230,56 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                 v = make_uint4(oka ? v.x : 0u, oka ? v.y : 0u, oka ? v.z : 0u, oka ? v.w : 0u);
                 wv = make_uint4(kin ? wv.x : 0u, kin ? wv.y : 0u, kin ? wv.z : 0u, kin ? wv.w : 0u);
             }
-            *(uint4*)(sA + r * LSTR + chunk * 16) = v;
-            *(uint4*)(sB + r * LSTR + chunk * 16) = wv;
+            if (X3) {
+                // row image: [hi plane: 32 bf16 = 64 B | lo plane: 64 B]; this thread's 4 k values are bytes chunk*8 .. +8 of each
+                uint2 h, l;
+                split_bf16x4(v, h, l);
+                *(uint2*)(sA + r * LSTR + chunk * 8) = h;
+                *(uint2*)(sA + r * LSTR + 64 + chunk * 8) = l;
+                split_bf16x4(wv, h, l);
+                *(uint2*)(sB + r * LSTR + chunk * 8) = h;
+                *(uint2*)(sB + r * LSTR + 64 + chunk * 8) = l;
+            } else {
+                *(uint4*)(sA + r * LSTR + chunk * 16) = v;
+                *(uint4*)(sB + r * LSTR + chunk * 16) = wv;
+            }
         }
     };
 
     auto compute_tile = [&]() {
+        if (X3) {
+            // K tile = 32: two 16-deep MFMA steps; per step the hi and lo fragments of both operands, three products per
+            // accumulator, small terms first, consecutive MFMAs on different accumulators
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                union { uint4 u; s16x8 s; } ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) {
+                    const unsigned char* p = sA + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                    ah[mi].u = *(const uint4*)p;
+                    al[mi].u = *(const uint4*)(p + 64);
+                }
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    const unsigned char* p = sB + (wc * 64 + ni * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                    bh[ni].u = *(const uint4*)p;
+                    bl[ni].u = *(const uint4*)(p + 64);
+                }
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+            }
+            return;
+        }
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             uint4 fa[2], fb[2];
@@ -497,9 +553,9 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // ---- split-K finish: C = epi(sum_split ws + bias + addend), same epilogue semantics and partial-sum layout as gemm_kernel.
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
-template <typename T, typename TO>
+template <typename T, typename TO, bool X3 = false>
 __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
-    gemm_body<T, TO>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
+    gemm_body<T, TO, X3>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
 
 // Several independent GEMMs of one plan step in ONE grid (gast_gemm_multi): the K <= 256 launches of a block (G2 / G3, the two
@@ -512,11 +568,11 @@ struct GemmBatch {
     int n;
 };
 static_assert(sizeof(GemmBatch) <= 3584, "GemmBatch travels as a kernel argument (4 KB limit)");
-template <typename T, typename TO>
+template <typename T, typename TO, bool X3 = false>
 __global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    gemm_body<T, TO>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
+    gemm_body<T, TO, X3>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
 }
 
 template <typename T, typename TO>
@@ -603,9 +659,9 @@ extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) { ret
 namespace {
 // validation + launch geometry shared by gast_gemm_ws / gast_gemm_multi
 int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gridM, int& gridN, int& vec_epi, int& splitk) {
-    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
+    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16 && a.dtype != GAST_F32X3) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.C || a.N < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
-    const int epc = a.dtype == GAST_F32 ? 4 : 8;
+    const int epc = a.dtype == GAST_BF16 ? 8 : 4;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_gemm_seg& g = a.seg[s];
         if (!g.A || !g.W || g.K < 1) return GAST_EINVAL;
@@ -655,6 +711,8 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+    else if (a.dtype == GAST_F32X3)
+        hipLaunchKernelGGL((gemm_kernel<float, float, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.out_f32)
         hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else
@@ -663,7 +721,7 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     if (splitk > 1) {
         // the finish kernel accumulates the column statistics with atomics: `partials` arrives zero-filled (gast_hip.h)
         dim3 fgrid(gridN * ((M + 7) / 8));
-        if (a.dtype == GAST_F32)
+        if (a.dtype != GAST_BF16)
             hipLaunchKernelGGL((splitk_finish_kernel<float, float>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
         else if (a.out_f32)
             hipLaunchKernelGGL((splitk_finish_kernel<bf16_t, float>), fgrid, block, 0, st, a, M, gridN, splitk, (const float*)ws);
@@ -699,6 +757,8 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     hipStream_t st = (hipStream_t)stream;
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
+    else if (args[0].dtype == GAST_F32X3)
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, true>), grid, block, 0, st, b);
     else if (args[0].out_f32)
         hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
     else

@@ -180,6 +180,179 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ fp32 storage, split-bf16 MFMA
+// GAST_F32X3: the operands are fp32 in memory; every thread owns an 8(m) x 4(col) block per 32-row step, applies the prologue in
+// fp32, splits each value into bf16 hi + lo (x - hi is exact in fp32) and -- because v_cvt_pk_bf16_f32 packs two DIFFERENT source
+// registers -- gets the m-major -> col-major transposition for free: LDS rows are [col][hi: 32 m = 64 B | lo: 64 B] (+16 B pad) and
+// the MFMA loop is gast_gemm's split loop: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+__device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
+    constexpr int BKM = 32;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
+    __shared__ __attribute__((aligned(16))) int sRowP[2][BKM];
+    __shared__ __attribute__((aligned(16))) int sRowQ[2][BKM];
+    __shared__ int sBad[2];
+    unsigned char* const sP = smem;
+    unsigned char* const sQ = smem + BT * LSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const gast_wgrad_seg& sg = a.seg[tc.seg];
+    const int m_begin = sp * mchunk;
+    const int m_end = min(M, m_begin + mchunk);
+    if (m_begin >= m_end) return;
+    const int ntile = (m_end - m_begin + BKM - 1) / BKM;
+
+    // staging role: threads 0..127 stage P, 128..255 stage Q; each owns an 8(m) x 4(col) block of the 32 x 128 step tile
+    const int op = tid >> 7, task = tid & 127;
+    const int mb = task & 3, rc = task >> 2;
+    const float* base = op == 0 ? (const float*)a.P : (const float*)sg.Q;
+    const int ld = op == 0 ? a.ldp : sg.ldq;
+    const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 4;
+    const bool cin = col < (op == 0 ? a.R : sg.S);
+    const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
+    const bool drop = op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
+    const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
+    float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (pro && cin) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sc[q] = sg.scale[col + q]; sh[q] = sg.shift[col + q]; }
+    }
+    unsigned char* const sdst = op == 0 ? sP : sQ;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto compute_rows = [&](int it, int buf) {
+        if (tid < 64) {      // wave 0; lanes 32..63 only take part in the ballot
+            int pr = 0, qr = 0;
+            if (tid < BKM) {
+                const int m = m_begin + it * BKM + tid;
+                rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
+                sRowP[buf][tid] = pr;
+                sRowQ[buf][tid] = qr;
+            }
+            const unsigned long long bad = __ballot(pr < 0);
+            if (tid == 0) sBad[buf] = bad != 0ull;
+        }
+    };
+
+    u32x4 rl[8];
+    const int colc = cin ? col : 0;
+    auto load_tile = [&](int buf) {
+        const int4* rp = (const int4*)((op == 0 ? sRowP[buf] : sRowQ[buf]) + mb * 8);
+        const int4 r0 = rp[0], r1 = rp[1];
+        const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gload16(rl[i], base + (long)(rows[i] < 0 ? 0 : rows[i]) * ld + colc);
+    };
+    auto store_tile = [&](int buf) {
+        float x[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i][0] = __uint_as_float(rl[i].x); x[i][1] = __uint_as_float(rl[i].y);
+            x[i][2] = __uint_as_float(rl[i].z); x[i][3] = __uint_as_float(rl[i].w);
+        }
+        const bool bad = __builtin_amdgcn_readfirstlane(sBad[buf]) != 0;
+        if (pro && cin) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = sRowQ[buf][mb * 8 + i];
+                const uint32_t e0 = (uint32_t)((long)(row < 0 ? 0 : row) * ld + col);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float y = fmaxf(fmaf(x[i][q], sc[q], sh[q]), 0.f);
+                    if (drop) y *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + q);
+                    x[i][q] = y;
+                }
+            }
+        }
+        // rows outside the chunk / the row map must read as zero (after the prologue: relu(shift) must not leak in)
+        if (bad) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int row = op == 0 ? sRowP[buf][mb * 8 + i] : sRowQ[buf][mb * 8 + i];
+                if (row < 0) { x[i][0] = 0.f; x[i][1] = 0.f; x[i][2] = 0.f; x[i][3] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const float x0 = x[2 * p2][q], x1 = x[2 * p2 + 1][q];
+                h[p2] = pack_bf16x2(x0, x1);
+                l[p2] = pack_bf16x2(x0 - __uint_as_float(h[p2] << 16), x1 - __uint_as_float(h[p2] & 0xffff0000u));
+            }
+            unsigned char* d = sdst + (rc * 4 + q) * LSTR + mb * 16;
+            *(uint4*)d = make_uint4(h[0], h[1], h[2], h[3]);
+            *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            union { uint4 u; s16x8 s; } ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const unsigned char* p = sP + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                ah[mi].u = *(const uint4*)p;
+                al[mi].u = *(const uint4*)(p + 64);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned char* p = sQ + (wc * 64 + ni * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                bh[ni].u = *(const uint4*)p;
+                bl[ni].u = *(const uint4*)(p + 64);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+        }
+    };
+
+    compute_rows(0, 0);
+    __syncthreads();
+    load_tile(0);
+    if (ntile > 1) compute_rows(1, 1);
+    for (int it = 0; it < ntile; ++it) {
+        __syncthreads();
+        gload_wait_n<0>();
+        store_tile(it & 1);
+        __syncthreads();
+        if (it + 1 < ntile) load_tile((it + 1) & 1);
+        if (it + 2 < ntile) compute_rows(it + 2, it & 1);
+        mfma_tile();
+    }
+
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        if (scol >= sg.S) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bf16
 __device__ __forceinline__ void transpose8x8_bf16(const u32x4 (&in)[8], uint4 (&out)[8]) {
     // in[i] = row i (8 bf16: cols 0..7 packed in 4 u32); out[q] = col q (8 bf16: rows 0..7).  One v_perm_b32 per output word
@@ -394,6 +567,10 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
     const int tile = blockIdx.x / splitM;
     wgrad_f32_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
+__global__ void __launch_bounds__(256, 3) wgrad_x3_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
+    const int tile = blockIdx.x / splitM;
+    wgrad_x3_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
+}
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
     const int tile = blockIdx.x / splitM;
@@ -439,6 +616,11 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
+__global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b) {
+    int d, tile, sp;
+    if (!wg_decode(b, d, tile, sp)) return;
+    wgrad_x3_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+}
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
     int d, tile, sp;
@@ -464,9 +646,9 @@ inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 // validation shared by gast_wgrad / gast_wgrad_multi; returns 0 and the tile counts, or an error code
 int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS, int bt = BT) {
-    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16) return GAST_EINVAL;
+    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16 && a.dtype != GAST_F32X3) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.P || !a.dW || a.R < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
-    const int epc = a.dtype == GAST_F32 ? 4 : 8;
+    const int epc = a.dtype == GAST_BF16 ? 8 : 4;
     if (a.R % epc || a.ldp % epc || !aligned16(a.P)) return GAST_EALIGN;
     tilesS = 0;
     for (int s = 0; s < a.nseg; ++s) {
@@ -491,7 +673,7 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
     int M, tilesR, tilesS;
     int rc = wgrad_check(a, M, tilesR, tilesS);
     if (rc) return rc;
-    const int bkm = a.dtype == GAST_F32 ? 32 : 64;
+    const int bkm = a.dtype == GAST_BF16 ? 64 : 32;
     const int tiles = tilesR * tilesS;
     static const int tgt = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 768;   // 3 resident blocks per CU
     int splitM = tgt / tiles;
@@ -509,6 +691,8 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
     dim3 grid(tiles * splitM), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
+    else if (a.dtype == GAST_F32X3)
+        hipLaunchKernelGGL(wgrad_x3_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
     else
         hipLaunchKernelGGL(wgrad_bf16_kernel, grid, block, 0, st, a, M, tilesS, splitM, mchunk);
     GAST_CHECK_LAUNCH();
@@ -537,7 +721,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         total_tiles += tilesR[d] * b.tilesS[d];
         tile_rows += (long)tilesR[d] * b.tilesS[d] * b.M[d];
     }
-    const int bkm = args[0].dtype == GAST_F32 ? 32 : 64;
+    const int bkm = args[0].dtype == GAST_BF16 ? 64 : 32;
     static const int tgt128 = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
     static const int tgt256 = getenv("GAST_WGRAD_BLOCKS256") ? atoi(getenv("GAST_WGRAD_BLOCKS256")) : 512;   // one resident block per CU
     static const int ring = getenv("GAST_WGRAD_RING") ? atoi(getenv("GAST_WGRAD_RING")) : 1;
@@ -591,6 +775,8 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]);
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, dim3(256), 0, st, b);
+    else if (args[0].dtype == GAST_F32X3)
+        hipLaunchKernelGGL(wgrad_x3_multi_kernel, grid, dim3(256), 0, st, b);
     else if (bt == 256) {
         constexpr int lds = wgrad_bf16_lds_bytes(256);
         static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_bf16_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

@@ -13,7 +13,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgast_hip.so')
 
-GAST_F32, GAST_BF16 = 0, 1
+GAST_F32, GAST_BF16, GAST_F32X3 = 0, 1, 2
 MAX_SEG = 8
 PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
 EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
@@ -219,6 +219,9 @@ class HipOps:
     def __init__(self):
         self.lib = load_library()
         self.launches = 0
+        # fp32 tensors: run the MFMA GEMMs / weight gradients on split-bf16 products (GAST_F32X3, include/gast_hip.h) instead of
+        # the fp32 matrix instruction.  Set by the model runner from GAST_HIP_DTYPE=bf16x3; storage stays fp32 everywhere.
+        self.x3 = False
         self._ws = {}            # per (device, stream): fp32 split-K workspace (allocated once, before any graph capture)
 
     SPLITK_WS_BYTES = 96 << 20
@@ -239,12 +242,13 @@ class HipOps:
                    xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         a.dtype = _dt(segs[0]['A'])
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
+        st_dtype = a.dtype
         a.B, a.Tn, a.J = (int(v) for v in dom)
         a.N = int(N)
         a.nseg = len(segs)
         for i, s in enumerate(segs):
             g = a.seg[i]
-            if _dt(s['A']) != a.dtype or _dt(s['W']) != a.dtype:
+            if _dt(s['A']) != st_dtype or _dt(s['W']) != st_dtype:
                 raise RuntimeError('gast_hip: mixed operand dtypes in gemm')
             g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
             g.W, g.ldw = _p(s['W']), _ld(s['W'])
@@ -263,6 +267,8 @@ class HipOps:
         a.xscale, a.xshift = _p(xscale), _p(xshift)
         a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
         a.drop = _drop(drop)
+        if self.x3 and st_dtype == GAST_F32:
+            a.dtype = GAST_F32X3
 
     def gemm(self, dom, N, segs, C_, cmap, **kw):
         a = _GemmArgs()
@@ -286,13 +292,13 @@ class HipOps:
             _check(self.lib.gast_gemm_multi(arr, len(chunk), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm_multi')
 
     def _wgrad_args(self, a, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
-        a.dtype = _dt(P)
+        a.dtype = st_dtype = _dt(P)
         a.B, a.Tn, a.J = (int(v) for v in dom)
         a.P, a.ldp, a.R, a.pmap = _p(P), _ld(P), int(R), _rm(pmap)
         a.nseg = len(segs)
         for i, s in enumerate(segs):
             g = a.seg[i]
-            if _dt(s['Q']) != a.dtype:
+            if _dt(s['Q']) != st_dtype:
                 raise RuntimeError('gast_hip: mixed operand dtypes in wgrad')
             g.Q, g.ldq, g.S, g.map = _p(s['Q']), _ld(s['Q']), int(s['S']), _rm(s['map'])
             g.pro = int(s.get('pro', PRO_NONE))
@@ -302,6 +308,8 @@ class HipOps:
             raise RuntimeError('gast_hip: dW must be fp32')
         a.dW, a.ldw, a.zero_first = _p(dW), _ld(dW), int(bool(zero_first))
         a.drop = _drop(drop)
+        if self.x3 and st_dtype == GAST_F32:
+            a.dtype = GAST_F32X3
 
     def wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=True):
         a = _WgradArgs()

@@ -14,8 +14,9 @@ What differs is everything below that surface: forward/backward run as one `torc
 fused launch plan of `gast_hip/engine.py` over hand-written gfx950 kernels.  There is no PyTorch/CPU fallback: calling
 the model with CPU tensors, or without `libgast_hip.so`, raises.
 
-Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (default; parity 1e-4) or `bf16`
-(bf16 activations/weights, fp32 accumulate/statistics; parity 1e-2).
+Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (default; fp32 MFMA, parity 1e-4), `bf16x3`
+(fp32 storage, every GEMM product as bf16 hi/lo split products on the bf16 matrix cores: fp32-class results) or `bf16`
+(bf16 activations/weights, fp32 accumulate/statistics).
 """
 import os
 
@@ -129,6 +130,7 @@ class _GastFunction(torch.autograd.Function):
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
         runner.engine.centered = runner.centered
+        ops.x3 = runner.x3
         pred, sv = runner.engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device))
         ctx.runner, ctx.packer, ctx.st, ctx.inp, ctx.sv = runner, packer, st, inp, sv
         return pred
@@ -173,11 +175,16 @@ class _Runner:
     @property
     def act_dtype(self):
         v = os.environ.get('GAST_HIP_DTYPE', 'fp32').lower()
-        if v in ('fp32', 'f32', 'float32'):
+        if v in ('fp32', 'f32', 'float32', 'bf16x3', 'x3'):
             return torch.float32
         if v in ('bf16', 'bfloat16'):
             return torch.bfloat16
-        raise ValueError('GAST_HIP_DTYPE must be fp32 or bf16, got %r' % v)
+        raise ValueError('GAST_HIP_DTYPE must be fp32, bf16x3 or bf16, got %r' % v)
+
+    @property
+    def x3(self):
+        """GAST_HIP_DTYPE=bf16x3: fp32 storage, GEMMs and weight gradients on split-bf16 MFMA products (include/gast_hip.h)."""
+        return os.environ.get('GAST_HIP_DTYPE', 'fp32').lower() in ('bf16x3', 'x3')
 
     @property
     def centered(self):

@@ -36,6 +36,10 @@ typedef void* gast_stream_t; /* hipStream_t */
 
 #define GAST_F32 0
 #define GAST_BF16 1
+/* fp32 storage like GAST_F32; the MFMA GEMMs (gast_gemm*, gast_wgrad*) split every operand into a bf16 hi/lo pair in
+ * registers and accumulate hi*hi + hi*lo + lo*hi on the bf16 matrix cores in fp32 ("bf16x3": ~2^-17 relative per product,
+ * 3/16 of the fp32 MFMA cost).  Every other entry point treats it as GAST_F32. */
+#define GAST_F32X3 2
 
 #define GAST_EINVAL (-1)   /* bad argument (null pointer, bad dtype, bad size) */
 #define GAST_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */

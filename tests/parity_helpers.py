@@ -56,16 +56,19 @@ def _grad_cosines(m, ref, min_numel=64):
 
 
 FP32_GRAD_TOL = dict(grad=2e-4, gabs=2e-5)
+# GAST_HIP_DTYPE=bf16x3 (fp32 storage, split-bf16 products: ~2^-17 relative per product instead of fp32's 2^-24): the same
+# elementwise check as fp32 with ten times the bound
+X3_GRAD_TOL = dict(grad=2e-3, gabs=2e-4)
 
 
-def _check_fp32_grads(m, ref, run_oracle):
+def _check_fp32_grads(m, ref, run_oracle, FP32_GRAD_TOL=FP32_GRAD_TOL):
     """fp32 gradients against the float64 oracle / the reference golden: 2e-4 of max|ref| (+2e-5) per parameter.  When that
     fails, ReLU inputs within eps of zero are evaluated both ways by the oracle (at most 32 of them, eps <= 1e-5: the fp32
     round-off of a pre-activation of magnitude ~1-10) and only the part of the error their decisions cannot explain counts."""
     worst = _grad_errors(m, ref, FP32_GRAD_TOL)
     info = dict(strict_score=worst[1], strict_worst=worst[0], eps=0.0, ties=0)
     if worst[1] > 1.0:
-        for eps in (1e-6, 1e-5):
+        for eps in ((1e-6, 1e-5) if FP32_GRAD_TOL['grad'] <= 2e-4 else (1e-5, 1e-4)):
             n, budget = _tie_budget(run_oracle, eps)
             info.update(eps=eps, ties=n)
             if n > 32:
