@@ -96,3 +96,28 @@ def _tie_budget(run_oracle, eps):
     return n, {k: np.abs(out['on'][k] - out['off'][k]) for k in out['on']}
 
 
+
+
+def _check_x3_grads(m, ref, run_oracle):
+    """GAST_HIP_DTYPE=bf16x3 gradients against the reference / float64 oracle.  First the fp32 procedure with ten times the bound
+    (X3_GRAD_TOL, ReLU ties up to |z| < 1e-4 evaluated both ways).  The split-bf16 products perturb pre-activations by ~1e-5
+    relative, so on the tiny-batch fixtures (34 .. 85 rows in the last stage) a few dozen ReLU inputs are undecidable AT ONCE and
+    the all-on / all-off spread no longer bounds every combination of decisions; when the elementwise check still fails and such
+    ties exist, the fallback is per-tensor: relative L2 distance < 1e-1 (one flipped element of a 34-row stage moves a tensor by
+    1-3 %; measured 2.3e-2 .. 5.8e-2 on the fixtures with 22 .. 101 ties, 2e-5 .. 4e-5 of max|g| on those without).  The at-size test (B=128) asserts 1e-2 relative L2 with no fallback."""
+    worst, info = _check_fp32_grads(m, ref, run_oracle, X3_GRAD_TOL)
+    if worst[1] > 1.0 and info['ties'] > 0:
+        rel = ('', 0.0)
+        gmax = max(float(np.abs(v).max()) for v in ref.values())
+        for k, p in m.named_parameters():
+            r = ref[k].astype(np.float64).ravel()
+            # (same exclusions as _grad_cosines: exact-zero gradients, the cancelling attention-score sums, tiny tensors)
+            if k in ZERO_GRADS or k.endswith(BF16_NOISY) or r.size < 64 or np.abs(r).max() < 1e-3 * gmax:
+                continue
+            g = p.grad.detach().float().cpu().numpy().astype(np.float64).ravel()
+            d = float(np.linalg.norm(g - r) / (np.linalg.norm(r) + 1e-300))
+            if d > rel[1]:
+                rel = (k, d)
+        info.update(elementwise_score=worst[1], elementwise_worst=worst[0], rel_l2_worst=rel)
+        worst = (rel[0], rel[1] / 1e-1)
+    return worst, info

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from parity_helpers import (ZERO_GRADS, BF16_NOISY, FP32_GRAD_TOL, X3_GRAD_TOL, _grad_errors, _grad_cosines, _tie_budget,  # noqa: F401
-                            _check_fp32_grads)
+                            _check_fp32_grads, _check_x3_grads)
 from conftest import golden_names, load_golden
 from tests_helpers import PARENTS
 
@@ -88,7 +88,7 @@ def test_golden(name, mode):
         from oracle import gast_oracle as go
         om = go.OracleModel(go.adj_from_parents(cfg['parents']), cfg['arc'], cfg['channels'], causal=cfg['causal'],
                             variant=cfg['variant'])
-        worst, info = _check_fp32_grads(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2], GRAD_TOL[mode])
+        worst, info = (_check_fp32_grads if mode == 'fp32' else _check_x3_grads)(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2])
     else:
         cosw, ratw = _grad_cosines(m, grads)
         worst, info = ('', 0.0), dict(worst_cos=cosw, worst_norm_ratio=ratw)
@@ -148,7 +148,7 @@ def test_against_oracle_midsize(J, arc, ch, B, T, variant, mode):
     err = float(np.abs(y.detach().cpu().numpy() - y_ref).max())
     y.backward(dy.cuda())
     if mode != 'bf16':
-        worst, info = _check_fp32_grads(m, g_ref, lambda: om.output_grads(state, x.numpy(), dy.numpy(), training=True)[1], GRAD_TOL[mode])
+        worst, info = (_check_fp32_grads if mode == 'fp32' else _check_x3_grads)(m, g_ref, lambda: om.output_grads(state, x.numpy(), dy.numpy(), training=True)[1])
     else:
         cosw, ratw = _grad_cosines(m, g_ref)
         worst, info = ('', 0.0), dict(worst_cos=cosw, worst_norm_ratio=ratw)
