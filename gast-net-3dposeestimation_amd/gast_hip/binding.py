@@ -28,7 +28,11 @@ class Dropout(namedtuple('Dropout', 'seed thresh inv_keep')):
 
 
 def dropout_params(p):
+    if not 0.0 <= p <= 1.0:
+        raise ValueError('dropout probability has to be between 0 and 1, got %r' % (p,))
     thresh = int(round(p * 65536))
+    if thresh >= 65536:            # p = 1: everything is dropped (nn.Dropout(1.0) returns zeros)
+        return 65536, 0.0
     inv_keep = 65536.0 / (65536 - thresh) if thresh else 1.0
     return thresh, inv_keep
 

@@ -48,13 +48,22 @@ class BNState:
     """scale/shift (+ mean/rstd in training) of one BatchNorm2d for the current batch."""
     __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
+    EVAL_COUNT = 1e300     # "infinitely many rows": the batch-statistics terms of the BatchNorm backward vanish
+
     def __init__(self, n, dev, count, pre=None):
-        """pre = (scale, shift) views of the eval-mode table (already filled): nothing to compute for this state."""
+        """pre = (scale, shift, mean, rstd) views of the eval-mode tables (already filled; mean / rstd None unless a backward pass
+        may follow): nothing to compute for this state.  Eval-mode BatchNorm is the fixed affine map y = scale*x + shift, whose
+        backward is dx = gamma*rstd*dz, dgamma = sum dz*(x-mean)*rstd, dbeta = sum dz with the RUNNING statistics -- exactly what
+        the training-mode backward kernels compute for count -> infinity."""
         self.scale = pre[0] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
         self.shift = pre[1] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
-        self.mean = torch.empty(n, dtype=torch.float32, device=dev)
-        self.rstd = torch.empty(n, dtype=torch.float32, device=dev)
-        self.count = count
+        if pre is not None and pre[2] is not None:
+            self.mean, self.rstd = pre[2], pre[3]
+            self.count = self.EVAL_COUNT
+        else:
+            self.mean = torch.empty(n, dtype=torch.float32, device=dev)
+            self.rstd = torch.empty(n, dtype=torch.float32, device=dev)
+            self.count = count
 
 
 class ZeroArena:
@@ -120,16 +129,17 @@ class Engine:
         sl = slice(off, off + n)
         if training:
             ops.bn_finalize(partials, nblk, col0, n, count, bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'],
-                            bn['num_batches_tracked'], BN_MOMENTUM, BN_EPS, st.scale[sl], st.shift[sl], st.mean[sl], st.rstd[sl],
-                            centered=centered)
+                            bn['num_batches_tracked'], bn.get('momentum', BN_MOMENTUM), bn.get('eps', BN_EPS), st.scale[sl],
+                            st.shift[sl], st.mean[sl], st.rstd[sl], centered=centered)
         elif not self._pre:       # (eval states are normally pre-filled by _eval_table)
-            ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], BN_EPS, n, st.scale[sl], st.shift[sl],
-                        centered=centered)
+            ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], bn.get('eps', BN_EPS), n, st.scale[sl],
+                        st.shift[sl], centered=centered)
 
-    def _eval_table(self, inp, bufs, dev):
+    def _eval_table(self, inp, bufs, dev, need_grad=False):
         """Eval mode: scale/shift of EVERY BatchNorm in one launch (they depend on parameters and running statistics only).
-        Returns {state name: (scale, shift)} views into one table; a state that spans two BatchNorms (bn_1|bn_2, lcat|gcat) gets
-        their concatenation."""
+        Returns {state name: (scale, shift, mean, rstd)} views into one table; a state that spans two BatchNorms (bn_1|bn_2,
+        lcat|gcat) gets their concatenation.  mean / rstd (running statistics) are only filled when a backward pass may follow
+        (need_grad: frozen-BatchNorm fine-tuning, gradients of an eval-mode forward), else None."""
         sp = self.spec
         L = len(sp.fw)
         groups = [('bn0', ['init_bn']), ('bnE', ['expand_bn'])]
@@ -139,18 +149,26 @@ class Engine:
                 groups += [('l%d.bn1' % s, ['l%d.bn0' % s]), ('l%d.bn2' % s, ['l%d.bn1' % s])]
             groups += [(g + 'bnY', [g + 'bn_1', g + 'bn_2']), (g + 'bnLG', [g + 'lcat_bn', g + 'gcat_bn']), (g + 'bnO', [g + 'cat_bn'])]
         total = sum((sum(inp[k + '.weight'].numel() for k in keys) + 3) // 4 * 4 for _, keys in groups)
-        table = torch.empty(2, total, dtype=torch.float32, device=dev)
-        jobs, out, o = [], {}, 0
+        if need_grad and self.centered:
+            raise NotImplementedError('gradients of an eval-mode forward are not available with GAST_HIP_CENTER=1')
+        table = torch.empty(4 if need_grad else 2, total, dtype=torch.float32, device=dev)
+        jobs, out, o = {}, {}, 0
         for name, keys in groups:
             o = (o + 3) // 4 * 4              # consumers load scale/shift with 16-byte accesses
             o0 = o
             for k in keys:
                 n = inp[k + '.weight'].numel()
-                jobs.append((inp[k + '.weight'], inp[k + '.bias'], bufs[k]['running_mean'], bufs[k]['running_var'], table[0, o:o + n],
-                             table[1, o:o + n], self.centered and k != 'init_bn'))      # the network input is never stored centred
+                eps = bufs[k].get('eps', BN_EPS)
+                jobs.setdefault(eps, []).append((inp[k + '.weight'], inp[k + '.bias'], bufs[k]['running_mean'], bufs[k]['running_var'],
+                                                 table[0, o:o + n], table[1, o:o + n],
+                                                 self.centered and k != 'init_bn'))      # the network input is never stored centred
+                if need_grad:     # parameter-sized torch ops, off the inference path
+                    table[2, o:o + n] = bufs[k]['running_mean']
+                    table[3, o:o + n] = torch.rsqrt(bufs[k]['running_var'].float() + eps)
                 o += n
-            out[name] = (table[0, o0:o], table[1, o0:o])
-        self.ops.bn_eval_multi(jobs, BN_EPS)
+            out[name] = (table[0, o0:o], table[1, o0:o], table[2, o0:o] if need_grad else None, table[3, o0:o] if need_grad else None)
+        for eps, js in jobs.items():          # one launch per distinct eps (the reference uses the default everywhere)
+            self.ops.bn_eval_multi(js, eps)
         return out
 
     def _bn_forward_group(self, items, training, centered=False):
@@ -165,7 +183,7 @@ class Engine:
             sl = slice(off, off + n)
             jobs.append(dict(partials=partials, nblk=nblk, col0=col0, N=n, count=count, gamma=bn['weight'], beta=bn['bias'],
                              running_mean=bn['running_mean'], running_var=bn['running_var'], nbt=bn['num_batches_tracked'],
-                             momentum=BN_MOMENTUM, eps=BN_EPS, scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl],
+                             momentum=bn.get('momentum', BN_MOMENTUM), eps=bn.get('eps', BN_EPS), scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl],
                              rstd=st.rstd[sl], centered=centered))
         self.ops.bn_finalize_multi(jobs)
 
@@ -195,9 +213,11 @@ class Engine:
             torch.cuda.current_stream(side.device).wait_stream(side)
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, x, inp, bufs, training, act_dtype, drop):
+    def forward(self, x, inp, bufs, training, act_dtype, drop, need_grad=True):
         """x: (B,T,J,F_in) fp32 contiguous device tensor.  inp: dict of packed fp32 tensors (see ModelSpec.pack).
-        bufs: dict of BN buffer dicts.  Returns (pred (B,T',J,3) fp32, saved dict for backward)."""
+        bufs: dict of BN buffer dicts (+ momentum / eps of each module).  need_grad: a backward pass may follow (only matters in
+        eval mode, where the BatchNorm states then also carry the running mean / rstd).
+        Returns (pred (B,T',J,3) fp32, saved dict for backward)."""
         sp, ops = self.spec, self.ops
         dev = x.device
         B, T_in, J, F_in = x.shape
@@ -207,7 +227,7 @@ class Engine:
         use_drop = training and drop is not None and drop.thresh != 0
         za = self.za
         za.begin(('fwd', tuple(x.shape), dt, training), dev)
-        self._pre = {} if training else self._eval_table(inp, bufs, dev)
+        self._pre = {} if training else self._eval_table(inp, bufs, dev, need_grad)
         pre = self._pre.get
 
         # ---- init_bn statistics + expand conv (gast_net.py:163-164)

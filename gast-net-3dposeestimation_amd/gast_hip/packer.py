@@ -50,10 +50,14 @@ class Layout:
 
 
 class Packer:
-    def __init__(self, model, spec):
+    def __init__(self, model, spec, named=None):
+        """named: explicit (name, tensor) list in `named_parameters()` order -- for nn.DataParallel replicas, whose parameters are
+        plain tensor attributes (model/gast_net.py: replica_parameters)."""
         self.spec = spec
-        self.params = [p for p in model.parameters()]
-        self.names = [n for n, _ in model.named_parameters()]
+        if named is None:
+            named = list(model.named_parameters())
+        self.params = [p for _, p in named]
+        self.names = [n for n, _ in named]
         self.index = {id(p): i for i, p in enumerate(self.params)}
         self.goff = []
         off = 0

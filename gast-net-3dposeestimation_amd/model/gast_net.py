@@ -18,7 +18,9 @@ Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (defa
 (fp32 storage, every GEMM product as bf16 hi/lo split products on the bf16 matrix cores: fp32-class results) or `bf16`
 (bf16 activations/weights, fp32 accumulate/statistics).
 """
+import contextlib
 import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -102,7 +104,12 @@ def bn_buffers(model):
     bufs = {}
 
     def add(key, bn):
-        bufs[key] = {'running_mean': bn.running_mean, 'running_var': bn.running_var, 'num_batches_tracked': bn.num_batches_tracked}
+        if not bn.track_running_stats or bn.momentum is None or not bn.affine:
+            raise NotImplementedError('gast_net (MI355X build): %s needs affine=True, track_running_stats=True and a numeric momentum '
+                                      '(the reference constructs BatchNorm2d(momentum=0.1))' % key)
+        # momentum / eps are read from the module on every call, so a VideoPose3D-style `bn.momentum = m` decay schedule works
+        bufs[key] = {'running_mean': bn.running_mean, 'running_var': bn.running_var, 'num_batches_tracked': bn.num_batches_tracked,
+                     'momentum': float(bn.momentum), 'eps': float(bn.eps)}
     add('init_bn', model.init_bn)
     add('expand_bn', model.expand_bn)
     for s, gab in enumerate(model.layers_graph_conv):
@@ -117,41 +124,65 @@ def bn_buffers(model):
     return bufs
 
 
+def replica_parameters(model):
+    """(name, tensor) of a DataParallel replica in `named_parameters()` order.  `Module._replicate_for_data_parallel` empties
+    `_parameters`; torch.nn.parallel.replicate then sets every broadcast copy as a plain attribute and records it, in registration
+    order, in the replica module's `_former_parameters`."""
+    out = []
+    for mname, mod in model.named_modules():
+        former = getattr(mod, '_former_parameters', None)
+        if former is None:
+            raise RuntimeError('gast_net (MI355X build): %r is marked as a replica but carries no _former_parameters; use '
+                               'torch.nn.DataParallel / torch.nn.parallel.replicate, or one process per GPU' % (mname or 'model'))
+        for k, t in former.items():
+            out.append(((mname + '.' if mname else '') + k, t))
+    return out
+
+
 class _GastFunction(torch.autograd.Function):
     """forward/backward of the whole spatio-temporal path as one autograd node.  Inputs: x and the raw parameters (in
     `model.parameters()` order); the packed operands are produced by one pack launch, the parameter gradients by one unpack
     launch out of a single flat fp32 buffer."""
 
     @staticmethod
-    def forward(ctx, runner, x, training, packer, st, bufs, *params):
-        ops = runner.engine.ops
+    def forward(ctx, runner, x, training, packer, st, bufs, engine, sink, *params):
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
+                               'reference never asks for it); pass x with requires_grad=False')
+        ops = engine.ops
         ops.run_pack(packer, st)
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
-        runner.engine.centered = runner.centered
+        engine.centered = runner.centered
         ops.x3 = runner.x3
-        pred, sv = runner.engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device))
-        ctx.runner, ctx.packer, ctx.st, ctx.inp, ctx.sv = runner, packer, st, inp, sv
+        pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
+                                  need_grad=any(ctx.needs_input_grad))
+        ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink = engine, packer, st, inp, sv, sink
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
-        runner, packer, st = ctx.runner, ctx.packer, ctx.st
+        engine, packer, st = ctx.engine, ctx.packer, ctx.st
+        if ctx.sv is None:
+            raise RuntimeError('gast_net (MI355X build): backward through the same forward a second time is not supported (the saved '
+                               'activations are released by the first backward, retain_graph has no effect); run forward again')
         dev = dpred.device
-        sink = runner.grad_sink
+        sink = ctx.sink
         # Every gradient kernel ACCUMULATES into its destination (split-M atomics, += for the directly written BatchNorm / e /
         # expand gradients, accumulate-mode unpack): G is either a fresh zero buffer or the caller's flat gradient buffer
-        # (FlatGradAllReduce / FlatAdam), which then sums over backward calls like autograd's .grad does.
-        G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
-        Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
-        gout = packer.grad_outputs(G, Sb)
-        runner.engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
-        ctx.sv = None
-        runner.engine.ops.run_unpack(packer, st, Sb, G, True)
+        # (FlatGradAllReduce / FlatAdam), which then sums over backward calls like autograd's .grad does.  With such a sink the
+        # gradients are NOT returned to autograd (hooks / torch.autograd.grad see None): they are already where p.grad points.
+        with torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext():
+            G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
+            Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
+            gout = packer.grad_outputs(G, Sb)
+            engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
+            ctx.sv = None
+            engine.ops.run_unpack(packer, st, Sb, G, True)
         if sink is not None:
-            return (None,) * 6 + (None,) * len(packer.params)
-        return (None,) * 6 + tuple(packer.grad_views(G))
+            return (None,) * 8 + (None,) * len(packer.params)
+        return (None,) * 8 + tuple(packer.grad_views(G))
 
 
 class _Runner:
@@ -161,6 +192,8 @@ class _Runner:
         self.spec = spec
         self.p_dropout = float(p_dropout)
         self._engine = None
+        self._engines = {}        # nn.DataParallel replicas: one engine (zero arena, queues, eval tables) per device
+        self._lock = threading.Lock()
         self._packer = None
         self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
         self._seeds = {}
@@ -169,8 +202,12 @@ class _Runner:
         self.ops_factory = None
 
     def __getstate__(self):
-        return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_packer': None, 'grad_sink': None, '_seeds': {},
-                'ops_factory': None}
+        return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
+                '_seeds': {}, 'ops_factory': None}
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self._lock = threading.Lock()
 
     @property
     def act_dtype(self):
@@ -193,16 +230,30 @@ class _Runner:
         and a running_mean that does not match the data (fresh fine-tuning set) would make it worse, hence opt-in."""
         return os.environ.get('GAST_HIP_CENTER', '0').lower() not in ('0', 'off', 'false', '')
 
+    def _new_engine(self):
+        if self.ops_factory is not None:
+            ops = self.ops_factory()
+        else:
+            from gast_hip.binding import HipOps
+            ops = HipOps()
+        return Engine(self.spec, ops)
+
     @property
     def engine(self):
         if self._engine is None:
-            if self.ops_factory is not None:
-                ops = self.ops_factory()
-            else:
-                from gast_hip.binding import HipOps
-                ops = HipOps()
-            self._engine = Engine(self.spec, ops)
+            self._engine = self._new_engine()
         return self._engine
+
+    def engine_for(self, dev):
+        """The engine of a DataParallel replica on `dev`: replicas run concurrently in threads and share this runner through the
+        shallow __dict__ copy of `_replicate_for_data_parallel`, so each device gets its own engine and op set (the mutable state of
+        a pass lives there)."""
+        key = str(dev)
+        with self._lock:
+            eng = self._engines.get(key)
+            if eng is None:
+                eng = self._engines[key] = self._new_engine()
+        return eng
 
     def dropout_state(self, training, dev):
         """A fresh dropout stream per training forward: the seed lives on the device (graph-capture friendly)."""
@@ -211,9 +262,10 @@ class _Runner:
         from gast_hip.binding import Dropout, dropout_params
         thresh, inv_keep = dropout_params(self.p_dropout)
         key = str(dev)
-        if key not in self._seeds:
-            s = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            self._seeds[key] = torch.tensor([s], dtype=torch.int32, device=dev)
+        with self._lock:
+            if key not in self._seeds:
+                s = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+                self._seeds[key] = torch.tensor([s], dtype=torch.int32, device=dev)
         seed = self._seeds[key]
         seed.add_(1)
         return Dropout(seed.clone(), thresh, inv_keep)
@@ -304,12 +356,27 @@ class SpatioTemporalModelBase(nn.Module):
             raise RuntimeError('gast_net (MI355X build): input is on %s. This implementation has no CPU fallback; move the '
                                'model and the batch to the GPU (`.cuda()`).' % x.device)
         x = x.contiguous().float()
-        if runner._packer is None or runner._packer.params[0] is not next(self.parameters()):
-            from gast_hip.packer import Packer
-            runner._packer = Packer(self, runner.spec)
-        packer = runner._packer
-        st = packer.state(x.device, runner.act_dtype)
-        return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), *packer.params)
+        from gast_hip.packer import Packer
+        with torch.cuda.device(x.device) if x.is_cuda else contextlib.nullcontext():    # kernels go to the stream of x's device
+            if getattr(self, '_is_replica', False):
+                # nn.DataParallel replica (reference trainval.py:56-61): its parameters are the broadcast, non-leaf copies held as
+                # plain attributes (`_parameters` is empty), fresh on every forward, and the runner object is shared with the other
+                # replicas' threads -- so: parameters by attribute walk, packing tables rebuilt for this call, a per-device engine,
+                # gradients returned to autograd (which reduces them onto the source device).  This is the compatibility path;
+                # one process per GPU with gast_hip.dist.FlatGradAllReduce is the fast one.
+                named = replica_parameters(self)
+                packer = Packer(self, runner.spec, named=named)
+                engine, sink = runner.engine_for(x.device), None
+            else:
+                first = next(self.parameters())
+                if first.device != x.device:
+                    raise RuntimeError('gast_net (MI355X build): the model is on %s, the batch on %s' % (first.device, x.device))
+                if runner._packer is None or runner._packer.params[0] is not first:
+                    runner._packer = Packer(self, runner.spec)
+                packer = runner._packer
+                engine, sink = runner.engine, runner.grad_sink
+            st = packer.state(x.device, runner.act_dtype)
+            return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, *packer.params)
 
 
 class SpatioTemporalModel(SpatioTemporalModelBase):

@@ -561,3 +561,69 @@ def test_dropout_gradients_by_finite_differences():
         an = float((grads[name] * v).sum())
         _log(test='dropout_fd', param=name, fd=fd, analytic=an)
         assert abs(fd - an) < 6e-2 * max(abs(an), abs(fd)) + 2e-4, (name, fd, an)
+
+
+def test_eval_mode_gradients_on_gpu():
+    """Gradients of an eval-mode forward (frozen BatchNorm): BatchNorm backward with the running statistics, vs the oracle."""
+    from oracle import gast_oracle as go
+    os.environ['GAST_HIP_DTYPE'] = 'fp32'
+    cfg, z, state, grads, post = load_golden('j17_a333_c16_dil')
+    m = build(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    _random_state(m, torch.Generator().manual_seed(3))
+    st = {k: v.detach().numpy().copy() for k, v in m.state_dict().items()}
+    om = go.OracleModel(go.adj_from_parents(cfg['parents']), cfg['arc'], cfg['channels'], causal=cfg['causal'], variant=cfg['variant'])
+    loss_ref, y_ref, g_ref, _ = om.loss_and_grads(st, z['x'], z['y3d'], training=False)
+    m.cuda().eval()
+    y = m(torch.from_numpy(z['x']).cuda())
+    loss = torch.mean(torch.norm(y - torch.from_numpy(z['y3d']).cuda(), dim=-1))
+    loss.backward()
+    assert float(np.abs(y.detach().cpu().numpy() - y_ref).max()) < 1e-4
+    assert abs(loss.item() - loss_ref) < 1e-5
+    worst = _grad_errors(m, g_ref, FP32_GRAD_TOL)
+    assert worst[1] <= 1.0, worst
+    for k, b in m.named_buffers():
+        np.testing.assert_array_equal(b.cpu().numpy(), st[k], err_msg=k)
+
+
+def test_data_parallel_replicas():
+    """reference trainval.py:56-61 wraps the model in nn.DataParallel whenever more than one GPU is visible.  (a) the replicas
+    torch.nn.parallel.replicate makes (broadcast, non-leaf parameter copies; here two on the one device, run one after the other)
+    reproduce the master's outputs and send their gradients back to the master's parameters; (b) with >= 2 GPUs the real
+    nn.DataParallel(device_ids=[0, 1]) forward/backward equals the single-device result on the two half batches."""
+    os.environ['GAST_HIP_DTYPE'] = 'fp32'
+    cfg, z, state, grads, post = load_golden('j17_a333_c16_dil')
+    m = build(cfg)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
+    m.cuda().train()
+    x, y3d = torch.from_numpy(z['x']).cuda(), torch.from_numpy(z['y3d']).cuda()
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    y0 = m(x)
+    torch.mean(torch.norm(y0 - y3d, dim=-1)).backward()
+    g0 = {k: p.grad.clone() for k, p in m.named_parameters()}
+    m.zero_grad()
+    m.load_state_dict(sd)
+    reps = torch.nn.parallel.replicate(m, [0, 0])
+    assert len(list(reps[1].parameters())) == 0
+    y1 = reps[1](x)
+    torch.mean(torch.norm(y1 - y3d, dim=-1)).backward()
+    assert (y1 - y0).abs().max().item() < 1e-5
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert (p.grad - g0[k]).abs().max().item() <= 2e-4 * g0[k].abs().max().item() + 2e-5, k
+    if torch.cuda.device_count() < 2:
+        return
+    m.zero_grad()
+    m.load_state_dict(sd)
+    dp = torch.nn.DataParallel(m, device_ids=[0, 1])
+    B = x.shape[0] // 2 * 2
+    yd = dp(x[:B])
+    assert yd.shape[0] == B and torch.isfinite(yd).all()
+    torch.mean(torch.norm(yd - y3d[:B], dim=-1)).backward()
+    for k, p in m.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    # per-replica BatchNorm statistics (DataParallel semantics): each half equals a single-device forward of that half
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        ya = m(x[:B // 2])
+    assert (yd[:B // 2].detach() - ya).abs().max().item() < 1e-4
