@@ -145,7 +145,7 @@ class _GastFunction(torch.autograd.Function):
     launch out of a single flat fp32 buffer."""
 
     @staticmethod
-    def forward(ctx, runner, x, training, packer, st, bufs, engine, sink, *params):
+    def forward(ctx, runner, x, training, packer, st, bufs, engine, sink, need_grad, *params):
         if ctx.needs_input_grad[1]:
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
@@ -157,7 +157,7 @@ class _GastFunction(torch.autograd.Function):
         engine.centered = runner.centered
         ops.x3 = runner.x3
         pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
-                                  need_grad=any(ctx.needs_input_grad))
+                                  need_grad=need_grad)
         ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink = engine, packer, st, inp, sv, sink
         return pred
 
@@ -181,8 +181,8 @@ class _GastFunction(torch.autograd.Function):
             ctx.sv = None
             engine.ops.run_unpack(packer, st, Sb, G, True)
         if sink is not None:
-            return (None,) * 8 + (None,) * len(packer.params)
-        return (None,) * 8 + tuple(packer.grad_views(G))
+            return (None,) * 9 + (None,) * len(packer.params)
+        return (None,) * 9 + tuple(packer.grad_views(G))
 
 
 class _Runner:
@@ -376,7 +376,9 @@ class SpatioTemporalModelBase(nn.Module):
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
             st = packer.state(x.device, runner.act_dtype)
-            return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, *packer.params)
+            # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)
+            need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
+            return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)
 
 
 class SpatioTemporalModel(SpatioTemporalModelBase):
