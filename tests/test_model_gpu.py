@@ -385,7 +385,10 @@ def test_bf16_vs_fp32_full_size(monkeypatch):
     rel = {}
     for k, a in outs['fp32'][2].items():
         b = outs['bf16x3'][2][k]
-        if k not in ZERO_GRADS and a.abs().max() > 1e-3 * gmax:
+        # (the theta / phi / concat_project gradients are sums of cancelling softmax-backward terms whose true value is ~0 at
+        #  initialisation -- C_k = 0, rows of att sum to 1 -- i.e. round-off in ANY precision: fp32 itself is 1e-2 .. 1e-1 off the
+        #  float64 truth there, see test_full_size_values_against_stock_torch)
+        if k not in ZERO_GRADS and not k.endswith(BF16_NOISY) and a.abs().max() > 1e-3 * gmax:
             rel[k] = float((a.double() - b.double()).norm() / (a.double().norm() + 1e-300))
     kw = max(rel, key=rel.get)
     _log(test='bf16x3_vs_fp32_full_train', max_abs=d3, dmpjpe_mm=dl3, worst_grad_rel_l2=(kw, rel[kw]))
