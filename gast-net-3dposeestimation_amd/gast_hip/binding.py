@@ -580,21 +580,24 @@ class HipOps:
             st['tables'] = tb
         return tb
 
-    def _unpack_tables(self, packer, st, dev, accumulate):
+    def _unpack_tables(self, packer, st, dev, accumulate, bucket=None):
         tb = self._tables(packer, st, dev)
-        key = 'unpack%d' % int(accumulate)
+        key = 'unpack%d' % int(accumulate) + ('' if bucket is None else ':%d' % bucket)
         if key not in tb:
             from gast_hip.packer import BASE_G
-            cp = self._copy_table(packer.unpack_jobs, dev, 4, accumulate)
+            cjobs = packer.unpack_jobs if bucket is None else packer.unpack_by_bucket[bucket]
+            ujobs = packer.unfold_jobs if bucket is None else packer.unfold_by_bucket[bucket]
+            cp = self._copy_table(cjobs, dev, 4, accumulate) if cjobs else (None, None, 0)
             uw = []
-            for j in packer.unfold_jobs:
+            for j in ujobs:
                 gW = packer.goff[packer.index[id(j['W'])]] * 4
                 gw = (packer.goff[packer.index[id(j['w'])]] + j['woff']) * 4
                 gb = packer.goff[packer.index[id(j['b'])]] * 4
                 uw += [self._word(j['dv'], 4), self._word(j['da'], 4), (j['W'].data_ptr() << 4), ((j['w'].data_ptr() + j['woff'] * 4) << 4),
                        (j['b'].data_ptr() << 4), (gW << 4) | BASE_G, (gw << 4) | BASE_G, (gb << 4) | BASE_G, j['Ci'], j['C'],
                        int(accumulate), 0]
-            tb[key] = (cp, torch.tensor(uw, dtype=torch.int64).to(dev), len(packer.unfold_jobs))
+            tb[key] = (cp, torch.tensor(uw, dtype=torch.int64).to(dev) if uw else None, len(ujobs),
+                       max((j['Ci'] for j in ujobs), default=0))
         return tb[key]
 
     def _bases(self, **kw):
@@ -639,10 +642,15 @@ class HipOps:
         ft, nf = tb['fold']
         _check(self.lib.gast_fold(_p(ft), nf, max(j['C'] for j in packer.fold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
 
-    def run_unpack(self, packer, st, Sb, G, accumulate):
+    def run_unpack(self, packer, st, Sb, G, accumulate, bucket=None):
+        """packed gradient scratch -> parameter-shaped gradients in the flat buffer; bucket = i: only the jobs whose destination
+        lies in packer.bucket_ranges[i] (Packer.set_buckets)."""
         dev = G.device
-        (jt, tt, nt), ut, nu = self._unpack_tables(packer, st, dev, accumulate)
+        (jt, tt, nt), ut, nu, maxci = self._unpack_tables(packer, st, dev, accumulate, bucket)
         bases = self._bases(S=Sb, G=G)
-        self.launches += 2
-        _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
-        _check(self.lib.gast_unfold(_p(ut), nu, max(j['Ci'] for j in packer.unfold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_unfold')
+        if nt:
+            self.launches += 1
+            _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
+        if nu:
+            self.launches += 1
+            _check(self.lib.gast_unfold(_p(ut), nu, maxci, C.cast(bases, C.c_void_p), _stream()), 'gast_unfold')

@@ -11,9 +11,19 @@ import torch.distributed as dist
 
 
 class FlatGradAllReduce:
-    """Makes every `p.grad` a view into one flat buffer and averages that buffer over the process group."""
+    """Makes every `p.grad` a view into one flat buffer and averages that buffer over the process group.
 
-    def __init__(self, params, process_group=None, model=None):
+    buckets = 1 (default): ONE all-reduce of the whole buffer in `sync()`, after backward.
+    buckets > 1 (needs `model=`): the buffer is cut, in parameter order, into the ranges whose gradients are complete at the same
+    point of the backward pass -- [layers_graph_conv.L-1], ..., [layers_graph_conv.1], [everything else] -- and each range is
+    all-reduced on a communication stream as soon as the engine reports its stage done (gast_hip/engine.py: `stage_done`), so the
+    exchange of the deepest block (2/3 of the parameters) overlaps the backward pass of the shallower stages; `sync()` then only
+    makes the compute stream wait for the communication stream.  Both modes produce identical sums (tests/test_dist_cpu.py).
+
+    The 1/world factor: applied in `sync()` by default; `attach(optimizer)` moves it into FlatAdam's `grad_scale` (one launch less
+    and one pass over the buffer less per step)."""
+
+    def __init__(self, params, process_group=None, model=None, buckets=1):
         """model: optional GAST model whose backward should accumulate straight into the flat buffer (skips 165 per-parameter
         AccumulateGrad kernels); `params` must then be `model.parameters()` in order."""
         self.params = [p for p in params if p.requires_grad]
@@ -26,21 +36,86 @@ class FlatGradAllReduce:
         for p in self.params:
             p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.force = False          # True: issue the collective even for a single rank (bench.py --force-collective)
+        self.scale_in_optimizer = False
+        self.ranges = [(0, n)]      # completion order
+        self._comm = None
+        self._issued = 0
         if model is not None and hasattr(model, '_runner'):
             if [id(p) for p in model.parameters()] != [id(p) for p in self.params]:
                 raise ValueError('FlatGradAllReduce(model=...) needs params == list(model.parameters())')
             model._runner.grad_sink = self.flat
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.force = False          # True: issue the collective even for a single rank (bench.py --force-collective)
+            if buckets > 1:
+                self.ranges = self._stage_ranges(model, n)
+                model._runner.grad_sync = self
+        elif buckets > 1:
+            raise ValueError('bucketed exchange needs model= (the engine reports when a stage\'s gradients are complete)')
+
+    @staticmethod
+    def _stage_ranges(model, n):
+        """[(start, end)] of the flat buffer in completion order: the blocks layers_graph_conv.{L-1 .. 1} (contiguous and last in
+        registration order, reference gast_net.py:155-157), then the rest [0, start of block 1)."""
+        starts, off = {}, 0
+        for name, p in model.named_parameters():
+            if name.startswith('layers_graph_conv.'):
+                starts.setdefault(int(name.split('.')[1]), off)
+            off += p.numel()
+        L = len(starts)
+        if L < 2:
+            return [(0, n)]
+        ends = {s: (starts[s + 1] if s + 1 < L else n) for s in range(L)}
+        assert all(starts[s] < ends[s] for s in range(L)) and ends[L - 1] == n, 'graph-conv blocks are not the tail of parameters()'
+        return [(starts[s], ends[s]) for s in range(L - 1, 0, -1)] + [(0, starts[1])]
+
+    def bucket_of_stage(self, s):
+        """index into `ranges` of the bucket that is complete when stage s >= 1 of the backward pass is done"""
+        return len(self.ranges) - 1 - s
+
+    def attach(self, optimizer):
+        """Fold the 1/world averaging into the optimizer's gradient scale (gast_hip.optim.FlatAdam)."""
+        if not hasattr(optimizer, 'grad_scale'):
+            raise TypeError('attach() needs an optimizer with a grad_scale attribute (gast_hip.optim.FlatAdam)')
+        optimizer.grad_scale = 1.0 / self.world
+        self.scale_in_optimizer = True
+        return self
 
     def zero_(self):
         self.flat.zero_()
+        self._issued = 0
+
+    def _active(self):
+        return self.world > 1 or self.force
+
+    def bucket_ready(self, i):
+        """Called by the model's backward (bucketed mode) when `ranges[i]` holds its final local gradients."""
+        assert i == self._issued, 'buckets complete in order'
+        self._issued += 1
+        if not self._active():
+            return
+        a, b = self.ranges[i]
+        if self.flat.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream(device=self.flat.device)
+            self._comm.wait_stream(torch.cuda.current_stream(self.flat.device))
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            dist.all_reduce(self.flat[a:b], op=dist.ReduceOp.SUM, group=self.group)
 
     def sync(self):
         """sum over ranks / world size, in place; no-op for a single process."""
-        if self.world > 1 or self.force:
+        if not self._active():
+            return
+        if len(self.ranges) > 1:
+            if self._issued != len(self.ranges):
+                raise RuntimeError('bucketed all-reduce: %d of %d buckets were issued by backward()' % (self._issued, len(self.ranges)))
+            if self._comm is not None:
+                torch.cuda.current_stream(self.flat.device).wait_stream(self._comm)
+        else:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+        if not self.scale_in_optimizer:
             self.flat.mul_(1.0 / self.world)
 
     def nbytes(self):

@@ -473,10 +473,12 @@ class Engine:
             ops.bn_bwd_apply(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n])
             o += n
 
-    def backward(self, sv, inp, dpred, gout):
+    def backward(self, sv, inp, dpred, gout, stage_done=None):
         """dpred: (B,T',J,3) fp32.  Every gradient is written into its destination `gout[key]` (packed fp32 scratch
         regions for the GEMM operands, views of the flat gradient buffer for directly-held parameters).  The destinations must
-        arrive ZERO-FILLED: split-M weight gradients, column sums and dC_k accumulate into them with atomics."""
+        arrive ZERO-FILLED: split-M weight gradients, column sums and dC_k accumulate into them with atomics.
+        stage_done(s), if given, is called for s = L-1 .. 1 as soon as every gradient of GraphAttentionBlock s has been enqueued
+        (its weight gradients flushed, its adjacency-softmax backward run): the hook of the bucketed gradient exchange."""
         sp, ops = self.spec, self.ops
         dev = dpred.device
         B, dt, drop = sv['B'], sv['dt'], sv['drop']
@@ -573,6 +575,11 @@ class Engine:
             self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
             dO = dOp
             self._wgrad_flush()
+            if stage_done is not None:
+                ops.semch_adj_bwd_multi(self._adjq, accumulate=True)     # (otherwise: one launch for all blocks at the end)
+                self._adjq = []
+                self._join(self._wside)
+                stage_done(s)
 
         # ---- expand conv + init_bn backward (dX is the gradient w.r.t. relu(expand_bn(E)))
         P0 = B * T[0] * J

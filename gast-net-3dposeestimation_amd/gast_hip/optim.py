@@ -18,6 +18,7 @@ class FlatAdam(torch.optim.Optimizer):
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super().__init__(params, defaults)
         self._ops = ops
+        self.grad_scale = 1.0      # gradients are multiplied by this inside the update kernel (1/world after a SUM all-reduce)
         self._flat = []
         for group in self.param_groups:
             ps = [p for p in group['params'] if p.requires_grad]
@@ -104,7 +105,8 @@ class FlatAdam(torch.optim.Optimizer):
             G = self._grad_buffer(st)
             b1, b2 = group['betas']
             self._get_ops().adam_step(st['P'], G, st['m'], st['v'], st['vmax'] if group['amsgrad'] else None, st['step'],
-                                      float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']))
+                                      float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
+                                      grad_scale=float(self.grad_scale))
         return loss
 
     # ------------------------------------------------------------------ (de)serialisation in torch.optim.Adam's per-parameter format

@@ -163,6 +163,31 @@ class Packer:
         self._block(m.shrink.weight, 0, 3, CL, CL, 1, 'shrink', 0, 'shrinkT')
         self.direct_index = {k: self.index[id(p)] for k, p in d.items()}
 
+    # ------------------------------------------------------------------------------------------ gradient buckets
+    def set_buckets(self, ranges):
+        """ranges: [(start, end)] of the flat gradient buffer (gast_hip.dist.FlatGradAllReduce.ranges).  Splits the unpack / unfold
+        job lists by the bucket their destination parameter lies in, so that a bucket can be completed (ops.run_unpack(...,
+        bucket=i)) and exchanged while the rest of the backward pass is still running."""
+        ranges = [tuple(r) for r in ranges]
+        if getattr(self, 'bucket_ranges', None) == ranges:
+            return
+        def bucket_of(off):
+            for i, (a, b) in enumerate(ranges):
+                if a <= off < b:
+                    return i
+            raise ValueError('gradient offset %d outside every bucket' % off)
+        self.unpack_by_bucket = [[] for _ in ranges]
+        self.unfold_by_bucket = [[] for _ in ranges]
+        for job in self.unpack_jobs:
+            self.unpack_by_bucket[bucket_of(job[1].off)].append(job)
+        for j in self.unfold_jobs:
+            self.unfold_by_bucket[bucket_of(self.goff[self.index[id(j['W'])]])].append(j)
+        self.bucket_ranges = ranges
+        for st in self._dev.values():       # device tables of the unbucketed lists stay valid; bucket tables are built on demand
+            if st.get('tables'):
+                for k in [k for k in st['tables'] if k.startswith('unpack') and ':' in k]:
+                    del st['tables'][k]
+
     # ------------------------------------------------------------------------------------------ buffers
     def state(self, dev, dt):
         """Per (device, dtype) persistent buffers + device job tables."""

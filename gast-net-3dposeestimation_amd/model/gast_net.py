@@ -158,7 +158,7 @@ class _GastFunction(torch.autograd.Function):
         ops.x3 = runner.x3
         pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
                                   need_grad=need_grad)
-        ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink = engine, packer, st, inp, sv, sink
+        ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink, ctx.runner = engine, packer, st, inp, sv, sink, runner
         return pred
 
     @staticmethod
@@ -177,9 +177,24 @@ class _GastFunction(torch.autograd.Function):
             G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
             Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
             gout = packer.grad_outputs(G, Sb)
-            engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
-            ctx.sv = None
-            engine.ops.run_unpack(packer, st, Sb, G, True)
+            gs = ctx.runner.grad_sync if sink is not None else None
+            if gs is not None and len(gs.ranges) > 1 and gs.flat is sink:
+                # bucketed exchange (gast_hip/dist.py): complete and hand over each bucket of the flat buffer as soon as its stage is done
+                packer.set_buckets(gs.ranges)
+
+                def stage_done(s_):
+                    b = gs.bucket_of_stage(s_)
+                    engine.ops.run_unpack(packer, st, Sb, G, True, bucket=b)
+                    gs.bucket_ready(b)
+                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout, stage_done=stage_done)
+                ctx.sv = None
+                last = len(gs.ranges) - 1
+                engine.ops.run_unpack(packer, st, Sb, G, True, bucket=last)
+                gs.bucket_ready(last)
+            else:
+                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
+                ctx.sv = None
+                engine.ops.run_unpack(packer, st, Sb, G, True)
         if sink is not None:
             return (None,) * 9 + (None,) * len(packer.params)
         return (None,) * 9 + tuple(packer.grad_views(G))
@@ -196,6 +211,7 @@ class _Runner:
         self._lock = threading.Lock()
         self._packer = None
         self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
+        self.grad_sync = None     # optional gast_hip.dist.FlatGradAllReduce in bucketed mode: told when a bucket of grad_sink is complete
         self._seeds = {}
         # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
         # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
@@ -203,7 +219,7 @@ class _Runner:
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                '_seeds': {}, 'ops_factory': None}
+                'grad_sync': None, '_seeds': {}, 'ops_factory': None}
 
     def __setstate__(self, state):
         self.__dict__.update(state)

@@ -192,14 +192,14 @@ def _run_pack(self, packer, st):
         bases[BASE_F][j['bias'].off] = float((w * j['b'].detach().double()).sum())
 
 
-def _run_unpack(self, packer, st, Sb, G, accumulate):
+def _run_unpack(self, packer, st, Sb, G, accumulate, bucket=None):
     from gast_hip.packer import BASE_S, BASE_G
     bases = {BASE_S: Sb, BASE_G: G}
-    for src, dst, R, S in packer.unpack_jobs:
+    for src, dst, R, S in (packer.unpack_jobs if bucket is None else packer.unpack_by_bucket[bucket]):
         d = _resolve(dst, bases, R, S)
         v = _resolve(src, bases, R, S)
         d.add_(v) if accumulate else d.copy_(v)
-    for j in packer.unfold_jobs:
+    for j in (packer.unfold_jobs if bucket is None else packer.unfold_by_bucket[bucket]):
         Ci, Cc = j['Ci'], j['C']
         dv = torch.as_strided(Sb, (Cc,), (1,), j['dv'].off).double()
         da = float(Sb[j['da'].off])

@@ -11,7 +11,7 @@ import torch.multiprocessing as mp
 from conftest import ROOT, PKG
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, buckets=1, arc=(3, 3)):
     for p in (ROOT, PKG, os.path.join(ROOT, 'tests')):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -25,10 +25,10 @@ def _worker(rank, world, port, out_dir):
     from tests_helpers import PARENTS
     torch.manual_seed(0)                                   # identical replicas
     adj = torch.from_numpy(adj_from_parents(PARENTS[17]))
-    m = use_oracle_ops(SpatioTemporalModelOptimized1f(adj, 17, 2, 17, filter_widths=[3, 3], channels=16, dropout=0.0))
-    sync = FlatGradAllReduce(m.parameters(), model=m)     # backward accumulates straight into the flat buffer
+    m = use_oracle_ops(SpatioTemporalModelOptimized1f(adj, 17, 2, 17, filter_widths=list(arc), channels=16, dropout=0.0))
+    sync = FlatGradAllReduce(m.parameters(), model=m, buckets=buckets)     # backward accumulates straight into the flat buffer
     g = torch.Generator().manual_seed(7)
-    X = torch.rand(6, 9, 17, 2, generator=g) * 2 - 1       # the global batch; sharded on dim 0
+    X = torch.rand(6, int(np.prod(arc)), 17, 2, generator=g) * 2 - 1       # the global batch; sharded on dim 0
     Y = torch.randn(6, 1, 17, 3, generator=g) * 0.3
     idx = shard_batch(6, rank, world)
     m.train()
@@ -37,7 +37,7 @@ def _worker(rank, world, port, out_dir):
     loss.backward()
     local = sync.flat.clone()
     sync.sync()
-    torch.save({'local': local, 'synced': sync.flat.clone(), 'views_ok': all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in m.parameters())},
+    torch.save({'local': local, 'synced': sync.flat.clone(), 'ranges': sync.ranges, 'views_ok': all(p.grad.data_ptr() >= sync.flat.data_ptr() for p in m.parameters())},
                os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.destroy_process_group()
 
@@ -51,3 +51,20 @@ def test_flat_grad_allreduce_world2(tmp_path):
     expect = (r0['local'] + r1['local']) / 2
     assert torch.allclose(r0['synced'], expect, atol=1e-7) and torch.equal(r0['synced'], r1['synced'])
     assert (r0['local'] - r1['local']).abs().max() > 1e-6    # the ranks really saw different shards
+
+
+def test_bucketed_allreduce_equals_monolithic_world2(tmp_path):
+    """Three buckets (layers_graph_conv.2 | .1 | the rest), each all-reduced as soon as the engine reports its stage done, give the
+    same averaged gradients as the single all-reduce after backward."""
+    port = 31500 + (os.getpid() % 2000)
+    d1, d3 = tmp_path / 'mono', tmp_path / 'bucketed'
+    d1.mkdir(); d3.mkdir()
+    mp.spawn(_worker, args=(2, port, str(d1), 1, (3, 3, 3)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + 1, str(d3), 3, (3, 3, 3)), nprocs=2, join=True)
+    a0, b0 = torch.load(os.path.join(d1, 'rank0.pt')), torch.load(os.path.join(d3, 'rank0.pt'))
+    b1 = torch.load(os.path.join(d3, 'rank1.pt'))
+    assert len(b0['ranges']) == 3 and b0['ranges'][-1][0] == 0 and b0['ranges'][0][1] == a0['synced'].numel()
+    assert sorted(b0['ranges']) == [(b0['ranges'][2][0], b0['ranges'][2][1]), b0['ranges'][1], b0['ranges'][0]]
+    assert sum(e - s for s, e in b0['ranges']) == a0['synced'].numel()          # the buckets tile the buffer
+    # (in bucketed mode the exchange has already happened when backward() returns: only the final buffers are comparable)
+    assert torch.allclose(b0['synced'], a0['synced'], atol=1e-7, rtol=1e-6) and torch.equal(b0['synced'], b1['synced'])
