@@ -6,15 +6,26 @@
 One "step" = the reference's training step on one synthetic batch (reference main.py:227-239): zero_grad -> forward ->
 mpjpe -> backward -> [gradient all-reduce over RCCL when N>1] -> Adam(amsgrad) step, on
 BASELINE.json configs[1]: SpatioTemporalModel, J=17, filter_widths 3,3,3 (27-frame receptive field), channels=128,
-B=128 sequences of T=27 frames per GPU (weak scaling), dropout 0.05, bf16 activations/weights (fp32 accumulate, statistics,
-master weights).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+B=128 sequences of T=27 frames per GPU (weak scaling), dropout 0.05.  Inputs are resident in HBM before the timed region.
+Rank 0 prints ONE JSON line.  `--gpus N` without a torchrun environment re-launches itself through torch.distributed.run
+(one rank per GPU, 127.0.0.1 rendezvous).
+
+Arithmetic (`--dtype`, default bf16x3): every GEMM / weight-gradient product runs on the bf16 matrix cores
+(v_mfma_f32_32x32x16_bf16, fp32 accumulation).  `bf16x3` keeps storage in fp32 and forms each product from bf16 hi/lo pairs
+(hi*hi + hi*lo + lo*hi): it is the mode that meets the north-star tolerance in TRAIN mode at this size (outputs 7e-5 from the fp32
+path against a bound of 1e-2, MPJPE shift 0.001 mm against 0.1 mm).  Plain `bf16` storage (2.9 ms/step) is 4-5e-2 off in train
+mode -- a floor any bf16-operand implementation shares, tests/test_bf16_floor_cpu.py shows it on the reference's own operators --
+and is reported next to the headline in `other_dtypes` when `--all-dtypes` is given.
 
 Extra objects in that line:
   roofline     -- for the dominant kernel (the MFMA GEMM `gemm_kernel`): algorithmic FLOPs/bytes per launch (SURVEY.md
                   App. C formulas, evaluated per launch from its arguments) / average launch duration measured live with
-                  HIP events on the launch stream during the timed steps.
-  cpu_baseline -- the numpy oracle (oracle/gast_oracle.py, a port: the reference itself cannot travel to the GPU box) timed
-                  on this host's cores on a bounded sample of the same workload (rank 0, N=1 only).
+                  HIP events on the launch stream (hipGraph replay of the step's GEMM launches).
+  parity       -- measured in the same run, before the timed region: the timed arithmetic against the fp32 HIP path and against the
+                  CPU restatement of the reference (oracle/torch_ops.py) on the same weights and batch, train mode, dropout off.
+  cpu_baseline -- the reference's operator sequence restated on stock PyTorch CPU operators (oracle/torch_ops.py, pinned to the
+                  reference fixtures; the reference itself cannot travel to the GPU box) timed on this host's cores on a bounded
+                  sample of the same workload (rank 0, N=1 only).
 """
 import argparse
 import json
@@ -33,6 +44,17 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PARENTS17 = [-1, 0, 1, 2, 0, 4, 5, 0, 7, 8, 9, 8, 11, 12, 8, 14, 15]   # reference reconstruction.py:95
+PARENTS = {17: PARENTS17,
+           19: [-1, 0, 1, 2, 3, 0, 5, 6, 7, 0, 9, 10, 11, 10, 13, 14, 10, 16, 17],      # reference reconstruction.py:87
+           15: [-1, 0, 1, 2, 3, 1, 5, 6, 0, 8, 9, 0, 11, 12, 1]}                        # reference common/humaneva_dataset.py:7
+# BASELINE.json configs[1..4] (per-GPU batch; configs[3] and [4] quote a global batch over 8 GPUs).  cfg1 is the metric's config.
+CONFIGS = {
+    'cfg1': dict(J=17, arc=[3, 3, 3], channels=128, batch=128, what='configs[1]: 17 joints, arc 3,3,3 (RF 27), B=128'),
+    'cfg2': dict(J=17, arc=[3, 3, 3, 3], channels=64, batch=256, what='configs[2]: 17 joints, arc 3,3,3,3 (RF 81), B=256, channels=64 '
+                 '(final width 1024 as in the shipped 81-frame checkpoints)'),
+    'cfg3': dict(J=19, arc=[3, 3, 3], channels=128, batch=64, what='configs[3]: 19-joint body+foot, arc 3,3,3, B=512 over 8 GPUs = 64 per GPU'),
+    'cfg4': dict(J=15, arc=[3, 3, 3], channels=128, batch=4, what='configs[4]: HumanEva-15, arc 3,3,3, B=32 over 8 GPUs = 4 per GPU'),
+}
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3}   # dense peaks (bf16x3: three bf16 products per FLOP pair)
 
@@ -242,7 +264,7 @@ class KernelTimer:
 
 
 # --------------------------------------------------------------------------------------------------------- cpu baseline
-def _stock_steps(device, autocast_bf16, B, budget_s, max_steps, warm_B=None):
+def _stock_steps(device, autocast_bf16, B, budget_s, max_steps, warm_B=None, min_steps=1):
     """Training steps (reference main.py:227-239: zero_grad, forward, mpjpe, backward, Adam amsgrad) of the oracle's
     restatement of the model on STOCK PyTorch operators (oracle/torch_ops.py: F.conv2d / F.batch_norm / matmul / softmax / cat,
     torch autograd) -- the operator sequence the reference issues -- on `device`.  Returns (steps, seconds)."""
@@ -275,25 +297,37 @@ def _stock_steps(device, autocast_bf16, B, budget_s, max_steps, warm_B=None):
         sync()
         t0 = time.time()
         n = 0
-        while n < max_steps and (n == 0 or time.time() - t0 < budget_s):
+        while n < max_steps and (n < min_steps or time.time() - t0 < budget_s):
             step(x, y)
             n += 1
         sync()
         return n, time.time() - t0
 
 
-def cpu_baseline(seconds_budget=20.0):
-    """The reference's CPU path restated on the same stock PyTorch CPU operators (ATen / oneDNN), all host cores, bounded sample."""
+def cpu_baseline(seconds_budget=45.0):
+    """The reference's CPU path restated on the same stock PyTorch CPU operators (ATen / oneDNN), all host cores, bounded sample:
+    one full-size untimed warm-up step, then 3 timed steps (more only if they fit the budget)."""
     B = 128
     threads = torch.get_num_threads()
-    n, dt = _stock_steps('cpu', False, B, seconds_budget, 3, warm_B=8)
+    n, dt = _stock_steps('cpu', False, B, seconds_budget, 6, warm_B=B, min_steps=3)
     return dict(value=round(B * n / dt, 3), unit='sequences/s', cores=int(threads), kind='port',
                 host_cpus=os.cpu_count(),
-                sample='%d full training step(s) (zero_grad+fwd+mpjpe+bwd+Adam amsgrad, fp32, B=128 T=27 J=17 C=128, dropout 0.05) of '
-                       'the oracle restatement on stock PyTorch CPU operators (oracle/torch_ops.py: the ATen operator sequence the '
-                       'reference issues; pinned to the reference fixtures by tests/test_oracle_golden.py), %d torch threads; the '
-                       'reference itself cannot travel to this box -- it measured 13.6 seq/s on 8 Xeon cores in the build '
-                       'container (BASELINE.md section 2)' % (n, threads))
+                sample='%d full training steps after one full-size warm-up step (zero_grad+fwd+mpjpe+bwd+Adam amsgrad, fp32, B=128 T=27 '
+                       'J=17 C=128, dropout 0.05) of the oracle restatement on stock PyTorch CPU operators (oracle/torch_ops.py: the '
+                       'ATen operator sequence the reference issues; pinned to the reference fixtures by tests/test_oracle_golden.py), '
+                       '%d torch threads; the reference itself cannot travel to this box -- it measured 13.6 seq/s on 8 Xeon cores in '
+                       'the build container (BASELINE.md section 2)' % (n, threads))
+
+
+def cpu_reference_forward(state, adj, fw, channels, x, y3d):
+    """Train-mode forward (batch statistics, dropout off) of the CPU restatement of the reference on `state` / `x`: (pred, mpjpe)."""
+    from oracle import gast_oracle as go
+    from oracle import torch_ops
+    with go.use_backend(torch_ops), torch.no_grad():
+        om = go.OracleModel(adj.numpy(), list(fw), channels, dropout=0.0, dtype=torch.float32)
+        pred, _ = om.forward({k: v.detach().cpu() for k, v in state.items()}, x.cpu(), training=True)
+    p = pred.v.float()
+    return p, float(torch.mean(torch.norm(p - y3d.cpu(), dim=-1)))
 
 
 def stock_gpu_baseline():
@@ -314,9 +348,15 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16'), choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32'])
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
-    ap.add_argument('--batch', type=int, default=128)
+    ap.add_argument('--config', default='cfg1', choices=sorted(CONFIGS), help='BASELINE.json configs[1..4]; cfg1 is the metric')
+    ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
+    ap.add_argument('--channels', type=int, default=None)
+    ap.add_argument('--overlap', action='store_true',
+                    help='N > 1: bucketed gradient exchange -- each stage\'s bucket is all-reduced on a communication stream while the '
+                         'backward pass of the shallower stages runs (default: one all-reduce between the two graphs of the step)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the parity object (timed arithmetic vs fp32 HIP path vs CPU restatement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stock-baseline', action='store_true',
                     help='also time the same model through stock PyTorch-ROCm operators on this GPU (SURVEY 8d comparator)')
@@ -342,28 +382,77 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     elif args.gpus > 1:
-        raise SystemExit('launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 '
-                         '--master-port P bench.py --gpus N ...')
+        # not under torchrun: start the N ranks ourselves (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
+               '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     dev = torch.device('cuda', local_rank)
     os.environ['GAST_HIP_DTYPE'] = args.dtype
+    cfg = CONFIGS[args.config]
+    J, arc = cfg['J'], cfg['arc']
+    C = args.channels or cfg['channels']
+    B = args.batch or cfg['batch']
+    T = int(np.prod(arc))
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline()          # before touching the GPU
+        cpu = cpu_baseline()          # before touching the GPU (always on the metric's config, configs[1])
 
     from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
     from gast_hip.dist import FlatGradAllReduce
-    B, T, J, C = args.batch, 27, 17, 128
     torch.manual_seed(0)
     cls = SpatioTemporalModel if args.variant == 'dilated' else SpatioTemporalModelOptimized1f
-    model = cls(adj_from_parents(PARENTS17), J, 2, J, filter_widths=[3, 3, 3], causal=False, dropout=0.05, channels=C).to(dev)
+    adj = adj_from_parents(PARENTS[J])
+    model = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.05, channels=C).to(dev)
     model.train()
     g = torch.Generator().manual_seed(1234 + rank)     # reference generator seed (common/generators.py:26), per-rank shard
     x = (torch.rand(B, T, J, 2, generator=g) * 2 - 1).to(dev)
     y3d = torch.randn(B, 1, J, 3, generator=g) * 0.3
     y3d[:, :, 0] = 0                                     # reference main.py:225
     y3d = y3d.to(dev)
-    sync = FlatGradAllReduce(model.parameters(), model=model)
+
+    # ---- parity, measured in this run before anything is timed: the same weights and batch, train mode (batch statistics), dropout
+    # off, through (a) the timed arithmetic, (b) the fp32 HIP path, (c) the CPU restatement of the reference on stock ATen operators
+    parity = None
+    if rank == 0 and not args.no_parity:
+        try:
+            pm = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.0, channels=C)
+            pm.load_state_dict(model.state_dict())
+            pm.to(dev).train()
+            sd = {k: v.clone() for k, v in pm.state_dict().items()}
+            outs = {}
+            for dt_ in dict.fromkeys((args.dtype, 'fp32')):
+                os.environ['GAST_HIP_DTYPE'] = dt_
+                pm.load_state_dict(sd)
+                with torch.no_grad():
+                    yy = pm(x).float()
+                outs[dt_] = (yy, float(torch.mean(torch.norm(yy - y3d, dim=-1))))
+            os.environ['GAST_HIP_DTYPE'] = args.dtype
+            d32 = float((outs[args.dtype][0] - outs['fp32'][0]).abs().max())
+            parity = {'mode': 'train-mode forward (batch-statistic BatchNorm), dropout off, same weights and batch as the timed step',
+                      'dtype': args.dtype, 'output_abs_max': round(float(outs['fp32'][0].abs().max()), 4),
+                      'vs_fp32_hip': {'max_abs': d32, 'mpjpe_shift_mm': abs(outs[args.dtype][1] - outs['fp32'][1]) * 1e3},
+                      'tolerance': {'max_abs': 1e-4 if args.dtype == 'fp32' else 1e-2, 'mpjpe_mm': 0.1,
+                                    'source': 'BASELINE.json north_star: 1e-4 fp32 / 1e-2 bf16, MPJPE within 0.1 mm'}}
+            if world == 1 and not args.no_cpu_baseline:
+                yc, lc = cpu_reference_forward(sd, adj, arc, C, x, y3d)
+                dc = float((outs[args.dtype][0].cpu() - yc).abs().max())
+                parity['vs_cpu_reference_restatement'] = {'max_abs': dc, 'mpjpe_shift_mm': abs(outs[args.dtype][1] - lc) * 1e3,
+                                                          'fp32_hip_max_abs': float((outs['fp32'][0].cpu() - yc).abs().max()),
+                                                          'what': 'oracle/torch_ops.py on stock PyTorch CPU operators, fp32'}
+                d32 = max(d32, dc)
+            parity['pass'] = bool(d32 < parity['tolerance']['max_abs'] and parity['vs_fp32_hip']['mpjpe_shift_mm'] < 0.1)
+            del pm, outs
+        except Exception as e:     # noqa: BLE001 -- never lose the bench line to the parity leg
+            parity = {'error': str(e).splitlines()[0][:200]}
+
+    sync = FlatGradAllReduce(model.parameters(), model=model, buckets=3 if (args.overlap and len(arc) >= 2) else 1)
     sync.force = args.force_collective
     use_graph = not args.no_graph
     if args.torch_tail:   # the eager-formula loss and torch's fused multi-tensor Adam (comparison only)
@@ -373,6 +462,7 @@ def main():
         from gast_hip.optim import FlatAdam
         from gast_hip.loss import mpjpe as loss_fn
         opt = FlatAdam(model.parameters(), lr=1e-3, amsgrad=True, ops=model._runner.engine.ops)
+        sync.attach(opt)          # the 1/world averaging rides in the Adam kernel's gradient scale
 
     timer = None
     if not args.no_kernel_timer and rank == 0:
@@ -400,7 +490,7 @@ def main():
     # the same stream, graph B = Adam -- no collective inside a captured graph, two graph launches + one RCCL call per step.
     mode, graph_note = 'eager', 'eager'
     graphs, static_loss = [], None
-    want = 'eager' if not use_graph else ('split' if (args.split_graph or (collective and not args.full_graph)) else 'full')
+    want = 'eager' if not use_graph else ('split' if (args.split_graph or (collective and not (args.full_graph or args.overlap))) else 'full')
     if want != 'eager':
         try:
             side = torch.cuda.Stream()
@@ -456,10 +546,13 @@ def main():
         dist.barrier(device_ids=[local_rank])
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = None
     if collective:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.zeros(world, dtype=torch.float64, device=dev)
+        tt[rank] = elapsed
+        dist.all_reduce(tt, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 4) for v in tt.tolist()]
+        elapsed = float(tt.max().item())
     # ---- per-kernel durations: the same step, eagerly, with a HIP-event pair around every launch (events cannot be
     # recorded inside a replayed graph; the kernels and their arguments are identical to the replayed ones)
     if timer and rank == 0:
@@ -504,15 +597,27 @@ def main():
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         out = {
-            'metric': 'sequences/sec (B=128, T=27, J=17) fwd+bwd', 'value': round(value, 1), 'unit': 'sequences/s',
+            'metric': 'sequences/sec (B=%d, T=%d, J=%d) fwd+bwd' % (B, T, J), 'value': round(value, 1), 'unit': 'sequences/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': 'BASELINE.json configs[1]: SpatioTemporalModel J=17 arc 3,3,3 (RF 27) channels=128, '
-                                   'B=%d/GPU x T=27, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)%s'
-                                   % (B, '+RCCL grad all-reduce' if world > 1 else '', ' [torch loss/optimizer]' if args.torch_tail else ''),
+            'config': {'workload': 'BASELINE.json %s; SpatioTemporalModel J=%d arc %s (RF %d) channels=%d, '
+                                   'B=%d/GPU x T=%d, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)%s'
+                                   % (cfg['what'], J, ','.join(map(str, arc)), T, C, B, T,
+                                      '+RCCL grad all-reduce' if world > 1 else '', ' [torch loss/optimizer]' if args.torch_tail else ''),
                        'variant': args.variant, 'global_batch': world * B, 'parallelism': 'dp%d' % world,
-                       'loss_last': round(float(loss.item()), 6), 'launch': graph_note},
+                       'arithmetic': {'bf16x3': 'fp32 storage; GEMM / weight-gradient products as bf16 hi/lo split products on '
+                                                'v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi), fp32 accumulate',
+                                      'bf16': 'bf16 storage and MFMA operands, fp32 accumulate / statistics / master weights',
+                                      'fp32': 'fp32 storage, v_mfma_f32_32x32x2_f32'}[args.dtype],
+                       'loss_last': round(float(loss.item()), 6), 'launch': graph_note,
+                       'rccl_world_size': world if collective else None,
+                       'gradient_exchange': (None if not collective else ('3 buckets all-reduced on a communication stream during backward'
+                                                                         if len(sync.ranges) > 1 else 'one flat all-reduce after backward'))},
         }
+        if collective:
+            out['per_rank_ms_per_step'] = per_rank_ms
+        if parity is not None:
+            out['parity'] = parity
         if timer:
             agg = timer.summary()
             peak_tf = MFMA_PEAK_TFLOPS[args.dtype]
@@ -535,14 +640,13 @@ def main():
                     peak, unit = peak_tf, 'TFLOP/s'
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-                    pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_bytes.json')))
-                    tname = 'unsigned short' if args.dtype == 'bf16' else 'float'
-                    fam = [v for k, v in pmc.items() if k.startswith(('gemm_kernel<' + tname, 'gemm_multi_kernel<' + tname,
-                                                                       'splitk_finish_kernel<' + tname))]
-                    calls = sum(v['launches'] for k, v in pmc.items() if k.startswith(('gemm_kernel<' + tname, 'gemm_multi_kernel<' + tname)))
+                    pmc_name = 'r02_pmc_hbm_bytes_%s.json' % args.dtype      # counters of the committed kernels, one file per arithmetic
+                    pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
+                    fam = [v for k, v in pmc.items() if k.startswith(('gemm_kernel<', 'gemm_multi_kernel<', 'gemm64_kernel<', 'splitk_finish_kernel<'))]
+                    calls = sum(v['launches'] for k, v in pmc.items() if k.startswith(('gemm_kernel<', 'gemm_multi_kernel<', 'gemm64_kernel<')))
                     traffic = round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in fam) / calls)
-                    tsrc = ('profiles/r01_pmc_hbm_bytes.json: sum of (2*FETCH_SIZE + WRITE_SIZE) KiB over the gemm / gemm_multi / splitk_finish '
-                            'kernels / %d gemm launches, rocprofv3 --pmc' % calls)
+                    tsrc = ('profiles/%s: sum of (2*FETCH_SIZE + WRITE_SIZE) KiB over the gemm / gemm_multi / splitk_finish '
+                            'kernels / %d gemm launches, two rocprofv3 --pmc passes of `bench.py --dtype %s --no-graph`' % (pmc_name, calls, args.dtype))
                 except Exception:
                     pass
                 out['roofline'] = {'kernel': 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)' % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
@@ -557,9 +661,9 @@ def main():
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)
             tot_roof = sum(v['roof_ms'] for v in agg.values()) / tsteps
             out['path_roofline'] = {'sum_kernel_roofline_ms_per_step': round(tot_roof, 4), 'frac_of_step': round(tot_roof / ms, 4)}
-        if fwd_ms:
+        if fwd_ms and args.config == 'cfg1' and C == 128:
             # 793.4 MB compulsory bf16 traffic (1587 MB fp32) and 160.7 GFLOP per B=128 forward of the dilated model
-            fb = (793.4e6 if args.dtype == 'bf16' else 1586.8e6) * (B / 128.0)
+            fb = (793.4e6 if args.dtype == 'bf16' else 1586.8e6) * (B / 128.0)     # (bf16x3 stores fp32)
             ff = 160.7e9 * (B / 128.0)
             roof = max(fb / (HBM_PEAK_GBS * 1e9), ff / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)) * 1e3
             out['forward_only'] = {'ms': round(fwd_ms, 4), 'sequences_per_s': round(B / fwd_ms * 1e3, 1), 'roofline_ms': round(roof, 4),
