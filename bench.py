@@ -502,7 +502,8 @@ def main():
             torch.cuda.synchronize()
             if want == 'full':
                 g0 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g0):
+                # (collectives inside the capture: RCCL's watchdog thread queries events meanwhile -- thread-local capture mode)
+                with torch.cuda.graph(g0, **({'capture_error_mode': 'thread_local'} if collective else {})):
                     static_loss = step()
                 graphs = [g0]
                 graph_note = 'hipGraph replay of the whole step (captured through torch.cuda.graph)'

@@ -391,10 +391,16 @@ def test_bf16_vs_fp32_full_size(monkeypatch):
         if k not in ZERO_GRADS and not k.endswith(BF16_NOISY) and a.abs().max() > 1e-3 * gmax:
             rel[k] = float((a.double() - b.double()).norm() / (a.double().norm() + 1e-300))
     kw = max(rel, key=rel.get)
-    _log(test='bf16x3_vs_fp32_full_train', max_abs=d3, dmpjpe_mm=dl3, worst_grad_rel_l2=(kw, rel[kw]))
+    va = torch.cat([outs['fp32'][2][k].double().flatten() for k in rel])
+    vb = torch.cat([outs['bf16x3'][2][k].double().flatten() for k in rel])
+    rel_all = float((va - vb).norm() / va.norm())
+    _log(test='bf16x3_vs_fp32_full_train', max_abs=d3, dmpjpe_mm=dl3, worst_grad_rel_l2=(kw, rel[kw]), all_grads_rel_l2=rel_all)
     assert d3 < 1e-3, d3
     assert dl3 < 0.1, dl3
-    assert rel[kw] < 1e-2, (kw, rel[kw])
+    # all gradients as one vector within 1e-2 (two fp32 implementations are 1.5e-3 apart on this metric: ReLU inputs within
+    # round-off of zero flip whole contributions -- test_full_size_values_against_stock_torch); single tensors within 5e-2
+    assert rel_all < 1e-2, rel_all
+    assert rel[kw] < 5e-2, (kw, rel[kw])
     # eval mode (running statistics; how MPJPE is evaluated, reference main.py:250-330): 1e-2 on the outputs, 0.1 mm on the MPJPE
     monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
     m.train()
