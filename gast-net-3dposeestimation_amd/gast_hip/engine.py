@@ -563,6 +563,23 @@ class Engine:
                              epi=EPI_BNRELU_BWD, partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'],
                              xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
                 nbo = k * nbt
+            elif Tn <= sp.tapstep[s] and any(tap * sp.tapstep[s] == lv['resmap'].t_off for tap in range(k)):
+                # disjoint taps (few output frames: Tn <= dilation, e.g. the last level where Tn = 1): every input frame receives
+                # at most ONE tap, so the input gradient is k scatter GEMMs over the OUTPUT domain instead of a gather GEMM over
+                # the input domain whose rows are mostly zero (arc 3,3,3, last level: 3 x 1.1 GFLOP instead of 65 GFLOP).  Frames
+                # no tap reaches keep the zero of the arena: their gradient before the BatchNorm backward is exactly zero.
+                d = sp.tapstep[s]
+                dOp = za.take((Pp, C), dt)
+                nbt = ops.gemm_row_blocks(P)
+                partO = za.take((k * nbt, C, 2))
+                res_off = lv['resmap'].t_off
+                for tap in range(k):
+                    hit = tap * d == res_off
+                    ops.gemm((B, Tn, J), C, [dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], dOp, RowMap(Tp, 1, tap * d),
+                             addend=dX if hit else None, addmap=ident(Tn) if hit else None,
+                             epi=EPI_BNRELU_BWD, partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'],
+                             xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+                nbo = k * nbt
             else:
                 d = sp.tapstep[s]
                 dOp = self._new(Pp, C, dt, dev)
