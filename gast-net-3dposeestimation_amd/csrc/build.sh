@@ -7,12 +7,12 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
 mkdir -p "$HERE/build"
 pids=()
-for f in gemm wgrad graph_ops norm_ops pack_ops optim_ops data_ops; do
-  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/../../include/gast_hip.h" -nt "$HERE/build/$f.o" ]; then
+for f in gemm gemm_big wgrad graph_ops norm_ops pack_ops optim_ops data_ops; do
+  if [ ! -f "$HERE/build/$f.o" ] || [ "$HERE/$f.hip" -nt "$HERE/build/$f.o" ] || [ "$HERE/common.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/gemm_big.h" -nt "$HERE/build/$f.o" ] || [ "$HERE/../../include/gast_hip.h" -nt "$HERE/build/$f.o" ]; then
     $HIPCC $FLAGS -c "$HERE/$f.hip" -o "$HERE/build/$f.o" &
     pids+=($!)
   fi
 done
 for p in "${pids[@]}"; do wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/build/gemm.o" "$HERE/build/wgrad.o" "$HERE/build/graph_ops.o" "$HERE/build/norm_ops.o" "$HERE/build/pack_ops.o" "$HERE/build/optim_ops.o" "$HERE/build/data_ops.o"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE/build/gemm.o" "$HERE/build/gemm_big.o" "$HERE/build/wgrad.o" "$HERE/build/graph_ops.o" "$HERE/build/norm_ops.o" "$HERE/build/pack_ops.o" "$HERE/build/optim_ops.o" "$HERE/build/data_ops.o"
 echo "built $OUT"

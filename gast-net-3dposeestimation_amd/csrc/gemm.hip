@@ -18,6 +18,7 @@
 // tile's global loads are issued before the MFMAs of the current one.  Blocks are remapped so that the N-tiles of
 // one M-panel run on the same XCD (shared L2).
 #include "common.h"
+#include "gemm_big.h"
 #include <stdlib.h>
 
 namespace {
@@ -708,6 +709,8 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int rc = gemm_plan(a, ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    BigPlan bp;
+    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
@@ -732,16 +735,26 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     return 0;
 }
 
+extern "C" int gast_gemm_path(const gast_gemm_args* args) {
+    if (!args) return GAST_EINVAL;
+    BigPlan bp;
+    return gast_gemm_big_plan(*args, bp) ? 1 : 0;
+}
+
 extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream) {
     if (!args || n < 1 || n > GAST_GEMM_MAX_BATCH) return GAST_EINVAL;
     GemmBatch b;
     b.n = 0;
     b.first[0] = 0;
+    gast_gemm_args big_a[GAST_GEMM_MAX_BATCH];
+    BigPlan big_p[GAST_GEMM_MAX_BATCH];
+    int nbig = 0;
     for (int d = 0; d < n; ++d) {
         if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32) return GAST_EINVAL;
         int M, gridM, gridN, vec_epi, splitk;
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
+        if (gast_gemm_big_plan(args[d], big_p[nbig])) { big_a[nbig++] = args[d]; continue; }
         if (splitk > 1) {                       // small-M job: its own split-K launch pair
             rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
             if (rc) return rc;
@@ -752,9 +765,13 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
         b.M[k] = M; b.gridM[k] = gridM; b.gridN[k] = gridN; b.vec_epi[k] = vec_epi;
         b.first[k + 1] = b.first[k] + gridM * gridN;
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (nbig) {
+        int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, st);
+        if (rc) return rc;
+    }
     if (b.n == 0) return 0;
     dim3 grid(b.first[b.n]), block(256);
-    hipStream_t st = (hipStream_t)stream;
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
     else if (args[0].dtype == GAST_F32X3)

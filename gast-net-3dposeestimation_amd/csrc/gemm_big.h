@@ -1,0 +1,14 @@
+// Internal interface between gemm.hip (argument validation, dispatch) and gemm_big.hip (the 256x256-tile GAST_F32X3 kernel).
+#pragma once
+#include "common.h"
+
+struct BigPlan {
+    int M, tilesM, tilesN;
+    int ntab;                     // floats in the scale table (= in the shift table) a block keeps in LDS
+    int taboff[GAST_MAX_SEG];     // offset of the segment's scale/shift in the tables (-1: no prologue)
+};
+
+// 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip
+int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
+int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
+int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);

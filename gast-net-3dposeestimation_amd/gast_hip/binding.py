@@ -10,6 +10,8 @@ from collections import namedtuple
 
 import torch
 
+from gast_hip.packer import X3Weight
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgast_hip.so')
 
@@ -47,7 +49,11 @@ class _Dropout(C.Structure):
 
 class _GemmSeg(C.Structure):
     _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('K', C.c_int), ('map', _RowMap), ('W', C.c_void_p), ('ldw', C.c_int),
-                ('pro', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('salt', C.c_uint32)]
+                ('pro', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('salt', C.c_uint32), ('Wx', C.c_void_p), ('ldwx', C.c_int)]
+
+
+class _X3ImageJob(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('R', C.c_int), ('K', C.c_int), ('ldw', C.c_int), ('img', C.c_void_p), ('ldimg', C.c_int)]
 
 
 class _GemmArgs(C.Structure):
@@ -114,6 +120,9 @@ def load_library():
         'gast_gemm_ws': [C.POINTER(_GemmArgs), vp, cl, vp],
         'gast_gemm_multi': [C.POINTER(_GemmArgs), ci, vp, cl, vp],
         'gast_gemm_splitk_ws_bytes': [cl, ci],
+        'gast_gemm_path': [C.POINTER(_GemmArgs)],
+        'gast_x3_image_multi': [C.POINTER(_X3ImageJob), ci, vp],
+        'gast_x3_image_ld': [ci],
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
         'gast_wgrad_multi': [C.POINTER(_WgradArgs), ci, vp],
         'gast_semch_adj_fwd': [vp, ci, vp, vp, vp],
@@ -158,6 +167,7 @@ def load_library():
         fn.restype = ci
     lib.gast_semch_agg_bwd_ws_floats.restype = C.c_long
     lib.gast_gemm_splitk_ws_bytes.restype = C.c_long
+    lib.gast_x3_image_ld.restype = C.c_long
     lib.gast_expand_bwd_ws_floats.restype = C.c_long
     lib.gast_version.restype = C.c_char_p
     lib.gast_version.argtypes = []
@@ -165,7 +175,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
@@ -252,10 +262,15 @@ class HipOps:
         a.nseg = len(segs)
         for i, s in enumerate(segs):
             g = a.seg[i]
-            if _dt(s['A']) != st_dtype or _dt(s['W']) != st_dtype:
+            W, img = s['W'], None
+            if isinstance(W, X3Weight):
+                W, img = W.t, W.img
+            if _dt(s['A']) != st_dtype or _dt(W) != st_dtype:
                 raise RuntimeError('gast_hip: mixed operand dtypes in gemm')
             g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
-            g.W, g.ldw = _p(s['W']), _ld(s['W'])
+            g.W, g.ldw = _p(W), _ld(W)
+            if img is not None and self.x3:
+                g.Wx, g.ldwx = _p(img), _ld(img)
             g.pro = int(s.get('pro', PRO_NONE))
             g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
             g.salt = int(s.get('salt', 0))
@@ -281,7 +296,26 @@ class HipOps:
         ws = self._splitk_ws(C_.device)
         _check(self.lib.gast_gemm_ws(C.byref(a), ws.data_ptr(), ws.numel() * 4, _stream()), 'gast_gemm')
 
-    GEMM_MAX_BATCH = 4
+    GEMM_MAX_BATCH = 3
+
+    def gemm_path(self, dom, N, segs, C_, cmap, **kw):
+        """0 / 1: the kernel gemm() would launch for these arguments (gast_gemm_path)"""
+        a = _GemmArgs()
+        self._gemm_args(a, dom, N, segs, C_, cmap, **kw)
+        return self.lib.gast_gemm_path(C.byref(a))
+
+    def x3_weight(self, W):
+        """fp32 [N][K] row-major operand -> X3Weight carrying a freshly built pre-split bf16 image (gast_x3_image_multi): what
+        Packer.inputs() hands the engine for every packed operand in GAST_F32X3 mode."""
+        if W.dtype != torch.float32:
+            raise RuntimeError('gast_hip: x3_weight needs an fp32 operand')
+        ld = int(self.lib.gast_x3_image_ld(int(W.shape[1])))
+        img = torch.empty(W.shape[0], ld, dtype=torch.bfloat16, device=W.device)
+        job = (_X3ImageJob * 1)()
+        job[0].W, job[0].R, job[0].K, job[0].ldw, job[0].img, job[0].ldimg = _p(W), W.shape[0], W.shape[1], _ld(W), _p(img), ld
+        self.launches += 1
+        _check(self.lib.gast_x3_image_multi(job, 1, _stream()), 'gast_x3_image_multi')
+        return X3Weight(W, img)
 
     def gemm_multi(self, jobs):
         """jobs: list of dicts with the arguments of gemm() (keys dom, N, segs, C_, cmap + keywords): independent GEMMs of one plan
@@ -641,6 +675,16 @@ class HipOps:
         _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
         ft, nf = tb['fold']
         _check(self.lib.gast_fold(_p(ft), nf, max(j['C'] for j in packer.fold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
+        if st.get('Xb') is not None:          # GAST_F32X3: the pre-split bf16 images of all packed operands, one launch
+            arr = tb.get('x3img')
+            if arr is None:
+                jobs = packer.image_jobs(st)
+                arr = (_X3ImageJob * len(jobs))()
+                for a, (wv, iv) in zip(arr, jobs):
+                    a.W, a.R, a.K, a.ldw, a.img, a.ldimg = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(iv), _ld(iv)
+                tb['x3img'] = arr
+            self.launches += 1
+            _check(self.lib.gast_x3_image_multi(arr, len(arr), _stream()), 'gast_x3_image_multi')
 
     def run_unpack(self, packer, st, Sb, G, accumulate, bucket=None):
         """packed gradient scratch -> parameter-shaped gradients in the flat buffer; bucket = i: only the jobs whose destination

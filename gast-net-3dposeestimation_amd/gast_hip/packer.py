@@ -49,6 +49,26 @@ class Layout:
         return Ref(base, None, off + row0 * c + col0, c, 1)
 
 
+class X3Weight:
+    """An fp32 [N][K] GEMM operand together with its pre-split bf16 image (GAST_F32X3; `gast_x3_image_multi`, include/gast_hip.h).
+    Slices like the tensor it wraps (`w[r0:r1]`, `w[:, k0:k1]`); a column slice that is not aligned to the 32-value groups of
+    the image drops the image (the GEMM then splits the fp32 operand itself)."""
+    __slots__ = ('t', 'img')
+
+    def __init__(self, t, img):
+        self.t, self.img = t, img
+
+    def __getitem__(self, idx):
+        rs, cs = idx if isinstance(idx, tuple) else (idx, slice(None))
+        img = None
+        if self.img is not None:
+            K = self.t.shape[1]
+            a, b, step = cs.indices(K)
+            if step == 1 and a % 32 == 0 and (b % 32 == 0 or b == K):
+                img = self.img[rs, 2 * a:2 * ((b + 31) // 32 * 32)]
+        return X3Weight(self.t[rs, cs], img)
+
+
 class Packer:
     def __init__(self, model, spec, named=None):
         """named: explicit (name, tensor) list in `named_parameters()` order -- for nn.DataParallel replicas, whose parameters are
@@ -189,20 +209,33 @@ class Packer:
                     del st['tables'][k]
 
     # ------------------------------------------------------------------------------------------ buffers
-    def state(self, dev, dt):
-        """Per (device, dtype) persistent buffers + device job tables."""
-        key = (str(dev), dt)
+    def state(self, dev, dt, x3=False):
+        """Per (device, dtype, x3) persistent buffers + device job tables.  x3 (GAST_F32X3): every packed fp32 operand also gets a
+        pre-split bf16 image (`Xb`), refreshed by ops.run_pack after the copy / fold launches."""
+        key = (str(dev), dt, bool(x3))
         st = self._dev.get(key)
         ptrs = tuple(p.data_ptr() for p in self.params)
         if st is None or st['ptrs'] != ptrs:
             st = {'ptrs': ptrs, 'Wb': torch.zeros(self.W.size, dtype=dt, device=dev),
-                  'Fb': torch.zeros(self.F.size, dtype=torch.float32, device=dev), 'tables': None}
+                  'Fb': torch.zeros(self.F.size, dtype=torch.float32, device=dev), 'tables': None, 'Xb': None}
+            if x3 and dt == torch.float32:
+                X = Layout()
+                for n, (_, r, c) in self.W.regions.items():
+                    X.add(n, r, 2 * ((c + 31) // 32 * 32))
+                st['X'] = X
+                st['Xb'] = torch.zeros(X.size, dtype=torch.bfloat16, device=dev)
             self._dev[key] = st
         return st
+
+    def image_jobs(self, st):
+        """(fp32 operand view, image view) per packed operand, for ops.run_pack."""
+        return [(self.W.view(st['Wb'], n), st['X'].view(st['Xb'], n)) for n in self.W.regions]
 
     def inputs(self, st):
         """engine `inp` dict: operand views (act dtype), fp32 packed views, raw parameters."""
         inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
+        if st.get('Xb') is not None:
+            inp = {n: X3Weight(w, st['X'].view(st['Xb'], n)) for n, w in inp.items()}
         for n in self.F.regions:
             v = self.F.view(st['Fb'], n)
             inp[n] = v.view(-1) if n.endswith('bias1') else v.view(NHEADS, self.spec.J, self.spec.J)

@@ -391,7 +391,7 @@ class SpatioTemporalModelBase(nn.Module):
                     runner._packer = Packer(self, runner.spec)
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
-            st = packer.state(x.device, runner.act_dtype)
+            st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None)
             # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
             return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)

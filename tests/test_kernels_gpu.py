@@ -205,6 +205,63 @@ def test_gemm_multi(ops, mode):
         _gemm_check(c, dt, bufs, mode)
 
 
+# large-M cases: with pre-split weight images (HipOps.x3_weight) GAST_F32X3 GEMMs of >= 8192 rows take the 256x256-tile kernel
+# (csrc/gemm_big.hip): taps + prologue + statistics + centred bias + N tail; channel concat; gather input gradient with zero rows,
+# addend, ReLU/dropout/BN-sum epilogue; K tails (168 = 5*32 + 8 and 72); a one-K-tile GEMM
+GEMM_BIG_CASES = [
+    ('big_taps_pro_stats', (24, 21, 17), 320, [(64, 27, 1, 0, 1), (64, 27, 1, 3, 1), (64, 27, 1, 6, 1)], 1, False, 'neg'),
+    ('big_concat_plain_stats', (30, 17, 17), 256, [(128, 17, 1, 0, 0), (256, 17, 1, 0, 0)], 1, False, False),
+    ('big_dgrad_gather_bwd', (20, 25, 17), 128, [(64, 19, 1, 0, 0), (64, 19, 1, -3, 0), (64, 19, 1, -6, 0)], 2, True, False),
+    ('big_ktail', (32, 16, 17), 136, [(5 * 32 + 8, 16, 1, 0, 0), (72, 16, 1, 0, 1)], 0, False, True),
+    ('big_one_tile', (31, 16, 17), 648, [(32, 16, 1, 0, 1)], 1, False, True),
+    ('big_strided_taps', (90, 5, 19), 96, [(32, 15, 3, 0, 1), (32, 15, 3, 1, 1), (32, 15, 3, 2, 1)], 1, False, False),
+]
+
+
+def _with_images(ops, jd):
+    for s in jd['segs']:
+        s['W'] = ops.x3_weight(s['W'])
+    return jd
+
+
+@pytest.mark.parametrize('case', GEMM_BIG_CASES, ids=[c[0] for c in GEMM_BIG_CASES])
+def test_gemm_big_x3(ops, case):
+    jd, jh, bufs = _gemm_case(case, torch.float32)
+    with x3_mode(ops, 'x3'):
+        assert ops.gemm_path(**_with_images(ops, jd)) == 1, 'the 256x256-tile kernel was not selected'
+        ops.gemm(**jd)
+    kc.gemm(**jh)
+    torch.cuda.synchronize()
+    _gemm_check(case, torch.float32, bufs, 'x3')
+
+
+def test_gemm_big_x3_multi(ops):
+    built = [_gemm_case(c, torch.float32) for c in GEMM_BIG_CASES[:3]]
+    with x3_mode(ops, 'x3'):
+        ops.gemm_multi([_with_images(ops, jd) for jd, _, _ in built])
+    torch.cuda.synchronize()
+    for c, (jd, jh, bufs) in zip(GEMM_BIG_CASES[:3], built):
+        kc.gemm(**jh)
+        _gemm_check(c, torch.float32, bufs, 'x3')
+
+
+def test_x3_image_layout(ops):
+    """img[r][(k>>5)*64 + (k&31)] = bf16(w), + 32: bf16(w - hi), zero padding up to a multiple of 32 K values"""
+    gen = torch.Generator().manual_seed(11)
+    W = rand(gen, 37, 72).cuda()
+    xw = ops.x3_weight(W)
+    torch.cuda.synchronize()
+    img = xw.img.float().cpu().numpy().reshape(37, 3, 2, 32)
+    Wp = np.zeros((37, 96), dtype=np.float32)
+    Wp[:, :72] = W.cpu().numpy()
+    hi = torch.from_numpy(Wp).to(torch.bfloat16).float().numpy()
+    lo = torch.from_numpy(Wp - hi).to(torch.bfloat16).float().numpy()
+    assert np.array_equal(img[:, :, 0, :].reshape(37, 96), hi)
+    assert np.array_equal(img[:, :, 1, :].reshape(37, 96), lo)
+    sl = xw[5:9, 32:72]                  # aligned column slice keeps its image, an unaligned one drops it
+    assert sl.img is not None and sl.img.data_ptr() == xw.img[5:, 64:].data_ptr() and xw[:, 8:40].img is None
+
+
 def test_gemm_out_f32_from_bf16(ops):
     gen = torch.Generator().manual_seed(5)
     dom, N, K = (2, 4, 17), 3, 64
