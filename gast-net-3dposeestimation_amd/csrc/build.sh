@@ -5,6 +5,8 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 OUT="$HERE/../gast_hip/libgast_hip.so"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
+# ABLATION=1: profiling build of gemm_big.hip with the GAST_GEMM_BIG_ABLATE run-time switches compiled in (scripts/gemm_big_ablate.py)
+if [ -n "$ABLATION" ]; then FLAGS="$FLAGS -DGAST_GEMM_BIG_ABLATION"; touch "$HERE/gemm_big.hip"; fi
 mkdir -p "$HERE/build"
 pids=()
 for f in gemm gemm_big wgrad graph_ops norm_ops pack_ops optim_ops data_ops; do

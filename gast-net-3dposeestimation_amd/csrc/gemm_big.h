@@ -6,6 +6,8 @@ struct BigPlan {
     int M, tilesM, tilesN;
     int ntab;                     // floats in the scale table (= in the shift table) a block keeps in LDS
     int taboff[GAST_MAX_SEG];     // offset of the segment's scale/shift in the tables (-1: no prologue)
+    int ablate;                   // GAST_GEMM_BIG_ABLATE (profiling aid, results are wrong when set): 1 no MFMA, 2 no fragment reads,
+                                  // 4 no weight DMA, 8 no activation loads, 16 no activation LDS writes, 32 no epilogue
 };
 
 // 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip

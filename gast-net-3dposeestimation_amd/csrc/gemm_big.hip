@@ -1,44 +1,58 @@
-// gast_gemm, big-tile path for GAST_F32X3 (fp32 storage, split-bf16 products on v_mfma_f32_32x32x16_bf16), gfx950.
+// gast_gemm, large-M path for GAST_F32X3 (fp32 storage, split-bf16 products on v_mfma_f32_32x32x16_bf16), gfx950.
 //
 // Same contract as gemm.hip (K segments with row maps = channel concat / temporal taps of reference gast_net.py:28-32,145-148,
-// 173-174; BN+ReLU load prologue; STATS / BNRELU_BWD epilogues), different machine mapping -- the 128x128 two-barrier loop of
-// gemm.hip runs the split-bf16 products at 19 % of the matrix-core peak (rocprof, profiles/r02_v0_*):
-//   * block tile 256x256, 512 threads = 8 waves (2 x 4), wave tile 128x64 = 4x2 MFMA tiles, one block per CU;
-//   * K tile = 32 fp32 values per row, held in LDS as a 128-byte row image [32 bf16 hi | 32 bf16 lo]; 16-byte chunks are
-//     XOR-swizzled by (row>>1)&7 so the fragment reads (ds_read_b128, 16 lanes per pass) are conflict-free;
-//   * TWO LDS stages, ONE barrier per K tile: while tile t is multiplied, tile t+1's weights stream global -> LDS by DMA
-//     (global_load_lds_dwordx4 from the pre-split weight image, gast_x3_image) and tile t+2's activations are in flight to
-//     registers (inline-asm loads, counted together with the DMA by one s_waitcnt vmcnt(0) at the top of the next iteration);
-//     activations go through registers because the BN+ReLU prologue and the hi/lo split are VALU work, and are written to
-//     the other stage right after the barrier;
-//   * 48 MFMAs per wave per K tile (3 products x 4x2 tiles x 2 k-steps) against 24 ds_read_b128 and 4+4 16-byte loads per
-//     thread: the loop is matrix-core bound by construction (21 B/clk/CU of operand traffic, L2 delivers 32);
-//   * epilogue straight from the accumulators: in the 32x32 layout a lane owns one column, so a store instruction writes two
-//     128-byte row segments of fp32 -- no LDS staging needed; the column statistics of a wave's 128 rows are exactly one
-//     128-row statistics block (partials[ceil(M/128)][N][2], the layout gemm.hip and the BatchNorm finalizes share).
+// 173-174; BN+ReLU load prologue; STATS / BNRELU_BWD epilogues), different machine mapping.  The 128x128 two-barrier loop of
+// gemm.hip runs the split-bf16 products at 19 % of the matrix-core peak (rocprof, profiles/r02_v0_*); a first 256x256-tile,
+// one-block-per-CU version of this file only tied it: with a prefetch distance of ONE K tile every iteration waited out the
+// memory latency (3.1 us per K tile against 1.3 us of MFMA work) and with one block per CU the 256 KB epilogues of all CUs ran
+// in lockstep with idle matrix cores.  Hence:
+//   * block tile 128 x 256, 256 threads = 4 waves (2 x 2), wave tile 64 x 128 = 2 x 4 MFMA tiles (128 accumulator registers),
+//     TWO blocks per CU (2 waves per SIMD, 256 VGPRs each): the blocks drift apart, so one block's epilogue / barrier stalls are
+//     covered by the other's MFMAs;
+//   * K step = 16 fp32 values per row, held in LDS as a 64-byte row image [16 bf16 hi | 16 bf16 lo]; the 16-byte chunks are
+//     XOR-swizzled by (row>>2)&3 so the fragment reads (ds_read_b128) are conflict-free;
+//   * prefetch distance TWO for both operands, one barrier per K step: weights stream global -> LDS by DMA
+//     (global_load_lds_dwordx4 from the pre-split weight image, gast_x3_image_multi) into a ring of three stages; activations
+//     pass through two register sets (the BN+ReLU prologue and the hi/lo split are VALU work) into two LDS stages; one counted
+//     s_waitcnt vmcnt(6) per iteration leaves the newest step's 4 DMA + 2 loads in flight (every iteration issues exactly
+//     that many -- past the last tile they re-request the last one -- so the count is exact);
+//   * 24 MFMAs per wave per K step against 12 ds_read_b128;
+//   * epilogue straight from the accumulators (in the 32x32 layout a lane owns one column: a store instruction writes two
+//     128-byte row segments), X / addend values fetched one 4-row unit ahead; the column statistics of a block's 128 rows
+//     are exactly one statistics block (partials[ceil(M/128)][N][2], the layout gemm.hip and the BatchNorm finalizes share).
 #include "common.h"
 #include "gemm_big.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace {
 
-constexpr int TM = 256, TN = 256, TK = 32;
-constexpr int ROWB = 128;
-constexpr int TILE_BYTES = 256 * ROWB;          // one operand tile
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;     // A | W
-constexpr int LDS_FIXED = 2 * STAGE_BYTES + 2 * TM * 4;
-constexpr int LDS_MAX = 160 * 1024;
-constexpr int MAX_TAB = (LDS_MAX - LDS_FIXED) / 8;   // floats of scale (and as many of shift) the block can keep in LDS
+constexpr int TM = 128, TN = 256, TK = 16;
+constexpr int ROWB = 64;                        // LDS row image: 16 bf16 hi | 16 bf16 lo
+constexpr int A_BYTES = TM * ROWB;              // 8 KB
+constexpr int W_BYTES = TN * ROWB;              // 16 KB
+constexpr int OFF_ROWS = 0;                     // crow[128] | addrow[128]
+constexpr int OFF_A = 2 * TM * 4;               // two activation stages
+constexpr int OFF_W = OFF_A + 2 * A_BYTES;      // three weight stages
+constexpr int OFF_TAB = OFF_W + 3 * W_BYTES;    // scale | shift tables
+constexpr int LDS_BLOCK = 80 * 1024;            // two blocks per CU
+constexpr int MAX_TAB = (LDS_BLOCK - OFF_TAB - 6 * 256 * 4) / 8;
 
-__device__ __forceinline__ void glds16(const void* g, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_wave_base) : "memory", "m0");
+// 16 bytes per lane global -> LDS (DMA): address = sbase + voff + OFF; lands at lds_wave_base + 16 * lane
+template <int OFF>
+__device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_wave_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(lds_wave_base), "n"(OFF) : "memory", "m0");
+}
+// 16 bytes per lane global -> registers, address = sbase + voff (scalar base: the per-step advance costs no VALU)
+__device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived (compile-time: the
-// epilogue is straight-line code per element)
-template <int EPI>
+// epilogue is straight-line code per element); ADD: an addend tensor is present
+template <int EPI, bool ADD>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int M = pl.M, N = a.N;
@@ -46,10 +60,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const int mt = lb / pl.tilesN, nt = lb - mt * pl.tilesN;
     const int m0 = mt * TM, n0 = nt * TN;
 
-    float* const sSc = (float*)(smem + 2 * STAGE_BYTES);
-    float* const sSh = sSc + pl.ntab;
-    int* const sCrow = (int*)(sSh + pl.ntab);
+    int* const sCrow = (int*)(smem + OFF_ROWS);
     int* const sAdd = sCrow + TM;
+    float* const sSc = (float*)(smem + OFF_TAB);
+    float* const sSh = sSc + pl.ntab;
 
     const int TJ = a.Tn * a.J;
     if (tid < TM) {
@@ -64,312 +78,356 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         sAdd[tid] = arow;
     }
 
-    // ---- this thread's staging duties.  A (registers): rows rbase + 64 i, 16-byte chunk `c` (4 fp32 values) of the K tile.
-    const int c = tid & 7, rbase = tid >> 3;
-    int pb[4], pt[4], pj[4];
-    bool mvalid[4];
-    uint32_t aoff_hi[4], aoff_lo[4];           // byte offsets of this thread's two 8-byte pieces inside an A tile
+    // ---- staging duties.  Activations (registers): rows rbase + 64 i (i < 2), 16-byte chunk c (4 fp32 values) of the K step.
+    // Per-row facts that are only needed when a stream enters a new K segment (the (b, t, j) position of the thread's rows, the
+    // weight row / chunk of its DMA pieces) are recomputed or re-read from LDS there instead of living in registers: the K loop
+    // runs at 250 of 256 VGPRs and a spill inside it costs an s_waitcnt vmcnt(0), i.e. the whole prefetch.
+    const int c = tid & 3, rbase = tid >> 2;
+    int* const sPos = (int*)(smem + OFF_TAB) + 2 * pl.ntab;      // [2][3][256]: b, t, j of this thread's two rows (-1: row past M)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = rbase + 64 * i;
-        const int m = m0 + row;
-        mvalid[i] = m < M;
-        const int mm = mvalid[i] ? m : 0;
-        pb[i] = mm / TJ;
-        const int rem = mm - pb[i] * TJ;
-        pt[i] = rem / a.J;
-        pj[i] = rem - pt[i] * a.J;
-        const int key = (row >> 1) & 7;
-        aoff_hi[i] = row * ROWB + (((c >> 1) ^ key) << 4) + (c & 1) * 8;
-        aoff_lo[i] = row * ROWB + (((4 + (c >> 1)) ^ key) << 4) + (c & 1) * 8;
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + rbase + 64 * i;
+        int b = -1, t = 0, j = 0;
+        if (m < M) { b = m / TJ; const int rem = m - b * TJ; t = rem / a.J; j = rem - t * a.J; }
+        sPos[(i * 3 + 0) * 256 + tid] = b;
+        sPos[(i * 3 + 1) * 256 + tid] = t;
+        sPos[(i * 3 + 2) * 256 + tid] = j;
     }
-    // W (DMA): wave w fills the 8-row pieces (w*4 + i); lane = (row r8, slot s8) and slot s8 receives source chunk s8 ^ key(row)
-    const int r8 = lane >> 3, s8 = lane & 7;
-    int wrow[4], wchunk[4];
-    uint32_t wlds[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (w * 4 + i) * 8 + r8;
-        wchunk[i] = s8 ^ ((row >> 1) & 7);
-        const int n = n0 + row;
-        wrow[i] = n < N ? n : N - 1;                       // rows past N: clamped (their columns are never stored)
-        wlds[i] = (w * 4 + i) * 8 * ROWB;
-    }
+    const int r16 = lane >> 2, s4 = lane & 3;
 
-    // segment state: pointers of the segment entered last
-    const float* pA[4];
-    const bf16_t* pW[4];
-    bool zrow[4];
-    int cur_seg = -1;
-    auto enter_seg = [&](int s) {
-        if (s == cur_seg) return;
-        cur_seg = s;
+    // Activation stream: per-thread byte offsets of its two rows inside the segment's tensor (they change with the segment's
+    // row map), added to a scalar base that advances with k
+    uint32_t offA[2];
+    bool zrow[2];
+    int seg_a = -1;
+    auto enter_a = [&](int s) {
+        if (s == seg_a) return;
+        seg_a = s;
         const gast_gemm_seg& sg = a.seg[s];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ts = pt[i] * sg.map.t_stride + sg.map.t_off;
-            const bool ok = mvalid[i] && ts >= 0 && ts < sg.map.T_total;
-            const long srow = ok ? ((long)pb[i] * sg.map.T_total + ts) * a.J + pj[i] : 0;
+        for (int i = 0; i < 2; ++i) {
+            const int b = sPos[(i * 3 + 0) * 256 + tid], t = sPos[(i * 3 + 1) * 256 + tid], j = sPos[(i * 3 + 2) * 256 + tid];
+            const int ts = t * sg.map.t_stride + sg.map.t_off;
+            const bool ok = b >= 0 && ts >= 0 && ts < sg.map.T_total;
+            const uint32_t srow = ok ? (uint32_t)((b * sg.map.T_total + ts) * a.J + j) : 0u;
             zrow[i] = !ok;                                   // out-of-range tap (or a row past M): reads as zero
-            pA[i] = (const float*)sg.A + srow * sg.lda + c * 4;
-            pW[i] = (const bf16_t*)sg.Wx + (long)wrow[i] * sg.ldwx + wchunk[i] * 8;
+            offA[i] = (srow * (uint32_t)sg.lda + c * 4) * 4u;
         }
     };
-    struct Tile { int seg, k0; };
-    int seg_l = 0, k_l = 0;
-    auto next_tile = [&](Tile& t) {
-        t.seg = seg_l; t.k0 = k_l;
-        k_l += TK;
-        if (k_l >= a.seg[seg_l].K) { k_l = 0; ++seg_l; }
-    };
+    // Weight stream (DMA): wave w fills the 16-row pieces (w*4 + i) of the 256 x 64 B tile, which is ONE contiguous 16 KB block
+    // of the k-group-major image; lane = (row r16, slot s4) and slot s4 receives source chunk s4 ^ key(row).  Per thread: one
+    // byte offset (the pieces are immediates), per step: a scalar base.
+    const uint32_t offW = (uint32_t)(n0 + w * 64 + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
+    // A tile descriptor carries everything the K loop needs to know about its segment (K, table offset, operand bases), fetched
+    // from the kernel arguments only when the generator enters a new segment: a dependent s_load per use costs ~200 clk.
+    struct Tile { int seg, k0, K, toff; const float* abase; const char* wbase; };
     int ntile = 0;
     for (int s = 0; s < a.nseg; ++s) ntile += (a.seg[s].K + TK - 1) / TK;
+    int seg_l = 0, k_l = 0, gen = 0, K_l = a.seg[0].K, toff_l = pl.taboff[0];
+    const float* A_l = (const float*)a.seg[0].A;
+    const char* W_l = (const char*)a.seg[0].Wx;
+    long ldg_l = (long)a.seg[0].ldwx * 2;                     // bytes per k-group of the weight image
+    Tile last_tile = {0, 0, K_l, toff_l, A_l, W_l};
+    auto next_tile = [&](Tile& t) {                          // tiles in order; past the end: the last tile again
+        if (gen >= ntile) { t = last_tile; return; }
+        t.seg = seg_l; t.k0 = k_l; t.K = K_l; t.toff = toff_l;
+        t.abase = A_l + k_l;
+        t.wbase = W_l + (long)(k_l >> 4) * ldg_l;
+        last_tile = t;
+        ++gen;
+        k_l += TK;
+        if (k_l >= K_l && seg_l + 1 < a.nseg) {
+            k_l = 0; ++seg_l;
+            K_l = a.seg[seg_l].K; toff_l = pl.taboff[seg_l];
+            A_l = (const float*)a.seg[seg_l].A; W_l = (const char*)a.seg[seg_l].Wx; ldg_l = (long)a.seg[seg_l].ldwx * 2;
+        }
+    };
 
-    u32x4 ra[4];
-    bool rz[4];
-    auto load_a = [&](const Tile& t) {                       // (enter_seg(t.seg) ran before)
-        const int K = a.seg[t.seg].K;
-        const bool kin = t.k0 + c * 4 < K;
+    u32x4 ra0[2], ra1[2];
+    bool rz0[2], rz1[2];
+#ifdef GAST_GEMM_BIG_ABLATION
+    const int abl = pl.ablate;          // profiling build only (build.sh ABLATION=1): runtime switches split the K loop's basic blocks
+#else
+    constexpr int abl = 0;
+#endif
+    auto load_a = [&](const Tile& t, u32x4 (&ra)[2], bool (&rz)[2]) {
+        enter_a(t.seg);
+        if (abl & 8) return;
+        const bool kin = t.k0 + c * 4 < t.K;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gload16(ra[i], kin ? pA[i] + t.k0 : pA[i] - c * 4);     // (past the K tail: any valid address, the values are zeroed)
+        for (int i = 0; i < 2; ++i) {
+            gload16s(ra[i], kin ? offA[i] : offA[i] - c * 16, t.abase);     // (past the K tail: any valid address, the values are zeroed)
             rz[i] = zrow[i] || !kin;
         }
     };
     auto dma_w = [&](const Tile& t, int stage) {
-        const uint32_t sW = lds0 + stage * STAGE_BYTES + TILE_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) glds16(pW[i] + t.k0 * 2, __builtin_amdgcn_readfirstlane(sW + wlds[i]));
+        if (abl & 4) return;
+        const uint32_t sW = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + stage * W_BYTES + w * 4 * 16 * ROWB);
+        // (the instruction offset of an LDS-DMA load moves the global AND the LDS address: one M0 base serves the four pieces)
+        glds16<0>(offW, t.wbase, sW);
+        glds16<1024>(offW, t.wbase, sW);
+        glds16<2048>(offW, t.wbase, sW);
+        glds16<3072>(offW, t.wbase, sW);
     };
-    auto write_a = [&](const Tile& t, int stage) {
-        unsigned char* sA = smem + stage * STAGE_BYTES;
-        const int toff = pl.taboff[t.seg];
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (toff >= 0) {
-            const int k = toff + min(t.k0 + c * 4, a.seg[t.seg].K - 4);
-            sc = *(const float4*)(sSc + k);
-            sh = *(const float4*)(sSh + k);
+    // scale / shift of a tile's prologue (this thread's 4 K values), fetched from the LDS tables one step before write_a uses them
+    float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch_tab = [&](const Tile& t) {
+        if (t.toff >= 0) {
+            const int k = t.toff + min(t.k0 + c * 4, t.K - 4);
+            tsc = *(const float4*)(sSc + k);
+            tsh = *(const float4*)(sSh + k);
         }
+    };
+    const int wa_key = (rbase >> 2) & 3;             // (rows rbase and rbase + 64 share the swizzle key)
+    const int wa_hi = rbase * ROWB + (((c >> 1) ^ wa_key) << 4) + (c & 1) * 8, wa_lo = rbase * ROWB + (((2 + (c >> 1)) ^ wa_key) << 4) + (c & 1) * 8;
+    auto write_a = [&](const Tile& t, int stage, const u32x4 (&ra)[2], const bool (&rz)[2]) {
+        if (abl & 16) return;
+        unsigned char* sA = smem + OFF_A + stage * A_BYTES;
+        const bool pro = t.toff >= 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             float x0 = __uint_as_float(ra[i].x), x1 = __uint_as_float(ra[i].y), x2 = __uint_as_float(ra[i].z), x3 = __uint_as_float(ra[i].w);
-            if (toff >= 0) {
-                x0 = fmaxf(fmaf(x0, sc.x, sh.x), 0.f);
-                x1 = fmaxf(fmaf(x1, sc.y, sh.y), 0.f);
-                x2 = fmaxf(fmaf(x2, sc.z, sh.z), 0.f);
-                x3 = fmaxf(fmaf(x3, sc.w, sh.w), 0.f);
-            }
-            if (rz[i]) { x0 = 0.f; x1 = 0.f; x2 = 0.f; x3 = 0.f; }      // (relu(shift) must not leak into zero rows / the K tail)
+            // BN + ReLU prologue; zero rows / the K tail must read as zero (relu(shift) must not leak in)
+            x0 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x0, tsc.x, tsh.x), 0.f) : x0);
+            x1 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x1, tsc.y, tsh.y), 0.f) : x1);
+            x2 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x2, tsc.z, tsh.z), 0.f) : x2);
+            x3 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x3, tsc.w, tsh.w), 0.f) : x3);
             uint2 h, l;
             h.x = pack_bf16x2(x0, x1);
             h.y = pack_bf16x2(x2, x3);
             l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
             l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
-            *(uint2*)(sA + aoff_hi[i]) = h;
-            *(uint2*)(sA + aoff_lo[i]) = l;
+            *(uint2*)(sA + wa_hi + i * 64 * ROWB) = h;
+            *(uint2*)(sA + wa_lo + i * 64 * ROWB) = l;
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[2][4];
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    int offA[4], keyA[4], offB[2], keyB[2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi) { const int row = wr * 128 + mi * 32 + li; offA[mi] = row * ROWB; keyA[mi] = (row >> 1) & 7; }
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) { const int row = wc * 64 + ni * 32 + li; offB[ni] = row * ROWB; keyB[ni] = (row >> 1) & 7; }
+    // fragment reads: row = (multiple of 32) + li, so the swizzle key is (li >> 2) & 3 for every MFMA tile; the lane's hi / lo
+    // chunk offsets are two registers and the tile / stage bases are immediates
+    const int fkey = (li >> 2) & 3;
+    const int ohi = li * ROWB + ((lh ^ fkey) << 4), olo = li * ROWB + (((2 + lh) ^ fkey) << 4);
 
-    // ---- pipeline.  Invariant at the top of iteration t (after the wait + barrier): stage t&1 holds tile t; the register set
-    // holds the activations of tile t+1.  Tiles 0 and 1 are requested back to back (one exposed latency, not two).
-    Tile cur, nxt, nn;
-    next_tile(cur);
-    enter_seg(cur.seg);
-    dma_w(cur, 0);
-    load_a(cur);
-    bool have_nxt = ntile > 1, have_nn = false;
-    u32x4 rb[4];
-    bool rzb[4];
-    if (have_nxt) {
-        next_tile(nxt);
-        enter_seg(nxt.seg);
-        const int K1 = a.seg[nxt.seg].K;
-        const bool kin1 = nxt.k0 + c * 4 < K1;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            gload16(rb[i], kin1 ? pA[i] + nxt.k0 : pA[i] - c * 4);
-            rzb[i] = zrow[i] || !kin1;
+    // ---- pipeline.  Tile j's activations travel in register set j & 1 and LDS stage j & 1, its weights in stage j % 3.
+    // Invariant at the top of iteration t (after the counted wait + barrier): LDS holds tile t; set (t+1)&1 holds tile t+1's
+    // activations; in flight: the weights of tile t+1 and the activations of tile t+2.
+    Tile d1, d2, d3;                   // tiles t+1, t+2, t+3
+    {
+        Tile d0;
+        next_tile(d0);
+        dma_w(d0, 0);
+        load_a(d0, ra0, rz0);
+        next_tile(d1);
+        dma_w(d1, 1);
+        load_a(d1, ra1, rz1);
+        for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
+            if (pl.taboff[s] >= 0) {
+                const float* sc = a.seg[s].scale;
+                const float* sh = a.seg[s].shift;
+                for (int k = tid; k < a.seg[s].K; k += 256) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
+            }
         }
-    }
-    for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
-        if (pl.taboff[s] >= 0) {
-            const float* sc = a.seg[s].scale;
-            const float* sh = a.seg[s].shift;
-            for (int k = tid; k < a.seg[s].K; k += 512) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
-        }
-    }
-    gload_wait_n<0>();
-    __syncthreads();                                   // tables complete
-    write_a(cur, 0);
-    if (have_nxt) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i] = rb[i]; rz[i] = rzb[i]; }
-    }
-    for (int t = 0; t < ntile; ++t) {
         gload_wait_n<0>();
-        __syncthreads();
-        if (have_nxt) {
-            const int st = (t + 1) & 1;
-            write_a(nxt, st);
-            enter_seg(nxt.seg);                        // (a no-op unless tile t+2's segment moved the pointers on)
-            dma_w(nxt, st);
-            have_nn = t + 2 < ntile;
-            if (have_nn) {
-                next_tile(nn);
-                enter_seg(nn.seg);
-                load_a(nn);
-            }
-        }
-        const unsigned char* sA = smem + (t & 1) * STAGE_BYTES;
-        const unsigned char* sW = sA + TILE_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            union { uint4 u; s16x8 s; } ah[4], al[4], bh[2], bl[2];
-            const int ch = ks * 2 + lh;
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                ah[mi].u = *(const uint4*)(sA + offA[mi] + ((ch ^ keyA[mi]) << 4));
-                al[mi].u = *(const uint4*)(sA + offA[mi] + (((4 + ch) ^ keyA[mi]) << 4));
-            }
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                bh[ni].u = *(const uint4*)(sW + offB[ni] + ((ch ^ keyB[ni]) << 4));
-                bl[ni].u = *(const uint4*)(sW + offB[ni] + (((4 + ch) ^ keyB[ni]) << 4));
-            }
-            // small terms first; consecutive MFMAs on different accumulators
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
-        }
-        nxt = nn; have_nxt = have_nn; have_nn = false;
+        __syncthreads();                                   // tables complete
+        fetch_tab(d0);
+        write_a(d0, 0, ra0, rz0);
+        next_tile(d2);
+        load_a(d2, ra0, rz0);
+        next_tile(d3);
+        fetch_tab(d1);
     }
+    // One K step.  Order after the barrier: the fragment reads of tile t go out first (their LDS latency is covered by the VALU
+    // work of write_a), then tile t+1's activations are written, the transfers of tiles t+2 / t+3 requested, and the MFMAs of
+    // tile t issued; the second half of the weight fragments is read under the first half's MFMAs.
+    union Frag { uint4 u; s16x8 s; };
+    auto mma3 = [&](int nh, const Frag (&ah)[2], const Frag (&al)[2], const Frag (&bh)[2], const Frag (&bl)[2]) {
+        if (abl & 1) {      // keep the fragment reads alive without the matrix cores
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[0][nh * 2 + q][0] += __uint_as_float(bh[q].u.x ^ bl[q].u.y ^ ah[q].u.z ^ al[q].u.w);
+            return;
+        }
+        // small terms first; consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+    };
+    auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
+        gload_wait_n<6>();
+        __syncthreads();
+        const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
+        const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * 128 * ROWB;
+        Frag ah[2], al[2], bh[2], bl[2];
+        if (!(abl & 2)) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                ah[mi].u = *(const uint4*)(sA + mi * 32 * ROWB + ohi);
+                al[mi].u = *(const uint4*)(sA + mi * 32 * ROWB + olo);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bh[q].u = *(const uint4*)(sW + q * 32 * ROWB + ohi);
+                bl[q].u = *(const uint4*)(sW + q * 32 * ROWB + olo);
+            }
+        }
+        if (wr_next) write_a(d1, (t + 1) & 1, ra, rz);          // tile t+1: registers -> LDS (its set is then free for tile t+3)
+        if (!(abl & 2)) {
+            if (do_mma) mma3(0, ah, al, bh, bl);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {                       // second column half: read under the first half's MFMAs
+                bh[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + ohi);
+                bl[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + olo);
+            }
+            if (do_mma) mma3(1, ah, al, bh, bl);
+        }
+        // the transfers of tiles t+2 / t+3 are requested AFTER the step's MFMAs have been issued: when the memory system pushes
+        // back, a wave stalls at the ISSUE of a VMEM instruction, and everything behind it in program order waits with it
+        dma_w(d2, (t + 2) % 3);
+        load_a(d3, ra, rz);
+        d1 = d2; d2 = d3; next_tile(d3);
+        fetch_tab(d1);                                          // (for the next step's write_a)
+    };
+    for (int t = 0; t < ntile; t += 2) {
+        // even step: tile t+1 lives in set 1; odd step: tile t+2 in set 0.  Past the last tile the odd step still runs its
+        // (re-requested, unused) transfers so that the loop has ONE exit and the counted waits stay exact.
+        step(t, t + 1 < ntile, true, ra1, rz1);
+        step(t + 1, t + 2 < ntile, t + 1 < ntile, ra0, rz0);
+    }
+    gload_wait_n<0>();                 // (the re-requested tiles past the end: nothing may land in LDS after this point)
+    __syncthreads();
 
+    if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][3][5] + acc[0][1][2] + acc[0][2][3] + acc[0][3][4] + acc[1][0][1] + acc[1][1][1] + acc[1][2][1]; return; }
     // ---- epilogue, straight from the accumulators (lane = column li of the MFMA tile; register r = row (r&3) + 8 (r>>2) + 4 lh).
-    // Branch-free and batched: per 32-row group `mi` the 2 x 16 X / addend values of the lane are loaded unconditionally from
-    // clamped addresses one group AHEAD of their use, rows that must not be stored (past M, unmapped by cmap) and columns past N
-    // only predicate the stores and the statistics.
+    // Branch-free: all global accesses are BUFFER loads / stores with the tensors' true extents as bounds -- an element that must
+    // not be touched (row past M or unmapped by cmap, column past N) simply gets an out-of-range offset (loads return 0, stores
+    // are dropped by the address unit).  Unit = 4 consecutive rows x the lane's 4 columns (one voffset per row, the columns are
+    // immediate offsets of 128 bytes); the X / addend values of a unit are requested one unit AHEAD of their use.
     constexpr bool bwd = EPI >= 2, xdrop = EPI == 3;
+    constexpr uint32_t OOB = 0x80000000u, RSRC3 = 0x00020000u;
     const uint32_t thresh = a.drop.thresh;
     const float inv_keep = a.drop.inv_keep;
     const uint32_t xkey = xdrop ? drop_key(a.drop, a.xsalt) : 0u;
-    float* const Cb = (float*)a.C;
-    const float* const Addb = (const float*)a.addend;
-    const float* const Xb = (const float*)a.X;
-    int ncol[2], ncl[2];
-    bool nin[2];
-    float bias[2], xs[2], xh[2], s1[2] = {0.f, 0.f}, s2[2] = {0.f, 0.f};
+    const long rowsC = (long)a.B * a.cmap.T_total * a.J;
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * 4), RSRC3);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * 4) : 0, RSRC3);
+    const long rowsAdd = ADD ? (long)a.B * a.addmap.T_total * a.J : 1;
+    const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(ADD ? a.addend : a.C), 0, ADD ? (int)(((rowsAdd - 1) * a.ldadd + N) * 4) : 0, RSRC3);
+    const int col0 = n0 + wc * 128 + li;               // the lane's first column; the others are + 32 ni
+    bool nin[4];
+    float bias[4], xs[4], xh[4], s1[4], s2[4];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        ncol[ni] = n0 + wc * 64 + ni * 32 + li;
-        nin[ni] = ncol[ni] < N;
-        ncl[ni] = nin[ni] ? ncol[ni] : N - 1;
-        bias[ni] = a.bias ? (a.bias_neg ? -a.bias[ncl[ni]] : a.bias[ncl[ni]]) : 0.f;
-        xs[ni] = bwd ? a.xscale[ncl[ni]] : 0.f;
-        xh[ni] = bwd ? a.xshift[ncl[ni]] : 0.f;
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = col0 + 32 * ni;
+        nin[ni] = n < N;
+        const int ncl = nin[ni] ? n : N - 1;
+        bias[ni] = a.bias ? (a.bias_neg ? -a.bias[ncl] : a.bias[ncl]) : 0.f;
+        xs[ni] = bwd ? a.xscale[ncl] : 0.f;
+        xh[ni] = bwd ? a.xshift[ncl] : 0.f;
+        s1[ni] = 0.f; s2[ni] = 0.f;
     }
-    // unit u = 8 rows of one 32-row group: mi = u >> 1, registers r = 8 (u & 1) .. + 7
-    int crow[2][8], arow[2][8];
-    float xv[2][2][8], av[2][2][8];
+    // unit u = (mi = u >> 2, q = u & 3): rows wr*64 + mi*32 + 8 q + 4 lh + {0..3} = accumulator registers 4 q .. 4 q + 3
+    int crow[2][4];
+    float xv[2][4][4], av[2][4][4];
     auto fetch = [&](int u, int buf) {
-        const int mi = u >> 1;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int base = wr * 128 + mi * 32 + 8 * (2 * (u & 1) + q) + 4 * lh;
-            const int4 c4 = *(const int4*)(sCrow + base);
-            crow[buf][4 * q] = c4.x; crow[buf][4 * q + 1] = c4.y; crow[buf][4 * q + 2] = c4.z; crow[buf][4 * q + 3] = c4.w;
-            if (Addb) {
-                const int4 a4 = *(const int4*)(sAdd + base);
-                arow[buf][4 * q] = a4.x; arow[buf][4 * q + 1] = a4.y; arow[buf][4 * q + 2] = a4.z; arow[buf][4 * q + 3] = a4.w;
-            }
-        }
+        const int base = wr * 64 + (u >> 2) * 32 + 8 * (u & 3) + 4 * lh;
+        const int4 c4 = *(const int4*)(sCrow + base);
+        crow[buf][0] = c4.x; crow[buf][1] = c4.y; crow[buf][2] = c4.z; crow[buf][3] = c4.w;
         if (bwd) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t off = crow[buf][r] >= 0 ? (uint32_t)(crow[buf][r] * a.ldx + col0) * 4u : OOB;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) xv[buf][ni][r] = Xb[(long)max(crow[buf][r], 0) * a.ldx + ncl[ni]];
+                for (int ni = 0; ni < 4; ++ni)
+                    xv[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, off + 128 * ni, 0, 0));
+            }
         }
-        if (Addb) {
+        if (ADD) {
+            const int4 a4 = *(const int4*)(sAdd + base);
+            const int ar[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
+            for (int r = 0; r < 4; ++r) {
+                const uint32_t off = ar[r] >= 0 ? (uint32_t)(ar[r] * a.ldadd + col0) * 4u : OOB;     // unmapped addend row: reads 0
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) av[buf][ni][r] = Addb[(long)max(arow[buf][r], 0) * a.ldadd + ncl[ni]];
-        } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) { arow[buf][r] = -1; av[buf][0][r] = 0.f; av[buf][1][r] = 0.f; }
+                for (int ni = 0; ni < 4; ++ni)
+                    av[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAdd, off + 128 * ni, 0, 0));
+            }
         }
     };
     fetch(0, 0);
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-        const int buf = u & 1, mi = u >> 1;
+        const int buf = u & 1, mi = u >> 2, q = u & 3;
         if (u + 1 < 8) fetch(u + 1, buf ^ 1);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < 4; ++r) {
             const int cr = crow[buf][r];
+            const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * 4u;
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
+            for (int ni = 0; ni < 4; ++ni) {
                 const bool ok = cr >= 0 && nin[ni];
-                float v = acc[mi][ni][8 * (u & 1) + r] + bias[ni];
-                v += arow[buf][r] >= 0 ? av[buf][ni][r] : 0.f;
+                float v = acc[mi][ni][4 * q + r] + bias[ni];
+                if (ADD) v += av[buf][ni][r];
                 if (bwd) {
                     const float x = xv[buf][ni][r];
                     v = fmaf(x, xs[ni], xh[ni]) > 0.f ? v : 0.f;
-                    if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)((long)max(cr, 0) * a.ldx + ncl[ni]));
+                    if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(cr * a.ldx + col0 + 32 * ni));
                     s1[ni] += ok ? v : 0.f;
                     s2[ni] += ok ? v * x : 0.f;
                 } else if (EPI == 1) {
                     s1[ni] += ok ? v : 0.f;
                     s2[ni] += ok ? v * v : 0.f;
                 }
-                if (ok) Cb[(long)cr * a.ldc + ncol[ni]] = v;
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rC, ok ? coff + 128 * ni : OOB, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);             // keep the units apart: interleaving them only adds register pressure
     }
-    if (EPI != 0 && m0 + wr * 128 < M) {
+    if (EPI != 0) {
+        // the two row-halves of the block (waves wr = 0 / 1) are one 128-row statistics block: combine through LDS
+        float* const sRed = (float*)(smem + OFF_A);      // [wr][256][2]
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < 4; ++ni) {
             s1[ni] += __shfl_xor(s1[ni], 32);
             s2[ni] += __shfl_xor(s2[ni], 32);
-            if (lh == 0 && nin[ni]) {
-                float* pp = a.partials + ((long)(mt * 2 + wr) * N + ncol[ni]) * 2;
-                pp[0] = s1[ni];
-                pp[1] = s2[ni];
+            if (lh == 0) {
+                const int cl = wc * 128 + ni * 32 + li;
+                sRed[(wr * TN + cl) * 2] = s1[ni];
+                sRed[(wr * TN + cl) * 2 + 1] = s2[ni];
             }
+        }
+        __syncthreads();
+        const int n = n0 + tid;
+        if (n < N) {
+            float* pp = a.partials + ((long)mt * N + n) * 2;
+            pp[0] = sRed[tid * 2] + sRed[(TN + tid) * 2];
+            pp[1] = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
         }
     }
 }
 
-__device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {
-    if (a.epi == GAST_EPI_BNRELU_BWD) return (a.xdrop && a.drop.thresh != 0) ? 3 : 2;
-    return a.epi;
+__host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {      // EPI * 2 + ADD
+    const int e = a.epi == GAST_EPI_BNRELU_BWD ? ((a.xdrop && a.drop.thresh != 0) ? 3 : 2) : a.epi;
+    return e * 2 + (a.addend ? 1 : 0);
 }
 
-template <int EPI>
-__global__ void __launch_bounds__(512) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
+template <int EPI, bool ADD>
+__global__ void __launch_bounds__(256, 2) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -379,27 +437,24 @@ struct BigBatch {
     int n;
 };
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
-__global__ void __launch_bounds__(512) gemm_big_multi_kernel(const BigBatch b) {
+// several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
+template <int EPI, bool ADD>
+__global__ void __launch_bounds__(256, 2) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    const int blk = blockIdx.x - b.first[d];
-    switch (epi_variant(b.a[d])) {
-        case 0: big_body<0>(b.a[d], b.pl[d], blk, smem); break;
-        case 1: big_body<1>(b.a[d], b.pl[d], blk, smem); break;
-        case 2: big_body<2>(b.a[d], b.pl[d], blk, smem); break;
-        default: big_body<3>(b.a[d], b.pl[d], blk, smem); break;
-    }
+    big_body<EPI, ADD>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
-// ---- pre-split weight image: img[r][(k>>5)*64 + (k&31)] = bf16 hi(W[r][k]),  + 32: bf16 lo; zero for K <= k < Kp
+// ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
+// zero for K <= k < Kp (rows past R are never written: the caller provides them zero-filled)
 struct ImageBatch { gast_x3_image_job j[GAST_X3_IMAGE_MAX_BATCH]; int first[GAST_X3_IMAGE_MAX_BATCH + 1]; int n; };
 static_assert(sizeof(ImageBatch) <= 3840, "ImageBatch travels as a kernel argument");
 __global__ void __launch_bounds__(256) x3_image_kernel(const ImageBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
     const gast_x3_image_job& j = b.j[d];
-    const int Kp4 = (j.K + 31) / 32 * 8;                          // 4-value chunks per padded row
+    const int Kp4 = (j.K + 15) / 16 * 4;                          // 4-value chunks per padded row
     const long idx = (long)(blockIdx.x - b.first[d]) * 256 + threadIdx.x;
     if (idx >= (long)j.R * Kp4) return;
     const int r = (int)(idx / Kp4), k = (int)(idx - (long)r * Kp4) * 4;
@@ -410,9 +465,9 @@ __global__ void __launch_bounds__(256) x3_image_kernel(const ImageBatch b) {
     h.y = pack_bf16x2(v.z, v.w);
     l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
     l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
-    bf16_t* o = (bf16_t*)j.img + (long)r * j.ldimg + (k >> 5) * 64 + (k & 31);
+    bf16_t* o = (bf16_t*)j.img + (long)(k >> 4) * j.ldimg + (long)r * 32 + (k & 15);
     *(uint2*)o = h;
-    *(uint2*)(o + 32) = l;
+    *(uint2*)(o + 16) = l;
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -421,18 +476,28 @@ bool big_setup_done[64] = {};
 
 }  // namespace
 
-// Can this GEMM run on the big-tile kernel?  Fills the plan when it can.  (Called by gast_gemm_ws / gast_gemm_multi in gemm.hip.)
+// Can this GEMM run on the large-M kernel?  Fills the plan when it can.  (Called by gast_gemm_ws / gast_gemm_multi in gemm.hip.)
 int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int enabled = getenv("GAST_GEMM_BIG") ? atoi(getenv("GAST_GEMM_BIG")) : 1;
     static const int min_rows = getenv("GAST_GEMM_BIG_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_MIN_M")) : 8192;
     if (!enabled || a.dtype != GAST_F32X3) return 0;
     const long Ml = (long)a.B * a.Tn * a.J;
+    static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
     if (Ml < min_rows || Ml > 0x7fffff00L || a.N < 32) return 0;
+    if (!all_shapes) {
+        // measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): the 128 x 256 tile loses to gemm.hip's 128 x 128 tile when
+        // half of it is empty (N <= 128), and its BNRELU_BWD epilogue (X / addend gathered per lane) only pays on long K loops
+        int ksum = 0;
+        for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
+        if (a.N < 256) return 0;
+        if (a.epi == GAST_EPI_BNRELU_BWD && ksum < 768) return 0;
+    }
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG) return 0;
     int ntab = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_gemm_seg& g = a.seg[s];
         if (!g.Wx || !aligned16(g.Wx) || g.ldwx % 8 || !g.A || !aligned16(g.A) || g.lda % 4 || g.K % 4 || g.K < 4) return 0;
+        if ((long)a.B * g.map.T_total * a.J * g.lda * 4 >= 0xffffffffL) return 0;      // 32-bit byte offsets into the activation tensor
         if (g.pro == GAST_PRO_BNRELU_DROP) return 0;
         pl.taboff[s] = -1;
         if (g.pro == GAST_PRO_BNRELU) {
@@ -445,6 +510,12 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     if (ntab > MAX_TAB) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
+    // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
+    const long rowsC = (long)a.B * a.cmap.T_total * a.J;
+    if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
+    if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
+    static const int ablate = getenv("GAST_GEMM_BIG_ABLATE") ? atoi(getenv("GAST_GEMM_BIG_ABLATE")) : 0;
+    pl.ablate = ablate;
     pl.M = (int)Ml;
     pl.tilesM = (pl.M + TM - 1) / TM;
     pl.tilesN = (a.N + TN - 1) / TN;
@@ -452,52 +523,89 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     return 1;
 }
 
-static int big_lds_bytes(int ntab) { return LDS_FIXED + 2 * ntab * 4; }
+static int big_lds_bytes(int ntab) { return OFF_TAB + 2 * ntab * 4 + 6 * 256 * 4; }
+
+typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
+static big_kernel_t big_kernel(int v) {
+    switch (v) {
+        case 0: return gemm_big_kernel<0, false>;
+        case 1: return gemm_big_kernel<0, true>;
+        case 2: return gemm_big_kernel<1, false>;
+        case 3: return gemm_big_kernel<1, true>;
+        case 4: return gemm_big_kernel<2, false>;
+        case 5: return gemm_big_kernel<2, true>;
+        case 6: return gemm_big_kernel<3, false>;
+        default: return gemm_big_kernel<3, true>;
+    }
+}
+
+typedef void (*big_multi_kernel_t)(const BigBatch);
+static big_multi_kernel_t big_multi_kernel(int v) {
+    switch (v) {
+        case 0: return gemm_big_multi_kernel<0, false>;
+        case 1: return gemm_big_multi_kernel<0, true>;
+        case 2: return gemm_big_multi_kernel<1, false>;
+        case 3: return gemm_big_multi_kernel<1, true>;
+        case 4: return gemm_big_multi_kernel<2, false>;
+        case 5: return gemm_big_multi_kernel<2, true>;
+        case 6: return gemm_big_multi_kernel<3, false>;
+        default: return gemm_big_multi_kernel<3, true>;
+    }
+}
 
 static void big_setup() {
     int dev = 0;
     hipGetDevice(&dev);               // function attributes are per device (nn.DataParallel replicas launch on several)
     dev &= 63;
     if (big_setup_done[dev]) return;
-    hipFuncSetAttribute((const void*)gemm_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    hipFuncSetAttribute((const void*)gemm_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    hipFuncSetAttribute((const void*)gemm_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    hipFuncSetAttribute((const void*)gemm_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
-    hipFuncSetAttribute((const void*)gemm_big_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX);
+    for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+    for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
     big_setup_done[dev] = true;
+    if (getenv("GAST_GEMM_BIG_DEBUG")) {
+        for (int v = 0; v < 8; v += 2) {
+            int nb = -1;
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v), 256, big_lds_bytes(0));
+            hipFuncAttributes fa;
+            hipFuncGetAttributes(&fa, (const void*)big_kernel(v));
+            fprintf(stderr, "gemm_big variant %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, nb, big_lds_bytes(0), fa.numRegs, (size_t)fa.localSizeBytes);
+        }
+    }
 }
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    const dim3 grid(pl.tilesM * pl.tilesN), block(512);
-    const int lds = big_lds_bytes(pl.ntab);
-    const int v = a.epi == GAST_EPI_BNRELU_BWD ? ((a.xdrop && a.drop.thresh != 0) ? 3 : 2) : a.epi;
-    if (v == 0) hipLaunchKernelGGL(gemm_big_kernel<0>, grid, block, lds, st, a, pl);
-    else if (v == 1) hipLaunchKernelGGL(gemm_big_kernel<1>, grid, block, lds, st, a, pl);
-    else if (v == 2) hipLaunchKernelGGL(gemm_big_kernel<2>, grid, block, lds, st, a, pl);
-    else hipLaunchKernelGGL(gemm_big_kernel<3>, grid, block, lds, st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a)), dim3(pl.tilesM * pl.tilesN), dim3(256), big_lds_bytes(pl.ntab), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
 int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st) {
     big_setup();
-    BigBatch b;
-    b.n = n;
-    b.first[0] = 0;
-    int ntab = 0;
-    for (int d = 0; d < n; ++d) {
-        b.a[d] = args[d];
-        b.pl[d] = pls[d];
-        b.first[d + 1] = b.first[d] + pls[d].tilesM * pls[d].tilesN;
-        if (pls[d].ntab > ntab) ntab = pls[d].ntab;
+    bool done[GAST_GEMM_MAX_BATCH] = {};
+    for (int d0 = 0; d0 < n; ++d0) {          // one grid per epilogue variant present in the batch
+        if (done[d0]) continue;
+        const int v = epi_variant(args[d0]);
+        BigBatch b;
+        b.n = 0;
+        b.first[0] = 0;
+        int ntab = 0;
+        for (int d = d0; d < n; ++d) {
+            if (done[d] || epi_variant(args[d]) != v) continue;
+            done[d] = true;
+            const int k = b.n++;
+            b.a[k] = args[d];
+            b.pl[k] = pls[d];
+            b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
+            if (pls[d].ntab > ntab) ntab = pls[d].ntab;
+        }
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v), dim3(b.first[1]), dim3(256), big_lds_bytes(ntab), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v), dim3(b.first[b.n]), dim3(256), big_lds_bytes(ntab), st, b);
+        GAST_CHECK_LAUNCH();
     }
-    hipLaunchKernelGGL(gemm_big_multi_kernel, dim3(b.first[n]), dim3(512), big_lds_bytes(ntab), st, b);
-    GAST_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" long gast_x3_image_ld(int K) { return (long)((K + 31) / 32) * 64; }
+extern "C" long gast_x3_image_ld(int R) { return (long)((R + 15) / 16 * 16 + 256) * 32; }
 
 extern "C" int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_stream_t stream) {
     if (!jobs || n < 0) return GAST_EINVAL;
@@ -508,9 +616,9 @@ extern "C" int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_st
         for (int d = 0; d < b.n; ++d) {
             const gast_x3_image_job& j = jobs[i0 + d];
             if (!j.W || !j.img || j.R < 1 || j.K < 4) return GAST_EINVAL;
-            if (j.K % 4 || j.ldw % 4 || !aligned16(j.W) || !aligned16(j.img) || j.ldimg % 8 || j.ldimg < gast_x3_image_ld(j.K)) return GAST_EALIGN;
+            if (j.K % 4 || j.ldw % 4 || !aligned16(j.W) || !aligned16(j.img) || j.ldimg % 8 || j.ldimg < (long)j.R * 32) return GAST_EALIGN;
             b.j[d] = j;
-            const long chunks = (long)j.R * ((j.K + 31) / 32 * 8);
+            const long chunks = (long)j.R * ((j.K + 15) / 16 * 4);
             b.first[d + 1] = b.first[d] + (int)((chunks + 255) / 256);
         }
         hipLaunchKernelGGL(x3_image_kernel, dim3(b.first[b.n]), dim3(256), 0, (hipStream_t)stream, b);

@@ -270,7 +270,7 @@ class HipOps:
             g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
             g.W, g.ldw = _p(W), _ld(W)
             if img is not None and self.x3:
-                g.Wx, g.ldwx = _p(img), _ld(img)
+                g.Wx, g.ldwx = _p(img), img.stride(0)
             g.pro = int(s.get('pro', PRO_NONE))
             g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
             g.salt = int(s.get('salt', 0))
@@ -309,8 +309,8 @@ class HipOps:
         Packer.inputs() hands the engine for every packed operand in GAST_F32X3 mode."""
         if W.dtype != torch.float32:
             raise RuntimeError('gast_hip: x3_weight needs an fp32 operand')
-        ld = int(self.lib.gast_x3_image_ld(int(W.shape[1])))
-        img = torch.empty(W.shape[0], ld, dtype=torch.bfloat16, device=W.device)
+        ld = int(self.lib.gast_x3_image_ld(int(W.shape[0])))
+        img = torch.zeros((W.shape[1] + 15) // 16, ld // 32, 32, dtype=torch.bfloat16, device=W.device)
         job = (_X3ImageJob * 1)()
         job[0].W, job[0].R, job[0].K, job[0].ldw, job[0].img, job[0].ldimg = _p(W), W.shape[0], W.shape[1], _ld(W), _p(img), ld
         self.launches += 1
@@ -681,7 +681,7 @@ class HipOps:
                 jobs = packer.image_jobs(st)
                 arr = (_X3ImageJob * len(jobs))()
                 for a, (wv, iv) in zip(arr, jobs):
-                    a.W, a.R, a.K, a.ldw, a.img, a.ldimg = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(iv), _ld(iv)
+                    a.W, a.R, a.K, a.ldw, a.img, a.ldimg = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(iv), iv.stride(0)
                 tb['x3img'] = arr
             self.launches += 1
             _check(self.lib.gast_x3_image_multi(arr, len(arr), _stream()), 'gast_x3_image_multi')

@@ -49,10 +49,18 @@ class Layout:
         return Ref(base, None, off + row0 * c + col0, c, 1)
 
 
+X3_PAD_ROWS = 256      # zero rows behind every pre-split weight image (a GEMM tile spans 256 weight rows from any start row)
+
+
+def x3_image_rows(R):
+    return (R + 15) // 16 * 16 + X3_PAD_ROWS
+
+
 class X3Weight:
-    """An fp32 [N][K] GEMM operand together with its pre-split bf16 image (GAST_F32X3; `gast_x3_image_multi`, include/gast_hip.h).
-    Slices like the tensor it wraps (`w[r0:r1]`, `w[:, k0:k1]`); a column slice that is not aligned to the 32-value groups of
-    the image drops the image (the GEMM then splits the fp32 operand itself)."""
+    """An fp32 [N][K] GEMM operand together with its pre-split bf16 image (GAST_F32X3; `gast_x3_image_multi`, include/gast_hip.h):
+    img is the k-group-major 3-D view [ceil(K/16)][rows + zero padding][32].  Slices like the tensor it wraps (`w[r0:r1]`,
+    `w[:, k0:k1]`); a column slice that is not aligned to the 16-value groups drops the image (the GEMM then splits the fp32
+    operand itself)."""
     __slots__ = ('t', 'img')
 
     def __init__(self, t, img):
@@ -62,10 +70,11 @@ class X3Weight:
         rs, cs = idx if isinstance(idx, tuple) else (idx, slice(None))
         img = None
         if self.img is not None:
-            K = self.t.shape[1]
+            R, K = self.t.shape
             a, b, step = cs.indices(K)
-            if step == 1 and a % 32 == 0 and (b % 32 == 0 or b == K):
-                img = self.img[rs, 2 * a:2 * ((b + 31) // 32 * 32)]
+            r0, _, rstep = rs.indices(R)
+            if step == 1 and rstep == 1 and a % 16 == 0 and (b % 16 == 0 or b == K):
+                img = self.img[a // 16:(b + 15) // 16, r0:]       # (keeps the rows behind the slice: tiles read 256 rows from r0)
         return X3Weight(self.t[rs, cs], img)
 
 
@@ -221,7 +230,7 @@ class Packer:
             if x3 and dt == torch.float32:
                 X = Layout()
                 for n, (_, r, c) in self.W.regions.items():
-                    X.add(n, r, 2 * ((c + 31) // 32 * 32))
+                    X.add(n, (c + 15) // 16, x3_image_rows(r) * 32)
                 st['X'] = X
                 st['Xb'] = torch.zeros(X.size, dtype=torch.bfloat16, device=dev)
             self._dev[key] = st
@@ -229,13 +238,17 @@ class Packer:
 
     def image_jobs(self, st):
         """(fp32 operand view, image view) per packed operand, for ops.run_pack."""
-        return [(self.W.view(st['Wb'], n), st['X'].view(st['Xb'], n)) for n in self.W.regions]
+        return [(self.W.view(st['Wb'], n), self._image(st, n)) for n in self.W.regions]
+
+    def _image(self, st, n):
+        g, per = st['X'].regions[n][1:]
+        return st['X'].view(st['Xb'], n).view(g, per // 32, 32)
 
     def inputs(self, st):
         """engine `inp` dict: operand views (act dtype), fp32 packed views, raw parameters."""
         inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
         if st.get('Xb') is not None:
-            inp = {n: X3Weight(w, st['X'].view(st['Xb'], n)) for n, w in inp.items()}
+            inp = {n: X3Weight(w, self._image(st, n)) for n, w in inp.items()}
         for n in self.F.regions:
             v = self.F.view(st['Fb'], n)
             inp[n] = v.view(-1) if n.endswith('bias1') else v.view(NHEADS, self.spec.J, self.spec.J)

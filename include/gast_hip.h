@@ -83,7 +83,7 @@ typedef struct {
     const float* shift;  /* [K] */
     uint32_t salt;       /* dropout stream id of tensor A (pro == BNRELU_DROP) */
     const void* Wx;      /* optional (GAST_F32X3): pre-split bf16 image of W made by gast_x3_image_multi, [N][ldwx]; lets the GEMM
-                          * take the 256x256-tile path whose weight tiles stream global -> LDS without passing registers */
+                          * take the large-M path (gemm_big.hip) whose weight tiles stream global -> LDS without passing registers */
     int ldwx;
 } gast_gemm_seg;
 
@@ -129,18 +129,21 @@ int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_strea
 #define GAST_GEMM_MAX_BATCH 3
 int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream);
 long gast_gemm_splitk_ws_bytes(long M, int N);
-/* which kernel gast_gemm_ws would launch for these arguments: 0 = the 128x128-tile kernel, 1 = the 256x256-tile GAST_F32X3 kernel
+/* which kernel gast_gemm_ws would launch for these arguments: 0 = the 128x128-tile kernel, 1 = the large-M GAST_F32X3 kernel
  * (needs every segment's Wx image, >= 8192 rows, N >= 32, no dropout prologue) */
 int gast_gemm_path(const gast_gemm_args* args);
-/* Pre-split weight image for GAST_F32X3: for every row r of the fp32 operand W[R][ldw] (K columns used) and every group of 32
- * K values, 32 bf16 "hi" = bf16(w) followed by 32 bf16 "lo" = bf16(w - hi):  img[r][(k >> 5) * 64 + (k & 31)] = hi,
- * img[...+ 32] = lo, zero for K <= k < 32 * ceil(K / 32).  ldimg >= gast_x3_image_ld(K) bf16 elements.  A column slice
- * W[:, k0:k1] with k0 % 32 == 0 (and k1 % 32 == 0 unless k1 == K) has the image img + 2 * k0; a row slice W[r0:] has
- * img + r0 * ldimg.  n jobs in one launch (GAST_X3_IMAGE_MAX_BATCH per launch). */
+/* Pre-split weight image for GAST_F32X3, k-group-major: for every group g of 16 K values and every row r of the fp32 operand
+ * W[R][ldw] (K columns used), 16 bf16 "hi" = bf16(w) followed by 16 bf16 "lo" = bf16(w - hi):
+ *   img[g * ldimg + r * 32 + (k & 15)] = hi,  img[... + 16] = lo,  g = k >> 4,  zero for K <= k < 16 * ceil(K / 16),
+ * so the 256 x 16 weight tile of one K step of the large-M GEMM is ONE contiguous 16 KB block.  ldimg (bf16 elements per
+ * k-group) >= gast_x3_image_ld(R) = 32 * (round_up(R, 16) + 256): the rows past R must exist and be ZERO-FILLED by the caller (a
+ * tile may start at any row and always spans 256).  A row slice W[r0:] has the image img + 32 * r0, a column slice W[:, k0:]
+ * with k0 % 16 == 0 the image img + (k0 / 16) * ldimg (same ldimg).  gast_gemm_seg.Wx / ldwx carry img / ldimg.
+ * n jobs in one launch (GAST_X3_IMAGE_MAX_BATCH per launch). */
 #define GAST_X3_IMAGE_MAX_BATCH 64
 typedef struct { const float* W; int R, K, ldw; void* img; int ldimg; } gast_x3_image_job;
 int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_stream_t stream);
-long gast_x3_image_ld(int K);
+long gast_x3_image_ld(int R);
 /* number of row blocks (first dimension of `partials`) gast_gemm uses for a domain of M rows */
 int gast_gemm_row_blocks(int M);
 

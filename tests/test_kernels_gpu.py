@@ -35,6 +35,8 @@ class x3_mode:
 
 @pytest.fixture(scope='module')
 def ops():
+    import os
+    os.environ.setdefault('GAST_GEMM_BIG_ALL', '1')     # kernel tests: every eligible shape on the large-M kernel (read once by the library)
     from gast_hip.binding import HipOps
     return HipOps()
 
@@ -205,7 +207,7 @@ def test_gemm_multi(ops, mode):
         _gemm_check(c, dt, bufs, mode)
 
 
-# large-M cases: with pre-split weight images (HipOps.x3_weight) GAST_F32X3 GEMMs of >= 8192 rows take the 256x256-tile kernel
+# large-M cases: with pre-split weight images (HipOps.x3_weight) GAST_F32X3 GEMMs of >= 8192 rows take the large-M kernel
 # (csrc/gemm_big.hip): taps + prologue + statistics + centred bias + N tail; channel concat; gather input gradient with zero rows,
 # addend, ReLU/dropout/BN-sum epilogue; K tails (168 = 5*32 + 8 and 72); a one-K-tile GEMM
 GEMM_BIG_CASES = [
@@ -215,6 +217,8 @@ GEMM_BIG_CASES = [
     ('big_ktail', (32, 16, 17), 136, [(5 * 32 + 8, 16, 1, 0, 0), (72, 16, 1, 0, 1)], 0, False, True),
     ('big_one_tile', (31, 16, 17), 648, [(32, 16, 1, 0, 1)], 1, False, True),
     ('big_strided_taps', (90, 5, 19), 96, [(32, 15, 3, 0, 1), (32, 15, 3, 1, 1), (32, 15, 3, 2, 1)], 1, False, False),
+    ('big_bwd_noadd', (22, 23, 17), 512, [(256, 23, 1, 0, 0)], 2, False, False),
+    ('big_plain_add', (22, 23, 17), 256, [(256, 23, 1, 0, 0)], 0, True, False),
 ]
 
 
@@ -224,42 +228,56 @@ def _with_images(ops, jd):
     return jd
 
 
+@pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
 @pytest.mark.parametrize('case', GEMM_BIG_CASES, ids=[c[0] for c in GEMM_BIG_CASES])
-def test_gemm_big_x3(ops, case):
+def test_gemm_big_x3(ops, case, nodrop):
+    if nodrop and case[4] != 2:
+        pytest.skip('only the BNRELU_BWD epilogue has a dropout variant')
     jd, jh, bufs = _gemm_case(case, torch.float32)
+    if nodrop:
+        jd['xdrop'] = jh['xdrop'] = False
     with x3_mode(ops, 'x3'):
-        assert ops.gemm_path(**_with_images(ops, jd)) == 1, 'the 256x256-tile kernel was not selected'
+        assert ops.gemm_path(**_with_images(ops, jd)) == 1, 'the large-M kernel (gemm_big.hip) was not selected'
         ops.gemm(**jd)
     kc.gemm(**jh)
     torch.cuda.synchronize()
     _gemm_check(case, torch.float32, bufs, 'x3')
 
 
-def test_gemm_big_x3_multi(ops):
-    built = [_gemm_case(c, torch.float32) for c in GEMM_BIG_CASES[:3]]
+@pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
+@pytest.mark.parametrize('first', [0, 3, 6])
+def test_gemm_big_x3_multi(ops, first, nodrop):
+    """every epilogue variant of the large-M kernel also inside a multi-job grid (3 jobs per launch)"""
+    cases = (GEMM_BIG_CASES + GEMM_BIG_CASES[:1])[first:first + 3]
+    built = [_gemm_case(c, torch.float32) for c in cases]
+    if nodrop:
+        for jd, jh, _ in built:
+            jd['xdrop'] = jh['xdrop'] = False
     with x3_mode(ops, 'x3'):
         ops.gemm_multi([_with_images(ops, jd) for jd, _, _ in built])
     torch.cuda.synchronize()
-    for c, (jd, jh, bufs) in zip(GEMM_BIG_CASES[:3], built):
+    for c, (jd, jh, bufs) in zip(cases, built):
         kc.gemm(**jh)
         _gemm_check(c, torch.float32, bufs, 'x3')
 
 
 def test_x3_image_layout(ops):
-    """img[r][(k>>5)*64 + (k&31)] = bf16(w), + 32: bf16(w - hi), zero padding up to a multiple of 32 K values"""
+    """k-group-major image: img[k>>4][r][k&15] = bf16(w), [...][16 + (k&15)] = bf16(w - hi); zero K padding and zero rows behind"""
     gen = torch.Generator().manual_seed(11)
     W = rand(gen, 37, 72).cuda()
     xw = ops.x3_weight(W)
     torch.cuda.synchronize()
-    img = xw.img.float().cpu().numpy().reshape(37, 3, 2, 32)
-    Wp = np.zeros((37, 96), dtype=np.float32)
+    img = xw.img.float().cpu().numpy()                # [5][48 + 256][32]
+    assert img.shape == (5, 48 + 256, 32)
+    Wp = np.zeros((37, 80), dtype=np.float32)
     Wp[:, :72] = W.cpu().numpy()
     hi = torch.from_numpy(Wp).to(torch.bfloat16).float().numpy()
     lo = torch.from_numpy(Wp - hi).to(torch.bfloat16).float().numpy()
-    assert np.array_equal(img[:, :, 0, :].reshape(37, 96), hi)
-    assert np.array_equal(img[:, :, 1, :].reshape(37, 96), lo)
+    assert np.array_equal(img[:, :37, :16].transpose(1, 0, 2).reshape(37, 80), hi)
+    assert np.array_equal(img[:, :37, 16:].transpose(1, 0, 2).reshape(37, 80), lo)
+    assert not img[:, 37:].any()
     sl = xw[5:9, 32:72]                  # aligned column slice keeps its image, an unaligned one drops it
-    assert sl.img is not None and sl.img.data_ptr() == xw.img[5:, 64:].data_ptr() and xw[:, 8:40].img is None
+    assert sl.img is not None and sl.img.data_ptr() == xw.img[2:, 5:].data_ptr() and xw[:, 8:40].img is None
 
 
 def test_gemm_out_f32_from_bf16(ops):
