@@ -44,7 +44,10 @@ class GraphAttentionBlock(nn.Module):
         self.cat_bn = nn.BatchNorm2d(2 * output_dim, momentum=0.1)
 
     def forward(self, x):
-        raise NotImplementedError('GraphAttentionBlock runs inside the fused HIP plan of SpatioTemporalModel')
+        """x: (B, C, T, J) -> (B, 2 C_out, T, J)   (reference :22-33).  Inside SpatioTemporalModel the block is part of the fused
+        plan; on its own it runs the same kernels as a forward-only plan (gast_hip/modules.py)."""
+        from gast_hip.modules import graph_attention_block_forward
+        return graph_attention_block_forward(self, x)
 
 
 class ModelSpec:

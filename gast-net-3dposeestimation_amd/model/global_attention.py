@@ -1,12 +1,13 @@
-"""Global graph attention: parameter containers (reference model/global_attention.py).
+"""Global graph attention (reference model/global_attention.py).
 
 Same constructor signatures, parameter names/shapes and initialisers as the reference (global_attention.py:12-50,
-86-101, 134-146).  The forward arithmetic (global_attention.py:52-82, 103-130) is part of the fused HIP plan
-(gast_hip/engine.py: G1 + ATT + G3): g/theta/phi are columns of one GEMM, the additive score
+86-101, 134-146).  Inside SpatioTemporalModel the forward arithmetic (global_attention.py:52-82, 103-130) is part of the fused
+HIP plan (gast_hip/engine.py: G1 + ATT + G3): g/theta/phi are columns of one GEMM, the additive score
 f_ij = LeakyReLU(w_theta.theta_i + w_phi.phi_j) is rank-1 so theta/phi fold into two C-vectors per head, and the
-(BT, 2Ci, J, J) concat tensor of the reference is never built.
+(BT, 2Ci, J, J) concat tensor of the reference is never built.  Called on their own, the modules run the same kernels as a
+small forward-only plan (gast_hip/modules.py).
 
-Only what the `state_dict` contract and the seed-for-seed initialisation test (tests/test_host_contract.py) need is kept:
+What the `state_dict` contract and the seed-for-seed initialisation test (tests/test_host_contract.py) need is kept:
 the registration ORDER of the sub-modules (it fixes both the key order and the order of the RNG draws) and their
 initialisers.  Activation helper modules of the reference (parameter-free) are not re-created.
 """
@@ -21,15 +22,7 @@ def _pointwise(c_in, c_out):
     return nn.Conv1d(c_in, c_out, kernel_size=1, stride=1, padding=0)
 
 
-class _FusedOnly(nn.Module):
-    """Parameter holder whose arithmetic lives in the fused plan of SpatioTemporalModel."""
-
-    def forward(self, x):
-        raise NotImplementedError('%s holds parameters only: it runs inside the fused HIP plan of SpatioTemporalModel'
-                                  % type(self).__name__)
-
-
-class GlobalGraph(_FusedOnly):
+class GlobalGraph(nn.Module):
     """One attention head: g / theta / phi projections, the learnable (J, J) offset C_k and the 2Ci -> 1 score projection."""
 
     def __init__(self, adj, in_channels, inter_channels=None):
@@ -49,8 +42,13 @@ class GlobalGraph(_FusedOnly):
             nn.init.kaiming_normal_(proj.weight)
             nn.init.constant_(proj.bias, 0)
 
+    def forward(self, x):
+        """x: (B*T, C, J) -> (B*T, g_channels, J)   (reference :52-82)"""
+        from gast_hip.modules import global_graph_forward
+        return global_graph_forward(self, x)
 
-class MultiGlobalGraph(_FusedOnly):
+
+class MultiGlobalGraph(nn.Module):
     """in_channels // inter_channels heads + the C -> C mixing convolution with its BatchNorm (reference :86-101)."""
 
     def __init__(self, adj, in_channels, inter_channels, dropout=None):
@@ -62,13 +60,23 @@ class MultiGlobalGraph(_FusedOnly):
         self.cat_bn = nn.BatchNorm2d(in_channels, momentum=0.1)
         self.dropout = None if dropout is None else nn.Dropout(dropout)
 
+    def forward(self, x):
+        """x: (B, T, J, C) -> (B, T, J, C)   (reference :103-130)"""
+        from gast_hip.modules import multi_global_forward
+        return multi_global_forward(self, x)
 
-class SingleGlobalGraph(_FusedOnly):
-    """Present in the reference's namespace (global_attention.py:133-173) but unreachable from gast_net.py (:17 is commented
-    out there): constructor only."""
+
+class SingleGlobalGraph(nn.Module):
+    """One full-width head + BatchNorm (reference global_attention.py:133-173); unreachable from gast_net.py (:17 is commented out
+    there) but part of the namespace `from model.gast_net import *` exports."""
 
     def __init__(self, adj, in_channels, output_channels, dropout=None):
         super().__init__()
         self.attentions = GlobalGraph(adj, in_channels, output_channels // 2)
         self.bn = nn.BatchNorm2d(in_channels, momentum=0.1)
         self.dropout = None if dropout is None else nn.Dropout(dropout)
+
+    def forward(self, x):
+        """x: (B, T, J, C) -> (B, T, J, C)   (reference :148-173)"""
+        from gast_hip.modules import single_global_forward
+        return single_global_forward(self, x)

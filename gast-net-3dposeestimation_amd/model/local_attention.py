@@ -1,9 +1,9 @@
-"""Local graph attention: parameter containers and skeleton patterns (reference model/local_attention.py).
+"""Local graph attention: parameters, skeleton patterns (reference model/local_attention.py).
 
 `SemCHGraphConv` / `LocalGraph` keep the reference's constructor signatures, parameter names, shapes and initialisers
-(local_attention.py:15-33, 60-128) so that checkpoints load unchanged.  The arithmetic of their forward
-(local_attention.py:35-53, 130-151) runs inside the fused HIP plan (gast_hip/engine.py: G1 + AGG + G2), so these modules
-only own parameters and the constant sparsity patterns.
+(local_attention.py:15-33, 60-128) so that checkpoints load unchanged.  Inside SpatioTemporalModel the arithmetic of their
+forward (local_attention.py:35-53, 130-151) runs in the fused HIP plan (gast_hip/engine.py: G1 + AGG + G2); called on their
+own they run the same kernels as a small forward-only plan (gast_hip/modules.py).
 """
 from __future__ import absolute_import, division
 
@@ -99,8 +99,9 @@ class SemCHGraphConv(nn.Module):
             self.register_parameter('bias', None)
 
     def forward(self, input):
-        raise NotImplementedError('SemCHGraphConv runs inside the fused HIP plan of SpatioTemporalModel; '
-                                  'standalone layer forward is not part of the accelerated path')
+        """input: (B, T, J, C_in) -> (B, T, J, C_out)   (reference :35-53; forward-only plan, gast_hip/modules.py)"""
+        from gast_hip.modules import graph_conv_forward
+        return graph_conv_forward(self, input, shared=False)
 
     def __repr__(self):
         return self.__class__.__name__ + ' (' + str(self.in_features) + ' -> ' + str(self.out_features) + ')'
@@ -120,4 +121,6 @@ class LocalGraph(nn.Module):
         self.dropout = nn.Dropout(dropout) if dropout is not None else None
 
     def forward(self, input):
-        raise NotImplementedError('LocalGraph runs inside the fused HIP plan of SpatioTemporalModel')
+        """input: (B, T, J, C) -> (B, T, J, C_out)   (reference :130-151; forward-only plan, gast_hip/modules.py)"""
+        from gast_hip.modules import local_graph_forward
+        return local_graph_forward(self, input)

@@ -1,0 +1,96 @@
+"""Stand-alone forward of the graph sub-modules (GraphAttentionBlock, LocalGraph, SemCHGraphConv, GlobalGraph, MultiGlobalGraph,
+SingleGlobalGraph, sem_graph_conv.SemGraphConv / LocalGraph) on the HIP op set against fixtures produced by the reference modules
+themselves (tests/golden/make_golden_modules.py): eval output, train-mode output (batch-statistics BatchNorm) and the BatchNorm
+buffers after the train-mode call.  fp32, tolerance 1e-4 (north star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, 'golden')
+
+CASES = ['mod_semch_j17_c32', 'mod_semch_bias_j15_c16', 'mod_local_j17_c32', 'mod_local_j19_c16', 'mod_global_head_j17_c32',
+         'mod_global_head_wide_j17_c32', 'mod_multi_global_j17_c32', 'mod_single_global_j16_c32', 'mod_gab_j17_c32', 'mod_gab_j15_c64',
+         'mod_semgc_j17_c32', 'mod_sem_local_j17_c32']
+
+
+def build(name, fx):
+    from model import gast_net, local_attention, global_attention, sem_graph_conv
+    adj = torch.from_numpy(fx['adj'])
+    x = fx['x']
+    kind = name.split('_j')[0]
+    if kind in ('mod_semch', 'mod_semch_bias'):
+        pat = torch.from_numpy((local_attention.skeleton_patterns(adj)[1] > 0).numpy().astype(np.float32))
+        Cin, Cout = fx['state/W'].shape[1], fx['state/W'].shape[2]
+        return local_attention.SemCHGraphConv(Cin, Cout, pat, bias='state/bias' in fx)
+    C = x.shape[1] if kind.startswith('mod_gab') or kind.startswith('mod_global_head') else x.shape[-1]
+    if kind == 'mod_local':
+        return local_attention.LocalGraph(adj, C, C, None)
+    if kind in ('mod_global_head', 'mod_global_head_wide'):
+        return global_attention.GlobalGraph(adj, C, fx['state/theta.weight'].shape[0])
+    if kind == 'mod_multi_global':
+        return global_attention.MultiGlobalGraph(adj, C, C // 4, None)
+    if kind == 'mod_single_global':
+        return global_attention.SingleGlobalGraph(adj, C, C, None)
+    if kind == 'mod_gab':
+        return gast_net.GraphAttentionBlock(adj, C, C, p_dropout=0.0)
+    if kind == 'mod_semgc':
+        return sem_graph_conv.SemGraphConv(C, C, local_attention.skeleton_patterns(adj)[1])
+    if kind == 'mod_sem_local':
+        return sem_graph_conv.LocalGraph(adj, C, C, None)
+    raise KeyError(kind)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('name', CASES)
+def test_module_forward_matches_reference(name):
+    fx = dict(np.load(os.path.join(GOLD, name + '.npz')))
+    mod = build(name, fx)
+    state = {k[len('state/'):]: torch.from_numpy(v) for k, v in fx.items() if k.startswith('state/')}
+    assert list(mod.state_dict().keys()) == list(state.keys()), 'state_dict keys / order differ from the reference module'
+    mod.load_state_dict(state, strict=True)
+    mod.cuda()
+    x = torch.from_numpy(fx['x']).cuda()
+    scale = max(1.0, float(np.abs(fx['y_eval']).max()))
+    with torch.no_grad():
+        mod.eval()
+        y = mod(x.clone())
+        assert tuple(y.shape) == fx['y_eval'].shape
+        err = float(np.abs(y.cpu().numpy() - fx['y_eval']).max())
+        assert err <= 1e-4 * scale, '%s eval: max err %.3e' % (name, err)
+        mod.train()
+        y = mod(x.clone())
+        err = float(np.abs(y.cpu().numpy() - fx['y_train']).max())
+        assert err <= 1e-4 * max(1.0, float(np.abs(fx['y_train']).max())), '%s train: max err %.3e' % (name, err)
+    sd = mod.state_dict()
+    for k, v in fx.items():
+        if k.startswith('post/'):
+            got = sd[k[len('post/'):]].cpu().numpy()
+            assert np.allclose(got, v, rtol=1e-4, atol=1e-5), '%s: BatchNorm buffer %s differs after the train-mode call' % (name, k)
+
+
+@pytest.mark.gpu
+def test_module_forward_refuses_autograd():
+    from model import local_attention
+    fx = dict(np.load(os.path.join(GOLD, 'mod_local_j17_c32.npz')))
+    mod = local_attention.LocalGraph(torch.from_numpy(fx['adj']), 32, 32, None).cuda()
+    with pytest.raises(NotImplementedError, match='inference-only'):
+        mod(torch.from_numpy(fx['x']).cuda())
+
+
+def test_sem_graph_conv_state_dict_and_init_match_reference():
+    """model/sem_graph_conv.py: same keys, shapes and seed-for-seed initial values as the fixture the reference produced
+    (the fixture's BatchNorm entries / e / bias were perturbed afterwards: only W and the conv weight are compared by value)."""
+    from model import sem_graph_conv
+    fx = dict(np.load(os.path.join(GOLD, 'mod_sem_local_j17_c32.npz')))
+    torch.manual_seed(7000 + 11)
+    mod = sem_graph_conv.LocalGraph(torch.from_numpy(fx['adj']), 32, 32, None)
+    sd = mod.state_dict()
+    ref = {k[len('state/'):]: v for k, v in fx.items() if k.startswith('state/')}
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert tuple(sd[k].shape) == ref[k].shape, k
+    for k in ('gcn_sym.W', 'gcn_con.W', 'cat_conv.weight'):
+        assert np.array_equal(sd[k].numpy(), ref[k]), '%s: initial values differ from the reference under the same seed' % k
