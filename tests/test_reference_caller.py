@@ -1,0 +1,144 @@
+"""The reference's CALLERS against the drop-in (SURVEY.md section 8 row b): create_model -> train() -> load_state_dict -> evaluate() with
+flip test-time augmentation, compared with fixtures the same scenario produced on the pure reference (tests/caller/
+run_reference_caller.py --impl reference).
+
+* CPU, build container: the reference's own main.py / common/generators.py are imported UNMODIFIED with this repository's `model`
+  package first on sys.path (the documented way to drop it in); the ops go through the numpy mirror so that the host side
+  (constructors behind `from model.gast_net import *`, autograd node, optimizer.step over model.parameters(), state_dict hand-over,
+  in-place edits of the output in evaluate()) runs without a GPU.
+* GPU box (no /root/reference there): the same steps restated line by line with this repository's device-resident generators (bit-exact
+  twins of the reference's, tests/test_generators.py) and the HIP path.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'caller'))
+import scenario as sc  # noqa: E402
+
+REF = '/root/reference'
+# after 2 optimizer steps the two implementations agree to fp32 round-off; over 7 steps Adam amplifies it (see scenario.py)
+TOL = {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)}
+
+
+def compare(got, ref, size):
+    tol = TOL[size]
+    assert abs(got['train_loss'] - ref['train_loss']) <= tol['loss'] * abs(ref['train_loss']), (got['train_loss'], ref['train_loss'])
+    # north star: MPJPE within 0.1 mm of the reference
+    assert abs(got['e1'] - ref['e1']) <= tol['mm'], 'MPJPE %.4f vs %.4f mm' % (got['e1'], ref['e1'])
+    assert abs(got['e2'] - ref['e2']) <= tol['mm'], 'P-MPJPE %.4f vs %.4f mm' % (got['e2'], ref['e2'])
+    assert got['pred'].shape == ref['pred'].shape
+    assert float(np.abs(got['pred'] - ref['pred']).max()) <= tol['pred']
+    keys = [k for k in ref if k.startswith('state/')]
+    assert sorted(k for k in got if k.startswith('state/')) == sorted(keys)
+    if tol['param'] is not None:
+        for k in keys:
+            if np.asarray(ref[k]).dtype.kind != 'f' or np.asarray(ref[k]).ndim == 0 or any(k.endswith(z) or z in k for z in sc.ZERO_GRAD_PARAMS) or 'running_' in k:
+                continue
+            d = float(np.abs(got[k] - ref[k]).max())
+            assert d <= tol['param'], '%s differs by %.3e after the training steps' % (k, d)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference checkout (build container only)')
+@pytest.mark.parametrize('size', ['short', 'epoch'])
+def test_reference_main_runs_on_the_dropin(size, tmp_path):
+    out = str(tmp_path / 'ours.npz')
+    r = subprocess.run([sys.executable, os.path.join(HERE, 'caller', 'run_reference_caller.py'), '--impl', 'ours', '--fake-backend',
+                        '--size', size, '--out', out], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    compare(dict(np.load(out)), dict(np.load(os.path.join(HERE, 'golden', 'reference_caller_%s.npz' % size))), size)
+
+
+def _mpjpe(pred, target):
+    return torch.mean(torch.norm(pred - target, dim=len(target.shape) - 1))          # reference common/loss.py:5-11
+
+
+def _p_mpjpe(predicted, target):
+    """reference common/loss.py:33-71 (Procrustes-aligned MPJPE), numpy"""
+    muX, muY = np.mean(target, axis=1, keepdims=True), np.mean(predicted, axis=1, keepdims=True)
+    X0, Y0 = target - muX, predicted - muY
+    normX, normY = np.sqrt(np.sum(X0 ** 2, axis=(1, 2), keepdims=True)), np.sqrt(np.sum(Y0 ** 2, axis=(1, 2), keepdims=True))
+    X0, Y0 = X0 / normX, Y0 / normY
+    H = np.matmul(X0.transpose(0, 2, 1), Y0)
+    U, s, Vt = np.linalg.svd(H)
+    V = Vt.transpose(0, 2, 1)
+    R = np.matmul(V, U.transpose(0, 2, 1))
+    sign_detR = np.sign(np.expand_dims(np.linalg.det(R), axis=1))
+    V[:, :, -1] *= sign_detR
+    s[:, -1] *= sign_detR.flatten()
+    R = np.matmul(V, U.transpose(0, 2, 1))
+    tr = np.expand_dims(np.sum(s, axis=1, keepdims=True), axis=2)
+    a = tr * normX / normY
+    t = muX - a * np.matmul(muY, R)
+    return np.mean(np.linalg.norm(a * np.matmul(predicted, R) + t - target, axis=len(target.shape) - 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('size', ['short', 'epoch'])
+def test_caller_steps_on_the_gpu(size, monkeypatch):
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
+    from gast_hip.generators import ChunkedGenerator, UnchunkedGenerator
+    from oracle.gast_oracle import adj_from_parents
+    cameras, poses_3d, poses_2d = sc.make_data(size)
+    adj = torch.from_numpy(adj_from_parents(sc.PARENTS))
+    fw = [int(x) for x in sc.ARCH.split(',')]
+    # main.py:150-187 create_model (args.stride == 1: the optimized twin trains, the dilated model evaluates)
+    torch.manual_seed(0)
+    model_pos_train = SpatioTemporalModelOptimized1f(adj, 17, 2, 17, filter_widths=fw, causal=False, dropout=0.0, channels=sc.CHANNELS)
+    model_pos = SpatioTemporalModel(adj, 17, 2, 17, filter_widths=fw, causal=False, dropout=0.0, channels=sc.CHANNELS)
+    pad = (model_pos.receptive_field() - 1) // 2
+    model_pos_train, model_pos = model_pos_train.cuda(), model_pos.cuda()                       # trainval.py:62-64
+    optimizer = torch.optim.Adam(model_pos_train.parameters(), lr=sc.LR, amsgrad=True)          # trainval.py:78
+    gen = ChunkedGenerator(sc.BATCH, cameras, poses_3d, poses_2d, 1, pad=pad, causal_shift=0, shuffle=True, augment=True,
+                           kps_left=sc.KPS_LEFT, kps_right=sc.KPS_RIGHT, joints_left=sc.JOINTS_LEFT, joints_right=sc.JOINTS_RIGHT)
+    # main.py:213-243 train()
+    model_pos_train.train()
+    tot, N = 0.0, 0
+    for _, batch_3d, batch_2d in gen.next_epoch():
+        inputs_3d, inputs_2d = batch_3d.float().clone(), batch_2d.float()
+        inputs_3d[:, :, 0] = 0
+        optimizer.zero_grad()
+        predicted = model_pos_train(inputs_2d)
+        loss = _mpjpe(predicted, inputs_3d)
+        tot += inputs_3d.shape[0] * inputs_3d.shape[1] * loss.item()
+        N += inputs_3d.shape[0] * inputs_3d.shape[1]
+        loss.backward()
+        optimizer.step()
+    got = {'train_loss': tot / N}
+    model_pos.load_state_dict(model_pos_train.state_dict())                                     # trainval.py:124
+    # main.py:299-353 evaluate() with test-time augmentation
+    jl, jr = sc.JOINTS_LEFT, sc.JOINTS_RIGHT
+
+    def evaluate(test_gen, return_predictions=False):
+        e1 = e2 = 0.0
+        n = 0
+        with torch.no_grad():
+            model_pos.eval()
+            for _, batch, batch_2d in test_gen.next_epoch():
+                pred = model_pos(batch_2d.float())
+                pred[1, :, :, 0] *= -1                                # (in-place edits of the model's output, as the reference does)
+                pred[1, :, jl + jr] = pred[1, :, jr + jl]
+                pred = torch.mean(pred, dim=0, keepdim=True)
+                if return_predictions:
+                    return pred.squeeze(0).cpu().numpy()
+                inputs_3d = batch.float().clone()
+                inputs_3d[:, :, 0] = 0
+                inputs_3d = inputs_3d[:1]
+                cnt = inputs_3d.shape[0] * inputs_3d.shape[1]
+                e1 += cnt * _mpjpe(pred, inputs_3d).item()
+                e2 += cnt * _p_mpjpe(pred.cpu().numpy().reshape(-1, 17, 3), inputs_3d.cpu().numpy().reshape(-1, 17, 3))
+                n += cnt
+        return e1 / n * 1000, e2 / n * 1000
+    kw = dict(pad=pad, causal_shift=0, augment=True, kps_left=sc.KPS_LEFT, kps_right=sc.KPS_RIGHT, joints_left=jl, joints_right=jr)
+    got['e1'], got['e2'] = evaluate(UnchunkedGenerator(cameras, poses_3d, poses_2d, **kw))
+    got['pred'] = evaluate(UnchunkedGenerator(None, None, poses_2d[:1], **kw), return_predictions=True)
+    for k, v in model_pos_train.state_dict().items():
+        got['state/' + k] = v.detach().cpu().numpy()
+    ref = dict(np.load(os.path.join(HERE, 'golden', 'reference_caller_%s.npz' % size)))
+    compare(got, {k: (float(v) if v.ndim == 0 else v) for k, v in ref.items()}, size)
