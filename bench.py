@@ -363,6 +363,7 @@ def main():
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--no-eager', action='store_true', help='skip the eager-launch timing of the same step (profiling runs: keeps the trace tail on the replayed graph)')
     ap.add_argument('--split-graph', action='store_true', help='force the two-graph step (the default for --gpus > 1)')
     ap.add_argument('--full-graph', action='store_true', help='--gpus > 1: capture the RCCL all-reduce inside one graph')
     ap.add_argument('--force-collective', action='store_true',
@@ -554,6 +555,18 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         per_rank_ms = [round(float(v) / args.steps * 1e3, 4) for v in tt.tolist()]
         elapsed = float(tt.max().item())
+    # ---- the same step launched eagerly (what an unchanged training script gets: it calls model(x) / loss.backward() /
+    # optimizer.step() kernel by kernel through ctypes; the hipGraph is built by this benchmark only)
+    eager_ms = None
+    if rank == 0 and world == 1 and mode != 'eager' and not args.no_eager:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+        te = time.perf_counter()
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - te) / 10 * 1e3
     # ---- per-kernel durations: the same step, eagerly, with a HIP-event pair around every launch (events cannot be
     # recorded inside a replayed graph; the kernels and their arguments are identical to the replayed ones)
     if timer and rank == 0:
@@ -615,6 +628,10 @@ def main():
                        'gradient_exchange': (None if not collective else ('3 buckets all-reduced on a communication stream during backward'
                                                                          if len(sync.ranges) > 1 else 'one flat all-reduce after backward'))},
         }
+        if eager_ms is not None:
+            out['eager_launch'] = {'ms_per_step': round(eager_ms, 4), 'sequences_per_s': round(B / eager_ms * 1e3, 1),
+                                   'note': 'the same step with every kernel launched eagerly from Python (ctypes), i.e. the speed of an '
+                                           'unchanged training loop around the drop-in module; `value` replays the step as one hipGraph'}
         if collective:
             out['per_rank_ms_per_step'] = per_rank_ms
         if parity is not None:
@@ -643,20 +660,26 @@ def main():
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
                     pmc_name = 'r02_pmc_hbm_bytes_%s.json' % args.dtype      # counters of the committed kernels, one file per arithmetic
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
-                    fam = [v for k, v in pmc.items() if k.startswith(('gemm_kernel<', 'gemm_multi_kernel<', 'gemm64_kernel<', 'splitk_finish_kernel<'))]
-                    calls = sum(v['launches'] for k, v in pmc.items() if k.startswith(('gemm_kernel<', 'gemm_multi_kernel<', 'gemm64_kernel<')))
+                    GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<')
+                    fam = [v for k, v in pmc.items() if k.startswith(GEMM_K)]
+                    # bytes of the family per step / gast_gemm(+_multi) API launches per step (a multi call may be two grids)
+                    calls = pmc['_meta']['steps'] * gm['launches'] / tsteps
                     traffic = round(sum(v['hbm_bytes_per_launch'] * v['launches'] for v in fam) / calls)
                     tsrc = ('profiles/%s: sum of (2*FETCH_SIZE + WRITE_SIZE) KiB over the gemm / gemm_multi / splitk_finish '
-                            'kernels / %d gemm launches, two rocprofv3 --pmc passes of `bench.py --dtype %s --no-graph`' % (pmc_name, calls, args.dtype))
+                            'kernels / %d gast_gemm launches, two rocprofv3 --pmc passes of `bench.py --dtype %s --no-graph`' % (pmc_name, calls, args.dtype))
                 except Exception:
                     pass
-                out['roofline'] = {'kernel': 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)' % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
+                out['roofline'] = {'kernel': ('gemm_big_kernel (large-M GAST_F32X3) + gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; '
+                                              'incl. split-K finish)' if args.dtype == 'bf16x3' else 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)') % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
                                    'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': tsrc,
                                    'launches_per_step': gm['launches'] / tsteps, 'avg_launch_us': round(avg_ms * 1e3, 2),
                                    'avg_launch_us_method': ('hipGraph replay of the step\'s gast_gemm launches alone, one HIP-event pair around 20 replays' if gemm_replay_ms else 'eager HIP-event pairs'),
                                    'eager_event_pair_avg_launch_us': round(eager_avg_ms * 1e3, 2), 'event_pair_overhead_us_subtracted': round(timer.overhead_ms * 1e3, 2),
                                    'alg_gflop_per_launch': round(gm['flops'] / gm['launches'] / 1e9, 3),
                                    'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
+            out['kernels_note'] = ('per-op durations from an EAGER pass with a HIP-event pair around every launch (events cannot be recorded inside a '
+                                   'replayed graph): the GPU clocks down between eager launches, so the column sums to more than ms_per_step; '
+                                   'the replayed step itself is broken down in profiles/r02_*_step_summary.txt (rocprofv3 --kernel-trace)')
             out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
                                   'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)

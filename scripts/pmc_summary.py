@@ -1,5 +1,6 @@
 """Per-kernel averages of rocprofv3 --pmc counter CSVs (one counter per pass).  Usage:
-python scripts/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json]
+python scripts/pmc_summary.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> [out.json [steps]]
+(steps = number of training steps the profiled command ran, stored under "_meta" so that bench.py can turn totals into per-step figures)
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KiB, and on gfx950 FETCH_SIZE counts the
 128-byte requests of 16-byte-per-lane coalesced loads at 64 bytes (MI355X_MICROARCH.md, section HBM)."""
 import csv, sys, json, re, collections
@@ -28,5 +29,7 @@ for k in sorted(fetch, key=lambda k: -fetch[k][1]):
 for k, v in list(out.items())[:14]:
     print('%-70s n=%4d fetch %9.1f KiB write %9.1f KiB -> hbm %8.2f MB/launch' % (k[:70], v['launches'], v['fetch_kib_per_launch'],
                                                                                v['write_kib_per_launch'], v['hbm_bytes_per_launch'] / 1e6))
+if len(sys.argv) > 4:
+    out['_meta'] = {'steps': int(sys.argv[4])}
 if len(sys.argv) > 3:
     json.dump(out, open(sys.argv[3], 'w'), indent=1)
