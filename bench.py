@@ -56,7 +56,8 @@ CONFIGS = {
     'cfg4': dict(J=15, arc=[3, 3, 3], channels=128, batch=4, what='configs[4]: HumanEva-15, arc 3,3,3, B=32 over 8 GPUs = 4 per GPU'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3}   # dense peaks (bf16x3: three bf16 products per FLOP pair)
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per
+# FLOP pair; fp8: the forward GEMMs run at the 5 PF fp8 rate, the gradient GEMMs -- 2/3 of the work -- at the bf16 rate: priced at bf16)
 
 
 def adj_from_parents(parents):
@@ -348,7 +349,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32'])
+    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32', 'fp8'])
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
     ap.add_argument('--config', default='cfg1', choices=sorted(CONFIGS), help='BASELINE.json configs[1..4]; cfg1 is the metric')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
@@ -622,7 +623,10 @@ def main():
                        'arithmetic': {'bf16x3': 'fp32 storage; GEMM / weight-gradient products as bf16 hi/lo split products on '
                                                 'v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi), fp32 accumulate',
                                       'bf16': 'bf16 storage and MFMA operands, fp32 accumulate / statistics / master weights',
-                                      'fp32': 'fp32 storage, v_mfma_f32_32x32x2_f32'}[args.dtype],
+                                      'fp32': 'fp32 storage, v_mfma_f32_32x32x2_f32',
+                                      'fp8': 'mixed fp8 (BASELINE.json configs[4]): bf16 storage; forward channel GEMMs with OCP e4m3 operands '
+                                             '(per-tensor power-of-two weight scales) on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulate; input / '
+                                             'weight gradients, statistics and softmax as in bf16 mode'}[args.dtype],
                        'loss_last': round(float(loss.item()), 6), 'launch': graph_note,
                        'rccl_world_size': world if collective else None,
                        'gradient_exchange': (None if not collective else ('3 buckets all-reduced on a communication stream during backward'
@@ -687,7 +691,7 @@ def main():
             out['path_roofline'] = {'sum_kernel_roofline_ms_per_step': round(tot_roof, 4), 'frac_of_step': round(tot_roof / ms, 4)}
         if fwd_ms and args.config == 'cfg1' and C == 128:
             # 793.4 MB compulsory bf16 traffic (1587 MB fp32) and 160.7 GFLOP per B=128 forward of the dilated model
-            fb = (793.4e6 if args.dtype == 'bf16' else 1586.8e6) * (B / 128.0)     # (bf16x3 stores fp32)
+            fb = (793.4e6 if args.dtype in ('bf16', 'fp8') else 1586.8e6) * (B / 128.0)     # (bf16x3 stores fp32)
             ff = 160.7e9 * (B / 128.0)
             roof = max(fb / (HBM_PEAK_GBS * 1e9), ff / (MFMA_PEAK_TFLOPS[args.dtype] * 1e12)) * 1e3
             out['forward_only'] = {'ms': round(fwd_ms, 4), 'sequences_per_s': round(B / fwd_ms * 1e3, 1), 'roofline_ms': round(roof, 4),

@@ -87,9 +87,24 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-template <typename T, typename TO, bool X3 = false>
+// 8 bf16 values (one 16-byte chunk) -> 8 OCP e4m3 bytes, each multiplied by `s` first (v_cvt_pk_fp8_f32: round to nearest even,
+// saturating).  GAST_BF16 with gast_gemm_args.f8_scale: the "mixed fp8" mode of BASELINE.json configs[4] -- bf16 storage, the
+// forward channel GEMMs' operands as fp8 on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; input / weight gradients stay bf16.
+__device__ __forceinline__ uint2 to_fp8x8(const uint4& v, float s) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int q[2] = {0, 0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const float lo = __uint_as_float(w[p] << 16) * s, hi = __uint_as_float(w[p] & 0xffff0000u) * s;
+        q[p >> 1] = (p & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, q[p >> 1], true) : __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, q[p >> 1], false);
+    }
+    return make_uint2((uint32_t)q[0], (uint32_t)q[1]);
+}
+
+template <typename T, typename TO, bool X3 = false, bool F8 = false>
 __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws, int blk) {
     static_assert(!X3 || sizeof(T) == 4, "the split-bf16 mode stores fp32");
+    static_assert(!F8 || sizeof(T) == 2, "the fp8-operand mode stores bf16");
     constexpr int EPC = Elem<T>::EPC;
     constexpr int BK = 8 * EPC;
     __shared__ __attribute__((aligned(16))) unsigned char smem[(BM + BN) * LSTR];   // A|B tiles, reused as the C staging tile
@@ -137,6 +152,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     const uint32_t thresh = a.drop.thresh;
     const float inv_keep = a.drop.inv_keep;
     const uint32_t seedv = (thresh != 0 && a.drop.seed) ? *a.drop.seed : 0u;   // read once: no compiler-tracked VMEM load in the K loop
+    const float f8_wscale = F8 ? a.f8_scale[0] : 1.f;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -231,7 +247,11 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                 v = make_uint4(oka ? v.x : 0u, oka ? v.y : 0u, oka ? v.z : 0u, oka ? v.w : 0u);
                 wv = make_uint4(kin ? wv.x : 0u, kin ? wv.y : 0u, kin ? wv.z : 0u, kin ? wv.w : 0u);
             }
-            if (X3) {
+            if (F8) {
+                // row image: 64 e4m3 bytes; this thread's 8 k values are bytes chunk*8 .. +8
+                *(uint2*)(sA + r * LSTR + chunk * 8) = to_fp8x8(v, 1.f);
+                *(uint2*)(sB + r * LSTR + chunk * 8) = to_fp8x8(wv, f8_wscale);
+            } else if (X3) {
                 // row image: [hi plane: 32 bf16 = 64 B | lo plane: 64 B]; this thread's 4 k values are bytes chunk*8 .. +8 of each
                 uint2 h, l;
                 split_bf16x4(v, h, l);
@@ -248,6 +268,22 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
     };
 
     auto compute_tile = [&]() {
+        if (F8) {
+            // K tile = 64 e4m3 values: four 16-deep steps, 8 bytes per lane and operand
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                long fa[2], fb[2];
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi) fa[mi] = *(const long*)(sA + (wr * 64 + mi * 32 + li) * LSTR + (kc * 2 + lh) * 8);
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) fb[ni] = *(const long*)(sB + (wc * 64 + ni * 32 + li) * LSTR + (kc * 2 + lh) * 8);
+#pragma unroll
+                for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+            }
+            return;
+        }
         if (X3) {
             // K tile = 32: two 16-deep MFMA steps; per step the hi and lo fragments of both operands, three products per
             // accumulator, small terms first, consecutive MFMAs on different accumulators
@@ -327,6 +363,15 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             compute_tile();
             if (!more) break;
         }
+    }
+    if (F8) {
+        const float ds = a.f8_scale[1];        // 1 / weight scale (a power of two)
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] *= ds;
     }
     if (splitk > 1) {
         // raw fp32 partial tile -> workspace [split][M][N]; bias / addend / epilogue run in splitk_finish_kernel
@@ -554,9 +599,9 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // ---- split-K finish: C = epi(sum_split ws + bias + addend), same epilogue semantics and partial-sum layout as gemm_kernel.
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
-template <typename T, typename TO, bool X3 = false>
+template <typename T, typename TO, bool X3 = false, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
-    gemm_body<T, TO, X3>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
+    gemm_body<T, TO, X3, F8>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
 
 // Several independent GEMMs of one plan step in ONE grid (gast_gemm_multi): the K <= 256 launches of a block (G2 / G3, the two
@@ -569,11 +614,11 @@ struct GemmBatch {
     int n;
 };
 static_assert(sizeof(GemmBatch) <= 3584, "GemmBatch travels as a kernel argument (4 KB limit)");
-template <typename T, typename TO, bool X3 = false>
+template <typename T, typename TO, bool X3 = false, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    gemm_body<T, TO, X3>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
+    gemm_body<T, TO, X3, F8>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
 }
 
 template <typename T, typename TO>
@@ -671,6 +716,7 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
         if (g.pro < 0 || g.pro > GAST_PRO_BNRELU_DROP) return GAST_EINVAL;
     }
     if (a.epi < 0 || a.epi > GAST_EPI_BNRELU_BWD) return GAST_EINVAL;
+    if (a.f8_scale && (a.dtype != GAST_BF16 || a.out_f32)) return GAST_EINVAL;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return GAST_EINVAL;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return GAST_EINVAL;
     long Ml = (long)a.B * a.Tn * a.J;
@@ -716,6 +762,8 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.dtype == GAST_F32X3)
         hipLaunchKernelGGL((gemm_kernel<float, float, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+    else if (a.f8_scale && !a.out_f32)
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, false, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.out_f32)
         hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else
@@ -750,7 +798,7 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     BigPlan big_p[GAST_GEMM_MAX_BATCH];
     int nbig = 0;
     for (int d = 0; d < n; ++d) {
-        if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32) return GAST_EINVAL;
+        if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32 || !args[d].f8_scale != !args[0].f8_scale) return GAST_EINVAL;
         int M, gridM, gridN, vec_epi, splitk;
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
@@ -776,10 +824,78 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
         hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
     else if (args[0].dtype == GAST_F32X3)
         hipLaunchKernelGGL((gemm_multi_kernel<float, float, true>), grid, block, 0, st, b);
+    else if (args[0].f8_scale && !args[0].out_f32)
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, false, true>), grid, block, 0, st, b);
     else if (args[0].out_f32)
         hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
     else
         hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b);
     GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+
+// ---- per-tensor power-of-two scales for the fp8 weight operands: out[0] = 2^floor(log2(448 / max|W|)), out[1] = 1 / out[0].
+// Three small launches: zero the slots (a kernel, not one memset node per tensor), max |W| by blocks of 16K elements (atomicMax on the bit pattern: non-negative floats order
+// like unsigned integers), then the conversion of every slot.
+namespace {
+struct F8ScaleBatch { gast_f8_scale_job j[GAST_F8_SCALE_MAX_BATCH]; int first[GAST_F8_SCALE_MAX_BATCH + 1]; int n; };
+static_assert(sizeof(F8ScaleBatch) <= 3840, "F8ScaleBatch travels as a kernel argument");
+constexpr int F8_CHUNK = 16384;
+__global__ void __launch_bounds__(256) f8_absmax_kernel(const F8ScaleBatch b) {
+    __shared__ float sred[4];
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    const gast_f8_scale_job& j = b.j[d];
+    const long total = (long)j.R * j.K, i0 = (long)(blockIdx.x - b.first[d]) * F8_CHUNK;
+    float m = 0.f;
+    for (long i = i0 + threadIdx.x; i < min(total, i0 + F8_CHUNK); i += 256) {
+        const int r = (int)(i / j.K), k = (int)(i - (long)r * j.K);
+        m = fmaxf(m, fabsf(bf2f(((const bf16_t*)j.W)[(long)r * j.ldw + k])));
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax((unsigned*)j.out, __float_as_uint(fmaxf(fmaxf(sred[0], sred[1]), fmaxf(sred[2], sred[3]))));
+}
+__global__ void __launch_bounds__(64) f8_scale_zero_kernel(const F8ScaleBatch b) {
+    if ((int)threadIdx.x < b.n) b.j[threadIdx.x].out[0] = 0.f;
+}
+__global__ void __launch_bounds__(64) f8_scale_finish_kernel(const F8ScaleBatch b) {
+    if ((int)threadIdx.x >= b.n) return;
+    float* out = b.j[threadIdx.x].out;
+    const float m = out[0];
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+        int e = (int)floorf(log2f(448.f / m));
+        e = e < -40 ? -40 : (e > 40 ? 40 : e);
+        s = exp2f((float)e);
+    }
+    out[0] = s;
+    out[1] = 1.f / s;
+}
+}  // namespace
+
+extern "C" int gast_f8_scale_multi(const gast_f8_scale_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 0) return GAST_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += GAST_F8_SCALE_MAX_BATCH) {
+        F8ScaleBatch b;
+        b.n = n - i0 < GAST_F8_SCALE_MAX_BATCH ? n - i0 : GAST_F8_SCALE_MAX_BATCH;
+        b.first[0] = 0;
+        for (int d = 0; d < b.n; ++d) {
+            const gast_f8_scale_job& j = jobs[i0 + d];
+            if (!j.W || !j.out || j.R < 1 || j.K < 1) return GAST_EINVAL;
+            b.j[d] = j;
+            b.first[d + 1] = b.first[d] + (int)(((long)j.R * j.K + F8_CHUNK - 1) / F8_CHUNK);
+        }
+        hipLaunchKernelGGL(f8_scale_zero_kernel, dim3(1), dim3(64), 0, st, b);
+        GAST_CHECK_LAUNCH();
+        hipLaunchKernelGGL(f8_absmax_kernel, dim3(b.first[b.n]), dim3(256), 0, st, b);
+        GAST_CHECK_LAUNCH();
+        hipLaunchKernelGGL(f8_scale_finish_kernel, dim3(1), dim3(64), 0, st, b);
+        GAST_CHECK_LAUNCH();
+    }
     return 0;
 }

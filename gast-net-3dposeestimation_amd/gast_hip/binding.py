@@ -10,7 +10,7 @@ from collections import namedtuple
 
 import torch
 
-from gast_hip.packer import X3Weight
+from gast_hip.packer import F8Weight, X3Weight
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgast_hip.so')
@@ -61,7 +61,11 @@ class _GemmArgs(C.Structure):
                 ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
                 ('bias', C.c_void_p), ('bias_neg', C.c_int), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
                 ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
-                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout)]
+                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('f8_scale', C.c_void_p)]
+
+
+class _F8ScaleJob(C.Structure):
+    _fields_ = [('W', C.c_void_p), ('R', C.c_int), ('K', C.c_int), ('ldw', C.c_int), ('out', C.c_void_p)]
 
 
 class _WgradSeg(C.Structure):
@@ -121,6 +125,7 @@ def load_library():
         'gast_gemm_multi': [C.POINTER(_GemmArgs), ci, vp, cl, vp],
         'gast_gemm_splitk_ws_bytes': [cl, ci],
         'gast_gemm_path': [C.POINTER(_GemmArgs)],
+        'gast_f8_scale_multi': [C.POINTER(_F8ScaleJob), ci, vp],
         'gast_x3_image_multi': [C.POINTER(_X3ImageJob), ci, vp],
         'gast_x3_image_ld': [ci],
         'gast_wgrad': [C.POINTER(_WgradArgs), vp],
@@ -175,7 +180,7 @@ def load_library():
     return lib
 
 
-EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
+EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_f8_scale_multi', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
@@ -236,6 +241,9 @@ class HipOps:
         # fp32 tensors: run the MFMA GEMMs / weight gradients on split-bf16 products (GAST_F32X3, include/gast_hip.h) instead of
         # the fp32 matrix instruction.  Set by the model runner from GAST_HIP_DTYPE=bf16x3; storage stays fp32 everywhere.
         self.x3 = False
+        # bf16 tensors: GEMMs whose weight operands all carry an fp8 scale (the forward GEMMs, gast_hip/packer.py) run with e4m3
+        # operands on v_mfma_f32_32x32x16_fp8_fp8 (GAST_HIP_DTYPE=fp8, BASELINE.json configs[4]); gradients stay bf16
+        self.f8 = False
         self._ws = {}            # per (device, stream): fp32 split-K workspace (allocated once, before any graph capture)
 
     SPLITK_WS_BYTES = 96 << 20
@@ -260,11 +268,15 @@ class HipOps:
         a.B, a.Tn, a.J = (int(v) for v in dom)
         a.N = int(N)
         a.nseg = len(segs)
+        f8_scales = []
         for i, s in enumerate(segs):
             g = a.seg[i]
             W, img = s['W'], None
             if isinstance(W, X3Weight):
                 W, img = W.t, W.img
+            elif isinstance(W, F8Weight):
+                f8_scales.append(W.scale)
+                W = W.t
             if _dt(s['A']) != st_dtype or _dt(W) != st_dtype:
                 raise RuntimeError('gast_hip: mixed operand dtypes in gemm')
             g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
@@ -288,6 +300,9 @@ class HipOps:
         a.drop = _drop(drop)
         if self.x3 and st_dtype == GAST_F32:
             a.dtype = GAST_F32X3
+        if (self.f8 and st_dtype == GAST_BF16 and not a.out_f32 and len(f8_scales) == len(segs)
+                and all(sc.data_ptr() == f8_scales[0].data_ptr() for sc in f8_scales)):
+            a.f8_scale = _p(f8_scales[0])
 
     def gemm(self, dom, N, segs, C_, cmap, **kw):
         a = _GemmArgs()
@@ -675,6 +690,16 @@ class HipOps:
         _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')
         ft, nf = tb['fold']
         _check(self.lib.gast_fold(_p(ft), nf, max(j['C'] for j in packer.fold_jobs), C.cast(bases, C.c_void_p), _stream()), 'gast_fold')
+        if st.get('F8s') is not None:         # fp8 mode: per-tensor power-of-two scales of the forward weight operands, one launch
+            arr = tb.get('f8scale')
+            if arr is None:
+                jobs = packer.f8_jobs(st)
+                arr = (_F8ScaleJob * len(jobs))()
+                for a, (wv, sv) in zip(arr, jobs):
+                    a.W, a.R, a.K, a.ldw, a.out = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(sv)
+                tb['f8scale'] = arr
+            self.launches += 1
+            _check(self.lib.gast_f8_scale_multi(arr, len(arr), _stream()), 'gast_f8_scale_multi')
         if st.get('Xb') is not None:          # GAST_F32X3: the pre-split bf16 images of all packed operands, one launch
             arr = tb.get('x3img')
             if arr is None:

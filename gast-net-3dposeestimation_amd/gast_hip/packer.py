@@ -78,6 +78,18 @@ class X3Weight:
         return X3Weight(self.t[rs, cs], img)
 
 
+class F8Weight:
+    """A bf16 [N][K] FORWARD GEMM operand together with its per-tensor fp8 scale {s, 1/s} (device, fp32, `gast_f8_scale_multi`):
+    GAST_HIP_DTYPE=fp8 runs the GEMMs whose weight segments all carry the same scale with e4m3 operands.  Slices keep the scale."""
+    __slots__ = ('t', 'scale')
+
+    def __init__(self, t, scale):
+        self.t, self.scale = t, scale
+
+    def __getitem__(self, idx):
+        return F8Weight(self.t[idx], self.scale)
+
+
 class Packer:
     def __init__(self, model, spec, named=None):
         """named: explicit (name, tensor) list in `named_parameters()` order -- for nn.DataParallel replicas, whose parameters are
@@ -218,15 +230,25 @@ class Packer:
                     del st['tables'][k]
 
     # ------------------------------------------------------------------------------------------ buffers
-    def state(self, dev, dt, x3=False):
+    def f8_regions(self):
+        """the forward operands that run in fp8: every packed operand except the transposed twins (input gradients stay bf16) and
+        the 3-row output layer"""
+        return [n for n in self.W.regions if not n.endswith('T') and n != 'shrink']
+
+    def f8_jobs(self, st):
+        return [(self.W.view(st['Wb'], n), st['F8s'][i]) for i, n in enumerate(self.f8_regions())]
+
+    def state(self, dev, dt, x3=False, f8=False):
         """Per (device, dtype, x3) persistent buffers + device job tables.  x3 (GAST_F32X3): every packed fp32 operand also gets a
         pre-split bf16 image (`Xb`), refreshed by ops.run_pack after the copy / fold launches."""
-        key = (str(dev), dt, bool(x3))
+        key = (str(dev), dt, bool(x3), bool(f8))
         st = self._dev.get(key)
         ptrs = tuple(p.data_ptr() for p in self.params)
         if st is None or st['ptrs'] != ptrs:
             st = {'ptrs': ptrs, 'Wb': torch.zeros(self.W.size, dtype=dt, device=dev),
-                  'Fb': torch.zeros(self.F.size, dtype=torch.float32, device=dev), 'tables': None, 'Xb': None}
+                  'Fb': torch.zeros(self.F.size, dtype=torch.float32, device=dev), 'tables': None, 'Xb': None, 'F8s': None}
+            if f8 and dt == torch.bfloat16:
+                st['F8s'] = torch.ones(len(self.f8_regions()), 2, dtype=torch.float32, device=dev)
             if x3 and dt == torch.float32:
                 X = Layout()
                 for n, (_, r, c) in self.W.regions.items():
@@ -249,6 +271,9 @@ class Packer:
         inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
         if st.get('Xb') is not None:
             inp = {n: X3Weight(w, self._image(st, n)) for n, w in inp.items()}
+        if st.get('F8s') is not None:
+            for i, n in enumerate(self.f8_regions()):
+                inp[n] = F8Weight(inp[n], st['F8s'][i])
         for n in self.F.regions:
             v = self.F.view(st['Fb'], n)
             inp[n] = v.view(-1) if n.endswith('bias1') else v.view(NHEADS, self.spec.J, self.spec.J)

@@ -159,6 +159,7 @@ class _GastFunction(torch.autograd.Function):
             inp = st['inp'] = packer.inputs(st)
         engine.centered = runner.centered
         ops.x3 = runner.x3
+        ops.f8 = runner.f8
         pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
                                   need_grad=need_grad)
         ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink, ctx.runner = engine, packer, st, inp, sv, sink, runner
@@ -233,14 +234,21 @@ class _Runner:
         v = os.environ.get('GAST_HIP_DTYPE', 'fp32').lower()
         if v in ('fp32', 'f32', 'float32', 'bf16x3', 'x3'):
             return torch.float32
-        if v in ('bf16', 'bfloat16'):
+        if v in ('bf16', 'bfloat16', 'fp8'):
             return torch.bfloat16
-        raise ValueError('GAST_HIP_DTYPE must be fp32, bf16x3 or bf16, got %r' % v)
+        raise ValueError('GAST_HIP_DTYPE must be fp32, bf16x3, bf16 or fp8, got %r' % v)
 
     @property
     def x3(self):
         """GAST_HIP_DTYPE=bf16x3: fp32 storage, GEMMs and weight gradients on split-bf16 MFMA products (include/gast_hip.h)."""
         return os.environ.get('GAST_HIP_DTYPE', 'fp32').lower() in ('bf16x3', 'x3')
+
+    @property
+    def f8(self):
+        """GAST_HIP_DTYPE=fp8 (BASELINE.json configs[4], "mixed fp8 channel GEMMs"): bf16 storage; the FORWARD channel GEMMs run with
+        OCP e4m3 operands (per-tensor power-of-two weight scales) on v_mfma_f32_32x32x16_fp8_fp8, fp32 accumulation; input and weight
+        gradients, statistics, softmax and master weights as in bf16 mode."""
+        return os.environ.get('GAST_HIP_DTYPE', 'fp32').lower() == 'fp8'
 
     @property
     def centered(self):
@@ -394,7 +402,8 @@ class SpatioTemporalModelBase(nn.Module):
                     runner._packer = Packer(self, runner.spec)
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
-            st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None)
+            st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None,
+                              f8=runner.f8 and runner.ops_factory is None)
             # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
             return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)

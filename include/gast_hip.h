@@ -117,6 +117,10 @@ typedef struct {
     int xdrop;            /* forward applied dropout to relu(bn(X)) */
     uint32_t xsalt;
     gast_dropout drop;
+    const float* f8_scale; /* optional (GAST_BF16, bf16 output): run this GEMM's operands as OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8
+                            * ("mixed fp8", BASELINE.json configs[4]).  Device pointer to {s, 1/s}: every weight is multiplied by s
+                            * (a power of two, gast_f8_scale_multi) before the conversion, the accumulators by 1/s; activations are
+                            * converted as they are (post-BatchNorm values are O(1)).  All segments share the scale. */
 } gast_gemm_args;
 
 int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
@@ -129,6 +133,11 @@ int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_strea
 #define GAST_GEMM_MAX_BATCH 3
 int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream);
 long gast_gemm_splitk_ws_bytes(long M, int N);
+/* Per-tensor fp8 scales: out[0] = 2^floor(log2(448 / max |W|)) (1 for an all-zero tensor), out[1] = 1 / out[0], for the bf16
+ * operands W[R][ldw] (K columns used); n jobs in one launch (GAST_F8_SCALE_MAX_BATCH per launch). */
+#define GAST_F8_SCALE_MAX_BATCH 64
+typedef struct { const void* W; int R, K, ldw; float* out; } gast_f8_scale_job;
+int gast_f8_scale_multi(const gast_f8_scale_job* jobs, int n, gast_stream_t stream);
 /* which kernel gast_gemm_ws would launch for these arguments: 0 = the 128x128-tile kernel, 1 = the large-M GAST_F32X3 kernel
  * (needs every segment's Wx image, >= 8192 rows, N >= 32, no dropout prologue) */
 int gast_gemm_path(const gast_gemm_args* args);

@@ -84,10 +84,28 @@ def _ld(a):
 
 
 # ------------------------------------------------------------------------------------------------ gemm / wgrad
+def quant_e4m3(x):
+    """OCP FP8 E4M3 (exponent bias 7, largest value 448, subnormal step 2^-9; the gfx950 format of v_cvt_pk_fp8_f32 /
+    v_mfma_f32_32x32x16_fp8_fp8): round to nearest even, saturating."""
+    x = np.asarray(x, np.float64)
+    a = np.minimum(np.abs(x), 448.0)
+    e = np.clip(np.floor(np.log2(np.maximum(a, 2.0 ** -30))), -6, 8)
+    q = 2.0 ** (e - 3)
+    return np.sign(x) * np.round(a / q) * q
+
+
+def f8_weight_scale(W):
+    """gast_f8_scale_multi: 2^floor(log2(448 / max|W|)) (1 for an all-zero tensor)"""
+    m = float(np.abs(np.asarray(W, np.float64)).max())
+    return 1.0 if m == 0.0 else float(2.0 ** np.clip(np.floor(np.log2(448.0 / m)), -40, 40))
+
+
 def gemm(dom, N, segs, C, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-         xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, round_fn=None, bias_neg=False):
+         xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, round_fn=None, bias_neg=False, f8_scale=None):
     """segs: list of dicts {A, K, map, W, pro, scale, shift, salt}.  drop = (seed, thresh, inv_keep) or None.
-    Writes C (and partials) in place.  round_fn emulates storage rounding (identity for fp32)."""
+    Writes C (and partials) in place.  round_fn emulates storage rounding (identity for fp32).  f8_scale = s: the fp8-operand mode
+    of gast_gemm_args.f8_scale -- activations (after the prologue, rounded to their bf16 storage type) and s * weights are rounded to
+    e4m3, the products accumulate exactly and the sum is multiplied by 1 / s."""
     B, Tn, J = dom
     M = B * Tn * J
     acc = np.zeros((M, N), dtype=np.float64)
@@ -95,7 +113,13 @@ def gemm(dom, N, segs, C, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLA
         rows = map_rows(s['map'], B, Tn, J)
         a, ok = _gather(s['A'], rows, s['K'])
         a = _prologue(a, ok, rows, _ld(s['A']), s['K'], s.get('pro', 0), s.get('scale'), s.get('shift'), s.get('salt', 0), drop)
-        acc += a @ np.asarray(s['W'][:N, :s['K']], np.float64).T
+        w = np.asarray(s['W'][:N, :s['K']], np.float64)
+        if f8_scale is not None:
+            if round_fn is not None and s.get('pro', 0):
+                a = round_fn(a)
+            acc += quant_e4m3(a) @ quant_e4m3(w * f8_scale).T / f8_scale
+            continue
+        acc += a @ w.T
     if bias is not None:
         acc += (-1.0 if bias_neg else 1.0) * np.asarray(bias, np.float64)[None, :N]
     crow = map_rows(cmap, B, Tn, J)

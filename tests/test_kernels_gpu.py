@@ -280,6 +280,37 @@ def test_x3_image_layout(ops):
     assert sl.img is not None and sl.img.data_ptr() == xw.img[2:, 5:].data_ptr() and xw[:, 8:40].img is None
 
 
+@pytest.mark.parametrize('case', [c for c in GEMM_CASES if c[0] in ('stats_two_tiles', 'dilated_taps', 'ktail', 'big', 'splitk_stats', 'concat3_drop')],
+                         ids=lambda c: c[0])
+def test_gemm_fp8_operands(ops, case):
+    """gast_gemm_args.f8_scale ("mixed fp8", BASELINE.json configs[4]): bf16 storage, operands as OCP e4m3 on the fp8 matrix
+    instruction -- against the contract evaluated on e4m3-rounded operands (which pins the number format: the FNUZ format of the
+    previous GPU generation would be off by a factor of two)."""
+    from gast_hip.packer import F8Weight
+    jd, jh, bufs = _gemm_case(case, torch.bfloat16)
+    # one weight scale per GEMM: computed by the library's kernel from the first segment's weights, checked against the contract
+    Wall = torch.cat([s['W'].reshape(-1) for s in jd['segs']]).view(1, -1).contiguous()
+    sc = torch.ones(1, 2, device='cuda')
+    from gast_hip.binding import _F8ScaleJob, _p
+    import ctypes
+    job = (_F8ScaleJob * 1)()
+    job[0].W, job[0].R, job[0].K, job[0].ldw, job[0].out = _p(Wall), 1, Wall.shape[1], Wall.shape[1], _p(sc)
+    assert ops.lib.gast_f8_scale_multi(job, 1, torch.cuda.current_stream().cuda_stream) == 0
+    torch.cuda.synchronize()
+    s_ref = kc.f8_weight_scale(np.concatenate([h['W'].reshape(-1) for h in jh['segs']]))
+    assert float(sc[0, 0]) == s_ref and float(sc[0, 1]) == 1.0 / s_ref
+    for s in jd['segs']:
+        s['W'] = F8Weight(s['W'], sc[0])
+    ops.f8 = True
+    try:
+        ops.gemm(**jd)
+    finally:
+        ops.f8 = False
+    kc.gemm(f8_scale=s_ref, **jh)
+    torch.cuda.synchronize()
+    _gemm_check(case, torch.bfloat16, bufs)
+
+
 def test_gemm_out_f32_from_bf16(ops):
     gen = torch.Generator().manual_seed(5)
     dom, N, K = (2, 4, 17), 3, 64
