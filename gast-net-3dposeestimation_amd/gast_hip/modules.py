@@ -19,11 +19,24 @@ entry points, so they raise when autograd would have to record them.  fp32, devi
 batch statistics and updates the running statistics exactly like nn.BatchNorm2d; nn.Dropout in train mode uses the library's
 counter-hash stream (same distribution as torch's, not the same stream -- as in the fused plan).
 """
+import functools
+
 import torch
 
 from gast_hip.engine import EPI_PLAIN, EPI_STATS, PRO_BNRELU, PRO_NONE, RowMap, ident
 
 _OPS = None
+
+
+def _on_input_device(fn):
+    """kernels are enqueued on the current stream of the CURRENT device: make that the device of the input tensor"""
+    @functools.wraps(fn)
+    def wrapped(mod, x, *a, **k):
+        if torch.is_tensor(x) and x.is_cuda:
+            with torch.cuda.device(x.device):
+                return fn(mod, x, *a, **k)
+        return fn(mod, x, *a, **k)
+    return wrapped
 
 
 def _ops():
@@ -119,6 +132,7 @@ def _graph_conv_pair(ops, X, dom, convs, shared):
     return Y, part, nba
 
 
+@_on_input_device
 def graph_conv_forward(mod, x, shared):
     """SemCHGraphConv.forward (shared=False, reference local_attention.py:35-53) / SemGraphConv.forward (shared=True,
     sem_graph_conv.py:35-52): x (B, T, J, Cin) -> (B, T, J, Cout)"""
@@ -131,6 +145,7 @@ def graph_conv_forward(mod, x, shared):
     return out
 
 
+@_on_input_device
 def local_graph_forward(mod, x, shared=False, dropout2d=False):
     """LocalGraph.forward: x (B, T, J, C) -> (B, T, J, Cout)   (reference local_attention.py:130-151; sem_graph_conv.py:130-153
     for the channel-shared twin, whose dropout is nn.Dropout2d)"""
@@ -203,6 +218,7 @@ def _attention(ops, X, dom, heads):
     return Ya
 
 
+@_on_input_device
 def global_graph_forward(mod, x):
     """GlobalGraph.forward: x (B*T, C, J) -> (B*T, g_channels, J)   (reference global_attention.py:52-82)"""
     x = _check(mod, x, 3)
@@ -212,6 +228,7 @@ def global_graph_forward(mod, x):
     return Ya.view(F, J, mod.g_channels).permute(0, 2, 1).contiguous()
 
 
+@_on_input_device
 def multi_global_forward(mod, x):
     """MultiGlobalGraph.forward: x (B, T, J, C) -> (B, T, J, C)   (reference global_attention.py:103-130)"""
     x = _check(mod, x, 4)
@@ -230,6 +247,7 @@ def multi_global_forward(mod, x):
     return out.view(B, T, J, C)
 
 
+@_on_input_device
 def single_global_forward(mod, x):
     """SingleGlobalGraph.forward: x (B, T, J, C) -> (B, T, J, C); one head whose value projection keeps the full width
     (output_channels == in_channels, the only configuration the reference's bn(in_channels) accepts; global_attention.py:148-173)"""
@@ -254,6 +272,7 @@ def single_global_forward(mod, x):
 
 
 # ------------------------------------------------------------------------------------------ GraphAttentionBlock
+@_on_input_device
 def graph_attention_block_forward(mod, x):
     """GraphAttentionBlock.forward: x (B, C, T, J) -> (B, 2 C_out, T, J)   (reference gast_net.py:22-33)"""
     x = _check(mod, x, 4)
