@@ -194,7 +194,10 @@ def test_full_size_properties(mode):
 
 @pytest.mark.parametrize('J,arc,ch,B,variant', [(17, (3, 3, 3), 128, 128, 'dilated'), (17, (3, 3, 3), 128, 128, 'strided'),
                                                 (17, (3, 3, 3, 3), 64, 32, 'dilated'), (19, (3, 3, 3), 128, 64, 'dilated'),
-                                                (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense')])
+                                                (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense'),
+                                                # configs[2] at its own width (C=128: 1024-wide last level) and a batch the float64
+                                                # stock reference fits in memory with (its (BT, 2Ci, J, J) concat tensors)
+                                                (17, (3, 3, 3, 3), 128, 64, 'dilated')])
 def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, monkeypatch):
     """VALUES at the BASELINE.json sizes (configs[1]: B=128, T=27, J=17, C=128; and the shapes of configs[2..4]): the HIP path
     in fp32 against the oracle restatement running on stock PyTorch-ROCm operators on the same GPU (oracle/torch_ops.py, pinned
@@ -300,6 +303,25 @@ def test_other_baseline_configs_properties(J, arc, B, monkeypatch):
         assert (yd - ys).abs().max().item() < tol * max(1.0, yd.abs().max().item())
         out[mode] = yd
     assert (out['fp32'] - out['bf16']).abs().max().item() < 3e-2 * max(1.0, out['fp32'].abs().max().item())
+    # bf16x3 (the benchmark's arithmetic) at the full size of this configuration, TRAIN mode (batch statistics), dropout off: the
+    # north-star bf16 bound with a 10x margin (the large-M GEMMs of these shapes run on csrc/gemm_big.hip)
+    tr = {}
+    for mode in ('fp32', 'bf16x3'):
+        monkeypatch.setenv('GAST_HIP_DTYPE', mode)
+        sd = {k: v.clone() for k, v in md.state_dict().items()}
+        md.train()
+        for mod in md.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        md._runner.p_dropout = 0.0
+        with torch.no_grad():
+            tr[mode] = md(x).clone()
+        md.load_state_dict(sd)
+        md.eval()
+    d3 = (tr['fp32'] - tr['bf16x3']).abs().max().item()
+    _log(test='bf16x3_vs_fp32_train_other_config', J=J, arc=list(arc), B=B, max_abs=d3, out_range=tr['fp32'].abs().max().item())
+    assert d3 < 1e-3, d3
+    md._runner.p_dropout = 0.05
     with torch.no_grad():
         assert md((torch.rand(2, RF + 5, J, 2, generator=gen) * 2 - 1).cuda()).shape == (2, 6, J, 3)
     ms.train()
