@@ -185,30 +185,33 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
 // fp32, splits each value into bf16 hi + lo (x - hi is exact in fp32) and -- because v_cvt_pk_bf16_f32 packs two DIFFERENT source
 // registers -- gets the m-major -> col-major transposition for free: LDS rows are [col][hi: 32 m = 64 B | lo: 64 B] (+16 B pad) and
 // the MFMA loop is gast_gemm's split loop: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
-__device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
+// TILE = edge of the square dW tile: 128 (4 waves as 2x2 of 64x64, three blocks per CU) or 256 (8 waves as 2x4 of 128x64, one block
+// per CU, GAST_WGRAD_X3_TILE=256: every staged operand value -- prologue, hi/lo split, transposing pack -- then feeds twice the MFMAs).
+template <int TILE>
+__device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
     constexpr int BKM = 32;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
+    constexpr int WGC = TILE / 64, MI = TILE / 64;     // wave columns; 32-row MFMA tiles per wave (wave tile: TILE/2 rows x 64 columns)
     __shared__ __attribute__((aligned(16))) int sRowP[2][BKM];
     __shared__ __attribute__((aligned(16))) int sRowQ[2][BKM];
     __shared__ int sBad[2];
     unsigned char* const sP = smem;
-    unsigned char* const sQ = smem + BT * LSTR;
+    unsigned char* const sQ = smem + TILE * LSTR;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w / WGC, wc = w % WGC;
     const int li = lane & 31, lh = lane >> 5;
-    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const TileCoord tc = decode_tile(a, tile, tilesS_total, TILE);
     const gast_wgrad_seg& sg = a.seg[tc.seg];
     const int m_begin = sp * mchunk;
     const int m_end = min(M, m_begin + mchunk);
     if (m_begin >= m_end) return;
     const int ntile = (m_end - m_begin + BKM - 1) / BKM;
 
-    // staging role: threads 0..127 stage P, 128..255 stage Q; each owns an 8(m) x 4(col) block of the 32 x 128 step tile
-    const int op = tid >> 7, task = tid & 127;
+    // staging role: the first TILE threads stage P, the others Q; each owns an 8(m) x 4(col) block of the 32 x TILE step tile
+    const int op = tid / TILE, task = tid - op * TILE;
     const int mb = task & 3, rc = task >> 2;
     const float* base = op == 0 ? (const float*)a.P : (const float*)sg.Q;
     const int ld = op == 0 ? a.ldp : sg.ldq;
-    const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 4;
+    const int col = (op == 0 ? tc.rt : tc.st) * TILE + rc * 4;
     const bool cin = col < (op == 0 ? a.R : sg.S);
     const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
     const bool drop = op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
@@ -220,9 +223,9 @@ __device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, i
     }
     unsigned char* const sdst = op == 0 ? sP : sQ;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][2];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
@@ -297,10 +300,10 @@ __device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, i
     auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            union { uint4 u; s16x8 s; } ah[2], al[2], bh[2], bl[2];
+            union { uint4 u; s16x8 s; } ah[MI], al[MI], bh[2], bl[2];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) {
-                const unsigned char* p = sP + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+            for (int mi = 0; mi < MI; ++mi) {
+                const unsigned char* p = sP + (wr * (TILE / 2) + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
                 ah[mi].u = *(const uint4*)p;
                 al[mi].u = *(const uint4*)(p + 64);
             }
@@ -311,15 +314,15 @@ __device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, i
                 bl[ni].u = *(const uint4*)(p + 64);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
         }
@@ -341,13 +344,13 @@ __device__ __forceinline__ void wgrad_x3_body(const gast_wgrad_args& a, int M, i
 
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
-        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        const int scol = tc.st * TILE + wc * 64 + ni * 32 + li;
         if (scol >= sg.S) continue;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
+        for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int rrow = tc.rt * TILE + wr * (TILE / 2) + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
             }
     }
@@ -568,8 +571,9 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
     wgrad_f32_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_x3_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
     const int tile = blockIdx.x / splitM;
-    wgrad_x3_body(a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
+    wgrad_x3_body<BT>(smem, a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
@@ -617,9 +621,17 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b
     wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_x3_body<BT>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+}
+// 256x256 tiles (GAST_WGRAD_X3_TILE=256): 512 threads, 72 KB of dynamic LDS, one block per CU
+__global__ void __launch_bounds__(512, 2) wgrad_x3_multi256_kernel(const WgBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3[];
+    int d, tile, sp;
+    if (!wg_decode(b, d, tile, sp)) return;
+    wgrad_x3_body<256>(dsmem_x3, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
@@ -711,7 +723,8 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     // on the C=256 stage (19 vs 74 tiles), 111 vs 86 us on the C=512 stage, 124 vs 105 us on the C=128 stage.  Kept for the
     // next step (a second LDS stage / loader waves), not selected by default.
     static const int tile_env = getenv("GAST_WGRAD_TILE") ? atoi(getenv("GAST_WGRAD_TILE")) : 128;
-    const int bt = (args[0].dtype == GAST_BF16 && tile_env == 256) ? 256 : BT;
+    static const int x3_tile_env = getenv("GAST_WGRAD_X3_TILE") ? atoi(getenv("GAST_WGRAD_X3_TILE")) : 128;
+    const int bt = ((args[0].dtype == GAST_BF16 && tile_env == 256) || (args[0].dtype == GAST_F32X3 && x3_tile_env == 256)) ? 256 : BT;
     long tile_rows = 0;
     int total_tiles = 0;
     for (int d = 0; d < n; ++d) {
@@ -775,7 +788,12 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]);
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, dim3(256), 0, st, b);
-    else if (args[0].dtype == GAST_F32X3)
+    else if (args[0].dtype == GAST_F32X3 && bt == 256) {
+        constexpr int lds = 2 * 256 * LSTR;
+        static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_x3_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (attr != hipSuccess) return (int)attr;
+        hipLaunchKernelGGL(wgrad_x3_multi256_kernel, grid, dim3(512), lds, st, b);
+    } else if (args[0].dtype == GAST_F32X3)
         hipLaunchKernelGGL(wgrad_x3_multi_kernel, grid, dim3(256), 0, st, b);
     else if (bt == 256) {
         constexpr int lds = wgrad_bf16_lds_bytes(256);
