@@ -705,6 +705,10 @@ def main():
             del model, opt, sync, graphs
             torch.cuda.empty_cache()
             out['stock_pytorch_rocm'] = stock_gpu_baseline()
+        if collective:
+            # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if collective:
         dist.destroy_process_group()
