@@ -37,9 +37,15 @@ __device__ __forceinline__ TileCoord decode_tile(const gast_wgrad_args& a, int t
     return c;
 }
 
+__device__ __forceinline__ bool is_ident(const gast_rowmap& mp, int Tn) { return mp.t_stride == 1 && mp.t_off == 0 && mp.T_total == Tn; }
+
 __device__ __forceinline__ void rows_for(const gast_wgrad_args& a, const gast_wgrad_seg& sg, int m, int M,
                                          int& prow, int& qrow) {
     prow = -1; qrow = -1;
+    if (is_ident(a.pmap, a.Tn) && is_ident(sg.map, a.Tn)) {     // (most jobs: no integer divisions on the per-step path)
+        if (m < M) { prow = m; qrow = m; }
+        return;
+    }
     if (m < M) {
         int TJ = a.Tn * a.J;
         int b = m / TJ, rem = m - b * TJ;
@@ -187,7 +193,9 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
 // the MFMA loop is gast_gemm's split loop: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 // TILE = edge of the square dW tile: 128 (4 waves as 2x2 of 64x64, three blocks per CU) or 256 (8 waves as 2x4 of 128x64, one block
 // per CU, GAST_WGRAD_X3_TILE=256: every staged operand value -- prologue, hi/lo split, transposing pack -- then feeds twice the MFMAs).
-template <int TILE>
+// DROP: some segment re-derives a dropout mask in its prologue (compile-time: without it the staging pass needs neither the per-row
+// element offsets -- eight serialised LDS reads per step -- nor the hash)
+template <int TILE, bool DROP>
 __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
     constexpr int BKM = 32;
     constexpr int WGC = TILE / 64, MI = TILE / 64;     // wave columns; 32-row MFMA tiles per wave (wave tile: TILE/2 rows x 64 columns)
@@ -214,7 +222,7 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
     const int col = (op == 0 ? tc.rt : tc.st) * TILE + rc * 4;
     const bool cin = col < (op == 0 ? a.R : sg.S);
     const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
-    const bool drop = op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
+    const bool drop = DROP && op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
     const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
     float sc[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f};
     if (pro && cin) {
@@ -247,12 +255,16 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
 
     u32x4 rl[8];
     const int colc = cin ? col : 0;
+    // (the operand a thread stages is the same for its whole wave: the base pointer can live in scalar registers)
+    const float* const sbase = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)base >> 32)) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)base));
     auto load_tile = [&](int buf) {
         const int4* rp = (const int4*)((op == 0 ? sRowP[buf] : sRowQ[buf]) + mb * 8);
         const int4 r0 = rp[0], r1 = rp[1];
         const int rows[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) gload16(rl[i], base + (long)(rows[i] < 0 ? 0 : rows[i]) * ld + colc);
+        for (int i = 0; i < 8; ++i)      // 32-bit byte offset + uniform base (wgrad_check bounds the operands to 4 GB)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(rl[i]) : "v"((uint32_t)((rows[i] < 0 ? 0 : rows[i]) * ld + colc) * 4u), "s"(sbase) : "memory");
     };
     auto store_tile = [&](int buf) {
         float x[8][4];
@@ -263,16 +275,20 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
         }
         const bool bad = __builtin_amdgcn_readfirstlane(sBad[buf]) != 0;
         if (pro && cin) {
+            if (DROP && drop) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = sRowQ[buf][mb * 8 + i];
-                const uint32_t e0 = (uint32_t)((long)(row < 0 ? 0 : row) * ld + col);
+                for (int i = 0; i < 8; ++i) {
+                    const int row = sRowQ[buf][mb * 8 + i];
+                    const uint32_t e0 = (uint32_t)((long)(row < 0 ? 0 : row) * ld + col);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    float y = fmaxf(fmaf(x[i][q], sc[q], sh[q]), 0.f);
-                    if (drop) y *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + q);
-                    x[i][q] = y;
+                    for (int q = 0; q < 4; ++q)
+                        x[i][q] = fmaxf(fmaf(x[i][q], sc[q], sh[q]), 0.f) * drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + q);
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[i][q] = fmaxf(fmaf(x[i][q], sc[q], sh[q]), 0.f);
             }
         }
         // rows outside the chunk / the row map must read as zero (after the prologue: relu(shift) must not leak in)
@@ -573,7 +589,7 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_kernel(const gast_wgrad_args
 __global__ void __launch_bounds__(256, 3) wgrad_x3_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
     const int tile = blockIdx.x / splitM;
-    wgrad_x3_body<BT>(smem, a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
+    wgrad_x3_body<BT, true>(smem, a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_args a, int M, int tilesS_total, int splitM, int mchunk) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
@@ -620,18 +636,19 @@ __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_f32_body(b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
+template <bool DROP>
 __global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BT * LSTR];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_body<BT>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_x3_body<BT, DROP>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 // 256x256 tiles (GAST_WGRAD_X3_TILE=256): 512 threads, 72 KB of dynamic LDS, one block per CU
 __global__ void __launch_bounds__(512, 2) wgrad_x3_multi256_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3[];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_body<256>(dsmem_x3, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_x3_body<256, true>(dsmem_x3, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
@@ -672,6 +689,11 @@ int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS, int 
     }
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
+    if (a.dtype == GAST_F32X3) {      // the bf16x3 kernel addresses its operands with 32-bit byte offsets
+        if ((long)a.B * a.pmap.T_total * a.J * a.ldp * 4 >= 0xffffffffL) return GAST_ERANGE;
+        for (int s = 0; s < a.nseg; ++s)
+            if ((long)a.B * a.seg[s].map.T_total * a.J * a.seg[s].ldq * 4 >= 0xffffffffL) return GAST_ERANGE;
+    }
     M = (int)Ml;
     tilesR = (a.R + bt - 1) / bt;
     return 0;
@@ -793,8 +815,13 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_x3_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (attr != hipSuccess) return (int)attr;
         hipLaunchKernelGGL(wgrad_x3_multi256_kernel, grid, dim3(512), lds, st, b);
-    } else if (args[0].dtype == GAST_F32X3)
-        hipLaunchKernelGGL(wgrad_x3_multi_kernel, grid, dim3(256), 0, st, b);
+    } else if (args[0].dtype == GAST_F32X3) {
+        bool any_drop = false;
+        for (int d = 0; d < n; ++d)
+            for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
+        if (any_drop) hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, grid, dim3(256), 0, st, b);
+        else hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, grid, dim3(256), 0, st, b);
+    }
     else if (bt == 256) {
         constexpr int lds = wgrad_bf16_lds_bytes(256);
         static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_bf16_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
