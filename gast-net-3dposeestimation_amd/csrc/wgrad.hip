@@ -14,6 +14,7 @@
 // M is split over blockIdx (split-M) and partial 128x128 tiles are combined with fp32 atomics into the zero-filled
 // gradient buffer.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -372,6 +373,216 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
     }
 }
 
+// Pipelined form of wgrad_x3_body (TILE 128): TWO LDS stages, TWO register sets, ONE barrier per step.  The step of wgrad_x3_body is
+//   wait(all loads) -> convert -> LDS write -> barrier -> issue loads -> MFMA -> barrier
+// with every phase of a wave serialised behind a barrier; here the MFMAs of tile t (stage t&1) and the wait / prologue / hi-lo
+// split / transposing LDS write of tile t+1 (stage (t+1)&1) form ONE branch-free region, followed by a single barrier, and the
+// loads of tiles t+2 and t+3 stay in flight across it (counted s_waitcnt vmcnt(8), as in gemm_big).  What makes the region
+// branch-free:
+//   * the operands are read with raw buffer loads; wave 0 turns the row map of each 32-row step into BYTE offsets and gives rows
+//     outside the chunk / the row map an out-of-range offset: the hardware returns zeros for them without touching memory, so
+//     neither the step tail nor an out-of-range tap needs a branch (only the dC operand has to read as zero: the product with a
+//     finite relu(shift) then vanishes);
+//   * the two staging roles are two instantiations of the loop (waves 0-1 stage dC: no prologue; waves 2-3 stage the activation:
+//     fma + max against a lower clamp that is -inf for a prologue-free segment);
+//   * the step count is padded to an even number and the loads / row tables run two tiles past the end (all out of range).
+// 72 KB of LDS: two blocks per CU.
+constexpr int wgrad_x3_pipe_lds_bytes() { return 2 * 2 * BT * LSTR; }
+constexpr uint32_t WG_OOB = 0xFFFF0000u;      // buffer size == first out-of-range byte offset (wgrad_check bounds the operands)
+typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
+
+template <bool DROP>
+__device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
+    constexpr int BKM = 32;
+    constexpr int STAGE = 2 * BT * LSTR;
+    __shared__ __attribute__((aligned(16))) uint32_t sOffP[2][BKM];
+    __shared__ __attribute__((aligned(16))) uint32_t sOffQ[2][BKM];
+
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const TileCoord tc = decode_tile(a, tile, tilesS_total, BT);
+    const gast_wgrad_seg& sg = a.seg[tc.seg];
+    const int m_begin = sp * mchunk;
+    const int m_end = min(M, m_begin + mchunk);
+    if (m_begin >= m_end) return;
+    const int ntile = ((m_end - m_begin + BKM - 1) / BKM + 1) & ~1;      // even
+
+    const int op = __builtin_amdgcn_readfirstlane(w >> 1);               // 0: dC (P) staging waves, 1: activation (Q) staging waves
+    const int task = tid & (BT - 1);
+    const int mb = task & 3, rc = task >> 2;
+    const float* base = op == 0 ? (const float*)a.P : (const float*)sg.Q;
+    const int ld = op == 0 ? a.ldp : sg.ldq;
+    const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 4;
+    const bool cin = col < (op == 0 ? a.R : sg.S);
+    const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
+    const bool drop = DROP && op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
+    const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
+    // prologue constants of this thread's 4 columns; identity (scale 1, shift 0, clamp -inf) without a prologue; columns past S
+    // feed only outputs that are never stored
+    float sc[4], sh[4];
+    const float lowclamp = pro ? 0.f : -__builtin_inff();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { sc[q] = 1.f; sh[q] = 0.f; }
+    if (pro && cin) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { sc[q] = sg.scale[col + q]; sh[q] = sg.shift[col + q]; }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sh[q]));      // (the compiler's wait for these loads lands here, not in the loop)
+    const uint32_t colbytes = (uint32_t)(cin ? col : 0) * 4u;
+    const int sdst_off = (op == 0 ? 0 : BT * LSTR) + rc * 4 * LSTR + mb * 16;
+    // buffer resource of this wave's operand: base, stride 0, WG_OOB bytes, raw 32-bit dwords
+    const float* const sbase = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)base >> 32)) << 32) |
+                                              (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)base));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)sbase, 0, (int)WG_OOB, 0x00020000);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    const uint32_t ldp4 = (uint32_t)a.ldp * 4u, ldq4 = (uint32_t)sg.ldq * 4u;
+    auto compute_rows = [&](int it, int buf) {      // wave 0 only
+        if (tid < BKM) {
+            const int m = m_begin + it * BKM + tid;
+            int pr, qr;
+            rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
+            sOffP[buf][tid] = pr < 0 ? WG_OOB : (uint32_t)pr * ldp4;
+            sOffQ[buf][tid] = qr < 0 ? WG_OOB : (uint32_t)qr * ldq4;
+        }
+    };
+
+    struct Set { u32x4 rl[8]; uint32_t off[8]; };
+    Set S0, S1;
+    auto load_tile = [&](Set& S, int buf) {
+        const uint4* rp = (const uint4*)((op == 0 ? sOffP[buf] : sOffQ[buf]) + mb * 8);
+        const uint4 r0 = rp[0], r1 = rp[1];
+        S.off[0] = r0.x + colbytes; S.off[1] = r0.y + colbytes; S.off[2] = r0.z + colbytes; S.off[3] = r0.w + colbytes;
+        S.off[4] = r1.x + colbytes; S.off[5] = r1.y + colbytes; S.off[6] = r1.z + colbytes; S.off[7] = r1.w + colbytes;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            S.rl[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)S.off[i], 0, 0));
+    };
+    auto store_tile = [&](const Set& S, unsigned char* stage, auto opc) {
+        constexpr int OP = decltype(opc)::value;
+        float x[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            x[i][0] = __uint_as_float(S.rl[i].x); x[i][1] = __uint_as_float(S.rl[i].y);
+            x[i][2] = __uint_as_float(S.rl[i].z); x[i][3] = __uint_as_float(S.rl[i].w);
+        }
+        if (OP == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) x[i][q] = fmaxf(fmaf(x[i][q], sc[q], sh[q]), lowclamp);
+            if (DROP && drop) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const uint32_t e0 = S.off[i] >> 2;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) x[i][q] *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + q);
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t h[4], l[4];
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) {
+                const float x0 = x[2 * p2][q], x1 = x[2 * p2 + 1][q];
+                h[p2] = pack_bf16x2(x0, x1);
+                l[p2] = pack_bf16x2(x0 - __uint_as_float(h[p2] << 16), x1 - __uint_as_float(h[p2] & 0xffff0000u));
+            }
+            unsigned char* d = stage + sdst_off + q * LSTR;
+            *(uint4*)d = make_uint4(h[0], h[1], h[2], h[3]);
+            *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    };
+    auto mfma_tile = [&](const unsigned char* stage) {
+        const unsigned char* const sP = stage;
+        const unsigned char* const sQ = stage + BT * LSTR;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            union { uint4 u; s16x8 s; } ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) {
+                const unsigned char* p = sP + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                ah[mi].u = *(const uint4*)p;
+                al[mi].u = *(const uint4*)(p + 64);
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const unsigned char* p = sQ + (wc * 64 + ni * 32 + li) * LSTR + (ks * 2 + lh) * 16;
+                bh[ni].u = *(const uint4*)p;
+                bl[ni].u = *(const uint4*)(p + 64);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+        }
+    };
+    unsigned char* const stage0 = smem;
+    unsigned char* const stage1 = smem + STAGE;
+
+    // prologue: offsets of tiles 0,1 -> loads 0,1 -> offsets of tiles 2,3 -> tile 0 into stage 0 -> load 2
+    if (w == 0) { compute_rows(0, 0); compute_rows(1, 1); }
+    __syncthreads();
+    load_tile(S0, 0);
+    load_tile(S1, 1);
+    __syncthreads();
+    if (w == 0) { compute_rows(2, 0); compute_rows(3, 1); }
+    auto run = [&](auto opc) {
+        store_tile(S0, stage0, opc);
+        __syncthreads();
+        load_tile(S0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        // steady state, two steps per trip.  Step t: MFMA on stage t&1 | tile t+1 (set (t+1)&1) -> stage (t+1)&1; barrier; load
+        // tile t+3 into the freed set; offsets of tile t+4.  (Tiles >= ntile: all offsets out of range, zeros, no traffic.)
+        for (int it = 0; it < ntile; it += 2) {
+            mfma_tile(stage0);
+            store_tile(S1, stage1, opc);
+            __syncthreads();
+            load_tile(S1, 1);
+            if (decltype(opc)::value == 0 && w == 0) compute_rows(it + 4, 0);
+            __builtin_amdgcn_sched_barrier(0);      // (the next step's conversions must not move up: they would wait for the loads just issued)
+            mfma_tile(stage1);
+                store_tile(S0, stage0, opc);
+            __syncthreads();
+            load_tile(S0, 0);
+            if (decltype(opc)::value == 0 && w == 0) compute_rows(it + 5, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if (op == 0) run(std::integral_constant<int, 0>());
+    else run(std::integral_constant<int, 1>());
+
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int scol = tc.st * BT + wc * 64 + ni * 32 + li;
+        if (scol >= sg.S) continue;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rrow = tc.rt * BT + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (rrow < a.R) atomicAdd(a.dW + (long)rrow * a.ldw + sg.wcol0 + scol, acc[mi][ni][r]);
+            }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ bf16
 __device__ __forceinline__ void transpose8x8_bf16(const u32x4 (&in)[8], uint4 (&out)[8]) {
     // in[i] = row i (8 bf16: cols 0..7 packed in 4 u32); out[q] = col q (8 bf16: rows 0..7).  One v_perm_b32 per output word
@@ -644,6 +855,13 @@ __global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b)
     wgrad_x3_body<BT, DROP>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 // 256x256 tiles (GAST_WGRAD_X3_TILE=256): 512 threads, 72 KB of dynamic LDS, one block per CU
+template <bool DROP>
+__global__ void __launch_bounds__(256, 2) wgrad_x3_pipe_multi_kernel(const WgBatch b) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3p[];
+    int d, tile, sp;
+    if (!wg_decode(b, d, tile, sp)) return;
+    wgrad_x3_pipe_body<DROP>(dsmem_x3p, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+}
 __global__ void __launch_bounds__(512, 2) wgrad_x3_multi256_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3[];
     int d, tile, sp;
@@ -690,9 +908,9 @@ int wgrad_check(const gast_wgrad_args& a, int& M, int& tilesR, int& tilesS, int 
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
     if (a.dtype == GAST_F32X3) {      // the bf16x3 kernel addresses its operands with 32-bit byte offsets
-        if ((long)a.B * a.pmap.T_total * a.J * a.ldp * 4 >= 0xffffffffL) return GAST_ERANGE;
+        if ((long)a.B * a.pmap.T_total * a.J * a.ldp * 4 >= 0xffff0000L || a.R > 16000) return GAST_ERANGE;
         for (int s = 0; s < a.nseg; ++s)
-            if ((long)a.B * a.seg[s].map.T_total * a.J * a.seg[s].ldq * 4 >= 0xffffffffL) return GAST_ERANGE;
+            if ((long)a.B * a.seg[s].map.T_total * a.J * a.seg[s].ldq * 4 >= 0xffff0000L || a.seg[s].S > 16000) return GAST_ERANGE;
     }
     M = (int)Ml;
     tilesR = (a.R + bt - 1) / bt;
@@ -794,8 +1012,11 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     b.first[0] = 0;
     b.tfirst[0] = 0;
     int max_split = 1;
-    static const int order = getenv("GAST_WGRAD_ORDER") ? atoi(getenv("GAST_WGRAD_ORDER")) : 0;   // 1 = chunk-major (measured slower)
-    b.chunk_major = order;
+    // block order: 1 = chunk-major.  bf16 / fp32 kernels: tile-major (chunk-major measured 3 % slower on the bf16 step); the pipelined
+    // bf16x3 kernel: chunk-major (PMC: 2.38 -> 1.07 GB fetched from HBM per launch on the C=256 stage, 535 -> 506 us)
+    static const int order = getenv("GAST_WGRAD_ORDER") ? atoi(getenv("GAST_WGRAD_ORDER")) : -1;
+    static const int x3_pipe = getenv("GAST_WGRAD_X3_PIPE") ? atoi(getenv("GAST_WGRAD_X3_PIPE")) : 1;
+    b.chunk_major = order >= 0 ? order : (args[0].dtype == GAST_F32X3 && bt == BT && x3_pipe) ? 1 : 0;
     for (int d = 0; d < n; ++d) {
         b.mchunk[d] = (int)(chunk < b.M[d] ? chunk : (b.M[d] + bkm - 1) / bkm * bkm);
         b.splitM[d] = (b.M[d] + b.mchunk[d] - 1) / b.mchunk[d];
@@ -819,7 +1040,15 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         bool any_drop = false;
         for (int d = 0; d < n; ++d)
             for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
-        if (any_drop) hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, grid, dim3(256), 0, st, b);
+        if (x3_pipe) {
+            constexpr int lds = wgrad_x3_pipe_lds_bytes();
+            static hipError_t at1 = hipFuncSetAttribute((const void*)wgrad_x3_pipe_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            static hipError_t at0 = hipFuncSetAttribute((const void*)wgrad_x3_pipe_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            if (at1 != hipSuccess || at0 != hipSuccess) return (int)(at1 != hipSuccess ? at1 : at0);
+            if (any_drop) hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<true>, grid, dim3(256), lds, st, b);
+            else hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<false>, grid, dim3(256), lds, st, b);
+        }
+        else if (any_drop) hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, grid, dim3(256), 0, st, b);
         else hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, grid, dim3(256), 0, st, b);
     }
     else if (bt == 256) {

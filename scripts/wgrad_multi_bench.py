@@ -10,6 +10,9 @@ from gast_hip.binding import HipOps, RowMap, Dropout, dropout_params
 ops = HipOps()
 B, J = 128, 17
 dt = torch.bfloat16
+if os.environ.get('GAST_HIP_DTYPE') == 'bf16x3':      # fp32 storage, split-bf16 products
+    dt = torch.float32
+    ops.x3 = True
 # stage -> (Tn, [(R, [(S, T_total_of_Q, t_off)])])
 SETS = {
     's0': (25, [(256, [(128, 25, 0), (256, 25, 0)]), (128, [(256, 25, 0)]), (128, [(128, 25, 0)]), (648, [(128, 25, 0)])]),
