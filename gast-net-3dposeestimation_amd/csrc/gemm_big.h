@@ -1,9 +1,10 @@
-// Internal interface between gemm.hip (argument validation, dispatch) and gemm_big.hip (the 256x256-tile GAST_F32X3 kernel).
+// Internal interface between gemm.hip (argument validation, dispatch) and gemm_big.hip (the 128x256 / 128x128-tile pipelined GAST_F32X3 kernel).
 #pragma once
 #include "common.h"
 
 struct BigPlan {
     int M, tilesM, tilesN;
+    int ni;                       // 32-column MFMA tiles per wave: 4 = 128x256 block tile, 2 = 128x128
     int ntab;                     // floats in the scale table (= in the shift table) a block keeps in LDS
     int taboff[GAST_MAX_SEG];     // offset of the segment's scale/shift in the tables (-1: no prologue)
     int ablate;                   // GAST_GEMM_BIG_ABLATE (profiling aid, results are wrong when set): 1 no MFMA, 2 no fragment reads,

@@ -27,16 +27,19 @@
 
 namespace {
 
-constexpr int TM = 128, TN = 256, TK = 16;
+// NI = 32-column MFMA tiles per wave: 4 (block tile 128 x 256) or 2 (128 x 128: the N <= 128 GEMMs, for which half of the wide
+// tile would be empty, and the short-K input gradients whose epilogue then holds half the registers)
+constexpr int TM = 128, TK = 16;
 constexpr int ROWB = 64;                        // LDS row image: 16 bf16 hi | 16 bf16 lo
 constexpr int A_BYTES = TM * ROWB;              // 8 KB
-constexpr int W_BYTES = TN * ROWB;              // 16 KB
 constexpr int OFF_ROWS = 0;                     // crow[128] | addrow[128]
 constexpr int OFF_A = 2 * TM * 4;               // two activation stages
 constexpr int OFF_W = OFF_A + 2 * A_BYTES;      // three weight stages
-constexpr int OFF_TAB = OFF_W + 3 * W_BYTES;    // scale | shift tables
 constexpr int LDS_BLOCK = 80 * 1024;            // two blocks per CU
-constexpr int MAX_TAB = (LDS_BLOCK - OFF_TAB - 6 * 256 * 4) / 8;
+constexpr int tn_of(int ni) { return 64 * ni; }
+constexpr int w_bytes(int ni) { return tn_of(ni) * ROWB; }             // 16 KB / 8 KB
+constexpr int off_tab(int ni) { return OFF_W + 3 * w_bytes(ni); }      // scale | shift tables
+constexpr int max_tab(int ni) { return (LDS_BLOCK - off_tab(ni) - 6 * 256 * 4) / 8; }
 
 // 16 bytes per lane global -> LDS (DMA): address = sbase + voff + OFF; lands at lds_wave_base + 16 * lane
 template <int OFF>
@@ -50,8 +53,10 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived (compile-time: the
 // epilogue is straight-line code per element); ADD: an addend tensor is present
-template <int EPI, bool ADD>
+template <int EPI, bool ADD, int NI>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
+    constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI);
+    constexpr int WROWS = TN / 4;                   // weight rows a wave's DMA fills per K step (16-row pieces: WROWS / 16)
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -117,7 +122,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     // Weight stream (DMA): wave w fills the 16-row pieces (w*4 + i) of the 256 x 64 B tile, which is ONE contiguous 16 KB block
     // of the k-group-major image; lane = (row r16, slot s4) and slot s4 receives source chunk s4 ^ key(row).  Per thread: one
     // byte offset (the pieces are immediates), per step: a scalar base.
-    const uint32_t offW = (uint32_t)(n0 + w * 64 + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
+    const uint32_t offW = (uint32_t)(n0 + w * WROWS + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
     // A tile descriptor carries everything the K loop needs to know about its segment (K, table offset, operand bases), fetched
     // from the kernel arguments only when the generator enters a new segment: a dependent s_load per use costs ~200 clk.
     struct Tile { int seg, k0, K, toff; const float* abase; const char* wbase; };
@@ -162,12 +167,14 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     };
     auto dma_w = [&](const Tile& t, int stage) {
         if (abl & 4) return;
-        const uint32_t sW = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + stage * W_BYTES + w * 4 * 16 * ROWB);
+        const uint32_t sW = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + stage * W_BYTES + w * WROWS * ROWB);
         // (the instruction offset of an LDS-DMA load moves the global AND the LDS address: one M0 base serves the four pieces)
         glds16<0>(offW, t.wbase, sW);
         glds16<1024>(offW, t.wbase, sW);
-        glds16<2048>(offW, t.wbase, sW);
-        glds16<3072>(offW, t.wbase, sW);
+        if (NI == 4) {
+            glds16<2048>(offW, t.wbase, sW);
+            glds16<3072>(offW, t.wbase, sW);
+        }
     };
     // scale / shift of a tile's prologue (this thread's 4 K values), fetched from the LDS tables one step before write_a uses them
     float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -202,11 +209,11 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
     };
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NI];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     // fragment reads: row = (multiple of 32) + li, so the swizzle key is (li >> 2) & 3 for every MFMA tile; the lane's hi / lo
@@ -267,10 +274,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
     };
     auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
-        gload_wait_n<6>();
+        gload_wait_n<NI + 2>();                                // (the newest step's NI DMA pieces + 2 activation loads stay in flight)
         __syncthreads();
         const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
-        const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * 128 * ROWB;
+        const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * (TN / 2) * ROWB;
         Frag ah[2], al[2], bh[2], bl[2];
         if (!(abl & 2)) {
 #pragma unroll
@@ -287,12 +294,14 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         if (wr_next) write_a(d1, (t + 1) & 1, ra, rz);          // tile t+1: registers -> LDS (its set is then free for tile t+3)
         if (!(abl & 2)) {
             if (do_mma) mma3(0, ah, al, bh, bl);
+            if (NI == 4) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {                       // second column half: read under the first half's MFMAs
-                bh[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + ohi);
-                bl[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + olo);
+                for (int q = 0; q < 2; ++q) {                   // second column half: read under the first half's MFMAs
+                    bh[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + ohi);
+                    bl[q].u = *(const uint4*)(sW + (2 + q) * 32 * ROWB + olo);
+                }
+                if (do_mma) mma3(1, ah, al, bh, bl);
             }
-            if (do_mma) mma3(1, ah, al, bh, bl);
         }
         // the transfers of tiles t+2 / t+3 are requested AFTER the step's MFMAs have been issued: when the memory system pushes
         // back, a wave stalls at the ISSUE of a VMEM instruction, and everything behind it in program order waits with it
@@ -310,7 +319,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     gload_wait_n<0>();                 // (the re-requested tiles past the end: nothing may land in LDS after this point)
     __syncthreads();
 
-    if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][3][5] + acc[0][1][2] + acc[0][2][3] + acc[0][3][4] + acc[1][0][1] + acc[1][1][1] + acc[1][2][1]; return; }
+    if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][NI - 1][5] + acc[0][1][2] + acc[1][0][1] + acc[1][1][1]; return; }
     // ---- epilogue, straight from the accumulators (lane = column li of the MFMA tile; register r = row (r&3) + 8 (r>>2) + 4 lh).
     // Branch-free: all global accesses are BUFFER loads / stores with the tensors' true extents as bounds -- an element that must
     // not be touched (row past M or unmapped by cmap, column past N) simply gets an out-of-range offset (loads return 0, stores
@@ -326,11 +335,11 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * 4) : 0, RSRC3);
     const long rowsAdd = ADD ? (long)a.B * a.addmap.T_total * a.J : 1;
     const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(ADD ? a.addend : a.C), 0, ADD ? (int)(((rowsAdd - 1) * a.ldadd + N) * 4) : 0, RSRC3);
-    const int col0 = n0 + wc * 128 + li;               // the lane's first column; the others are + 32 ni
-    bool nin[4];
-    float bias[4], xs[4], xh[4], s1[4], s2[4];
+    const int col0 = n0 + wc * (TN / 2) + li;          // the lane's first column; the others are + 32 ni
+    bool nin[NI];
+    float bias[NI], xs[NI], xh[NI], s1[NI], s2[NI];
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < NI; ++ni) {
         const int n = col0 + 32 * ni;
         nin[ni] = n < N;
         const int ncl = nin[ni] ? n : N - 1;
@@ -341,7 +350,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     }
     // unit u = (mi = u >> 2, q = u & 3): rows wr*64 + mi*32 + 8 q + 4 lh + {0..3} = accumulator registers 4 q .. 4 q + 3
     int crow[2][4];
-    float xv[2][4][4], av[2][4][4];
+    float xv[2][NI][4], av[2][NI][4];
     auto fetch = [&](int u, int buf) {
         const int base = wr * 64 + (u >> 2) * 32 + 8 * (u & 3) + 4 * lh;
         const int4 c4 = *(const int4*)(sCrow + base);
@@ -351,7 +360,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             for (int r = 0; r < 4; ++r) {
                 const uint32_t off = crow[buf][r] >= 0 ? (uint32_t)(crow[buf][r] * a.ldx + col0) * 4u : OOB;
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     xv[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, off + 128 * ni, 0, 0));
             }
         }
@@ -362,7 +371,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             for (int r = 0; r < 4; ++r) {
                 const uint32_t off = ar[r] >= 0 ? (uint32_t)(ar[r] * a.ldadd + col0) * 4u : OOB;     // unmapped addend row: reads 0
 #pragma unroll
-                for (int ni = 0; ni < 4; ++ni)
+                for (int ni = 0; ni < NI; ++ni)
                     av[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAdd, off + 128 * ni, 0, 0));
             }
         }
@@ -377,7 +386,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             const int cr = crow[buf][r];
             const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * 4u;
 #pragma unroll
-            for (int ni = 0; ni < 4; ++ni) {
+            for (int ni = 0; ni < NI; ++ni) {
                 const bool ok = cr >= 0 && nin[ni];
                 float v = acc[mi][ni][4 * q + r] + bias[ni];
                 if (ADD) v += av[buf][ni][r];
@@ -400,18 +409,18 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         // the two row-halves of the block (waves wr = 0 / 1) are one 128-row statistics block: combine through LDS
         float* const sRed = (float*)(smem + OFF_A);      // [wr][256][2]
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
             s1[ni] += __shfl_xor(s1[ni], 32);
             s2[ni] += __shfl_xor(s2[ni], 32);
             if (lh == 0) {
-                const int cl = wc * 128 + ni * 32 + li;
+                const int cl = wc * (TN / 2) + ni * 32 + li;
                 sRed[(wr * TN + cl) * 2] = s1[ni];
                 sRed[(wr * TN + cl) * 2 + 1] = s2[ni];
             }
         }
         __syncthreads();
         const int n = n0 + tid;
-        if (n < N) {
+        if (tid < TN && n < N) {
             float* pp = a.partials + ((long)mt * N + n) * 2;
             pp[0] = sRed[tid * 2] + sRed[(TN + tid) * 2];
             pp[1] = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
@@ -424,10 +433,10 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
     return e * 2 + (a.addend ? 1 : 0);
 }
 
-template <int EPI, bool ADD>
+template <int EPI, bool ADD, int NI>
 __global__ void __launch_bounds__(256, 2) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD, NI>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -438,12 +447,12 @@ struct BigBatch {
 };
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
-template <int EPI, bool ADD>
+template <int EPI, bool ADD, int NI>
 __global__ void __launch_bounds__(256, 2) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    big_body<EPI, ADD, NI>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -484,13 +493,23 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     const long Ml = (long)a.B * a.Tn * a.J;
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
     if (Ml < min_rows || Ml > 0x7fffff00L || a.N < 32) return 0;
+    // tile width, measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): 128 x 128 (NI = 2, 143-167 VGPRs, three blocks per
+    // CU) for N <= 192 -- half of the wide tile would be empty -- and for every BNRELU_BWD epilogue (its X / addend values are
+    // gathered per lane from the accumulator layout: at NI = 4 that epilogue spills 27-60 registers; at NI = 2 the short-K input
+    // gradients run 10-16 % faster than on gemm.hip's kernel, the K = 768 one 7 % faster than at NI = 4); 128 x 256 (NI = 4)
+    // otherwise (a wash on the forward GEMMs, 5 % better on the K = 1800 input gradient).  GAST_GEMM_BIG_NI=2|4 forces one width
+    // (kernel tests), GAST_GEMM_BIG_BWD_NI=4|0 restores the round-2a rule for the BNRELU_BWD epilogue (4: wide tile for K >= 768,
+    // gemm.hip below; 0: same, spelled as "no narrow BWD"), GAST_GEMM_BIG_NARROW=0 keeps N <= 192 on gemm.hip.
+    static const int ni_env = getenv("GAST_GEMM_BIG_NI") ? atoi(getenv("GAST_GEMM_BIG_NI")) : 0;
+    static const int bwd_ni = getenv("GAST_GEMM_BIG_BWD_NI") ? atoi(getenv("GAST_GEMM_BIG_BWD_NI")) : 2;
+    static const int narrow = getenv("GAST_GEMM_BIG_NARROW") ? atoi(getenv("GAST_GEMM_BIG_NARROW")) : 1;
+    int ksum = 0;
+    for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
+    const bool bwd_epi = a.epi == GAST_EPI_BNRELU_BWD;
+    pl.ni = (ni_env == 2 || ni_env == 4) ? ni_env : (a.N <= 192 || (bwd_epi && bwd_ni == 2)) ? 2 : 4;
     if (!all_shapes) {
-        // measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): the 128 x 256 tile loses to gemm.hip's 128 x 128 tile when
-        // half of it is empty (N <= 128), and its BNRELU_BWD epilogue (X / addend gathered per lane) only pays on long K loops
-        int ksum = 0;
-        for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
-        if (a.N < 256) return 0;
-        if (a.epi == GAST_EPI_BNRELU_BWD && ksum < 768) return 0;
+        if (a.N <= 192 && !narrow) return 0;
+        if (bwd_epi && bwd_ni != 2 && ksum < 768) return 0;
     }
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG) return 0;
     int ntab = 0;
@@ -507,7 +526,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
-    if (ntab > MAX_TAB) return 0;
+    if (ntab > max_tab(pl.ni)) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
@@ -518,63 +537,70 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     pl.ablate = ablate;
     pl.M = (int)Ml;
     pl.tilesM = (pl.M + TM - 1) / TM;
-    pl.tilesN = (a.N + TN - 1) / TN;
+    pl.tilesN = (a.N + tn_of(pl.ni) - 1) / tn_of(pl.ni);
     pl.ntab = ntab;
     return 1;
 }
 
-static int big_lds_bytes(int ntab) { return OFF_TAB + 2 * ntab * 4 + 6 * 256 * 4; }
+static int big_lds_bytes(int ntab, int ni) { return off_tab(ni) + 2 * ntab * 4 + 6 * 256 * 4; }
 
 typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
-static big_kernel_t big_kernel(int v) {
+template <int NI>
+static big_kernel_t big_kernel_ni(int v) {
     switch (v) {
-        case 0: return gemm_big_kernel<0, false>;
-        case 1: return gemm_big_kernel<0, true>;
-        case 2: return gemm_big_kernel<1, false>;
-        case 3: return gemm_big_kernel<1, true>;
-        case 4: return gemm_big_kernel<2, false>;
-        case 5: return gemm_big_kernel<2, true>;
-        case 6: return gemm_big_kernel<3, false>;
-        default: return gemm_big_kernel<3, true>;
+        case 0: return gemm_big_kernel<0, false, NI>;
+        case 1: return gemm_big_kernel<0, true, NI>;
+        case 2: return gemm_big_kernel<1, false, NI>;
+        case 3: return gemm_big_kernel<1, true, NI>;
+        case 4: return gemm_big_kernel<2, false, NI>;
+        case 5: return gemm_big_kernel<2, true, NI>;
+        case 6: return gemm_big_kernel<3, false, NI>;
+        default: return gemm_big_kernel<3, true, NI>;
     }
 }
+static big_kernel_t big_kernel(int v, int ni) { return ni == 2 ? big_kernel_ni<2>(v) : big_kernel_ni<4>(v); }
 
 typedef void (*big_multi_kernel_t)(const BigBatch);
-static big_multi_kernel_t big_multi_kernel(int v) {
+template <int NI>
+static big_multi_kernel_t big_multi_kernel_ni(int v) {
     switch (v) {
-        case 0: return gemm_big_multi_kernel<0, false>;
-        case 1: return gemm_big_multi_kernel<0, true>;
-        case 2: return gemm_big_multi_kernel<1, false>;
-        case 3: return gemm_big_multi_kernel<1, true>;
-        case 4: return gemm_big_multi_kernel<2, false>;
-        case 5: return gemm_big_multi_kernel<2, true>;
-        case 6: return gemm_big_multi_kernel<3, false>;
-        default: return gemm_big_multi_kernel<3, true>;
+        case 0: return gemm_big_multi_kernel<0, false, NI>;
+        case 1: return gemm_big_multi_kernel<0, true, NI>;
+        case 2: return gemm_big_multi_kernel<1, false, NI>;
+        case 3: return gemm_big_multi_kernel<1, true, NI>;
+        case 4: return gemm_big_multi_kernel<2, false, NI>;
+        case 5: return gemm_big_multi_kernel<2, true, NI>;
+        case 6: return gemm_big_multi_kernel<3, false, NI>;
+        default: return gemm_big_multi_kernel<3, true, NI>;
     }
 }
+static big_multi_kernel_t big_multi_kernel(int v, int ni) { return ni == 2 ? big_multi_kernel_ni<2>(v) : big_multi_kernel_ni<4>(v); }
 
 static void big_setup() {
     int dev = 0;
     hipGetDevice(&dev);               // function attributes are per device (nn.DataParallel replicas launch on several)
     dev &= 63;
     if (big_setup_done[dev]) return;
-    for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
-    for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+    for (int ni = 2; ni <= 4; ni += 2) {
+        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v, ni), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v, ni), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+    }
     big_setup_done[dev] = true;
     if (getenv("GAST_GEMM_BIG_DEBUG")) {
-        for (int v = 0; v < 8; v += 2) {
-            int nb = -1;
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v), 256, big_lds_bytes(0));
-            hipFuncAttributes fa;
-            hipFuncGetAttributes(&fa, (const void*)big_kernel(v));
-            fprintf(stderr, "gemm_big variant %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, nb, big_lds_bytes(0), fa.numRegs, (size_t)fa.localSizeBytes);
-        }
+        for (int ni = 2; ni <= 4; ni += 2)
+            for (int v = 0; v < 8; v += 2) {
+                int nb = -1;
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni), 256, big_lds_bytes(0, ni));
+                hipFuncAttributes fa;
+                hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni));
+                fprintf(stderr, "gemm_big variant %d NI %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, nb, big_lds_bytes(0, ni), fa.numRegs, (size_t)fa.localSizeBytes);
+            }
     }
 }
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a)), dim3(pl.tilesM * pl.tilesN), dim3(256), big_lds_bytes(pl.ntab), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni), dim3(pl.tilesM * pl.tilesN), dim3(256), big_lds_bytes(pl.ntab, pl.ni), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -582,15 +608,15 @@ int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t
 int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st) {
     big_setup();
     bool done[GAST_GEMM_MAX_BATCH] = {};
-    for (int d0 = 0; d0 < n; ++d0) {          // one grid per epilogue variant present in the batch
+    for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
-        const int v = epi_variant(args[d0]);
+        const int v = epi_variant(args[d0]), ni = pls[d0].ni;
         BigBatch b;
         b.n = 0;
         b.first[0] = 0;
         int ntab = 0;
         for (int d = d0; d < n; ++d) {
-            if (done[d] || epi_variant(args[d]) != v) continue;
+            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni) continue;
             done[d] = true;
             const int k = b.n++;
             b.a[k] = args[d];
@@ -598,8 +624,8 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v), dim3(b.first[1]), dim3(256), big_lds_bytes(ntab), st, b.a[0], b.pl[0]);
-        else hipLaunchKernelGGL(big_multi_kernel(v), dim3(b.first[b.n]), dim3(256), big_lds_bytes(ntab), st, b);
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni), dim3(b.first[1]), dim3(256), big_lds_bytes(ntab, ni), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni), dim3(b.first[b.n]), dim3(256), big_lds_bytes(ntab, ni), st, b);
         GAST_CHECK_LAUNCH();
     }
     return 0;

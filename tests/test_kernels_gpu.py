@@ -392,10 +392,12 @@ def test_wgrad_multi(ops, mode):
                                                ('GAST_WGRAD_RING=2', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_ORDER=1', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_X3_PIPE=0', 'test_wgrad_multi and x3', 1),
+                                               ('GAST_GEMM_BIG_NI=2', 'test_gemm_big_x3', None),
+                                               ('GAST_GEMM_BIG_NI=4', 'test_gemm_big_x3', None),
                                                ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
 def test_optin_kernel_variants(knob, select, npass):
     """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles, two
-    register sets in flight, chunk-major block order, the un-pipelined bf16x3 weight-gradient kernel, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
+    register sets in flight, chunk-major block order, the un-pipelined bf16x3 weight-gradient kernel, both tile widths of the large-M GEMM on every case, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
     in a child process."""
     import os
     import subprocess
