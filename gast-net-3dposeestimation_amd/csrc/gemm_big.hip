@@ -61,7 +61,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int M = pl.M, N = a.N;
-    const int lb = xcd_remap(blk, pl.tilesM * pl.tilesN);
+    // split-K (the M = B*J rows of the last stage: few output tiles, long K): blk = tile * splitk + split; a split multiplies
+    // a contiguous range of the K steps and leaves its raw partial tile in the workspace (gemm.hip's splitk_finish_kernel)
+    const int splitk = pl.splitk, sp = blk % splitk;
+    const int lb = xcd_remap(blk / splitk, pl.tilesM * pl.tilesN);
     const int mt = lb / pl.tilesN, nt = lb - mt * pl.tilesN;
     const int m0 = mt * TM, n0 = nt * TN;
 
@@ -126,13 +129,18 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     // A tile descriptor carries everything the K loop needs to know about its segment (K, table offset, operand bases), fetched
     // from the kernel arguments only when the generator enters a new segment: a dependent s_load per use costs ~200 clk.
     struct Tile { int seg, k0, K, toff; const float* abase; const char* wbase; };
-    int ntile = 0;
-    for (int s = 0; s < a.nseg; ++s) ntile += (a.seg[s].K + TK - 1) / TK;
-    int seg_l = 0, k_l = 0, gen = 0, K_l = a.seg[0].K, toff_l = pl.taboff[0];
-    const float* A_l = (const float*)a.seg[0].A;
-    const char* W_l = (const char*)a.seg[0].Wx;
-    long ldg_l = (long)a.seg[0].ldwx * 2;                     // bytes per k-group of the weight image
-    Tile last_tile = {0, 0, K_l, toff_l, A_l, W_l};
+    int ntile_all = 0;
+    for (int s = 0; s < a.nseg; ++s) ntile_all += (a.seg[s].K + TK - 1) / TK;
+    const int tps = (ntile_all + splitk - 1) / splitk;
+    const int ntile = min(ntile_all, (sp + 1) * tps) - sp * tps;       // this block's K steps (> 0: the host leaves no empty range)
+    int seg_l = 0, k_l = sp * tps;                                     // (in K steps while the first segment is being located)
+    while (k_l >= (a.seg[seg_l].K + TK - 1) / TK) { k_l -= (a.seg[seg_l].K + TK - 1) / TK; ++seg_l; }
+    k_l *= TK;
+    int gen = 0, K_l = a.seg[seg_l].K, toff_l = pl.taboff[seg_l];
+    const float* A_l = (const float*)a.seg[seg_l].A;
+    const char* W_l = (const char*)a.seg[seg_l].Wx;
+    long ldg_l = (long)a.seg[seg_l].ldwx * 2;                 // bytes per k-group of the weight image
+    Tile last_tile = {seg_l, k_l, K_l, toff_l, A_l + k_l, W_l + (long)(k_l >> 4) * ldg_l};
     auto next_tile = [&](Tile& t) {                          // tiles in order; past the end: the last tile again
         if (gen >= ntile) { t = last_tile; return; }
         t.seg = seg_l; t.k0 = k_l; t.K = K_l; t.toff = toff_l;
@@ -320,6 +328,22 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     __syncthreads();
 
     if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][NI - 1][5] + acc[0][1][2] + acc[1][0][1] + acc[1][1][1]; return; }
+    if (splitk > 1) {
+        float* const wsp = pl.ws + (long)sp * M * N;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+            const int n = n0 + wc * (TN / 2) + 32 * ni + li;
+            if (n >= N) continue;
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (m < M) wsp[(long)m * N + n] = acc[mi][ni][r];
+                }
+        }
+        return;
+    }
     // ---- epilogue, straight from the accumulators (lane = column li of the MFMA tile; register r = row (r&3) + 8 (r>>2) + 4 lh).
     // Branch-free: all global accesses are BUFFER loads / stores with the tensors' true extents as bounds -- an element that must
     // not be touched (row past M or unmapped by cmap, column past N) simply gets an out-of-range offset (loads return 0, stores
@@ -486,13 +510,15 @@ bool big_setup_done[64] = {};
 }  // namespace
 
 // Can this GEMM run on the large-M kernel?  Fills the plan when it can.  (Called by gast_gemm_ws / gast_gemm_multi in gemm.hip.)
-int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
+int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws, long ws_bytes) {
     static const int enabled = getenv("GAST_GEMM_BIG") ? atoi(getenv("GAST_GEMM_BIG")) : 1;
     static const int min_rows = getenv("GAST_GEMM_BIG_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_MIN_M")) : 8192;
     if (!enabled || a.dtype != GAST_F32X3) return 0;
     const long Ml = (long)a.B * a.Tn * a.J;
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
-    if (Ml < min_rows || Ml > 0x7fffff00L || a.N < 32) return 0;
+    if (Ml > 0x7fffff00L || a.N < 32) return 0;
+    const bool small_m = Ml < min_rows;
+    if (small_m && !ws) return 0;
     // tile width, measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): 128 x 128 (NI = 2, 143-167 VGPRs, three blocks per
     // CU) for N <= 192 -- half of the wide tile would be empty -- and for every BNRELU_BWD epilogue (its X / addend values are
     // gathered per lane from the accumulator layout: at NI = 4 that epilogue spills 27-60 registers; at NI = 2 the short-K input
@@ -539,6 +565,33 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     pl.tilesM = (pl.M + TM - 1) / TM;
     pl.tilesN = (a.N + tn_of(pl.ni) - 1) / tn_of(pl.ni);
     pl.ntab = ntab;
+    pl.splitk = 1;
+    pl.ws = (float*)ws;
+    if (small_m) {
+        // the M = B*J stage (opt-in, GAST_GEMM_BIG_SPLIT=1): split the K loop so that every CU holds 2-3 blocks (a lone block waits
+        // out the memory latency of every 16-deep K step: 0.63 us per step).  Measured (scripts/gemm_table.py bf16x3, B = 128): correct
+        // and SLOWER than gemm.hip's split-K path on every shape of that stage (K = 1536, N = 512: 42.8 vs 40.3 us; N = 2568,
+        // K = 512: 69.7 vs 44.2; the K = 512 input gradients 38.9 vs 33.1) -- this kernel's per-block set-up (position tables,
+        // scale / shift tables, two barriers before the first MFMA) and its 4-byte partial-tile stores are amortised over 50-200 K
+        // steps on the large-M shapes, not over 8-16.
+        static const int split_on = getenv("GAST_GEMM_BIG_SPLIT") ? atoi(getenv("GAST_GEMM_BIG_SPLIT")) : 0;
+        static const int split_target = getenv("GAST_GEMM_BIG_SPLIT_TARGET") ? atoi(getenv("GAST_GEMM_BIG_SPLIT_TARGET")) : 640;
+        if (!split_on) return 0;
+        int nsteps = 0;
+        for (int s = 0; s < a.nseg; ++s) nsteps += (a.seg[s].K + TK - 1) / TK;
+        const int tiles = pl.tilesM * pl.tilesN;
+        int sk = split_target / tiles;
+        if (sk > 8) sk = 8;
+        if (sk > nsteps / 4) sk = nsteps / 4;
+        if (sk < 1) sk = 1;
+        while (sk > 1 && (long)sk * pl.M * a.N * (long)sizeof(float) > ws_bytes) --sk;
+        if (sk > 1) {
+            const int tps = (nsteps + sk - 1) / sk;
+            sk = (nsteps + tps - 1) / tps;            // no empty K ranges
+        }
+        if (sk < 2 && tiles < 128) return 0;          // few tiles, short K: gemm.hip
+        pl.splitk = sk;
+    }
     return 1;
 }
 
@@ -600,7 +653,7 @@ static void big_setup() {
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni), dim3(pl.tilesM * pl.tilesN), dim3(256), big_lds_bytes(pl.ntab, pl.ni), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni), dim3(pl.tilesM * pl.tilesN * pl.splitk), dim3(256), big_lds_bytes(pl.ntab, pl.ni), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }

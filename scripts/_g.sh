@@ -1,3 +1,3 @@
-for e in "GAST_GEMM_BIG_NARROW=0 GAST_GEMM_BIG_BWD_NI=4" "GAST_GEMM_BIG_NARROW=1 GAST_GEMM_BIG_BWD_NI=4" "GAST_GEMM_BIG_NARROW=0 GAST_GEMM_BIG_BWD_NI=2" "GAST_GEMM_BIG_NARROW=1 GAST_GEMM_BIG_BWD_NI=2" "GAST_GEMM_BIG_NARROW=0 GAST_GEMM_BIG_BWD_NI=4"; do
-echo "== $e"; env $e timeout 200 python bench.py --no-cpu-baseline --no-kernel-timer --no-eager --no-parity 2>&1 | tail -1 | cut -c90-200
-done
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "gemm and not optin" 2>&1 | tail -3
+echo "== split big"; timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "M=2176|total" | grep -v wgrad
+echo "== old"; GAST_GEMM_BIG_SPLIT=0 timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "M=2176|total" | grep -v wgrad

@@ -261,6 +261,25 @@ def test_gemm_big_x3_multi(ops, first, nodrop):
         _gemm_check(c, torch.float32, bufs, 'x3')
 
 
+GEMM_SMALL_X3_CASES = [
+    ('small_stats_k1536', (128, 1, 17), 512, [(512, 3, 1, 0, 1), (512, 3, 1, 1, 1), (512, 3, 1, 2, 1)], 1, False, False),
+    ('small_plain_wide', (128, 1, 17), 648, [(256, 1, 1, 0, 1)], 0, False, True),
+    ('small_bwd_add', (96, 1, 19), 256, [(520, 1, 1, 0, 0)], 2, True, False),
+]
+
+
+@pytest.mark.parametrize('case', GEMM_SMALL_X3_CASES, ids=[c[0] for c in GEMM_SMALL_X3_CASES])
+def test_gemm_small_x3_images(ops, case):
+    """The M = B*J stage with pre-split weight images: gemm.hip's split-K path by default, the pipelined kernel with split-K under
+    GAST_GEMM_BIG_SPLIT=1 (test_optin_kernel_variants) -- same results either way."""
+    jd, jh, bufs = _gemm_case(case, torch.float32)
+    with x3_mode(ops, 'x3'):
+        ops.gemm(**_with_images(ops, jd))
+    kc.gemm(**jh)
+    torch.cuda.synchronize()
+    _gemm_check(case, torch.float32, bufs, 'x3')
+
+
 def test_x3_image_layout(ops):
     """k-group-major image: img[k>>4][r][k&15] = bf16(w), [...][16 + (k&15)] = bf16(w - hi); zero K padding and zero rows behind"""
     gen = torch.Generator().manual_seed(11)
@@ -394,6 +413,7 @@ def test_wgrad_multi(ops, mode):
                                                ('GAST_WGRAD_X3_PIPE=0', 'test_wgrad_multi and x3', 1),
                                                ('GAST_GEMM_BIG_NI=2', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_NI=4', 'test_gemm_big_x3', None),
+                                               ('GAST_GEMM_BIG_SPLIT=1', 'test_gemm_small_x3_images', 3),
                                                ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
 def test_optin_kernel_variants(knob, select, npass):
     """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles, two
