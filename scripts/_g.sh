@@ -1,3 +1,2 @@
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "gemm and not optin" 2>&1 | tail -3
-echo "== split big"; timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "M=2176|total" | grep -v wgrad
-echo "== old"; GAST_GEMM_BIG_SPLIT=0 timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "M=2176|total" | grep -v wgrad
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "strided or pack or x3_image or gemm_big_x3" 2>&1 | tail -3
+bash scripts/_prof.sh 40 | grep -E "steps=|strided|x3_image"
