@@ -558,7 +558,7 @@ def main():
         elapsed = float(tt.max().item())
     # ---- the same step launched eagerly (what an unchanged training script gets: it calls model(x) / loss.backward() /
     # optimizer.step() kernel by kernel through ctypes; the hipGraph is built by this benchmark only)
-    eager_ms = None
+    eager_ms = module_graph_ms = None
     if rank == 0 and world == 1 and mode != 'eager' and not args.no_eager:
         for _ in range(3):
             step()
@@ -568,6 +568,24 @@ def main():
             step()
         torch.cuda.synchronize()
         eager_ms = (time.perf_counter() - te) / 10 * 1e3
+        # ... and with GAST_HIP_GRAPH=1: the module itself replays its forward / backward from hipGraphs it captured on the third
+        # call (model(x) and loss.backward() of an unchanged loop), the loss / optimizer launches stay eager
+        try:
+            model._runner.graph_mode = True
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            te = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            module_graph_ms = (time.perf_counter() - te) / 10 * 1e3
+        except Exception as e:   # noqa: BLE001 -- never lose the bench line to this leg
+            module_graph_ms = None
+            print('module graph leg failed: %s' % (str(e).splitlines()[0][:200],), file=sys.stderr)
+        finally:
+            model._runner.graph_mode = False
+            model._runner._graphs = {}
     # ---- per-kernel durations: the same step, eagerly, with a HIP-event pair around every launch (events cannot be
     # recorded inside a replayed graph; the kernels and their arguments are identical to the replayed ones)
     if timer and rank == 0:
@@ -633,6 +651,10 @@ def main():
                                                                          if len(sync.ranges) > 1 else 'one flat all-reduce after backward'))},
         }
         if eager_ms is not None:
+            if module_graph_ms is not None:
+                out['module_graph'] = {'ms_per_step': round(module_graph_ms, 4), 'sequences_per_s': round(B / module_graph_ms * 1e3, 1),
+                                       'note': 'GAST_HIP_GRAPH=1: the same eager loop, model(x) / loss.backward() replayed from the hipGraphs the '
+                                               'module captures by itself on the third call of a shape (loss and optimizer launched eagerly)'}
             out['eager_launch'] = {'ms_per_step': round(eager_ms, 4), 'sequences_per_s': round(B / eager_ms * 1e3, 1),
                                    'note': 'the same step with every kernel launched eagerly from Python (ctypes), i.e. the speed of an '
                                            'unchanged training loop around the drop-in module; `value` replays the step as one hipGraph'}

@@ -204,6 +204,83 @@ class _GastFunction(torch.autograd.Function):
         return (None,) * 9 + tuple(packer.grad_views(G))
 
 
+class _GraphEntry:
+    """GAST_HIP_GRAPH=1: the captured forward (and backward) hipGraphs of one (shape, mode, arithmetic) of a model, their static
+    input / output buffers and the activations the backward graph reads (all in the graphs' private memory pool)."""
+
+    WARMUP = 2      # eager calls before the capture (lazy workspaces, job tables, zero arenas are created by them)
+
+    def __init__(self):
+        self.calls = 0
+        self.fwd = self.bwd = None
+        self.gen = 0
+        self.x = self.pred = self.dpred = self.G = self.sink = None
+        self.packer = None
+        self.keep = None
+
+
+def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, need_grad):
+    """Capture what _GastFunction.forward / .backward launch for this call as two hipGraphs sharing one memory pool: the saved
+    activations of the forward capture are the operands of the backward capture.  Nothing runs here; the caller replays."""
+    dev = x.device
+    ops = engine.ops
+    entry.x = x.clone()
+    entry.packer, entry.sink = packer, sink
+    pool = torch.cuda.graph_pool_handle()
+    engine.centered = runner.centered
+    ops.x3 = runner.x3
+    ops.f8 = runner.f8
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g, pool=pool):
+        ops.run_pack(packer, st)
+        inp = st.get('inp')
+        if inp is None:
+            inp = st['inp'] = packer.inputs(st)
+        pred, sv = engine.forward(entry.x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, dev), need_grad=need_grad)
+    entry.fwd, entry.pred = g, pred
+    entry.keep = (sv, inp, pool)
+    if need_grad:
+        entry.dpred = torch.zeros_like(pred)
+        gb = torch.cuda.CUDAGraph()
+        with torch.no_grad(), torch.cuda.graph(gb, pool=pool):
+            G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
+            Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
+            engine.backward(sv, inp, entry.dpred, packer.grad_outputs(G, Sb))
+            ops.run_unpack(packer, st, Sb, G, True)
+        entry.bwd, entry.G = gb, G
+        entry.keep += (Sb,)
+
+
+class _GraphedFunction(torch.autograd.Function):
+    """The same autograd node as _GastFunction with its kernels replayed from the captured hipGraphs (GAST_HIP_GRAPH=1)."""
+
+    @staticmethod
+    def forward(ctx, entry, x, *params):
+        if ctx.needs_input_grad[1]:
+            raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
+                               'reference never asks for it); pass x with requires_grad=False')
+        entry.x.copy_(x)
+        entry.fwd.replay()
+        entry.gen += 1
+        ctx.entry, ctx.gen = entry, entry.gen
+        return entry.pred.clone()
+
+    @staticmethod
+    def backward(ctx, dpred):
+        e = ctx.entry
+        if e.bwd is None:
+            raise RuntimeError('gast_net (MI355X build, GAST_HIP_GRAPH=1): this forward was captured without gradients')
+        if ctx.gen != e.gen:
+            raise RuntimeError('gast_net (MI355X build, GAST_HIP_GRAPH=1): another forward of the same shape ran since the one this '
+                               'backward belongs to; the captured graphs keep ONE set of activations (call backward before the next '
+                               'forward, or unset GAST_HIP_GRAPH)')
+        e.dpred.copy_(dpred)
+        e.bwd.replay()
+        if e.sink is not None:
+            return (None, None) + (None,) * len(e.packer.params)
+        return (None, None) + tuple(e.packer.grad_views(e.G.clone()))      # (a copy: the next replay rewrites G in place)
+
+
 class _Runner:
     """Per-model glue: op set, activation dtype, dropout stream."""
 
@@ -217,13 +294,17 @@ class _Runner:
         self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
         self.grad_sync = None     # optional gast_hip.dist.FlatGradAllReduce in bucketed mode: told when a bucket of grad_sink is complete
         self._seeds = {}
+        # GAST_HIP_GRAPH=1: forward / backward of every (shape, mode) replayed from hipGraphs captured on the third call, so an
+        # unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140 Python launches
+        self.graph_mode = os.environ.get('GAST_HIP_GRAPH', '0') not in ('0', '')
+        self._graphs = {}
         # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
         # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
         self.ops_factory = None
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, '_seeds': {}, 'ops_factory': None}
+                'grad_sync': None, '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode, '_graphs': {}}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
@@ -400,12 +481,26 @@ class SpatioTemporalModelBase(nn.Module):
                     raise RuntimeError('gast_net (MI355X build): the model is on %s, the batch on %s' % (first.device, x.device))
                 if runner._packer is None or runner._packer.params[0] is not first:
                     runner._packer = Packer(self, runner.spec)
+                    runner._graphs = {}          # (captured graphs hold the old parameters' addresses)
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
             st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None,
                               f8=runner.f8 and runner.ops_factory is None)
             # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
+            gs = runner.grad_sync
+            if (runner.graph_mode and x.is_cuda and runner.ops_factory is None and not getattr(self, '_is_replica', False)
+                    and not (gs is not None and len(gs.ranges) > 1)):      # (the bucketed exchange hooks into the eager backward)
+                key = (tuple(x.shape), self.training, need_grad, str(x.device), runner.act_dtype, runner.x3, runner.f8, runner.centered,
+                       None if sink is None else sink.data_ptr())
+                entry = runner._graphs.get(key)
+                if entry is None:
+                    entry = runner._graphs[key] = _GraphEntry()
+                entry.calls += 1
+                if entry.calls > _GraphEntry.WARMUP:
+                    if entry.fwd is None:
+                        _capture_graphs(entry, runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad)
+                    return _GraphedFunction.apply(entry, x, *packer.params)
             return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)
 
 

@@ -1,2 +1,7 @@
-timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "strided or pack or x3_image or gemm_big_x3" 2>&1 | tail -3
-bash scripts/_prof.sh 40 | grep -E "steps=|strided|x3_image"
+cd /tmp; export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+for e in "X=1" "GAST_AGG_FWD_JSPLIT=2 GAST_AGG_BWD_JSPLIT=2" "GAST_AGG_FWD_JSPLIT=4 GAST_AGG_BWD_JSPLIT=4" "GAST_AGG_BWD_BLOCKS=2048" "GAST_AGG_BWD_BLOCKS=4096 GAST_AGG_FWD_JSPLIT=3"; do
+  rm -rf /tmp/prof
+  env $e timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --steps 6 --warmup 2 > /tmp/log.txt 2>&1
+  echo "== $e"; python $R/scripts/kstat.py $(find /tmp/prof -name "*kernel_stats.csv" | head -1) semch_agg
+done

@@ -594,6 +594,61 @@ def test_dropout_gradients_by_finite_differences():
         assert abs(fd - an) < 6e-2 * max(abs(an), abs(fd)) + 2e-4, (name, fd, an)
 
 
+@pytest.mark.parametrize('mode', ['fp32', 'bf16x3'])
+def test_module_graph_mode_matches_eager(mode, monkeypatch):
+    """GAST_HIP_GRAPH=1 (reference callers run `model(x)` / `loss.backward()` eagerly: main.py:213-243): from the third call of a
+    (shape, mode) on, forward and backward are replayed from captured hipGraphs -- same outputs, losses, parameter trajectory and
+    BatchNorm buffers as the eager module over six optimizer steps with dropout, same eval output; a backward that belongs to an
+    overwritten forward fails loudly."""
+    monkeypatch.setenv('GAST_HIP_DTYPE', mode)
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    gen = torch.Generator().manual_seed(9)
+    xs = [(torch.rand(6, 11, 17, 2, generator=gen) * 2 - 1).cuda() for _ in range(6)]
+    ys = [(torch.randn(6, 3, 17, 3, generator=gen) * 0.3).cuda() for _ in range(6)]
+    runs = {}
+    for graph in (False, True):
+        torch.manual_seed(3)
+        m = build(cfg, dropout=0.1).cuda().train()
+        _random_state(m, torch.Generator().manual_seed(5))
+        m._runner.graph_mode = graph
+        # (SGD, not Adam: Adam turns the round-off of analytically zero gradients into +-lr steps, which is noise between ANY two runs)
+        opt = torch.optim.SGD(m.parameters(), lr=0.05, momentum=0.9)
+        torch.manual_seed(11)                       # (the dropout stream's seed is drawn from the CPU generator at the first forward)
+        outs, losses = [], []
+        for x, y in zip(xs, ys):
+            opt.zero_grad(set_to_none=True)
+            pred = m(x)
+            loss = torch.mean(torch.norm(pred - y, dim=-1))
+            loss.backward()
+            opt.step()
+            outs.append(pred.detach().clone())
+            losses.append(float(loss.detach()))
+        m.eval()
+        with torch.no_grad():
+            ev = [m(xs[0]).clone() for _ in range(4)][-1]        # (the fourth call of the eval shape is a replay)
+        runs[graph] = dict(outs=outs, losses=losses, ev=ev, sd={k: v.clone() for k, v in m.state_dict().items()}, m=m)
+    a, b = runs[False], runs[True]
+    assert b['m']._runner._graphs and all(e.fwd is not None for e in b['m']._runner._graphs.values()), 'nothing was captured'
+    tol = 2e-5 if mode == 'fp32' else 2e-4         # (split-M atomics: the summation order of the weight gradients is not fixed)
+    for i, (pa, pb) in enumerate(zip(a['outs'], b['outs'])):
+        assert float((pa - pb).abs().max()) < tol * (1 + float(pa.abs().max())), 'step %d' % i
+        assert abs(a['losses'][i] - b['losses'][i]) < tol * (1 + abs(a['losses'][i]))
+    assert float((a['ev'] - b['ev']).abs().max()) < 10 * tol * (1 + float(a['ev'].abs().max()))
+    for k, v in a['sd'].items():
+        w = b['sd'][k]
+        if v.dtype.is_floating_point:
+            assert float((v - w).abs().max()) < 10 * tol * (1 + float(v.abs().max())), k
+        else:
+            assert torch.equal(v, w), k             # num_batches_tracked
+    # one set of activations per captured shape: the older forward's backward must refuse
+    m = b['m'].train()
+    p1 = m(xs[0])
+    p2 = m(xs[1])
+    with pytest.raises(RuntimeError, match='another forward'):
+        p1.sum().backward()
+    p2.sum().backward()
+
+
 def test_eval_mode_gradients_on_gpu():
     """Gradients of an eval-mode forward (frozen BatchNorm): BatchNorm backward with the running statistics, vs the oracle."""
     from oracle import gast_oracle as go
