@@ -756,13 +756,7 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     BigPlan bp;
-    if (gast_gemm_big_plan(a, bp, ws, ws_bytes)) {      // GAST_F32X3 GEMMs on the pipelined kernel (gemm_big.hip)
-        rc = gast_gemm_big_launch(a, bp, st);
-        if (rc || bp.splitk == 1) return rc;
-        hipLaunchKernelGGL((splitk_finish_kernel<float, float>), dim3(gridN * ((M + 7) / 8)), dim3(256), 0, st, a, M, gridN, bp.splitk, (const float*)ws);
-        GAST_CHECK_LAUNCH();
-        return 0;
-    }
+    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
@@ -808,10 +802,7 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
         int M, gridM, gridN, vec_epi, splitk;
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
-        if (gast_gemm_big_plan(args[d], big_p[nbig], ws, ws_bytes)) {
-            if (big_p[nbig].splitk == 1) { big_a[nbig++] = args[d]; continue; }
-            splitk = big_p[nbig].splitk;        // (small-M job on the pipelined kernel: launched below with its finish kernel)
-        }
+        if (gast_gemm_big_plan(args[d], big_p[nbig])) { big_a[nbig++] = args[d]; continue; }
         if (splitk > 1) {                       // small-M job: its own split-K launch pair
             rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
             if (rc) return rc;

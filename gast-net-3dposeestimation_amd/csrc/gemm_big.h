@@ -4,9 +4,8 @@
 
 struct BigPlan {
     int M, tilesM, tilesN;
-    int ni;                       // 32-column MFMA tiles per wave: 4 = 128x256 block tile, 2 = 128x128
-    int splitk;                   // K ranges per output tile (> 1: raw partial tiles go to ws[split][M][N], gemm.hip finishes them)
-    float* ws;
+    int ni;                       // 32-column MFMA tiles per wave: 4 = 256-column block tile, 2 = 128
+    int mw;                       // 64-row wave rows per block: 2 = 128-row block tile (256 threads), 4 = 256 rows (512 threads)
     int ntab;                     // floats in the scale table (= in the shift table) a block keeps in LDS
     int taboff[GAST_MAX_SEG];     // offset of the segment's scale/shift in the tables (-1: no prologue)
     int ablate;                   // GAST_GEMM_BIG_ABLATE (profiling aid, results are wrong when set): 1 no MFMA, 2 no fragment reads,
@@ -14,7 +13,6 @@ struct BigPlan {
 };
 
 // 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip
-// ws / ws_bytes: the caller's split-K workspace (may be null: GEMMs below the large-M row count then stay on gemm.hip)
-int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws = nullptr, long ws_bytes = 0);
+int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
 int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);

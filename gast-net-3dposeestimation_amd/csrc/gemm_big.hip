@@ -29,17 +29,22 @@ namespace {
 
 // NI = 32-column MFMA tiles per wave: 4 (block tile 128 x 256) or 2 (128 x 128: the N <= 128 GEMMs, for which half of the wide
 // tile would be empty, and the short-K input gradients whose epilogue then holds half the registers)
-constexpr int TM = 128, TK = 16;
+// MW = 64-row wave rows per block: 2 (128-row block tile, 256 threads, two or three blocks per CU) or 4 (256-row block tile, 512
+// threads = 8 waves, ONE block per CU: the 256 x 64 B weight tile of a K step then serves 256 rows -- 2/3 of the operand bytes per
+// FLOP of the 128 x 256 tile)
+constexpr int TK = 16;
 constexpr int ROWB = 64;                        // LDS row image: 16 bf16 hi | 16 bf16 lo
-constexpr int A_BYTES = TM * ROWB;              // 8 KB
-constexpr int OFF_ROWS = 0;                     // crow[128] | addrow[128]
-constexpr int OFF_A = 2 * TM * 4;               // two activation stages
-constexpr int OFF_W = OFF_A + 2 * A_BYTES;      // three weight stages
-constexpr int LDS_BLOCK = 80 * 1024;            // two blocks per CU
+constexpr int OFF_ROWS = 0;                     // crow[TM] | addrow[TM]
+constexpr int tm_of(int mw) { return 64 * mw; }
+constexpr int nt_of(int mw) { return 128 * mw; }                       // threads per block
+constexpr int a_bytes(int mw) { return tm_of(mw) * ROWB; }             // 8 KB / 16 KB
+constexpr int off_a(int mw) { return 2 * tm_of(mw) * 4; }              // two activation stages
+constexpr int off_w(int mw) { return off_a(mw) + 2 * a_bytes(mw); }    // three weight stages
+constexpr int lds_block(int mw) { return mw == 2 ? 80 * 1024 : 160 * 1024; }
 constexpr int tn_of(int ni) { return 64 * ni; }
 constexpr int w_bytes(int ni) { return tn_of(ni) * ROWB; }             // 16 KB / 8 KB
-constexpr int off_tab(int ni) { return OFF_W + 3 * w_bytes(ni); }      // scale | shift tables
-constexpr int max_tab(int ni) { return (LDS_BLOCK - off_tab(ni) - 6 * 256 * 4) / 8; }
+constexpr int off_tab(int ni, int mw) { return off_w(mw) + 3 * w_bytes(ni); }      // scale | shift tables
+constexpr int max_tab(int ni, int mw) { return (lds_block(mw) - off_tab(ni, mw) - 6 * nt_of(mw) * 4) / 8; }
 
 // 16 bytes per lane global -> LDS (DMA): address = sbase + voff + OFF; lands at lds_wave_base + 16 * lane
 template <int OFF>
@@ -53,18 +58,18 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived (compile-time: the
 // epilogue is straight-line code per element); ADD: an addend tensor is present
-template <int EPI, bool ADD, int NI>
+template <int EPI, bool ADD, int NI, int MW>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
-    constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI);
-    constexpr int WROWS = TN / 4;                   // weight rows a wave's DMA fills per K step (16-row pieces: WROWS / 16)
+    constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
+    constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW);
+    constexpr int WROWS = TN / (2 * MW);            // weight rows a wave's DMA fills per K step
+    constexpr int WPIECES = WROWS / 16;             // ... in 16-row (1 KB) pieces: 4, 2 or 1
+    static_assert(WPIECES >= 1, "tile too narrow for the wave count");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int M = pl.M, N = a.N;
-    // split-K (the M = B*J rows of the last stage: few output tiles, long K): blk = tile * splitk + split; a split multiplies
-    // a contiguous range of the K steps and leaves its raw partial tile in the workspace (gemm.hip's splitk_finish_kernel)
-    const int splitk = pl.splitk, sp = blk % splitk;
-    const int lb = xcd_remap(blk / splitk, pl.tilesM * pl.tilesN);
+    const int lb = xcd_remap(blk, pl.tilesM * pl.tilesN);
     const int mt = lb / pl.tilesN, nt = lb - mt * pl.tilesN;
     const int m0 = mt * TM, n0 = nt * TN;
 
@@ -86,20 +91,20 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         sAdd[tid] = arow;
     }
 
-    // ---- staging duties.  Activations (registers): rows rbase + 64 i (i < 2), 16-byte chunk c (4 fp32 values) of the K step.
+    // ---- staging duties.  Activations (registers): rows rbase + TM/2 i (i < 2), 16-byte chunk c (4 fp32 values) of the K step.
     // Per-row facts that are only needed when a stream enters a new K segment (the (b, t, j) position of the thread's rows, the
     // weight row / chunk of its DMA pieces) are recomputed or re-read from LDS there instead of living in registers: the K loop
     // runs at 250 of 256 VGPRs and a spill inside it costs an s_waitcnt vmcnt(0), i.e. the whole prefetch.
     const int c = tid & 3, rbase = tid >> 2;
-    int* const sPos = (int*)(smem + OFF_TAB) + 2 * pl.ntab;      // [2][3][256]: b, t, j of this thread's two rows (-1: row past M)
+    int* const sPos = (int*)(smem + OFF_TAB) + 2 * pl.ntab;      // [2][3][NT]: b, t, j of this thread's two rows (-1: row past M)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int m = m0 + rbase + 64 * i;
+        const int m = m0 + rbase + (TM / 2) * i;
         int b = -1, t = 0, j = 0;
         if (m < M) { b = m / TJ; const int rem = m - b * TJ; t = rem / a.J; j = rem - t * a.J; }
-        sPos[(i * 3 + 0) * 256 + tid] = b;
-        sPos[(i * 3 + 1) * 256 + tid] = t;
-        sPos[(i * 3 + 2) * 256 + tid] = j;
+        sPos[(i * 3 + 0) * NT + tid] = b;
+        sPos[(i * 3 + 1) * NT + tid] = t;
+        sPos[(i * 3 + 2) * NT + tid] = j;
     }
     const int r16 = lane >> 2, s4 = lane & 3;
 
@@ -114,7 +119,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         const gast_gemm_seg& sg = a.seg[s];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int b = sPos[(i * 3 + 0) * 256 + tid], t = sPos[(i * 3 + 1) * 256 + tid], j = sPos[(i * 3 + 2) * 256 + tid];
+            const int b = sPos[(i * 3 + 0) * NT + tid], t = sPos[(i * 3 + 1) * NT + tid], j = sPos[(i * 3 + 2) * NT + tid];
             const int ts = t * sg.map.t_stride + sg.map.t_off;
             const bool ok = b >= 0 && ts >= 0 && ts < sg.map.T_total;
             const uint32_t srow = ok ? (uint32_t)((b * sg.map.T_total + ts) * a.J + j) : 0u;
@@ -129,18 +134,13 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     // A tile descriptor carries everything the K loop needs to know about its segment (K, table offset, operand bases), fetched
     // from the kernel arguments only when the generator enters a new segment: a dependent s_load per use costs ~200 clk.
     struct Tile { int seg, k0, K, toff; const float* abase; const char* wbase; };
-    int ntile_all = 0;
-    for (int s = 0; s < a.nseg; ++s) ntile_all += (a.seg[s].K + TK - 1) / TK;
-    const int tps = (ntile_all + splitk - 1) / splitk;
-    const int ntile = min(ntile_all, (sp + 1) * tps) - sp * tps;       // this block's K steps (> 0: the host leaves no empty range)
-    int seg_l = 0, k_l = sp * tps;                                     // (in K steps while the first segment is being located)
-    while (k_l >= (a.seg[seg_l].K + TK - 1) / TK) { k_l -= (a.seg[seg_l].K + TK - 1) / TK; ++seg_l; }
-    k_l *= TK;
-    int gen = 0, K_l = a.seg[seg_l].K, toff_l = pl.taboff[seg_l];
-    const float* A_l = (const float*)a.seg[seg_l].A;
-    const char* W_l = (const char*)a.seg[seg_l].Wx;
-    long ldg_l = (long)a.seg[seg_l].ldwx * 2;                 // bytes per k-group of the weight image
-    Tile last_tile = {seg_l, k_l, K_l, toff_l, A_l + k_l, W_l + (long)(k_l >> 4) * ldg_l};
+    int ntile = 0;
+    for (int s = 0; s < a.nseg; ++s) ntile += (a.seg[s].K + TK - 1) / TK;
+    int seg_l = 0, k_l = 0, gen = 0, K_l = a.seg[0].K, toff_l = pl.taboff[0];
+    const float* A_l = (const float*)a.seg[0].A;
+    const char* W_l = (const char*)a.seg[0].Wx;
+    long ldg_l = (long)a.seg[0].ldwx * 2;                     // bytes per k-group of the weight image
+    Tile last_tile = {0, 0, K_l, toff_l, A_l, W_l};
     auto next_tile = [&](Tile& t) {                          // tiles in order; past the end: the last tile again
         if (gen >= ntile) { t = last_tile; return; }
         t.seg = seg_l; t.k0 = k_l; t.K = K_l; t.toff = toff_l;
@@ -178,8 +178,8 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         const uint32_t sW = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + stage * W_BYTES + w * WROWS * ROWB);
         // (the instruction offset of an LDS-DMA load moves the global AND the LDS address: one M0 base serves the four pieces)
         glds16<0>(offW, t.wbase, sW);
-        glds16<1024>(offW, t.wbase, sW);
-        if (NI == 4) {
+        if (WPIECES >= 2) glds16<1024>(offW, t.wbase, sW);
+        if (WPIECES == 4) {
             glds16<2048>(offW, t.wbase, sW);
             glds16<3072>(offW, t.wbase, sW);
         }
@@ -193,7 +193,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             tsh = *(const float4*)(sSh + k);
         }
     };
-    const int wa_key = (rbase >> 2) & 3;             // (rows rbase and rbase + 64 share the swizzle key)
+    const int wa_key = (rbase >> 2) & 3;             // (rows rbase and rbase + TM/2 share the swizzle key)
     const int wa_hi = rbase * ROWB + (((c >> 1) ^ wa_key) << 4) + (c & 1) * 8, wa_lo = rbase * ROWB + (((2 + (c >> 1)) ^ wa_key) << 4) + (c & 1) * 8;
     auto write_a = [&](const Tile& t, int stage, const u32x4 (&ra)[2], const bool (&rz)[2]) {
         if (abl & 16) return;
@@ -212,8 +212,8 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             h.y = pack_bf16x2(x2, x3);
             l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
             l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
-            *(uint2*)(sA + wa_hi + i * 64 * ROWB) = h;
-            *(uint2*)(sA + wa_lo + i * 64 * ROWB) = l;
+            *(uint2*)(sA + wa_hi + i * (TM / 2) * ROWB) = h;
+            *(uint2*)(sA + wa_lo + i * (TM / 2) * ROWB) = l;
         }
     };
 
@@ -245,7 +245,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             if (pl.taboff[s] >= 0) {
                 const float* sc = a.seg[s].scale;
                 const float* sh = a.seg[s].shift;
-                for (int k = tid; k < a.seg[s].K; k += 256) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
+                for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
             }
         }
         gload_wait_n<0>();
@@ -282,7 +282,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
     };
     auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
-        gload_wait_n<NI + 2>();                                // (the newest step's NI DMA pieces + 2 activation loads stay in flight)
+        gload_wait_n<WPIECES + 2>();                           // (the newest step's DMA pieces + 2 activation loads stay in flight)
         __syncthreads();
         const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
         const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * (TN / 2) * ROWB;
@@ -328,22 +328,6 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     __syncthreads();
 
     if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][NI - 1][5] + acc[0][1][2] + acc[1][0][1] + acc[1][1][1]; return; }
-    if (splitk > 1) {
-        float* const wsp = pl.ws + (long)sp * M * N;
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) {
-            const int n = n0 + wc * (TN / 2) + 32 * ni + li;
-            if (n >= N) continue;
-#pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wr * 64 + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    if (m < M) wsp[(long)m * N + n] = acc[mi][ni][r];
-                }
-        }
-        return;
-    }
     // ---- epilogue, straight from the accumulators (lane = column li of the MFMA tile; register r = row (r&3) + 8 (r>>2) + 4 lh).
     // Branch-free: all global accesses are BUFFER loads / stores with the tensors' true extents as bounds -- an element that must
     // not be touched (row past M or unmapped by cmap, column past N) simply gets an out-of-range offset (loads return 0, stores
@@ -431,7 +415,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     }
     if (EPI != 0) {
         // the two row-halves of the block (waves wr = 0 / 1) are one 128-row statistics block: combine through LDS
-        float* const sRed = (float*)(smem + OFF_A);      // [wr][256][2]
+        float* const sRed = (float*)(smem + OFF_A);      // [wr][TN][2]
 #pragma unroll
         for (int ni = 0; ni < NI; ++ni) {
             s1[ni] += __shfl_xor(s1[ni], 32);
@@ -443,11 +427,14 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             }
         }
         __syncthreads();
-        const int n = n0 + tid;
-        if (tid < TN && n < N) {
-            float* pp = a.partials + ((long)mt * N + n) * 2;
-            pp[0] = sRed[tid * 2] + sRed[(TN + tid) * 2];
-            pp[1] = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
+        // a 256-row block is two 128-row statistics blocks (wave rows 0-1 and 2-3)
+        const int hb = tid / TN, cl = tid - hb * TN;
+        const int n = n0 + cl;
+        const int sblk = mt * (MW / 2) + hb;
+        if (hb < MW / 2 && n < N && (long)sblk * 128 < M) {
+            float* pp = a.partials + ((long)sblk * N + n) * 2;
+            pp[0] = sRed[((2 * hb) * TN + cl) * 2] + sRed[((2 * hb + 1) * TN + cl) * 2];
+            pp[1] = sRed[((2 * hb) * TN + cl) * 2 + 1] + sRed[((2 * hb + 1) * TN + cl) * 2 + 1];
         }
     }
 }
@@ -457,10 +444,10 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
     return e * 2 + (a.addend ? 1 : 0);
 }
 
-template <int EPI, bool ADD, int NI>
-__global__ void __launch_bounds__(256, 2) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
+template <int EPI, bool ADD, int NI, int MW>
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD, NI>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD, NI, MW>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -471,12 +458,12 @@ struct BigBatch {
 };
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
-template <int EPI, bool ADD, int NI>
-__global__ void __launch_bounds__(256, 2) gemm_big_multi_kernel(const BigBatch b) {
+template <int EPI, bool ADD, int NI, int MW>
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD, NI>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    big_body<EPI, ADD, NI, MW>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -510,15 +497,15 @@ bool big_setup_done[64] = {};
 }  // namespace
 
 // Can this GEMM run on the large-M kernel?  Fills the plan when it can.  (Called by gast_gemm_ws / gast_gemm_multi in gemm.hip.)
-int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws, long ws_bytes) {
+int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int enabled = getenv("GAST_GEMM_BIG") ? atoi(getenv("GAST_GEMM_BIG")) : 1;
     static const int min_rows = getenv("GAST_GEMM_BIG_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_MIN_M")) : 8192;
     if (!enabled || a.dtype != GAST_F32X3) return 0;
     const long Ml = (long)a.B * a.Tn * a.J;
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
-    if (Ml > 0x7fffff00L || a.N < 32) return 0;
-    const bool small_m = Ml < min_rows;
-    if (small_m && !ws) return 0;
+    // (the M = B*J stage stays on gemm.hip's split-K path: a split-K version of this kernel was built and measured slower on every
+    // shape of that stage -- DESIGN.md, round 2b; it also cost the BNRELU_BWD variants 50 registers, and is gone)
+    if (Ml < min_rows || Ml > 0x7fffff00L || a.N < 32) return 0;
     // tile width, measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): 128 x 128 (NI = 2, 143-167 VGPRs, three blocks per
     // CU) for N <= 192 -- half of the wide tile would be empty -- and for every BNRELU_BWD epilogue (its X / addend values are
     // gathered per lane from the accumulator layout: at NI = 4 that epilogue spills 27-60 registers; at NI = 2 the short-K input
@@ -533,6 +520,10 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws, long ws_b
     for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
     const bool bwd_epi = a.epi == GAST_EPI_BNRELU_BWD;
     pl.ni = (ni_env == 2 || ni_env == 4) ? ni_env : (a.N <= 192 || (bwd_epi && bwd_ni == 2)) ? 2 : 4;
+    // block rows: 256 (MW = 4, one 8-wave block per CU) at the wide tile with GAST_GEMM_BIG_MW=4, else 128
+    static const int mw_env = getenv("GAST_GEMM_BIG_MW") ? atoi(getenv("GAST_GEMM_BIG_MW")) : 2;
+    static const int mw_min_k = getenv("GAST_GEMM_BIG_MW_MIN_K") ? atoi(getenv("GAST_GEMM_BIG_MW_MIN_K")) : 0;
+    pl.mw = (mw_env == 4 && pl.ni == 4 && ksum >= mw_min_k) ? 4 : 2;
     if (!all_shapes) {
         if (a.N <= 192 && !narrow) return 0;
         if (bwd_epi && bwd_ni != 2 && ksum < 768) return 0;
@@ -552,7 +543,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws, long ws_b
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
-    if (ntab > max_tab(pl.ni)) return 0;
+    if (ntab > max_tab(pl.ni, pl.mw)) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
@@ -562,98 +553,77 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl, void* ws, long ws_b
     static const int ablate = getenv("GAST_GEMM_BIG_ABLATE") ? atoi(getenv("GAST_GEMM_BIG_ABLATE")) : 0;
     pl.ablate = ablate;
     pl.M = (int)Ml;
-    pl.tilesM = (pl.M + TM - 1) / TM;
+    pl.tilesM = (pl.M + tm_of(pl.mw) - 1) / tm_of(pl.mw);
     pl.tilesN = (a.N + tn_of(pl.ni) - 1) / tn_of(pl.ni);
     pl.ntab = ntab;
-    pl.splitk = 1;
-    pl.ws = (float*)ws;
-    if (small_m) {
-        // the M = B*J stage (opt-in, GAST_GEMM_BIG_SPLIT=1): split the K loop so that every CU holds 2-3 blocks (a lone block waits
-        // out the memory latency of every 16-deep K step: 0.63 us per step).  Measured (scripts/gemm_table.py bf16x3, B = 128): correct
-        // and SLOWER than gemm.hip's split-K path on every shape of that stage (K = 1536, N = 512: 42.8 vs 40.3 us; N = 2568,
-        // K = 512: 69.7 vs 44.2; the K = 512 input gradients 38.9 vs 33.1) -- this kernel's per-block set-up (position tables,
-        // scale / shift tables, two barriers before the first MFMA) and its 4-byte partial-tile stores are amortised over 50-200 K
-        // steps on the large-M shapes, not over 8-16.
-        static const int split_on = getenv("GAST_GEMM_BIG_SPLIT") ? atoi(getenv("GAST_GEMM_BIG_SPLIT")) : 0;
-        static const int split_target = getenv("GAST_GEMM_BIG_SPLIT_TARGET") ? atoi(getenv("GAST_GEMM_BIG_SPLIT_TARGET")) : 640;
-        if (!split_on) return 0;
-        int nsteps = 0;
-        for (int s = 0; s < a.nseg; ++s) nsteps += (a.seg[s].K + TK - 1) / TK;
-        const int tiles = pl.tilesM * pl.tilesN;
-        int sk = split_target / tiles;
-        if (sk > 8) sk = 8;
-        if (sk > nsteps / 4) sk = nsteps / 4;
-        if (sk < 1) sk = 1;
-        while (sk > 1 && (long)sk * pl.M * a.N * (long)sizeof(float) > ws_bytes) --sk;
-        if (sk > 1) {
-            const int tps = (nsteps + sk - 1) / sk;
-            sk = (nsteps + tps - 1) / tps;            // no empty K ranges
-        }
-        if (sk < 2 && tiles < 128) return 0;          // few tiles, short K: gemm.hip
-        pl.splitk = sk;
-    }
     return 1;
 }
 
-static int big_lds_bytes(int ntab, int ni) { return off_tab(ni) + 2 * ntab * 4 + 6 * 256 * 4; }
+static int big_lds_bytes(int ntab, int ni, int mw) { return off_tab(ni, mw) + 2 * ntab * 4 + 6 * nt_of(mw) * 4; }
 
 typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
-template <int NI>
+template <int NI, int MW>
 static big_kernel_t big_kernel_ni(int v) {
     switch (v) {
-        case 0: return gemm_big_kernel<0, false, NI>;
-        case 1: return gemm_big_kernel<0, true, NI>;
-        case 2: return gemm_big_kernel<1, false, NI>;
-        case 3: return gemm_big_kernel<1, true, NI>;
-        case 4: return gemm_big_kernel<2, false, NI>;
-        case 5: return gemm_big_kernel<2, true, NI>;
-        case 6: return gemm_big_kernel<3, false, NI>;
-        default: return gemm_big_kernel<3, true, NI>;
+        case 0: return gemm_big_kernel<0, false, NI, MW>;
+        case 1: return gemm_big_kernel<0, true, NI, MW>;
+        case 2: return gemm_big_kernel<1, false, NI, MW>;
+        case 3: return gemm_big_kernel<1, true, NI, MW>;
+        case 4: return gemm_big_kernel<2, false, NI, MW>;
+        case 5: return gemm_big_kernel<2, true, NI, MW>;
+        case 6: return gemm_big_kernel<3, false, NI, MW>;
+        default: return gemm_big_kernel<3, true, NI, MW>;
     }
 }
-static big_kernel_t big_kernel(int v, int ni) { return ni == 2 ? big_kernel_ni<2>(v) : big_kernel_ni<4>(v); }
+// (the 256-row block tile exists at the wide tile only)
+static big_kernel_t big_kernel(int v, int ni, int mw) { return mw == 4 ? big_kernel_ni<4, 4>(v) : ni == 2 ? big_kernel_ni<2, 2>(v) : big_kernel_ni<4, 2>(v); }
 
 typedef void (*big_multi_kernel_t)(const BigBatch);
-template <int NI>
+template <int NI, int MW>
 static big_multi_kernel_t big_multi_kernel_ni(int v) {
     switch (v) {
-        case 0: return gemm_big_multi_kernel<0, false, NI>;
-        case 1: return gemm_big_multi_kernel<0, true, NI>;
-        case 2: return gemm_big_multi_kernel<1, false, NI>;
-        case 3: return gemm_big_multi_kernel<1, true, NI>;
-        case 4: return gemm_big_multi_kernel<2, false, NI>;
-        case 5: return gemm_big_multi_kernel<2, true, NI>;
-        case 6: return gemm_big_multi_kernel<3, false, NI>;
-        default: return gemm_big_multi_kernel<3, true, NI>;
+        case 0: return gemm_big_multi_kernel<0, false, NI, MW>;
+        case 1: return gemm_big_multi_kernel<0, true, NI, MW>;
+        case 2: return gemm_big_multi_kernel<1, false, NI, MW>;
+        case 3: return gemm_big_multi_kernel<1, true, NI, MW>;
+        case 4: return gemm_big_multi_kernel<2, false, NI, MW>;
+        case 5: return gemm_big_multi_kernel<2, true, NI, MW>;
+        case 6: return gemm_big_multi_kernel<3, false, NI, MW>;
+        default: return gemm_big_multi_kernel<3, true, NI, MW>;
     }
 }
-static big_multi_kernel_t big_multi_kernel(int v, int ni) { return ni == 2 ? big_multi_kernel_ni<2>(v) : big_multi_kernel_ni<4>(v); }
+static big_multi_kernel_t big_multi_kernel(int v, int ni, int mw) {
+    return mw == 4 ? big_multi_kernel_ni<4, 4>(v) : ni == 2 ? big_multi_kernel_ni<2, 2>(v) : big_multi_kernel_ni<4, 2>(v);
+}
 
 static void big_setup() {
     int dev = 0;
     hipGetDevice(&dev);               // function attributes are per device (nn.DataParallel replicas launch on several)
     dev &= 63;
     if (big_setup_done[dev]) return;
-    for (int ni = 2; ni <= 4; ni += 2) {
-        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v, ni), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
-        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v, ni), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+    for (int c = 0; c < 3; ++c) {          // (NI, MW) = (2, 2), (4, 2), (4, 4)
+        const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
+        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
     }
     big_setup_done[dev] = true;
     if (getenv("GAST_GEMM_BIG_DEBUG")) {
-        for (int ni = 2; ni <= 4; ni += 2)
+        for (int c = 0; c < 3; ++c) {
+            const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
             for (int v = 0; v < 8; v += 2) {
                 int nb = -1;
-                hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni), 256, big_lds_bytes(0, ni));
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni, mw), nt_of(mw), big_lds_bytes(0, ni, mw));
                 hipFuncAttributes fa;
-                hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni));
-                fprintf(stderr, "gemm_big variant %d NI %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, nb, big_lds_bytes(0, ni), fa.numRegs, (size_t)fa.localSizeBytes);
+                (void)hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni, mw));
+                fprintf(stderr, "gemm_big variant %d NI %d MW %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, mw, nb, big_lds_bytes(0, ni, mw), fa.numRegs, (size_t)fa.localSizeBytes);
             }
+        }
     }
 }
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni), dim3(pl.tilesM * pl.tilesN * pl.splitk), dim3(256), big_lds_bytes(pl.ntab, pl.ni), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -663,13 +633,13 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
     bool done[GAST_GEMM_MAX_BATCH] = {};
     for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
-        const int v = epi_variant(args[d0]), ni = pls[d0].ni;
+        const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw;
         BigBatch b;
         b.n = 0;
         b.first[0] = 0;
         int ntab = 0;
         for (int d = d0; d < n; ++d) {
-            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni) continue;
+            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni || pls[d].mw != mw) continue;
             done[d] = true;
             const int k = b.n++;
             b.a[k] = args[d];
@@ -677,8 +647,8 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni), dim3(b.first[1]), dim3(256), big_lds_bytes(ntab, ni), st, b.a[0], b.pl[0]);
-        else hipLaunchKernelGGL(big_multi_kernel(v, ni), dim3(b.first[b.n]), dim3(256), big_lds_bytes(ntab, ni), st, b);
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b);
         GAST_CHECK_LAUNCH();
     }
     return 0;

@@ -1,7 +1,4 @@
-cd /tmp; export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-for e in "X=1" "GAST_AGG_FWD_JSPLIT=2 GAST_AGG_BWD_JSPLIT=2" "GAST_AGG_FWD_JSPLIT=4 GAST_AGG_BWD_JSPLIT=4" "GAST_AGG_BWD_BLOCKS=2048" "GAST_AGG_BWD_BLOCKS=4096 GAST_AGG_FWD_JSPLIT=3"; do
-  rm -rf /tmp/prof
-  env $e timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --steps 6 --warmup 2 > /tmp/log.txt 2>&1
-  echo "== $e"; python $R/scripts/kstat.py $(find /tmp/prof -name "*kernel_stats.csv" | head -1) semch_agg
-done
+timeout 900 python -m pytest tests/test_kernels_gpu.py -x -q -k "gemm" 2>&1 | tail -2
+echo "== MW=2"; timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "gemm" | grep -v "M=2176"
+echo "== MW=4"; GAST_GEMM_BIG_MW=4 timeout 300 python scripts/gemm_table.py bf16x3 2>&1 | grep -E "gemm" | grep -v "M=2176"
+for e in "X=1" "GAST_GEMM_BIG_MW=4" "X=1" "GAST_GEMM_BIG_MW=4 GAST_GEMM_BIG_MW_MIN_K=700"; do echo "== $e"; env $e timeout 200 python bench.py --no-cpu-baseline --no-kernel-timer --no-eager --no-parity 2>&1 | tail -1 | cut -c90-200; done

@@ -270,8 +270,7 @@ GEMM_SMALL_X3_CASES = [
 
 @pytest.mark.parametrize('case', GEMM_SMALL_X3_CASES, ids=[c[0] for c in GEMM_SMALL_X3_CASES])
 def test_gemm_small_x3_images(ops, case):
-    """The M = B*J stage with pre-split weight images: gemm.hip's split-K path by default, the pipelined kernel with split-K under
-    GAST_GEMM_BIG_SPLIT=1 (test_optin_kernel_variants) -- same results either way."""
+    """The M = B*J stage with pre-split weight images attached to its operands: gemm.hip's split-K path reads the fp32 weights."""
     jd, jh, bufs = _gemm_case(case, torch.float32)
     with x3_mode(ops, 'x3'):
         ops.gemm(**_with_images(ops, jd))
@@ -413,7 +412,7 @@ def test_wgrad_multi(ops, mode):
                                                ('GAST_WGRAD_X3_PIPE=0', 'test_wgrad_multi and x3', 1),
                                                ('GAST_GEMM_BIG_NI=2', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_NI=4', 'test_gemm_big_x3', None),
-                                               ('GAST_GEMM_BIG_SPLIT=1', 'test_gemm_small_x3_images', 3),
+                                               ('GAST_GEMM_BIG_MW=4', 'test_gemm_big_x3', None),
                                                ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
 def test_optin_kernel_variants(knob, select, npass):
     """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles, two
