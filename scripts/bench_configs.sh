@@ -1,4 +1,4 @@
-O=gpurun_out/r02k; mkdir -p $O
+O=gpurun_out/r02_configs; mkdir -p $O
 for a in "--config cfg2" "--config cfg2 --channels 128" "--config cfg3" "--config cfg4" "--config cfg4 --dtype fp8" "--config cfg4 --batch 32 --dtype fp8" "--variant strided" "--dtype bf16" "--dtype fp32"; do
   n=$(echo $a | tr -d ' -' )
   timeout 300 python bench.py $a --no-cpu-baseline --no-kernel-timer --no-eager > $O/$n.json 2> $O/$n.err

@@ -1,6 +1,6 @@
 cd /tmp; export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r02j; mkdir -p $O
+O=$R/gpurun_out/r02_evidence; mkdir -p $O
 timeout 900 python $R/bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 600 $O/bench_default.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python $R/bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --steps 6 --warmup 2 > $O/trace.log 2>&1
