@@ -951,6 +951,9 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
     return 0;
 }
 
+// (hipFuncSetAttribute is per device and nn.DataParallel replicas launch from several threads: set on every launch, like graph_ops.hip)
+static hipError_t wgrad_dyn_lds(const void* fn, int bytes) { return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); }
+
 extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_t stream) {
     if (!args || n < 1 || n > GAST_WGRAD_MAX_BATCH) return GAST_EINVAL;
     WgBatch b;     // 2.4 KB: filled on the host, passed by value (kernel argument)
@@ -1033,7 +1036,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, dim3(256), 0, st, b);
     else if (args[0].dtype == GAST_F32X3 && bt == 256) {
         constexpr int lds = 2 * 256 * LSTR;
-        static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_x3_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t attr = wgrad_dyn_lds((const void*)wgrad_x3_multi256_kernel, lds);
         if (attr != hipSuccess) return (int)attr;
         hipLaunchKernelGGL(wgrad_x3_multi256_kernel, grid, dim3(512), lds, st, b);
     } else if (args[0].dtype == GAST_F32X3) {
@@ -1042,8 +1045,8 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
             for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
         if (x3_pipe) {
             constexpr int lds = wgrad_x3_pipe_lds_bytes();
-            static hipError_t at1 = hipFuncSetAttribute((const void*)wgrad_x3_pipe_multi_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            static hipError_t at0 = hipFuncSetAttribute((const void*)wgrad_x3_pipe_multi_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            const hipError_t at1 = wgrad_dyn_lds((const void*)wgrad_x3_pipe_multi_kernel<true>, lds);
+            const hipError_t at0 = wgrad_dyn_lds((const void*)wgrad_x3_pipe_multi_kernel<false>, lds);
             if (at1 != hipSuccess || at0 != hipSuccess) return (int)(at1 != hipSuccess ? at1 : at0);
             if (any_drop) hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<true>, grid, dim3(256), lds, st, b);
             else hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<false>, grid, dim3(256), lds, st, b);
@@ -1053,7 +1056,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     }
     else if (bt == 256) {
         constexpr int lds = wgrad_bf16_lds_bytes(256);
-        static hipError_t attr = hipFuncSetAttribute((const void*)wgrad_bf16_multi256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        const hipError_t attr = wgrad_dyn_lds((const void*)wgrad_bf16_multi256_kernel, lds);
         if (attr != hipSuccess) return (int)attr;
         hipLaunchKernelGGL(wgrad_bf16_multi256_kernel, grid, dim3(512), lds, st, b);
     } else if (ring == 2)
