@@ -167,3 +167,30 @@ def test_dropout_params_edge_cases():
     assert t == 16384 and abs(k - 4.0 / 3.0) < 1e-12
     with pytest.raises(ValueError):
         dropout_params(1.5)
+
+
+def test_graph_mode_leaves_the_cpu_mirror_path_alone(monkeypatch):
+    """GAST_HIP_GRAPH=1 is read by the runner at construction and only ever engages for CUDA inputs on the HIP op set: with the numpy
+    op mirror (or any call that cannot be captured) the module keeps its eager path and gives the same result."""
+    from tests_helpers import PARENTS
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    torch.manual_seed(0)
+    m0 = build(cfg)
+    monkeypatch.setenv('GAST_HIP_GRAPH', '1')
+    torch.manual_seed(0)
+    m1 = build(cfg)
+    assert m1._runner.graph_mode and not m0._runner.graph_mode
+    use_oracle_ops(m0)
+    use_oracle_ops(m1)
+    x = torch.rand(3, 11, 17, 2) * 2 - 1
+    outs = []
+    for m in (m0, m1):
+        m.train()
+        ys = [m(x) for _ in range(4)]          # (the fourth call would be a replay on the GPU)
+        ys[-1].sum().backward()
+        outs.append((ys[-1].detach(), [p.grad.clone() for p in m.parameters()]))
+    assert not m1._runner._graphs
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1], outs[1][1]):
+        assert torch.equal(a, b)
