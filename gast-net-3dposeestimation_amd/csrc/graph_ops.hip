@@ -1389,11 +1389,26 @@ static int attn_wave_ci4(int dtype, int C, int nheads, int ldg, int ldy, const v
     if ((ldg * es) % al || (ldy * es) % al || ((uintptr_t)G % al) || ((uintptr_t)Y % al)) return 0;
     return Ci / 4;
 }
-static int attn_wave_grid(int F, int nheads) {
+// Grid of the wave-per-unit kernels: one unit per wave until the cap.  A unit is a ~15 us dependent chain, so the cap is ONE round of
+// resident blocks (256 CUs x the blocks whose LDS fits a CU): at 768 blocks the 64-channel-head backward (66 KB per block, two per CU)
+// ran a second, half-empty round -- 85 vs 71 us; the fp32 forward kernels (17-27 KB) fit 5+ blocks per CU: 31.5 -> 25.9 us at 1280.
+// smem = 0: the historical 768 (the bf16 MFMA kernels, tuned at that value).
+static int attn_wave_grid(int F, int nheads, size_t smem = 0, int max_cap = 768) {
     long units = (long)F * nheads;
-    long g = (units + 3) / 4;                          // one unit per wave until the grid cap (a unit is a ~15 us dependent chain)
-    if (g > 768) g = 768;
+    long g = (units + 3) / 4;
+    long cap = 768;
+    if (smem) {
+        long per_cu = (long)(160 * 1024 / smem);
+        if (per_cu < 1) per_cu = 1;
+        cap = 256 * per_cu;
+        if (cap > max_cap) cap = max_cap;
+        cap -= cap % 4;
+    }
+    if (g > cap) g = cap;
     return g < 1 ? 1 : (int)g;
+}
+static size_t attn_wave_bwd_smem(int es, int ci4) {      // 4 * AttnW<CI4>::BWD_FLOATS * sizeof(float), fp32 storage only (es == 4)
+    return es == 4 ? (size_t)4 * (4 * JMAX * JP + 2 * JMAX * (ci4 * 4 + 4) + 32) * sizeof(float) : 0;
 }
 
 // bf16 + 16-byte aligned row tiles: the MFMA kernels (GAST_ATTN_MFMA=0 keeps the VALU wave kernels)
@@ -1424,7 +1439,7 @@ static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
+    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads, sizeof(T) == 4 ? smem : 0, 1280)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
                        ldac, C_k, F, J, nheads, (T*)Y, ldy);
     GAST_CHECK_LAUNCH();
     return 0;
@@ -1434,7 +1449,7 @@ template <typename T, int CI4>
 static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                 int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
                                 hipStream_t st) {
-    const int grid = attn_wave_grid(F, nheads);
+    const int grid = attn_wave_grid(F, nheads, attn_wave_bwd_smem((int)sizeof(T), CI4));
     const int C = nheads * CI4 * 4;
     const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;
     bool mfma = false;
@@ -1508,7 +1523,9 @@ extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, 
 
 extern "C" long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads) {
     if (nheads < 1 || F < 1 || J < 1) return 0;
-    return (long)(attn_wave_grid(F, nheads) * 4 / nheads + 1) * (C + 2 * nheads + nheads * J * J);
+    // (the larger of the two grids the backward may use: fp32 wave kernels / everything else)
+    const int g4 = attn_wave_grid(F, nheads, attn_wave_bwd_smem(4, C / nheads / 4)), g2 = attn_wave_grid(F, nheads);
+    return (long)((g4 > g2 ? g4 : g2) * 4 / nheads + 1) * (C + 2 * nheads + nheads * J * J);
 }
 
 extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
