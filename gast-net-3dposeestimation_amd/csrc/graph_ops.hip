@@ -743,17 +743,49 @@ __global__ void __launch_bounds__(256) attn_fwd_wave_kernel(const T* __restrict_
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) ckrow[j] = (lane < J && j < J) ? Ck[((long)h * J + lane) * J + j] : 0.f;
     const int rg = lane / CI4, c4 = lane - rg * CI4;
+    // the next unit's tiles are requested before this unit's dependent chain starts (registers -> LDS at the top of the next trip)
+    constexpr int NPF = (JMAX * CI4 + 63) / 64;
+    float4 pg[NPF];
+    float pa = 0.f, pc = 0.f;
+    auto prefetch = [&](int u) {
+        const int f = u / nheads;
+        if (lane < J) {
+            const T* acp = AC + ((long)f * J + lane) * ldac;
+            pa = Elem<T>::ld(acp + h);
+            pc = Elem<T>::ld(acp + nheads + h);
+        }
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int t = lane + 64 * q, j = t / CI4, cc = t - j * CI4;
+            if (t < J * CI4) pg[q] = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+        }
+    };
+    // (only where the look-ahead registers cost no occupancy: at 32-channel heads they cross 168 VGPRs -- a resident block per CU, 53 -> 73 us
+    // in the backward; at 128-channel heads, 308 VGPRs, they would spill)
+    constexpr bool LOOKAHEAD = CI4 == 16;
+    if (LOOKAHEAD && gw < F * nheads) prefetch(gw);
     for (int u = gw; u < F * nheads; u += nw) {
         const int f = u / nheads;
         float a_i = 0.f;
-        if (lane < J) {
-            const T* acp = AC + ((long)f * J + lane) * ldac;
-            a_i = Elem<T>::ld(acp + h);
-            sc[lane] = Elem<T>::ld(acp + nheads + h);
-        }
-        for (int t = lane; t < J * CI4; t += 64) {
-            const int j = t / CI4, cc = t - j * CI4;
-            *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+        if constexpr (LOOKAHEAD) {
+            a_i = lane < J ? pa : 0.f;
+            if (lane < J) sc[lane] = pc;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int t = lane + 64 * q, j = t / CI4, cc = t - j * CI4;
+                if (t < J * CI4) *(float4*)(sg + j * W::GS + cc * 4) = pg[q];
+            }
+            if (u + nw < F * nheads) prefetch(u + nw);
+        } else {
+            if (lane < J) {
+                const T* acp = AC + ((long)f * J + lane) * ldac;
+                a_i = Elem<T>::ld(acp + h);
+                sc[lane] = Elem<T>::ld(acp + nheads + h);
+            }
+            for (int t = lane; t < J * CI4; t += 64) {
+                const int j = t / CI4, cc = t - j * CI4;
+                *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+            }
         }
         wave_lds_sync();
         attn_row(lane, J, a_i, sc, ckrow, satt, nullptr, nullptr);
@@ -808,18 +840,56 @@ __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict_
     for (int q = 0; q < NP; ++q) ckacc[q] = 0.f;
     float4 gsum = make_float4(0, 0, 0, 0);
     float da_sum = 0.f, dc_sum = 0.f;
+    // the next unit's tiles are requested before this unit's dependent chain starts (registers -> LDS at the top of the next trip)
+    constexpr int NPF = (JMAX * CI4 + 63) / 64;
+    float4 pg[NPF], pdy[NPF];
+    float pa = 0.f, pc = 0.f;
+    auto prefetch = [&](int u) {
+        const int f = u / nheads;
+        if (lane < J) {
+            const T* acp = AC + ((long)f * J + lane) * ldac;
+            pa = Elem<T>::ld(acp + h);
+            pc = Elem<T>::ld(acp + nheads + h);
+        }
+#pragma unroll
+        for (int q = 0; q < NPF; ++q) {
+            const int t = lane + 64 * q, j = t / CI4, cc = t - j * CI4;
+            if (t < J * CI4) {
+                pg[q] = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+                pdy[q] = ld4(dY + ((long)f * J + j) * lddy + h * W::CI + cc * 4);
+            }
+        }
+    };
+    // (only where the look-ahead registers cost no occupancy: at 32-channel heads they cross 168 VGPRs -- a resident block per CU, 53 -> 73 us
+    // in the backward; at 128-channel heads, 308 VGPRs, they would spill)
+    constexpr bool LOOKAHEAD = CI4 == 16;
+    if (LOOKAHEAD && gw < F * nheads) prefetch(gw);
     for (int u = gw; u < F * nheads; u += nw) {
         const int f = u / nheads;
         float a_i = 0.f;
-        if (lane < J) {
-            const T* acp = AC + ((long)f * J + lane) * ldac;
-            a_i = Elem<T>::ld(acp + h);
-            sc[lane] = Elem<T>::ld(acp + nheads + h);
-        }
-        for (int t = lane; t < J * CI4; t += 64) {
-            const int j = t / CI4, cc = t - j * CI4;
-            *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
-            *(float4*)(sdy + j * W::GS + cc * 4) = ld4(dY + ((long)f * J + j) * lddy + h * W::CI + cc * 4);
+        if constexpr (LOOKAHEAD) {
+            a_i = lane < J ? pa : 0.f;
+            if (lane < J) sc[lane] = pc;
+#pragma unroll
+            for (int q = 0; q < NPF; ++q) {
+                const int t = lane + 64 * q, j = t / CI4, cc = t - j * CI4;
+                if (t < J * CI4) {
+                    *(float4*)(sg + j * W::GS + cc * 4) = pg[q];
+                    *(float4*)(sdy + j * W::GS + cc * 4) = pdy[q];
+                }
+            }
+            if (u + nw < F * nheads) prefetch(u + nw);
+        } else {
+            if (lane < J) {
+                const T* acp = AC + ((long)f * J + lane) * ldac;
+                a_i = Elem<T>::ld(acp + h);
+                sc[lane] = Elem<T>::ld(acp + nheads + h);
+            }
+            for (int t = lane; t < J * CI4; t += 64) {
+                const int j = t / CI4, cc = t - j * CI4;
+                *(float4*)(sg + j * W::GS + cc * 4) = ld4(G + ((long)f * J + j) * ldg + h * W::CI + cc * 4);
+                *(float4*)(sdy + j * W::GS + cc * 4) = ld4(dY + ((long)f * J + j) * lddy + h * W::CI + cc * 4);
+            }
         }
         wave_lds_sync();
         attn_row(lane, J, a_i, sc, ckrow, satt, sp, sds);
@@ -1390,25 +1460,22 @@ static int attn_wave_ci4(int dtype, int C, int nheads, int ldg, int ldy, const v
     return Ci / 4;
 }
 // Grid of the wave-per-unit kernels: one unit per wave until the cap.  A unit is a ~15 us dependent chain, so the cap is ONE round of
-// resident blocks (256 CUs x the blocks whose LDS fits a CU): at 768 blocks the 64-channel-head backward (66 KB per block, two per CU)
-// ran a second, half-empty round -- 85 vs 71 us; the fp32 forward kernels (17-27 KB) fit 5+ blocks per CU: 31.5 -> 25.9 us at 1280.
-// smem = 0: the historical 768 (the bf16 MFMA kernels, tuned at that value).
-static int attn_wave_grid(int F, int nheads, size_t smem = 0, int max_cap = 768) {
+// resident blocks, 256 CUs x the occupancy the runtime reports for the kernel (LDS and registers): at 768 blocks the 64-channel-head
+// backward (66 KB of LDS per block, two per CU) ran a second, half-empty round -- 85 vs 71 us; the fp32 forward kernels fit 3-5
+// blocks per CU.  per_cu = 0: the historical 768 (the bf16 kernels, tuned at that value).
+constexpr int ATTN_MAX_GRID = 2048;
+static int attn_wave_grid(int F, int nheads, int per_cu = 0) {
     long units = (long)F * nheads;
     long g = (units + 3) / 4;
-    long cap = 768;
-    if (smem) {
-        long per_cu = (long)(160 * 1024 / smem);
-        if (per_cu < 1) per_cu = 1;
-        cap = 256 * per_cu;
-        if (cap > max_cap) cap = max_cap;
-        cap -= cap % 4;
-    }
+    long cap = per_cu > 0 ? 256L * per_cu : 768;
+    if (cap > ATTN_MAX_GRID) cap = ATTN_MAX_GRID;
     if (g > cap) g = cap;
     return g < 1 ? 1 : (int)g;
 }
-static size_t attn_wave_bwd_smem(int es, int ci4) {      // 4 * AttnW<CI4>::BWD_FLOATS * sizeof(float), fp32 storage only (es == 4)
-    return es == 4 ? (size_t)4 * (4 * JMAX * JP + 2 * JMAX * (ci4 * 4 + 4) + 32) * sizeof(float) : 0;
+static int attn_blocks_per_cu(const void* kernel, size_t smem) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, smem) != hipSuccess || nb < 1) nb = 1;
+    return nb;
 }
 
 // bf16 + 16-byte aligned row tiles: the MFMA kernels (GAST_ATTN_MFMA=0 keeps the VALU wave kernels)
@@ -1439,7 +1506,8 @@ static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads, sizeof(T) == 4 ? smem : 0, 1280)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
+    static const int per_cu = sizeof(T) == 4 ? attn_blocks_per_cu((const void*)attn_fwd_wave_kernel<T, CI4>, smem) : 0;
+    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads, per_cu)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
                        ldac, C_k, F, J, nheads, (T*)Y, ldy);
     GAST_CHECK_LAUNCH();
     return 0;
@@ -1449,7 +1517,8 @@ template <typename T, int CI4>
 static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                 int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
                                 hipStream_t st) {
-    const int grid = attn_wave_grid(F, nheads, attn_wave_bwd_smem((int)sizeof(T), CI4));
+    static const int per_cu = sizeof(T) == 4 ? attn_blocks_per_cu((const void*)attn_bwd_wave_kernel<T, CI4>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
+    const int grid = attn_wave_grid(F, nheads, per_cu);
     const int C = nheads * CI4 * 4;
     const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;
     bool mfma = false;
@@ -1523,9 +1592,10 @@ extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, 
 
 extern "C" long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads) {
     if (nheads < 1 || F < 1 || J < 1) return 0;
-    // (the larger of the two grids the backward may use: fp32 wave kernels / everything else)
-    const int g4 = attn_wave_grid(F, nheads, attn_wave_bwd_smem(4, C / nheads / 4)), g2 = attn_wave_grid(F, nheads);
-    return (long)((g4 > g2 ? g4 : g2) * 4 / nheads + 1) * (C + 2 * nheads + nheads * J * J);
+    // (an upper bound: the backward's grid depends on the occupancy of the kernel variant it picks, at most ATTN_MAX_GRID blocks)
+    long g = ((long)F * nheads + 3) / 4;
+    if (g > ATTN_MAX_GRID) g = ATTN_MAX_GRID;
+    return (g * 4 / nheads + 1) * (long)(C + 2 * nheads + nheads * J * J);
 }
 
 extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
