@@ -123,6 +123,13 @@ class Engine:
     def _new(self, rows, cols, dt, dev, zero=False):
         return (torch.zeros if zero else torch.empty)(rows, cols, dtype=dt, device=dev)
 
+    def _new_rows128(self, rows, cols, dt, dev):
+        """(rows, cols) view of a buffer whose row pitch is a multiple of 128 bytes: the G1 output [h | g | a, c] is 5C + 8 columns
+        wide, and with that pitch every row of every column block starts in the middle of a cache line for the aggregation /
+        attention kernels that read it in 256-byte pieces."""
+        per = 128 // torch.empty((), dtype=dt).element_size()
+        return torch.empty(rows, (cols + per - 1) // per * per, dtype=dt, device=dev)[:, :cols]
+
     def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0, centered=False):
         """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n)."""
         ops = self.ops
@@ -340,7 +347,7 @@ class Engine:
         Wbc = inp[g + 'Bbc']      # [2C][3C]
         nb = ops.gemm_row_blocks(P)
         # G1: everything that reads X in one pass (local_attention.py:37-38, global_attention.py:56-72)
-        H = self._new(P, N1, dt, dev)
+        H = self._new_rows128(P, N1, dt, dev)
         ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1)], H, im, bias=inp[g + 'bias1'])
         cen = self.centered
         # ---- everything both branches touch is allocated here, on the main stream, before the fork
@@ -668,7 +675,7 @@ class Engine:
                                       key=g + 'bn_2')], grads, one_apply=(dY, st['Y'], P))
         # attention core + aggregation backward fill the column blocks of dH
         H = st['H']
-        dH = self._new(P, N1, dt, dev)
+        dH = self._new_rows128(P, N1, dt, dev)
         dCk = grads[g + 'C_k']          # accumulated with atomics: gradient destinations arrive zeroed (see backward())
         # (+ the bias gradients of g / theta / phi = column sums of these dH columns, reduced in the same pass)
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk,
