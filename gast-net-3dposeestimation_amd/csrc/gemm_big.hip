@@ -427,14 +427,23 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             }
         }
         __syncthreads();
-        // a 256-row block is two 128-row statistics blocks (wave rows 0-1 and 2-3)
-        const int hb = tid / TN, cl = tid - hb * TN;
-        const int n = n0 + cl;
-        const int sblk = mt * (MW / 2) + hb;
-        if (hb < MW / 2 && n < N && (long)sblk * 128 < M) {
-            float* pp = a.partials + ((long)sblk * N + n) * 2;
-            pp[0] = sRed[((2 * hb) * TN + cl) * 2] + sRed[((2 * hb + 1) * TN + cl) * 2];
-            pp[1] = sRed[((2 * hb) * TN + cl) * 2 + 1] + sRed[((2 * hb + 1) * TN + cl) * 2 + 1];
+        if constexpr (MW == 2) {
+            const int n = n0 + tid;
+            if (tid < TN && n < N) {
+                float* pp = a.partials + ((long)mt * N + n) * 2;
+                pp[0] = sRed[tid * 2] + sRed[(TN + tid) * 2];
+                pp[1] = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
+            }
+        } else {
+            // a 256-row block is two 128-row statistics blocks (wave rows 0-1 and 2-3)
+            const int hb = tid / TN, cl = tid - hb * TN;
+            const int n = n0 + cl;
+            const int sblk = mt * (MW / 2) + hb;
+            if (hb < MW / 2 && n < N && (long)sblk * 128 < M) {
+                float* pp = a.partials + ((long)sblk * N + n) * 2;
+                pp[0] = sRed[((2 * hb) * TN + cl) * 2] + sRed[((2 * hb + 1) * TN + cl) * 2];
+                pp[1] = sRed[((2 * hb) * TN + cl) * 2 + 1] + sRed[((2 * hb + 1) * TN + cl) * 2 + 1];
+            }
         }
     }
 }
