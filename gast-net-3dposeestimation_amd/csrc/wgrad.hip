@@ -391,7 +391,10 @@ constexpr int wgrad_x3_pipe_lds_bytes() { return 2 * 2 * BT * LSTR; }
 constexpr uint32_t WG_OOB = 0xFFFF0000u;      // buffer size == first out-of-range byte offset (wgrad_check bounds the operands)
 typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
 
-template <bool DROP>
+// NP = split products per FLOP pair: 3 (hi*hi + hi*lo + lo*hi: fp32-class, the default), 2 (the activation operand as its bf16 hi
+// part only: dC_hi*q_hi + dC_lo*q_hi) or 1 (plain bf16 products): GAST_WGRAD_X3_PRODUCTS.  A weight gradient feeds nothing but the
+// optimizer -- the forward outputs and the input-gradient chain do not see it -- so fewer products is a precision lever for dW alone.
+template <bool DROP, int NP>
 __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
     constexpr int BKM = 32;
     constexpr int STAGE = 2 * BT * LSTR;
@@ -488,6 +491,7 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
                 }
             }
         }
+        constexpr bool LO = NP == 3 || (NP == 2 && OP == 0);      // is this operand's lo part multiplied at all?
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t h[4], l[4];
@@ -495,11 +499,11 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
             for (int p2 = 0; p2 < 4; ++p2) {
                 const float x0 = x[2 * p2][q], x1 = x[2 * p2 + 1][q];
                 h[p2] = pack_bf16x2(x0, x1);
-                l[p2] = pack_bf16x2(x0 - __uint_as_float(h[p2] << 16), x1 - __uint_as_float(h[p2] & 0xffff0000u));
+                if (LO) l[p2] = pack_bf16x2(x0 - __uint_as_float(h[p2] << 16), x1 - __uint_as_float(h[p2] & 0xffff0000u));
             }
             unsigned char* d = stage + sdst_off + q * LSTR;
             *(uint4*)d = make_uint4(h[0], h[1], h[2], h[3]);
-            *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
+            if (LO) *(uint4*)(d + 64) = make_uint4(l[0], l[1], l[2], l[3]);
         }
     };
     auto mfma_tile = [&](const unsigned char* stage) {
@@ -512,22 +516,26 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
             for (int mi = 0; mi < 2; ++mi) {
                 const unsigned char* p = sP + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
                 ah[mi].u = *(const uint4*)p;
-                al[mi].u = *(const uint4*)(p + 64);
+                if (NP >= 2) al[mi].u = *(const uint4*)(p + 64);
             }
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const unsigned char* p = sQ + (wc * 64 + ni * 32 + li) * LSTR + (ks * 2 + lh) * 16;
                 bh[ni].u = *(const uint4*)p;
-                bl[ni].u = *(const uint4*)(p + 64);
+                if (NP == 3) bl[ni].u = *(const uint4*)(p + 64);
             }
+            if (NP >= 2) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+            }
+            if (NP == 3) {
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+                for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+            }
 #pragma unroll
             for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -855,12 +863,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b)
     wgrad_x3_body<BT, DROP>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 // 256x256 tiles (GAST_WGRAD_X3_TILE=256): 512 threads, 72 KB of dynamic LDS, one block per CU
-template <bool DROP>
+template <bool DROP, int NP>
 __global__ void __launch_bounds__(256, 2) wgrad_x3_pipe_multi_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3p[];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_pipe_body<DROP>(dsmem_x3p, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_x3_pipe_body<DROP, NP>(dsmem_x3p, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(512, 2) wgrad_x3_multi256_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3[];
@@ -1045,11 +1053,14 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
             for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
         if (x3_pipe) {
             constexpr int lds = wgrad_x3_pipe_lds_bytes();
-            const hipError_t at1 = wgrad_dyn_lds((const void*)wgrad_x3_pipe_multi_kernel<true>, lds);
-            const hipError_t at0 = wgrad_dyn_lds((const void*)wgrad_x3_pipe_multi_kernel<false>, lds);
-            if (at1 != hipSuccess || at0 != hipSuccess) return (int)(at1 != hipSuccess ? at1 : at0);
-            if (any_drop) hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<true>, grid, dim3(256), lds, st, b);
-            else hipLaunchKernelGGL(wgrad_x3_pipe_multi_kernel<false>, grid, dim3(256), lds, st, b);
+            static const int np_env = getenv("GAST_WGRAD_X3_PRODUCTS") ? atoi(getenv("GAST_WGRAD_X3_PRODUCTS")) : 3;
+            typedef void (*kern_t)(const WgBatch);
+            const kern_t kern = np_env == 1 ? (any_drop ? wgrad_x3_pipe_multi_kernel<true, 1> : wgrad_x3_pipe_multi_kernel<false, 1>)
+                              : np_env == 2 ? (any_drop ? wgrad_x3_pipe_multi_kernel<true, 2> : wgrad_x3_pipe_multi_kernel<false, 2>)
+                                            : (any_drop ? wgrad_x3_pipe_multi_kernel<true, 3> : wgrad_x3_pipe_multi_kernel<false, 3>);
+            const hipError_t at = wgrad_dyn_lds((const void*)kern, lds);
+            if (at != hipSuccess) return (int)at;
+            hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, b);
         }
         else if (any_drop) hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, grid, dim3(256), 0, st, b);
         else hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, grid, dim3(256), 0, st, b);

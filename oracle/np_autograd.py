@@ -104,14 +104,33 @@ def mul_const(a, c):
     return out
 
 
-# Tie handling for parity tests.  A ReLU / LeakyReLU input closer to zero than the fp32 round-off of the path under test is
-# undecidable for it: whichever side it lands on, the gradient changes by that element's whole contribution.  With
-# TIES['eps'] > 0 inputs with |v| < eps are decided by TIES['side'] ('on': treated as positive, 'off': as negative) and counted,
-# so a test can evaluate both decisions and budget the difference (tests/test_model_gpu.py).  eps = 0 is the plain function.
-TIES = {'eps': 0.0, 'side': 'on', 'count': 0}
+# Tie handling for parity tests.  A ReLU / LeakyReLU input closer to zero than the round-off of the path under test is
+# undecidable for it: whichever side it lands on, the gradient changes by that element's whole contribution.  Two tools:
+#  * TIES['eps'] > 0: inputs with |v| < eps are decided by TIES['side'] ('on': treated as positive, 'off': as negative) and
+#    counted, so a test can evaluate both decisions and budget the difference (tests/parity_helpers.py::_tie_budget);
+#  * TIES['forced'] = [mask, ...]: the decisions of the path under test itself (tests/plan_decisions.py reads them off its saved
+#    pre-activations), one boolean array per relu / leaky_relu call in call order, in the call's own layout.  The oracle then
+#    differentiates the SAME piecewise-linear branch and the comparison is elementwise again.  Where a forced decision differs
+#    from the oracle's own `v > 0` is counted in TIES['flips'], and the largest |v| among those inputs is kept in
+#    TIES['flip_max']: the test asserts it is of the size of the tested arithmetic's round-off, i.e. that only genuinely
+#    undecidable inputs were decided differently.
+# eps = 0 and forced = None is the plain function.
+TIES = {'eps': 0.0, 'side': 'on', 'count': 0, 'forced': None, 'pos': 0, 'flips': 0, 'flip_max': 0.0}
 
 
 def _positive(v):
+    forced = TIES.get('forced')
+    if forced is not None:
+        m = forced[TIES['pos']]
+        TIES['pos'] += 1
+        m = np.asarray(m.cpu() if hasattr(m, 'cpu') else m, dtype=bool)
+        assert m.shape == v.shape, ('forced decision %d has shape %s, the call sees %s' % (TIES['pos'] - 1, m.shape, v.shape))
+        dis = m != (v > 0)
+        n = int(dis.sum())
+        if n:
+            TIES['flips'] += n
+            TIES['flip_max'] = max(TIES['flip_max'], float(np.abs(v[dis]).max()))
+        return m
     eps = TIES['eps']
     if eps <= 0:
         return v > 0

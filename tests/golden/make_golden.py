@@ -52,6 +52,8 @@ CONFIGS = [
     # variant 'dense' = SpatioTemporalModel(dense=True), the ablation of gast_net.py:145-146 (temporal kernels 7 and 19 wide)
     ('j17_a333_c16_dense', 17, (3, 3, 3), 16, False, 'dense', 3, 29),
     ('j19_a33_c32_dense_causal', 19, (3, 3), 32, True, 'dense', 2, 12),
+    # the five-level plan of the shipped 243-frame model (reconstruction.py:225-227: arc 3,3,3,3,3), small width, T = RF + 2
+    ('j17_a33333_c8_dil', 17, (3, 3, 3, 3, 3), 8, False, 'dilated', 2, 245),
 ]
 
 

@@ -9,6 +9,7 @@ import torch
 from parity_helpers import (ZERO_GRADS, BF16_NOISY, FP32_GRAD_TOL, X3_GRAD_TOL, _grad_errors, _grad_cosines, _tie_budget,  # noqa: F401
                             _check_fp32_grads, _check_x3_grads)
 from conftest import golden_names, load_golden
+from plan_decisions import plan_decisions
 from tests_helpers import PARENTS
 
 pytestmark = pytest.mark.gpu
@@ -22,11 +23,12 @@ pytestmark = pytest.mark.gpu
 #   test_bf16_vs_fp32_full_size.
 # Gradients: fp32 -> _check_fp32_grads (2e-4 of max|ref|, undecidable ReLU ties evaluated both ways by the oracle);
 #   bf16 -> _grad_cosines (direction and scale).  TOL['grad'/'gabs'] below are only used by the bf16 skip logic of _grad_errors.
-# bf16x3: fp32 storage, GEMM products as three bf16 MFMA products (hi*hi + hi*lo + lo*hi): bounded at 1e-3 on outputs -- ten
-#   times inside the north-star bf16 tolerance (measured ~1e-5 .. 1e-4) -- and checked elementwise on gradients like fp32 with ten
-#   times its bound (X3_GRAD_TOL).
+# bf16x3 (the arithmetic bench.py times): fp32 storage, GEMM products as three bf16 MFMA products (hi*hi + hi*lo + lo*hi).  It is held
+#   to the north star's FP32 bound on outputs, 1e-4 -- 2e-4 where the measured value says so (stated at the test) -- not to the bf16
+#   bound, and checked elementwise on gradients like fp32 against the float64 oracle evaluated on the branch the path took
+#   (tests/plan_decisions.py, parity_helpers._check_x3_grads; X3_GRAD_TOL).
 TOL = {'fp32': dict(out=1e-4, out_eval=1e-4, grad=5e-3, gabs=5e-5, out_rel=1e-4),
-       'bf16x3': dict(out=1e-3, out_eval=1e-3, grad=5e-3, gabs=5e-5, out_rel=1e-3),
+       'bf16x3': dict(out=1e-4, out_eval=1e-4, grad=5e-3, gabs=5e-5, out_rel=1e-4),
        'bf16': dict(out=8e-2, out_eval=1e-2, grad=6e-1, gabs=3e-2, out_rel=3e-2)}
 GRAD_TOL = {'fp32': FP32_GRAD_TOL, 'bf16x3': X3_GRAD_TOL}
 METRICS = []
@@ -34,6 +36,8 @@ BF16_COS, BF16_RATIO = 0.85, 0.7     # per-parameter cosine / norm ratio of bf16
 
 
 def _log(**kw):
+    if os.environ.get('GAST_WGRAD_X3_PRODUCTS'):
+        kw['wgrad_products'] = os.environ['GAST_WGRAD_X3_PRODUCTS']
     METRICS.append(kw)
     try:
         import json
@@ -61,6 +65,13 @@ def mode(request, monkeypatch):
     return request.param
 
 
+@pytest.fixture(params=['fp32', 'bf16x3'])
+def mode2(request, monkeypatch):
+    """the reference's arithmetic and the one bench.py times: every end-to-end test runs in both"""
+    monkeypatch.setenv('GAST_HIP_DTYPE', request.param)
+    return request.param
+
+
 @pytest.mark.parametrize('name', golden_names())
 def test_golden(name, mode):
     """P1 + P2 of SURVEY.md 8c: eval forward, train forward + all parameter gradients + BN buffers, vs the reference."""
@@ -83,12 +94,15 @@ def test_golden(name, mode):
     y3d = torch.from_numpy(z['y3d']).cuda()
     loss = torch.mean(torch.norm(y - y3d, dim=-1))   # mpjpe, reference common/loss.py:5-11
     dloss_mm = abs(loss.item() - float(z['loss'])) * 1000
+    decisions = plan_decisions(y.grad_fn.sv, cfg['J']) if mode != 'bf16' else None
     loss.backward()
     if mode != 'bf16':
         from oracle import gast_oracle as go
         om = go.OracleModel(go.adj_from_parents(cfg['parents']), cfg['arc'], cfg['channels'], causal=cfg['causal'],
                             variant=cfg['variant'])
-        worst, info = (_check_fp32_grads if mode == 'fp32' else _check_x3_grads)(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2])
+        run = lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2]      # noqa: E731
+        worst, info = (_check_fp32_grads(m, grads, run, decisions=decisions) if mode == 'fp32' else
+                       _check_x3_grads(m, grads, run, decisions))
     else:
         cosw, ratw = _grad_cosines(m, grads)
         worst, info = ('', 0.0), dict(worst_cos=cosw, worst_norm_ratio=ratw)
@@ -146,9 +160,12 @@ def test_against_oracle_midsize(J, arc, ch, B, T, variant, mode):
     y = m(x.cuda())
     tol = TOL[mode]
     err = float(np.abs(y.detach().cpu().numpy() - y_ref).max())
+    decisions = plan_decisions(y.grad_fn.sv, J) if mode != 'bf16' else None
     y.backward(dy.cuda())
     if mode != 'bf16':
-        worst, info = (_check_fp32_grads if mode == 'fp32' else _check_x3_grads)(m, g_ref, lambda: om.output_grads(state, x.numpy(), dy.numpy(), training=True)[1])
+        run = lambda: om.output_grads(state, x.numpy(), dy.numpy(), training=True)[1]      # noqa: E731
+        worst, info = (_check_fp32_grads(m, g_ref, run, decisions=decisions) if mode == 'fp32' else
+                       _check_x3_grads(m, g_ref, run, decisions))
     else:
         cosw, ratw = _grad_cosines(m, g_ref)
         worst, info = ('', 0.0), dict(worst_cos=cosw, worst_norm_ratio=ratw)
@@ -192,22 +209,37 @@ def test_full_size_properties(mode):
         assert p.grad is not None and torch.isfinite(p.grad).all(), k
 
 
-@pytest.mark.parametrize('J,arc,ch,B,variant', [(17, (3, 3, 3), 128, 128, 'dilated'), (17, (3, 3, 3), 128, 128, 'strided'),
-                                                (17, (3, 3, 3, 3), 64, 32, 'dilated'), (19, (3, 3, 3), 128, 64, 'dilated'),
-                                                (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense'),
-                                                # configs[2] at its own width (C=128: 1024-wide last level) and a batch the float64
-                                                # stock reference fits in memory with (its (BT, 2Ci, J, J) concat tensors)
-                                                (17, (3, 3, 3, 3), 128, 64, 'dilated')])
-def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, monkeypatch):
-    """VALUES at the BASELINE.json sizes (configs[1]: B=128, T=27, J=17, C=128; and the shapes of configs[2..4]): the HIP path
-    in fp32 against the oracle restatement running on stock PyTorch-ROCm operators on the same GPU (oracle/torch_ops.py, pinned
-    on CPU to the reference fixtures and the numpy oracle) -- eval output, train output, loss, every parameter gradient and
-    the BatchNorm buffers after the step.  Tolerances: 1e-4 on outputs (north star); gradients 2e-3 relative L2 per tensor
-    (two fp32 implementations with different summation orders; ReLU inputs within round-off of zero flip whole contributions,
-    which the tie-aware numpy oracle of the smaller tests can resolve and this one cannot)."""
+FULL_SIZE = [(17, (3, 3, 3), 128, 128, 'dilated'), (17, (3, 3, 3), 128, 128, 'strided'),
+             (17, (3, 3, 3, 3), 64, 32, 'dilated'), (19, (3, 3, 3), 128, 64, 'dilated'),
+             (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense'),
+             # configs[2] at its own width (C=128: 1024-wide last level) and a batch the float64 stock reference fits in memory with
+             (17, (3, 3, 3, 3), 128, 64, 'dilated'),
+             # the shipped 243-frame shape (reference reconstruction.py:225-227)
+             (17, (3, 3, 3, 3, 3), 32, 16, 'dilated')]
+# bounds of test_full_size_values_against_stock_torch per arithmetic: outputs (north star: 1e-4 fp32; bf16x3 is held to 2e-4 -- measured
+# 7.6e-5 at configs[1], 1.2e-4 at configs[2]'s RF 81), loss, and the gradient distances to the float64 oracle evaluated on the path's own
+# ReLU branch: all gradients as one vector (relative L2), worst single tensor (relative L2, floored), elementwise (of max|ref|)
+FULL_TOL = {'fp32': dict(out=1e-4, loss=1e-5, agg=3e-4, tensor=3e-3, elem=2e-3, buf=1e-4),
+            'bf16x3': dict(out=2e-4, loss=2e-5, agg=1e-3, tensor=1e-2, elem=5e-3, buf=2e-4)}
+
+
+@pytest.mark.parametrize('x3', [False, True], ids=['fp32', 'bf16x3'])
+@pytest.mark.parametrize('J,arc,ch,B,variant', FULL_SIZE)
+def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, x3, monkeypatch):
+    """VALUES at the BASELINE.json sizes (configs[1]: B=128, T=27, J=17, C=128; the shapes of configs[2..4]; the 243-frame model), for
+    fp32 AND for bf16x3 -- the arithmetic bench.py times: the HIP path against the oracle restatement in FLOAT64 on stock PyTorch-ROCm
+    operators on the same GPU (oracle/torch_ops.py, pinned on CPU to the reference fixtures and to the numpy oracle): eval output,
+    train output, loss, BatchNorm buffers after the step, and every parameter gradient.
+    Gradients: a ReLU input within the arithmetic's round-off of zero is undecidable and flips a whole contribution, so the float64
+    oracle is evaluated a second time on the branch of the piecewise-linear function the HIP path took (its own decisions, read off
+    its saved pre-activations: tests/plan_decisions.py; they may differ from the oracle's only below FLIP_EPS, asserted) -- against THAT
+    the comparison is elementwise and tight.  The unforced distance and the stock-fp32 yard-stick are logged next to it."""
     from oracle import gast_oracle as go
     from oracle import torch_ops
-    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    from parity_helpers import forced_oracle, FLIP_EPS
+    mode = 'bf16x3' if x3 else 'fp32'
+    tol = FULL_TOL[mode]
+    monkeypatch.setenv('GAST_HIP_DTYPE', mode)
     cfg = dict(J=J, parents=PARENTS[J], arc=list(arc), channels=ch, causal=False, variant=variant)
     torch.manual_seed(0)
     m = build(cfg, dropout=0.0)
@@ -218,14 +250,6 @@ def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, monkeypatc
     x = (torch.rand(B, rf, J, 2, generator=gen) * 2 - 1).cuda()
     y3d = (torch.randn(B, 1, J, 3, generator=gen) * 0.3).cuda()
     state = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    adj = go.adj_from_parents(PARENTS[J])
-    with go.use_backend(torch_ops):      # float64: the reference is the truth, the differences are the HIP path's
-        om = go.OracleModel(adj, list(arc), ch, dropout=0.0, variant=variant, dtype=torch.float64)
-        y_eval_ref, _ = om.forward(state, x, training=False)
-        loss_ref, y_ref, g_ref, buf_ref = om.loss_and_grads(state, x, y3d, training=True)
-        # the same stock operators in fp32: the yard-stick for what fp32 can deliver on these gradients
-        om32 = go.OracleModel(adj, list(arc), ch, dropout=0.0, variant=variant, dtype=torch.float32)
-        _, _, g_s32, _ = om32.loss_and_grads(state, x, y3d, training=True)
     m.eval()
     with torch.no_grad():
         y_eval = m(x)
@@ -233,45 +257,54 @@ def test_full_size_values_against_stock_torch(J, arc, ch, B, variant, monkeypatc
     m.zero_grad()
     y = m(x)
     loss = torch.mean(torch.norm(y - y3d, dim=-1))
+    decisions = plan_decisions(y.grad_fn.sv, J)
     loss.backward()
+    adj = go.adj_from_parents(PARENTS[J])
+    with go.use_backend(torch_ops):      # float64: the reference is the truth, the differences are the HIP path's
+        om = go.OracleModel(adj, list(arc), ch, dropout=0.0, variant=variant, dtype=torch.float64)
+        y_eval_ref, _ = om.forward(state, x, training=False)
+        loss_ref, y_ref, g_ref, buf_ref = om.loss_and_grads(state, x, y3d, training=True)
+        (_, _, g_forced, _), flips, flip_max = forced_oracle(lambda: om.loss_and_grads(state, x, y3d, training=True), decisions)
+        # the same stock operators in fp32: the yard-stick for what fp32 delivers on the unforced distance
+        om32 = go.OracleModel(adj, list(arc), ch, dropout=0.0, variant=variant, dtype=torch.float32)
+        _, _, g_s32, _ = om32.loss_and_grads(state, x, y3d, training=True)
     e_eval = (y_eval.double() - y_eval_ref.v).abs().max().item()
     e_train = (y.double() - y_ref).abs().max().item()
-    # Gradients.  An fp32 ReLU input within round-off of zero is undecidable and flips a whole contribution, and the attention
-    # score gradients are sums of cancelling terms: ANY fp32 implementation is percents off the float64 truth on some tensors at
-    # these sizes (the tie-aware numpy oracle of the smaller tests resolves the flips; here they are measured against the stock
-    # fp32 operators: all gradients as one vector, relative L2 distance to the truth -- measured ours / stock: 1.5e-3 / 1.6e-3 at
-    # B=128 dilated, 1.4e-3 / 1.2e-3 strided, 4.7e-3 / 8.3e-2 for arc 3,3,3,3, 1.6e-3 / 2.5e-3 for J=19, 1e-5 / 2.2e-3 for J=15).
-    # Criterion: in aggregate no worse than 3e-3 or 3x the stock operators; per tensor 3e-2 of its norm (floored at 1e-4 of the
-    # model's largest gradient).  Which tensor a flip lands in differs between implementations, so a per-tensor ratio is not
-    # a stable yard-stick (the 'score' below is logged only).
     gmax = max(float(v.abs().max()) for v in g_ref.values())
-    worst, worst_rel, tot_d, tot_s, tot_r = ('', 0.0, 0.0, 0.0), ('', 0.0), 0.0, 0.0, 0.0
+    worst_t, worst_e, tot_f, tot_d, tot_s, tot_r = ('', 0.0), ('', 0.0), 0.0, 0.0, 0.0, 0.0
     for k, p in m.named_parameters():
-        r = g_ref[k]
-        d_ours = float((p.grad.double() - r).norm())
-        d_stock = float((g_s32[k].double() - r).norm())
-        nr = float(r.norm()) + 1e-4 * gmax * r.numel() ** 0.5
-        score = d_ours / (3 * d_stock + 2e-4 * nr)
-        if score > worst[1]:
-            worst = (k, score, d_ours / nr, d_stock / nr)
-        # (the attention-score parameters are sums of cancelling softmax-backward terms over all positions: their relative
-        #  error moves between 1e-2 and 3.4e-2 from run to run with the atomics order; stock fp32 shows the same -- bound 1e-1)
-        rel = d_ours / nr * (0.3 if k.endswith(BF16_NOISY) else 1.0)
-        if rel > worst_rel[1]:
-            worst_rel = (k, rel)
-        tot_d += d_ours ** 2; tot_s += d_stock ** 2; tot_r += float(r.norm()) ** 2
-    agg_ours, agg_stock = (tot_d / tot_r) ** 0.5, (tot_s / tot_r) ** 0.5
-    _log(test='stock_torch_full_%d_%s_c%d_b%d_%s' % (J, ''.join(map(str, arc)), ch, B, variant), eval_err=e_eval, train_err=e_train,
-         dloss=abs(loss.item() - loss_ref), worst_score_vs_stock=worst, worst_tensor_rel_l2=worst_rel, grad_rel_l2_all=(agg_ours, agg_stock))
-    assert e_eval < 1e-4 and e_train < 1e-4, (e_eval, e_train)
-    assert abs(loss.item() - loss_ref) < 1e-5
-    assert worst_rel[1] < 3e-2, worst_rel
-    assert agg_ours < max(3e-3, 3 * agg_stock), (agg_ours, agg_stock)
+        g = p.grad.double()
+        r, rf_ = g_ref[k], g_forced[k]
+        nr = float(rf_.norm()) + 1e-4 * gmax * rf_.numel() ** 0.5
+        # (the attention-score parameters are sums of cancelling softmax-backward terms over all positions: fp32 atomics order moves
+        #  them by percents of their own -- tiny -- norm; weighted 0.3 as before)
+        rel = float((g - rf_).norm()) / nr * (0.3 if k.endswith(BF16_NOISY) else 1.0)
+        if rel > worst_t[1]:
+            worst_t = (k, rel)
+        el = float((g - rf_).abs().max()) / (float(rf_.abs().max()) + 1e-4 * gmax) * (0.3 if k.endswith(BF16_NOISY) else 1.0)
+        if k not in ZERO_GRADS and el > worst_e[1]:
+            worst_e = (k, el)
+        tot_f += float((g - rf_).norm()) ** 2
+        tot_d += float((g - r).norm()) ** 2
+        tot_s += float((g_s32[k].double() - r).norm()) ** 2
+        tot_r += float(r.norm()) ** 2
+    agg_forced, agg_unforced, agg_stock = (tot_f / tot_r) ** 0.5, (tot_d / tot_r) ** 0.5, (tot_s / tot_r) ** 0.5
+    berr = 0.0
     for k, b in m.named_buffers():
         if k.endswith('num_batches_tracked'):
             assert int(b) == int(buf_ref[k])
         else:
-            assert (b.double() - buf_ref[k]).abs().max().item() < 1e-4 * max(1.0, float(buf_ref[k].abs().max())), k
+            berr = max(berr, (b.double() - buf_ref[k]).abs().max().item() / max(1.0, float(buf_ref[k].abs().max())))
+    _log(test='stock_torch_full_%d_%s_c%d_b%d_%s' % (J, ''.join(map(str, arc)), ch, B, variant), mode=mode, eval_err=e_eval, train_err=e_train,
+         dloss=abs(loss.item() - loss_ref), relu_flips=flips, relu_flip_max=flip_max, grad_rel_l2_forced=agg_forced,
+         grad_rel_l2_unforced=(agg_unforced, agg_stock), worst_tensor_rel_l2_forced=worst_t, worst_elem_forced=worst_e, buffer_err=berr)
+    assert e_eval < tol['out'] and e_train < tol['out'], (e_eval, e_train)
+    assert abs(loss.item() - loss_ref) < tol['loss']
+    assert flip_max < FLIP_EPS[mode], (flips, flip_max)
+    assert agg_forced < tol['agg'], agg_forced
+    assert worst_t[1] < tol['tensor'], worst_t
+    assert worst_e[1] < tol['elem'], worst_e
+    assert berr < tol['buf'], berr
 
 
 @pytest.mark.parametrize('J,arc,B', [(17, (3, 3, 3, 3), 256), (19, (3, 3, 3), 64), (15, (3, 3, 3), 32)])
@@ -460,9 +493,8 @@ def test_bf16_vs_fp32_full_size(monkeypatch):
     check_train('centred_warm')
 
 
-def test_dropout_statistics():
+def test_dropout_statistics(mode2):
     """Train-mode dropout cannot match torch's RNG stream; check that it is active, unbiased and reproducible per seed."""
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=32, causal=False, variant='dilated')
     torch.manual_seed(1)
     m = build(cfg, dropout=0.25).cuda().train()
@@ -484,8 +516,9 @@ def test_cpu_input_raises_loudly():
         m(torch.zeros(1, 9, 17, 2))
 
 
-def test_training_trajectory_matches_reference():
-    """P6: 12 training steps -- this model + gast_hip.loss.mpjpe + gast_hip.optim.FlatAdam(amsgrad) in fp32 --
+def test_training_trajectory_matches_reference(mode2):
+    """P6: 12 training steps -- this model + gast_hip.loss.mpjpe + gast_hip.optim.FlatAdam(amsgrad), in fp32 and in
+    bf16x3 (the arithmetic bench.py times: "MPJPE within 0.1 mm of reference" must hold for the timed mode) --
     against the reference's own trajectory (reference model + common.loss.mpjpe + optim.Adam(amsgrad=True) on CPU,
     tests/golden/make_golden_trajectory.py): same init, same three batches cycled, dropout 0.
     Adam divides by sqrt(v): a parameter whose gradient is round-off (init_bn.bias, g.bias, ... mathematically zero) still moves
@@ -495,7 +528,6 @@ def test_training_trajectory_matches_reference():
     0.1 mm (measured <= 5e-3), the whole trajectory within 2 mm, the final eval prediction within 1e-2."""
     from gast_hip.loss import mpjpe
     from gast_hip.optim import FlatAdam
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
     z = np.load(os.path.join(os.path.dirname(__file__), 'golden', 'trajectory_j17_a333_c16_str.npz'))
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3, 3], channels=16, causal=False, variant='strided')
     m = build(cfg)
@@ -517,18 +549,17 @@ def test_training_trajectory_matches_reference():
     err_final = float((y.cpu() - torch.from_numpy(z['y_final'])).abs().max())
     perr = {k[len('final/'):]: float(np.abs(m.state_dict()[k[len('final/'):]].cpu().numpy() - z[k]).max())
             for k in z.files if k.startswith('final/')}
-    _log(test='trajectory', per_step_dloss_mm=per_step, worst_dloss_mm=worst, err_final=err_final, param_err=perr)
+    _log(test='trajectory', mode=mode2, per_step_dloss_mm=per_step, worst_dloss_mm=worst, err_final=err_final, param_err=perr)
     assert max(per_step[:4]) < 0.1, per_step         # "MPJPE within 0.1 mm" while round-off has not been amplified yet (measured <= 5e-3)
     assert worst < 2.0, per_step
     assert err_final < 1e-2, err_final               # eval prediction after 12 Adam steps (outputs of magnitude ~1)
     assert all(v < 1.2e-2 for v in perr.values()), perr      # at most lr per step and parameter
 
 
-def test_flat_gradient_buffer_accumulates_like_autograd():
+def test_flat_gradient_buffer_accumulates_like_autograd(mode2):
     """With a flat gradient sink (FlatGradAllReduce / FlatAdam) every gradient kernel adds into the caller's buffer: two backward
     passes without zeroing give twice the gradient of one, and equal the sink-less autograd result."""
     from gast_hip.dist import FlatGradAllReduce
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
     torch.manual_seed(3)
     m = build(cfg).cuda().train()
@@ -551,12 +582,13 @@ def test_flat_gradient_buffer_accumulates_like_autograd():
         assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 2e-5, k
 
 
-def test_dropout_gradients_by_finite_differences():
+def test_dropout_gradients_by_finite_differences(monkeypatch):
     """With dropout active the backward pass must use exactly the masks of its forward pass (they are regenerated from the counter
     stream at four places: the materialised local|global post-activation, the branch input-gradient epilogue, the temporal
     residual and its backward).  Independent check: central finite differences of the loss along random parameter directions
-    with the dropout seed pinned, fp32."""
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
+    with the dropout seed pinned, fp32 (a property of the mask bookkeeping, not of the GEMM arithmetic; the split products' rounding is
+    not a smooth function of the weights, so finite differences at eps = 2.5e-4 are taken in fp32 only)."""
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
     torch.manual_seed(11)
     m = build(cfg, dropout=0.25).cuda().train()
@@ -651,10 +683,9 @@ def test_module_graph_mode_matches_eager(mode, monkeypatch):
     p2.sum().backward()
 
 
-def test_eval_mode_gradients_on_gpu():
+def test_eval_mode_gradients_on_gpu(mode2):
     """Gradients of an eval-mode forward (frozen BatchNorm): BatchNorm backward with the running statistics, vs the oracle."""
     from oracle import gast_oracle as go
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
     cfg, z, state, grads, post = load_golden('j17_a333_c16_dil')
     m = build(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)
@@ -665,21 +696,23 @@ def test_eval_mode_gradients_on_gpu():
     m.cuda().eval()
     y = m(torch.from_numpy(z['x']).cuda())
     loss = torch.mean(torch.norm(y - torch.from_numpy(z['y3d']).cuda(), dim=-1))
+    decisions = plan_decisions(y.grad_fn.sv, cfg['J'])
     loss.backward()
     assert float(np.abs(y.detach().cpu().numpy() - y_ref).max()) < 1e-4
     assert abs(loss.item() - loss_ref) < 1e-5
-    worst = _grad_errors(m, g_ref, FP32_GRAD_TOL)
+    run = lambda: om.loss_and_grads(st, z['x'], z['y3d'], training=False)[2]      # noqa: E731
+    worst, info = (_check_fp32_grads(m, g_ref, run, decisions=decisions) if mode2 == 'fp32' else _check_x3_grads(m, g_ref, run, decisions))
+    _log(test='eval_mode_grads', mode=mode2, worst=worst, **info)
     assert worst[1] <= 1.0, worst
     for k, b in m.named_buffers():
         np.testing.assert_array_equal(b.cpu().numpy(), st[k], err_msg=k)
 
 
-def test_data_parallel_replicas():
+def test_data_parallel_replicas(mode2):
     """reference trainval.py:56-61 wraps the model in nn.DataParallel whenever more than one GPU is visible.  (a) the replicas
     torch.nn.parallel.replicate makes (broadcast, non-leaf parameter copies; here two on the one device, run one after the other)
     reproduce the master's outputs and send their gradients back to the master's parameters; (b) with >= 2 GPUs the real
     nn.DataParallel(device_ids=[0, 1]) forward/backward equals the single-device result on the two half batches."""
-    os.environ['GAST_HIP_DTYPE'] = 'fp32'
     cfg, z, state, grads, post = load_golden('j17_a333_c16_dil')
     m = build(cfg)
     m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()}, strict=True)

@@ -46,13 +46,16 @@ def test_plan_matches_reference_golden(name, centered, monkeypatch):
     y3d = torch.from_numpy(z['y3d'])
     loss = torch.mean(torch.norm(y - y3d, dim=-1))
     assert abs(loss.item() - float(z['loss'])) < 1e-5
+    from plan_decisions import plan_decisions
+    decisions = plan_decisions(y.grad_fn.sv, cfg['J'])      # (what the plan decided at every ReLU / LeakyReLU, before backward frees it)
     loss.backward()
-    # gradients: 2e-4 of max|ref| per parameter; ReLU inputs within 1e-6 of zero are undecidable between two fp32 summation orders
-    # (the golden j17_a333_c16_dil_causal has one at |z| ~ 3e-8) and are evaluated both ways by the oracle (parity_helpers)
+    # gradients: 2e-4 of max|ref| per parameter; ReLU inputs within round-off of zero are undecidable between two fp32 summation
+    # orders (the golden j17_a333_c16_dil_causal has one at |z| ~ 3e-8, the 245-frame j17_a33333_c8_dil twelve below 1e-6): when the
+    # strict check fails the float64 oracle is evaluated on the branch the plan took (tests/plan_decisions.py, parity_helpers)
     from oracle import gast_oracle as go
     from parity_helpers import _check_fp32_grads
     om = go.OracleModel(go.adj_from_parents(cfg['parents']), cfg['arc'], cfg['channels'], causal=cfg['causal'], variant=cfg['variant'])
-    worst, info = _check_fp32_grads(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2])
+    worst, info = _check_fp32_grads(m, grads, lambda: om.loss_and_grads(state, z['x'], z['y3d'])[2], decisions=decisions)
     assert worst[1] <= 1.0, (worst, info)
     for k, b in m.named_buffers():
         if k.endswith('num_batches_tracked'):

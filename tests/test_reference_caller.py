@@ -81,8 +81,9 @@ def _p_mpjpe(predicted, target):
 @pytest.mark.gpu
 @pytest.mark.parametrize('graph', ['eager', 'module_graphs'])
 @pytest.mark.parametrize('size', ['short', 'epoch'])
-def test_caller_steps_on_the_gpu(size, graph, monkeypatch):
-    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+@pytest.mark.parametrize('arith', ['fp32', 'bf16x3'])
+def test_caller_steps_on_the_gpu(size, graph, arith, monkeypatch):
+    monkeypatch.setenv('GAST_HIP_DTYPE', arith)      # the reference's arithmetic and the one bench.py times
     # module_graphs: GAST_HIP_GRAPH=1 -- from the third batch of a shape on, model(x) / loss.backward() replay captured hipGraphs
     monkeypatch.setenv('GAST_HIP_GRAPH', '1' if graph == 'module_graphs' else '0')
     from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
