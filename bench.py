@@ -371,7 +371,17 @@ def main():
                     help='single process: still create the RCCL process group and run the all-reduce / barriers of the N > 1 path '
                          '(exercises that code path on a 1-GPU box)')
     ap.add_argument('--torch-tail', action='store_true', help='eager mpjpe formula + torch fused Adam instead of the HIP loss/optimizer')
+    ap.add_argument('--no-twin', action='store_true', help='skip the second model variant (SpatioTemporalModelOptimized1f) in the N = 1 line')
+    ap.add_argument('--dry-run-cpu', action='store_true',
+                    help='LAUNCHER DRY RUN, not a measurement: the same self-launch / rendezvous / per-rank seeds / (bucketed) gradient exchange / '
+                         'single JSON line on rank 0, over the gloo backend with the kernels replaced by the test-suite\'s numpy op mirror '
+                         '(tests/fake_backend.py); `value` is null.  Exists so that the first multi-GPU run is not the first execution of '
+                         'that code (tests/test_dist_cpu.py)')
     args = ap.parse_args()
+    dry = args.dry_run_cpu
+    if dry:
+        args.no_graph = args.no_parity = args.no_cpu_baseline = args.no_kernel_timer = args.no_eager = args.no_twin = True
+        args.torch_tail = True        # (the fused loss / flat Adam are HIP launches without a CPU form)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
@@ -381,8 +391,11 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        if dry:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group('nccl', rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
     elif args.gpus > 1:
         # not under torchrun: start the N ranks ourselves (one process per GPU, RCCL over xGMI) and relay rank 0's JSON line
         import socket
@@ -394,7 +407,15 @@ def main():
         cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr',
                '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd, env=env))
-    dev = torch.device('cuda', local_rank)
+    dev = torch.device('cpu') if dry else torch.device('cuda', local_rank)
+    if dry:
+        args.dtype = 'fp32'
+        sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+        def _sync():
+            pass
+    else:
+        _sync = torch.cuda.synchronize
     os.environ['GAST_HIP_DTYPE'] = args.dtype
     cfg = CONFIGS[args.config]
     J, arc = cfg['J'], cfg['arc']
@@ -412,6 +433,9 @@ def main():
     cls = SpatioTemporalModel if args.variant == 'dilated' else SpatioTemporalModelOptimized1f
     adj = adj_from_parents(PARENTS[J])
     model = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.05, channels=C).to(dev)
+    if dry:
+        from fake_backend import use_oracle_ops      # (dry run only: the host plan on the numpy mirror of the op set)
+        use_oracle_ops(model)
     model.train()
     g = torch.Generator().manual_seed(1234 + rank)     # reference generator seed (common/generators.py:26), per-rank shard
     x = (torch.rand(B, T, J, 2, generator=g) * 2 - 1).to(dev)
@@ -440,8 +464,11 @@ def main():
             parity = {'mode': 'train-mode forward (batch-statistic BatchNorm), dropout off, same weights and batch as the timed step',
                       'dtype': args.dtype, 'output_abs_max': round(float(outs['fp32'][0].abs().max()), 4),
                       'vs_fp32_hip': {'max_abs': d32, 'mpjpe_shift_mm': abs(outs[args.dtype][1] - outs['fp32'][1]) * 1e3},
-                      'tolerance': {'max_abs': 1e-4 if args.dtype == 'fp32' else 1e-2, 'mpjpe_mm': 0.1,
-                                    'source': 'BASELINE.json north_star: 1e-4 fp32 / 1e-2 bf16, MPJPE within 0.1 mm'}}
+                      # bf16x3 is fp32 storage with fp32-class products: it is gated at 2e-4 (twice the north star's fp32 bound; measured
+                      # 7e-5 .. 1.2e-4 over the BASELINE configs), NOT at the 1e-2 the north star grants bf16
+                      'tolerance': {'max_abs': {'fp32': 1e-4, 'bf16x3': 2e-4}.get(args.dtype, 1e-2), 'mpjpe_mm': 0.1,
+                                    'source': 'BASELINE.json north_star: 1e-4 fp32 / 1e-2 bf16, MPJPE within 0.1 mm; bf16x3 '
+                                              '(fp32 storage, split-bf16 products) is held to 2e-4'}}
             if world == 1 and not args.no_cpu_baseline:
                 yc, lc = cpu_reference_forward(sd, adj, arc, C, x, y3d)
                 dc = float((outs[args.dtype][0].cpu() - yc).abs().max())
@@ -458,7 +485,7 @@ def main():
     sync.force = args.force_collective
     use_graph = not args.no_graph
     if args.torch_tail:   # the eager-formula loss and torch's fused multi-tensor Adam (comparison only)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, fused=True, capturable=use_graph)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, amsgrad=True, **({} if dry else dict(fused=True, capturable=use_graph)))
         loss_fn = lambda p, t: torch.mean(torch.norm(p - t, dim=-1))    # noqa: E731 -- mpjpe, reference common/loss.py:5-11
     else:                 # reference trainval.py:78 Adam(amsgrad=True) / common/loss.py mpjpe as single HIP launches (row f1)
         from gast_hip.optim import FlatAdam
@@ -535,19 +562,21 @@ def main():
             return step()
         return static_loss
 
+    def barrier():
+        if collective:
+            dist.barrier() if dry else dist.barrier(device_ids=[local_rank])
+
     for _ in range(args.warmup):
         run_step()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
+    _sync()
+    barrier()
+    _sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run_step()
-    torch.cuda.synchronize()
-    if collective:
-        dist.barrier(device_ids=[local_rank])
-    torch.cuda.synchronize()
+    _sync()
+    barrier()
+    _sync()
     elapsed = time.perf_counter() - t0
     per_rank_ms = None
     if collective:
@@ -585,7 +614,7 @@ def main():
             print('module graph leg failed: %s' % (str(e).splitlines()[0][:200],), file=sys.stderr)
         finally:
             model._runner.graph_mode = False
-            model._runner._graphs = {}
+            model._runner._graphs.clear()
     # ---- per-kernel durations: the same step, eagerly, with a HIP-event pair around every launch (events cannot be
     # recorded inside a replayed graph; the kernels and their arguments are identical to the replayed ones)
     if timer and rank == 0:
@@ -626,13 +655,60 @@ def main():
         except Exception:
             fwd_ms = None
 
+    # ---- "report both model variants".  The headline (`value`) is the north-star-named dilated SpatioTemporalModel;
+    # the twin the reference actually trains with at stride 1 (SpatioTemporalModelOptimized1f, reference main.py:166-171) is timed here in
+    # the same run, same config / batch / arithmetic / step definition / steps / warm-up, as its own replayed hipGraph.
+    twin = None
+    if rank == 0 and world == 1 and not args.no_twin and use_graph and mode == 'full' and not args.torch_tail:
+        try:
+            tcls = SpatioTemporalModelOptimized1f if args.variant == 'dilated' else SpatioTemporalModel
+            torch.manual_seed(0)
+            tm = tcls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.05, channels=C).to(dev).train()
+            tsync = FlatGradAllReduce(tm.parameters(), model=tm, buckets=1)
+            topt = FlatAdam(tm.parameters(), lr=1e-3, amsgrad=True, ops=tm._runner.engine.ops)
+            tsync.attach(topt)
+
+            def tstep():
+                tsync.zero_()
+                l_ = loss_fn(tm(x), y3d)
+                l_.backward()
+                tsync.sync()
+                topt.step()
+                return l_
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    tstep()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            tg = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(tg):
+                tloss = tstep()
+            for _ in range(args.warmup):
+                tg.replay()
+            torch.cuda.synchronize()
+            tt0 = time.perf_counter()
+            for _ in range(args.steps):
+                tg.replay()
+            torch.cuda.synchronize()
+            tms = (time.perf_counter() - tt0) / args.steps * 1e3
+            twin = {'variant': 'strided' if args.variant == 'dilated' else 'dilated', 'model': tcls.__name__, 'ms_per_step': round(tms, 4),
+                    'sequences_per_s': round(B / tms * 1e3, 1), 'steps': args.steps, 'warmup': args.warmup, 'loss_last': round(float(tloss.item()), 6),
+                    'note': 'same config, batch, arithmetic and step definition as `value`, own hipGraph; the strided twin does 0.31x the '
+                            'FLOPs of the dilated model on T = RF windows (SURVEY.md App. C) and is what reference main.py:166-171 trains'}
+            del tm, tsync, topt, tg
+        except Exception as e:   # noqa: BLE001 -- never lose the bench line to this leg
+            twin = {'error': str(e).splitlines()[0][:200]}
+
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         value = world * B * args.steps / elapsed
         out = {
-            'metric': 'sequences/sec (B=%d, T=%d, J=%d) fwd+bwd' % (B, T, J), 'value': round(value, 1), 'unit': 'sequences/s',
+            'metric': 'sequences/sec (B=%d, T=%d, J=%d) fwd+bwd' % (B, T, J), 'value': None if dry else round(value, 1), 'unit': 'sequences/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
+            'data': 'synthetic' if not dry else 'DRY RUN of the launcher on CPU (gloo, numpy op mirror): not a measurement',
             'config': {'workload': 'BASELINE.json %s; SpatioTemporalModel J=%d arc %s (RF %d) channels=%d, '
                                    'B=%d/GPU x T=%d, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)%s'
                                    % (cfg['what'], J, ','.join(map(str, arc)), T, C, B, T,
@@ -647,9 +723,22 @@ def main():
                                              'weight gradients, statistics and softmax as in bf16 mode'}[args.dtype],
                        'loss_last': round(float(loss.item()), 6), 'launch': graph_note,
                        'rccl_world_size': world if collective else None,
-                       'gradient_exchange': (None if not collective else ('3 buckets all-reduced on a communication stream during backward'
-                                                                         if len(sync.ranges) > 1 else 'one flat all-reduce after backward'))},
+                       'collective_backend': None if not collective else ('gloo (dry run)' if dry else 'nccl (= RCCL over xGMI)'),
+                       'per_rank_input_seeds': [1234 + r for r in range(world)],
+                       'gradient_exchange': (None if not collective else {
+                           'what': ('%d buckets of the flat fp32 gradient buffer, each all-reduced on a communication stream as soon as its '
+                                    'stage of the backward pass is done' % len(sync.ranges)) if len(sync.ranges) > 1
+                                   else 'one all-reduce(sum) of the flat fp32 gradient buffer after backward',
+                           'bytes_per_step': sync.nbytes(), 'buckets': len(sync.ranges),
+                           'bucket_bytes': [4 * (b_ - a_) for a_, b_ in sync.ranges],
+                           'overlap_with_backward': len(sync.ranges) > 1,
+                           'averaging': '1/world folded into the Adam kernel (grad_scale)' if sync.scale_in_optimizer else 'in-place scale after the all-reduce'})},
         }
+        if dry:
+            out['dry_run'] = True
+        if world > 1:
+            out['cpu_baseline'] = None
+            out['cpu_baseline_note'] = 'reported by the N = 1 run only (rank 0 at N = 1 times the CPU restatement; see BENCH line of --gpus 1)'
         if eager_ms is not None:
             if module_graph_ms is not None:
                 out['module_graph'] = {'ms_per_step': round(module_graph_ms, 4), 'sequences_per_s': round(B / module_graph_ms * 1e3, 1),
@@ -658,6 +747,9 @@ def main():
             out['eager_launch'] = {'ms_per_step': round(eager_ms, 4), 'sequences_per_s': round(B / eager_ms * 1e3, 1),
                                    'note': 'the same step with every kernel launched eagerly from Python (ctypes), i.e. the speed of an '
                                            'unchanged training loop around the drop-in module; `value` replays the step as one hipGraph'}
+        if twin is not None:
+            out['variants'] = {args.variant: {'ms_per_step': round(ms, 4), 'sequences_per_s': round(value, 1), 'headline': True},
+                               twin.get('variant', 'twin'): twin}
         if collective:
             out['per_rank_ms_per_step'] = per_rank_ms
         if parity is not None:

@@ -24,6 +24,7 @@
 #include "gemm_big.h"
 #include <stdlib.h>
 #include <stdio.h>
+#include <atomic>
 
 namespace {
 
@@ -501,7 +502,7 @@ __global__ void __launch_bounds__(256) x3_image_kernel(const ImageBatch b) {
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
-bool big_setup_done[64] = {};
+std::atomic<bool> big_setup_done[64];      // (zero-initialised: static storage)
 
 }  // namespace
 
@@ -609,13 +610,13 @@ static void big_setup() {
     int dev = 0;
     hipGetDevice(&dev);               // function attributes are per device (nn.DataParallel replicas launch on several)
     dev &= 63;
-    if (big_setup_done[dev]) return;
+    if (big_setup_done[dev].load(std::memory_order_acquire)) return;      // (idempotent set-up: a racing first call repeats it)
     for (int c = 0; c < 3; ++c) {          // (NI, MW) = (2, 2), (4, 2), (4, 4)
         const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
         for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
         for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
     }
-    big_setup_done[dev] = true;
+    big_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BIG_DEBUG")) {
         for (int c = 0; c < 3; ++c) {
             const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;

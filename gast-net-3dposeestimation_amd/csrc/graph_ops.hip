@@ -3,6 +3,7 @@
 // (reference model/global_attention.py:52-82).  All of them are HBM/latency bound (AI < 5 F/B): coalesced channel-major
 // accesses, the J x J tiles live in LDS, no MFMA.
 #include "common.h"
+#include <atomic>
 
 namespace {
 
@@ -1477,6 +1478,20 @@ static int attn_blocks_per_cu(const void* kernel, size_t smem) {
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, 256, smem) != hipSuccess || nb < 1) nb = 1;
     return nb;
 }
+// The occupancy of one kernel instantiation (its dynamic LDS size is a compile-time constant of the instantiation), cached PER DEVICE:
+// nn.DataParallel replicas launch from several threads on several devices.  A racing first call computes the same value twice.
+struct AttnOcc {
+    std::atomic<int> v[64];
+    AttnOcc() { for (auto& x : v) x.store(0, std::memory_order_relaxed); }
+    int get(const void* kernel, size_t smem) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        dev &= 63;
+        int nb = v[dev].load(std::memory_order_relaxed);
+        if (nb == 0) { nb = attn_blocks_per_cu(kernel, smem); v[dev].store(nb, std::memory_order_relaxed); }
+        return nb;
+    }
+};
 
 // bf16 + 16-byte aligned row tiles: the MFMA kernels (GAST_ATTN_MFMA=0 keeps the VALU wave kernels)
 static bool attn_mfma_ok(int ld_a, const void* a, int ld_b, const void* b) {
@@ -1506,7 +1521,8 @@ static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac
         hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    static const int per_cu = sizeof(T) == 4 ? attn_blocks_per_cu((const void*)attn_fwd_wave_kernel<T, CI4>, smem) : 0;
+    static AttnOcc occ;
+    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_fwd_wave_kernel<T, CI4>, smem) : 0;
     hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads, per_cu)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
                        ldac, C_k, F, J, nheads, (T*)Y, ldy);
     GAST_CHECK_LAUNCH();
@@ -1517,7 +1533,8 @@ template <typename T, int CI4>
 static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                 int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
                                 hipStream_t st) {
-    static const int per_cu = sizeof(T) == 4 ? attn_blocks_per_cu((const void*)attn_bwd_wave_kernel<T, CI4>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
+    static AttnOcc occ;
+    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_bwd_wave_kernel<T, CI4>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
     const int grid = attn_wave_grid(F, nheads, per_cu);
     const int C = nheads * CI4 * 4;
     const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;

@@ -90,7 +90,10 @@ class FlatGradAllReduce:
 
     def bucket_ready(self, i):
         """Called by the model's backward (bucketed mode) when `ranges[i]` holds its final local gradients."""
-        assert i == self._issued, 'buckets complete in order'
+        if i != self._issued:
+            # a second backward() before sync() (gradient accumulation) would all-reduce ranges that already hold reduced sums
+            raise RuntimeError('bucketed all-reduce: bucket %d reported complete, bucket %d expected -- the bucketed exchange runs ONE '
+                               'backward() per sync() (no gradient accumulation; use the monolithic mode for that)' % (i, self._issued))
         self._issued += 1
         if not self._active():
             return
@@ -107,6 +110,7 @@ class FlatGradAllReduce:
     def sync(self):
         """sum over ranks / world size, in place; no-op for a single process."""
         if not self._active():
+            self._issued = 0
             return
         if len(self.ranges) > 1:
             if self._issued != len(self.ranges):
@@ -117,6 +121,7 @@ class FlatGradAllReduce:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         if not self.scale_in_optimizer:
             self.flat.mul_(1.0 / self.world)
+        self._issued = 0      # the next backward starts a new round whichever way the buffer gets zeroed (zero_(), FlatAdam.zero_grad(), ...)
 
     def nbytes(self):
         return self.flat.numel() * 4

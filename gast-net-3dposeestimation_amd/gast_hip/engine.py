@@ -157,7 +157,10 @@ class Engine:
             groups += [(g + 'bnY', [g + 'bn_1', g + 'bn_2']), (g + 'bnLG', [g + 'lcat_bn', g + 'gcat_bn']), (g + 'bnO', [g + 'cat_bn'])]
         total = sum((sum(inp[k + '.weight'].numel() for k in keys) + 3) // 4 * 4 for _, keys in groups)
         if need_grad and self.centered:
-            raise NotImplementedError('gradients of an eval-mode forward are not available with GAST_HIP_CENTER=1')
+            # (an eval-mode forward with autograd merely enabled is common and must work; only an actual backward() is unsupported
+            # with centred storage -- Engine.backward raises)
+            need_grad = False
+            self._no_eval_grad = True
         table = torch.empty(4 if need_grad else 2, total, dtype=torch.float32, device=dev)
         jobs, out, o = {}, {}, 0
         for name, keys in groups:
@@ -234,7 +237,9 @@ class Engine:
         use_drop = training and drop is not None and drop.thresh != 0
         za = self.za
         za.begin(('fwd', tuple(x.shape), dt, training), dev)
+        self._no_eval_grad = False
         self._pre = {} if training else self._eval_table(inp, bufs, dev, need_grad)
+        sv['no_eval_grad'] = self._no_eval_grad
         pre = self._pre.get
 
         # ---- init_bn statistics + expand conv (gast_net.py:163-164)
@@ -488,6 +493,8 @@ class Engine:
         (its weight gradients flushed, its adjacency-softmax backward run): the hook of the bucketed gradient exchange."""
         sp, ops = self.spec, self.ops
         dev = dpred.device
+        if sv.get('no_eval_grad'):
+            raise NotImplementedError('gradients of an eval-mode forward are not available with GAST_HIP_CENTER=1')
         B, dt, drop = sv['B'], sv['dt'], sv['drop']
         J = sp.J
         T = sv['T']

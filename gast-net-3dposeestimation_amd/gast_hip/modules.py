@@ -14,10 +14,13 @@ its own over the same kernels:
     SingleGlobalGraph               one full-width head -> bn -> ReLU (+ dropout)                     :148-173
     GraphAttentionBlock             cat(x, local, global) as three K segments -> cat_conv + cat_bn -> ReLU      gast_net.py:22-33
 
-Forward only (inference, feature extraction, unit checks): the hand-written backward exists for the fused plan, not for these
-entry points, so they raise when autograd would have to record them.  fp32, device tensors, no CPU fallback.  Train mode uses
-batch statistics and updates the running statistics exactly like nn.BatchNorm2d; nn.Dropout in train mode uses the library's
-counter-hash stream (same distribution as torch's, not the same stream -- as in the fused plan).
+Two paths per module.  Under torch.no_grad() (inference, feature extraction): the fused forward plans below (BatchNorm + ReLU applied
+in the consumers' load prologues, statistics from the producers' epilogues).  When autograd has to record the call (a parameter or the
+input requires a gradient): the same arithmetic composed from the four differentiable blocks of gast_hip/autograd_ops.py (Gemm, BnRelu,
+SemchAgg, Attn), whose backward passes are the fused plan's own backward kernels -- the modules are trainable, including the gradient
+with respect to their input, like the reference's.  fp32, device tensors, no CPU fallback.  Train mode uses batch statistics and
+updates the running statistics exactly like nn.BatchNorm2d; nn.Dropout in train mode uses the library's counter-hash stream (same
+distribution as torch's, not the same stream -- as in the fused plan).
 """
 import functools
 
@@ -52,23 +55,25 @@ def _check(mod, x, ndim):
         raise RuntimeError('%s (MI355X build): input is on %s; this implementation has no CPU fallback' % (type(mod).__name__, x.device))
     if x.dim() != ndim:
         raise RuntimeError('%s: expected a %d-D input, got shape %s' % (type(mod).__name__, ndim, tuple(x.shape)))
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters())):
-        raise NotImplementedError('%s (MI355X build): the stand-alone forward is inference-only (wrap the call in torch.no_grad()); '
-                                  'gradients are implemented for the fused plan of SpatioTemporalModel' % type(mod).__name__)
     return x.contiguous().float()
 
 
-def _pattern(mod, pat, dev):
-    """device pattern table (+ nnz, row degree) of a 0/1 (J, J) pattern, cached on the module"""
+def _needs_grad(mod, x):
+    """does autograd have to record this call?  (then the differentiable composition runs instead of the fused forward plan)"""
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in mod.parameters()))
+
+
+def _pattern(mod, pat, dev, full=False):
+    """device pattern table (+ nnz, max row degree[, max column degree]) of a 0/1 (J, J) pattern, cached on the module"""
     from model.local_attention import pattern_table
     cache = mod.__dict__.setdefault('_gast_pat', {})
     key = str(dev)
     if key not in cache:
         tab, nnz = pattern_table(pat)
         J = pat.shape[0]
-        dr = int(tab[2 + 2 * (J + 1) + 3 * nnz])
-        cache[key] = (tab.to(dev), nnz, dr)
-    return cache[key]
+        off = 2 + 2 * (J + 1) + 3 * nnz
+        cache[key] = (tab.to(dev), nnz, int(tab[off]), int(tab[off + 1]))
+    return cache[key] if full else cache[key][:3]
 
 
 def _bn_state(ops, bn, partials, nblk, col0, n, count, scale, shift):
@@ -102,6 +107,57 @@ def _gemm_stats(ops, dom, N, segs, P, dev, bias=None):
     part = torch.zeros(nb, N, 2, dtype=torch.float32, device=dev)
     ops.gemm(dom, N, segs, out, ident(dom[1]), epi=EPI_STATS, partials=part, bias=bias)
     return out, part, nb
+
+
+# ------------------------------------------------------------------------------------------ differentiable compositions
+def _drop_state(mod_dropout, training, dev):
+    use, d = _dropout(mod_dropout, training, dev)
+    return d if use else None
+
+
+def _graph_conv_pair_grad(X, dom, convs, shared):
+    """differentiable twin of _graph_conv_pair: Y (P, 2 Cout)"""
+    from gast_hip.autograd_ops import Gemm, SemchAgg
+    B, T, J = dom
+    dev = X.device
+    Cout = convs[0].out_features
+    W4 = torch.cat([c.W[q].t() for c in convs for q in (0, 1)], dim=0)                       # [4 Cout][Cin]; autograd splits dW4 back
+    H = Gemm.apply(X, W4, None, dom)
+    metas, es = [], []
+    for c in convs:
+        pat = (c.adj if c.adj.dim() == 2 else c.adj[0]) > 0
+        tab, nnz, dr, dc = _pattern(c, pat, dev, full=True)
+        metas.append((tab, nnz, dr, dc))
+        es.append(c.e.expand(Cout, nnz) if shared else c.e)                                    # (shared: autograd sums de over the channels)
+    return SemchAgg.apply(H, es[0], es[1], (metas[0], metas[1], B * T, J, Cout))
+
+
+def _bnrelu_grad(X, bn, drop=None, salt=0):
+    from gast_hip.autograd_ops import BnRelu
+    return BnRelu.apply(X, bn.weight, bn.bias, bn, drop, salt)
+
+
+def _attention_grad(X, dom, heads):
+    """differentiable twin of _attention: theta / phi folded into one C-vector per head by torch ops on the parameters"""
+    from gast_hip.autograd_ops import Gemm, Attn
+    B, T, J = dom
+    C = X.shape[1]
+    Wg, bg, va, ba, vc, bc = [], [], [], [], [], []
+    for h in heads:
+        Ci = h.inter_channels
+        w = h.concat_project[0].weight.view(2 * Ci)
+        Wg.append(h.g.weight.view(h.g_channels, C))
+        bg.append(h.g.bias)
+        va.append(h.theta.weight.view(Ci, C).t() @ w[:Ci])
+        ba.append((w[:Ci] * h.theta.bias).sum().view(1))
+        vc.append(h.phi.weight.view(Ci, C).t() @ w[Ci:])
+        bc.append((w[Ci:] * h.phi.bias).sum().view(1))
+    W = torch.cat(Wg + [torch.stack(va), torch.stack(vc)], dim=0)
+    bias = torch.cat(bg + ba + bc)
+    H = Gemm.apply(X, W, bias, dom)
+    Cg = W.shape[0] - 2 * len(heads)
+    Ck = torch.stack([h.C_k for h in heads])
+    return Attn.apply(H[:, :Cg], H[:, Cg:], Ck, B * T, J, len(heads))
 
 
 # ------------------------------------------------------------------------------------------ SemCH / Sem graph convolution
@@ -138,7 +194,10 @@ def graph_conv_forward(mod, x, shared):
     sem_graph_conv.py:35-52): x (B, T, J, Cin) -> (B, T, J, Cout)"""
     x = _check(mod, x, 4)
     B, T, J, Cin = x.shape
-    Y, _, _ = _graph_conv_pair(_ops(), x.view(B * T * J, Cin), (B, T, J), (mod, mod), shared)
+    if _needs_grad(mod, x):
+        Y = _graph_conv_pair_grad(x.reshape(B * T * J, Cin), (B, T, J), (mod, mod), shared)
+    else:
+        Y, _, _ = _graph_conv_pair(_ops(), x.view(B * T * J, Cin), (B, T, J), (mod, mod), shared)
     out = Y[:, :mod.out_features].reshape(B, T, J, mod.out_features)
     if mod.bias is not None:
         out = out + mod.bias.view(1, 1, -1)
@@ -154,6 +213,20 @@ def local_graph_forward(mod, x, shared=False, dropout2d=False):
     B, T, J, C = x.shape
     P, dev, dom = B * T * J, x.device, (B, T, J)
     Co = mod.gcn_sym.out_features
+    if _needs_grad(mod, x):
+        from gast_hip.autograd_ops import Gemm
+        Y = _graph_conv_pair_grad(x.reshape(P, C), dom, (mod.gcn_sym, mod.gcn_con), shared)
+        if mod.gcn_sym.bias is not None or mod.gcn_con.bias is not None:
+            zero = torch.zeros(Co, dtype=torch.float32, device=dev)
+            Y = Y + torch.cat([zero if c.bias is None else c.bias for c in (mod.gcn_sym, mod.gcn_con)]).view(1, -1)
+        Z = torch.cat([_bnrelu_grad(Y[:, :Co], mod.bn_1), _bnrelu_grad(Y[:, Co:], mod.bn_2)], dim=1)
+        L = Gemm.apply(Z, mod.cat_conv.weight.view(Co, 2 * Co), None, dom)
+        if dropout2d:
+            out = _bnrelu_grad(L, mod.cat_bn).view(B, T, J, Co)
+            if mod.dropout is not None and mod.training:
+                out = mod.dropout(out.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+            return out
+        return _bnrelu_grad(L, mod.cat_bn, _drop_state(mod.dropout, mod.training, dev), 1).view(B, T, J, Co)
     Y, partY, nba = _graph_conv_pair(ops, x.view(P, C), dom, (mod.gcn_sym, mod.gcn_con), shared)
     if mod.gcn_sym.bias is not None or mod.gcn_con.bias is not None:
         # biased convolutions (SemGraphConv default): the bias shifts the BatchNorm input; statistics from a column pass
@@ -224,7 +297,7 @@ def global_graph_forward(mod, x):
     x = _check(mod, x, 3)
     F, C, J = x.shape
     X = x.permute(0, 2, 1).contiguous().view(F * J, C)
-    Ya = _attention(_ops(), X, (F, 1, J), [mod])
+    Ya = _attention_grad(X, (F, 1, J), [mod]) if _needs_grad(mod, x) else _attention(_ops(), X, (F, 1, J), [mod])
     return Ya.view(F, J, mod.g_channels).permute(0, 2, 1).contiguous()
 
 
@@ -235,6 +308,11 @@ def multi_global_forward(mod, x):
     ops = _ops()
     B, T, J, C = x.shape
     P, dev, dom = B * T * J, x.device, (B, T, J)
+    if _needs_grad(mod, x):
+        from gast_hip.autograd_ops import Gemm
+        Ya = _attention_grad(x.reshape(P, C), dom, list(mod.attentions))
+        G = Gemm.apply(Ya, mod.cat_conv.weight.view(C, C), None, dom)
+        return _bnrelu_grad(G, mod.cat_bn, _drop_state(mod.dropout, mod.training, dev), 2).view(B, T, J, C)
     Ya = _attention(ops, x.view(P, C), dom, list(mod.attentions))
     Wgc = mod.cat_conv.weight.view(C, C)
     G, partG, nb = _gemm_stats(ops, dom, C, [dict(A=Ya, K=C, map=ident(T), W=Wgc)], P, dev)
@@ -258,6 +336,9 @@ def single_global_forward(mod, x):
         raise RuntimeError('SingleGlobalGraph: the head emits %d channels but bn expects %d (the reference fails the same way unless '
                            'output_channels == in_channels)' % (mod.attentions.g_channels, C))
     P, dev = B * T * J, x.device
+    if _needs_grad(mod, x):
+        Ya = _attention_grad(x.reshape(P, C), (B, T, J), [mod.attentions])
+        return _bnrelu_grad(Ya, mod.bn, _drop_state(mod.dropout, mod.training, dev), 3).view(B, T, J, C)
     Ya = _attention(ops, x.view(P, C), (B, T, J), [mod.attentions])
     nb = ops.rowwise_blocks(P, C)
     # statistics of the attention output (no GEMM in between): one column pass
@@ -284,6 +365,10 @@ def graph_attention_block_forward(mod, x):
     G = mod.global_graph_layer(xr).reshape(P, -1)
     Co2 = mod.cat_conv.weight.shape[0]
     Wbc = mod.cat_conv.weight.view(Co2, -1)
+    if _needs_grad(mod, x):
+        from gast_hip.autograd_ops import Gemm
+        O = Gemm.apply(torch.cat([xr.reshape(P, C), L, G], dim=1), Wbc, None, dom)
+        return _bnrelu_grad(O, mod.cat_bn).view(B, T, J, Co2).permute(0, 3, 1, 2).contiguous()
     kL, kG = L.shape[1], G.shape[1]
     segs = [dict(A=xr.view(P, C), K=C, map=ident(T), W=Wbc[:, :C]), dict(A=L, K=kL, map=ident(T), W=Wbc[:, C:C + kL]),
             dict(A=G, K=kG, map=ident(T), W=Wbc[:, C + kL:C + kL + kG])]

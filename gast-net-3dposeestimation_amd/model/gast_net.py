@@ -18,6 +18,7 @@ Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (defa
 (fp32 storage, every GEMM product as bf16 hi/lo split products on the bf16 matrix cores: fp32-class results) or `bf16`
 (bf16 activations/weights, fp32 accumulate/statistics).
 """
+import collections
 import contextlib
 import os
 import threading
@@ -230,6 +231,12 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     engine.centered = runner.centered
     ops.x3 = runner.x3
     ops.f8 = runner.f8
+    # the split-K workspace is keyed by launch stream (gast_hip/binding.py): create the capture stream's one HERE, outside the capture,
+    # so that it lives in the ordinary allocator and not in (and pinned by) the first captured entry's private pool
+    if torch.cuda.graph.default_capture_stream is None:
+        torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
+    with torch.cuda.stream(torch.cuda.graph.default_capture_stream):
+        ops._splitk_ws(dev)
     g = torch.cuda.CUDAGraph()
     with torch.no_grad(), torch.cuda.graph(g, pool=pool):
         ops.run_pack(packer, st)
@@ -297,14 +304,20 @@ class _Runner:
         # GAST_HIP_GRAPH=1: forward / backward of every (shape, mode) replayed from hipGraphs captured on the third call, so an
         # unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140 Python launches
         self.graph_mode = os.environ.get('GAST_HIP_GRAPH', '0') not in ('0', '')
-        self._graphs = {}
+        # least-recently-used cache of (shape, mode, arithmetic) -> _GraphEntry, bounded: a captured entry pins its private memory
+        # pool (every saved activation of that shape), and the reference's evaluate() feeds whole videos of many different lengths
+        # (main.py:299-353) -- an unbounded cache would grow by one pool per video length.  The evicted entry's graphs and pool are
+        # released with it; a shape that keeps being evicted before its third call simply stays on the eager path.
+        self._graphs = collections.OrderedDict()
+        self.graph_cache_max = max(1, int(os.environ.get('GAST_HIP_GRAPH_MAX', '8')))
         # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
         # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
         self.ops_factory = None
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode, '_graphs': {}}
+                'grad_sync': None, '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode,
+                '_graphs': collections.OrderedDict(), 'graph_cache_max': self.graph_cache_max}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
@@ -481,7 +494,7 @@ class SpatioTemporalModelBase(nn.Module):
                     raise RuntimeError('gast_net (MI355X build): the model is on %s, the batch on %s' % (first.device, x.device))
                 if runner._packer is None or runner._packer.params[0] is not first:
                     runner._packer = Packer(self, runner.spec)
-                    runner._graphs = {}          # (captured graphs hold the old parameters' addresses)
+                    runner._graphs = collections.OrderedDict()          # (captured graphs hold the old parameters' addresses)
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
             st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None,
@@ -496,6 +509,10 @@ class SpatioTemporalModelBase(nn.Module):
                 entry = runner._graphs.get(key)
                 if entry is None:
                     entry = runner._graphs[key] = _GraphEntry()
+                    while len(runner._graphs) > runner.graph_cache_max:
+                        runner._graphs.popitem(last=False)       # least recently used: its graphs, static buffers and pool go with it
+                else:
+                    runner._graphs.move_to_end(key)
                 entry.calls += 1
                 if entry.calls > _GraphEntry.WARMUP:
                     if entry.fwd is None:

@@ -5,8 +5,9 @@ Run in the build container only (needs /root/reference):   python tests/golden/m
 
 For every case: the reference module (local_attention / global_attention / gast_net / sem_graph_conv, imported unmodified) is
 built under a fixed seed, its parameters and BatchNorm buffers are pushed away from their trivial initial values, and we record
-the state_dict, the input, the eval-mode output, the train-mode output (no dropout: batch-statistics BatchNorm) and the
-BatchNorm buffers after that train-mode call.  tests/test_modules_gpu.py loads the state into the MI355X modules and compares.
+the state_dict, the input, the eval-mode output, the train-mode output (no dropout: batch-statistics BatchNorm), the
+BatchNorm buffers after that train-mode call, and -- the modules are trainable -- the gradients of sum(y * dy) for a seeded dy with
+respect to every parameter and to the input (train mode, from the recorded state).  tests/test_modules_gpu.py loads the state into the MI355X modules and compares.
 """
 import os
 import sys
@@ -104,6 +105,18 @@ def main():
         for k, v in mod.state_dict().items():
             if 'running_' in k or 'num_batches' in k:
                 out['post/' + k] = v.detach().numpy().copy()
+        # gradients of the reference module (the sub-modules are trainable nn.Modules): train mode from the
+        # recorded state, loss = sum(y * dy) with a seeded dy -> every parameter gradient and the input gradient
+        mod.load_state_dict({k[len('state/'):]: torch.from_numpy(v) for k, v in out.items() if k.startswith('state/')})
+        mod.train()
+        xg = x.clone().requires_grad_(True)
+        y = mod(xg)
+        dy = torch.randn(y.shape, generator=gen)
+        (y * dy).sum().backward()
+        out['dy'] = dy.numpy()
+        out['dx'] = xg.grad.numpy().copy()
+        for k, p in mod.named_parameters():
+            out['grad/' + k] = p.grad.numpy().copy()
         np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
         print('%-32s x %s -> y %s' % (name, tuple(x.shape), out['y_eval'].shape))
 

@@ -58,7 +58,7 @@ def _grad_cosines(m, ref, min_numel=64):
 FP32_GRAD_TOL = dict(grad=2e-4, gabs=2e-5)
 # GAST_HIP_DTYPE=bf16x3 (fp32 storage, split-bf16 products: ~2^-17 relative per product instead of fp32's 2^-24): the same
 # elementwise check as fp32 with a wider bound (measured values are logged by the GPU tests; see X3_GRAD_TOL's users)
-X3_GRAD_TOL = dict(grad=2e-3, gabs=2e-4)
+X3_GRAD_TOL = dict(grad=1e-3, gabs=1e-4)      # (measured on the goldens / mid-size cases: <= 0.36 of this bound)
 # largest |pre-activation| (BatchNorm-normalised units, O(1) scale) at which the path under test may decide a ReLU differently from
 # the float64 oracle: its own round-off on that quantity, with margin
 FLIP_EPS = {'fp32': 2e-5, 'bf16x3': 2e-3}

@@ -68,3 +68,32 @@ def test_bucketed_allreduce_equals_monolithic_world2(tmp_path):
     assert sum(e - s for s, e in b0['ranges']) == a0['synced'].numel()          # the buckets tile the buffer
     # (in bucketed mode the exchange has already happened when backward() returns: only the final buffers are comparable)
     assert torch.allclose(b0['synced'], a0['synced'], atol=1e-7, rtol=1e-6) and torch.equal(b0['synced'], b1['synced'])
+
+
+@pytest.mark.parametrize('overlap', [False, True], ids=['monolithic', 'bucketed'])
+def test_bench_launcher_dry_run_world2(overlap):
+    """`python bench.py --gpus 2` exactly as a user (or the driver's fallback) would start it, minus the GPU: bench.py re-launches
+    itself through torch.distributed.run on a free 127.0.0.1 port, every rank builds its shard from its own seed, runs the step with
+    the (monolithic or bucketed) flat-gradient exchange over gloo, the barrier + max-over-ranks timing, and rank 0 prints ONE JSON
+    line.  `--dry-run-cpu` swaps the HIP op set for the numpy mirror and marks the line as not-a-measurement."""
+    import json
+    import subprocess
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--dry-run-cpu', '--batch', '4', '--channels', '16',
+           '--steps', '2', '--warmup', '1'] + (['--overlap'] if overlap else [])
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]                      # one line, from rank 0 only
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['steps'] == 2 and d['warmup'] == 1 and d['scaling'] == 'weak'
+    assert d['dry_run'] is True and d['value'] is None and 'DRY RUN' in d['data']
+    assert d['cpu_baseline'] is None and 'N = 1' in d['cpu_baseline_note']
+    cfg = d['config']
+    assert cfg['rccl_world_size'] == 2 and cfg['global_batch'] == 8 and cfg['parallelism'] == 'dp2'
+    assert cfg['per_rank_input_seeds'] == [1234, 1235]
+    gx = cfg['gradient_exchange']
+    assert gx['buckets'] == (3 if overlap else 1) and gx['overlap_with_backward'] is overlap
+    assert sum(gx['bucket_bytes']) == gx['bytes_per_step'] > 0
+    assert len(d['per_rank_ms_per_step']) == 2 and d['ms_per_step'] == max(d['per_rank_ms_per_step'])
+    assert np.isfinite(cfg['loss_last'])

@@ -120,8 +120,11 @@ def test_shape243_matches_reference(mode):
     loss = torch.mean(torch.norm(y - y3d, dim=-1))
     loss.backward()
     assert float((y_eval.cpu() - torch.from_numpy(z['y_eval'])).abs().max()) < TOL
-    assert float((y.detach().cpu() - torch.from_numpy(z['y_train'])).abs().max()) < TOL
-    assert abs(loss.item() - float(z['loss'])) < 1e-5
+    # train mode (batch statistics): bf16x3's 16-bit operands are amplified ~2x per temporal level -- 4e-4 stated for five levels
+    # (measured 1.9e-4; tests/test_model_gpu.py::x3_depth_factor), fp32 1e-4 (measured 9e-6)
+    ttol = TOL if mode == 'fp32' else 4 * TOL
+    assert float((y.detach().cpu() - torch.from_numpy(z['y_train'])).abs().max()) < ttol
+    assert abs(loss.item() - float(z['loss'])) < (1e-5 if mode == 'fp32' else 4e-5)
     dgen = torch.Generator().manual_seed(SHAPE243['seed'] + 2)
     gtol = 2e-3 if mode == 'fp32' else 1e-2
     gmax = max(float(z['gnorm/' + k]) for k, _ in m.named_parameters())

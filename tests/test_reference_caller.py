@@ -22,26 +22,38 @@ sys.path.insert(0, os.path.join(HERE, 'caller'))
 import scenario as sc  # noqa: E402
 
 REF = '/root/reference'
-# after 2 optimizer steps the two implementations agree to fp32 round-off; over 7 steps Adam amplifies it (see scenario.py)
-TOL = {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)}
+# after 2 optimizer steps the two implementations agree to fp32 round-off; over 7 steps Adam amplifies it (see scenario.py).
+# bf16x3 (fp32 storage, split-bf16 products: ~2^-17 per product, the arithmetic bench.py times) starts from a 100x larger round-off, and
+# Adam's first steps move every parameter by lr * sign(gradient): a gradient within 4e-5 of zero flips and that parameter ends 2 lr away
+# -- so its parameter / loss bounds after the optimizer steps are wider; the north star's MPJPE bound (0.1 mm) is the same for both.
+TOL = {'fp32': {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)},
+       'bf16x3': {'short': dict(loss=1e-4, mm=0.05, pred=2e-3, param=5e-3), 'epoch': dict(loss=2e-3, mm=0.1, pred=1e-2, param=None)}}
 
 
-def compare(got, ref, size):
-    tol = TOL[size]
-    assert abs(got['train_loss'] - ref['train_loss']) <= tol['loss'] * abs(ref['train_loss']), (got['train_loss'], ref['train_loss'])
-    # north star: MPJPE within 0.1 mm of the reference
-    assert abs(got['e1'] - ref['e1']) <= tol['mm'], 'MPJPE %.4f vs %.4f mm' % (got['e1'], ref['e1'])
-    assert abs(got['e2'] - ref['e2']) <= tol['mm'], 'P-MPJPE %.4f vs %.4f mm' % (got['e2'], ref['e2'])
-    assert got['pred'].shape == ref['pred'].shape
-    assert float(np.abs(got['pred'] - ref['pred']).max()) <= tol['pred']
+def compare(got, ref, size, arith='fp32', log=None):
+    tol = TOL[arith][size]
+    m = {'train_loss_rel': abs(got['train_loss'] - ref['train_loss']) / abs(ref['train_loss']), 'mpjpe_mm': abs(got['e1'] - ref['e1']),
+         'p_mpjpe_mm': abs(got['e2'] - ref['e2']), 'pred_max_abs': float(np.abs(got['pred'] - ref['pred']).max())}
     keys = [k for k in ref if k.startswith('state/')]
+    worst = ('', 0.0)
+    for k in keys:
+        if np.asarray(ref[k]).dtype.kind != 'f' or np.asarray(ref[k]).ndim == 0 or any(k.endswith(z) or z in k for z in sc.ZERO_GRAD_PARAMS) or 'running_' in k:
+            continue
+        d = float(np.abs(got[k] - ref[k]).max()) if k in got else float('inf')
+        if d > worst[1]:
+            worst = (k, d)
+    m['param_max_abs'] = worst
+    if log is not None:
+        log(m)
+    assert m['train_loss_rel'] <= tol['loss'], (got['train_loss'], ref['train_loss'])
+    # north star: MPJPE within 0.1 mm of the reference
+    assert m['mpjpe_mm'] <= tol['mm'], 'MPJPE %.4f vs %.4f mm' % (got['e1'], ref['e1'])
+    assert m['p_mpjpe_mm'] <= tol['mm'], 'P-MPJPE %.4f vs %.4f mm' % (got['e2'], ref['e2'])
+    assert got['pred'].shape == ref['pred'].shape
+    assert m['pred_max_abs'] <= tol['pred'], m
     assert sorted(k for k in got if k.startswith('state/')) == sorted(keys)
     if tol['param'] is not None:
-        for k in keys:
-            if np.asarray(ref[k]).dtype.kind != 'f' or np.asarray(ref[k]).ndim == 0 or any(k.endswith(z) or z in k for z in sc.ZERO_GRAD_PARAMS) or 'running_' in k:
-                continue
-            d = float(np.abs(got[k] - ref[k]).max())
-            assert d <= tol['param'], '%s differs by %.3e after the training steps' % (k, d)
+        assert worst[1] <= tol['param'], '%s differs by %.3e after the training steps' % worst
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference checkout (build container only)')
@@ -145,4 +157,9 @@ def test_caller_steps_on_the_gpu(size, graph, arith, monkeypatch):
     for k, v in model_pos_train.state_dict().items():
         got['state/' + k] = v.detach().cpu().numpy()
     ref = dict(np.load(os.path.join(HERE, 'golden', 'reference_caller_%s.npz' % size)))
-    compare(got, {k: (float(v) if v.ndim == 0 else v) for k, v in ref.items()}, size)
+    def log(m):
+        import json
+        os.makedirs(os.path.join(HERE, '..', 'gpurun_out'), exist_ok=True)
+        with open(os.path.join(HERE, '..', 'gpurun_out', 'model_parity_metrics.jsonl'), 'a') as f:
+            f.write(json.dumps(dict(test='reference_caller', size=size, graph=graph, mode=arith, **m)) + '\n')
+    compare(got, {k: (float(v) if v.ndim == 0 else v) for k, v in ref.items()}, size, arith, log)
