@@ -53,7 +53,11 @@ CONFIGS = {
     'cfg2': dict(J=17, arc=[3, 3, 3, 3], channels=64, batch=256, what='configs[2]: 17 joints, arc 3,3,3,3 (RF 81), B=256, channels=64 '
                  '(final width 1024 as in the shipped 81-frame checkpoints)'),
     'cfg3': dict(J=19, arc=[3, 3, 3], channels=128, batch=64, what='configs[3]: 19-joint body+foot, arc 3,3,3, B=512 over 8 GPUs = 64 per GPU'),
-    'cfg4': dict(J=15, arc=[3, 3, 3], channels=128, batch=4, what='configs[4]: HumanEva-15, arc 3,3,3, B=32 over 8 GPUs = 4 per GPU'),
+    'cfg4': dict(J=15, arc=[3, 3, 3], channels=128, batch=4, what='configs[4]: HumanEva-15, arc 3,3,3, B=32 over 8 GPUs = 4 per GPU -- reported in '
+                 'bf16x3 unless --dtype fp8 is given: the mixed-fp8 mode exists (forward GEMMs on e4m3 MFMA) but does not meet any parity bound '
+                 'in train mode (3 mantissa bits through 13 BatchNorm\'d layers: outputs move by 0.4 on a range of 1.15; parity.pass = false)'),
+    # not a BASELINE.json config: the shipped 243-frame shape (reference reconstruction.py:225-227, trainval.py -arc 3,3,3,3,3 -ch 32)
+    'cfg243': dict(J=17, arc=[3, 3, 3, 3, 3], channels=32, batch=128, what='243-frame model: 17 joints, arc 3,3,3,3,3 (RF 243), channels=32, B=128'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per
@@ -103,26 +107,50 @@ class KernelTimer:
         v = sorted(a.elapsed_time(b) for a, b in pairs)
         self.overhead_ms = v[len(v) // 2]
 
-    def replay_only(self, name='gemm', reps=20):
+    def classify(self, name, a, k):
+        """which kernel / plan step a gast_gemm(+_multi) call is: 'big' (gemm_big_kernel: the large-M GAST_F32X3 kernel -- the single
+        dominant kernel of the step), 'small' (gemm_kernel + split-K finish: the M = B*J stage), and for the temporal convolution of the
+        north star's "conv path": 'conv_fwd' (k taps of one BatchNorm'd tensor as K segments) / 'conv_dgrad' (its input gradient)"""
+        try:
+            if name == 'gemm_multi':
+                jobs = a[0]
+                j0 = dict(jobs[0])
+                big = self.ops.gemm_path(j0.pop('dom'), j0.pop('N'), j0.pop('segs'), j0.pop('C_'), j0.pop('cmap'), **j0)
+                taps = len(jobs) >= 2 and all(len(j['segs']) == 1 and j['segs'][0]['A'].data_ptr() == jobs[0]['segs'][0]['A'].data_ptr()
+                                              and j.get('epi', 0) == 2 for j in jobs)
+                return ('big' if big else 'small'), ('conv_dgrad' if taps else None)
+            big = self.ops.gemm_path(*a, **k)
+            segs = a[2]
+            same = len(segs) >= 2 and all(sg['A'].data_ptr() == segs[0]['A'].data_ptr() for sg in segs)
+            conv = None
+            if same and segs[0].get('pro', 0) != 0:
+                conv = 'conv_fwd'
+            elif same and k.get('addend') is not None:
+                conv = 'conv_dgrad'
+            return ('big' if big else 'small'), conv
+        except Exception:
+            return 'small', None
+
+    def replay_only(self, name='gemm', reps=20, pred=None):
         """Average duration of the `name` launches of one step, timed the way they run in the benchmark proper: all of them
         (same arguments and buffers as in the instrumented pass) captured into a hipGraph of their own and replayed `reps` times
         between ONE event pair -- back-to-back dispatch at full clocks.  (The per-launch event pairs of the eager pass leave the
         GPU idle between launches; its kernels run ~20 % slower than in the replayed step.)  Returns ms per launch or None."""
-        calls = [r for r in self.calls if r[0] == name]
+        calls = [r for r in self.calls if r[0] == name and (pred is None or pred(r))]
         if not calls:
             return None
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                for _, orig, a, k, _, _ in calls:
-                    orig(*a, **k)
+                for r in calls:
+                    r[1](*r[2], **r[3])
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for _, orig, a, k, _, _ in calls:
-                    orig(*a, **k)
+                for r in calls:
+                    r[1](*r[2], **r[3])
             for _ in range(3):
                 g.replay()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -150,7 +178,8 @@ class KernelTimer:
             e1.record()
             self.records.append((name, e0, e1, fl, by))
             if name in ('gemm', 'gemm_multi'):
-                self.calls.append(['gemm', orig, a, k, e0, e1])
+                kern, conv = self.classify(name, a, k)
+                self.calls.append(['gemm', orig, a, k, e0, e1, kern, conv, fl, by])
             return r
         setattr(self.ops, name, wrapped)
 
@@ -351,7 +380,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32', 'fp8'])
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
-    ap.add_argument('--config', default='cfg1', choices=sorted(CONFIGS), help='BASELINE.json configs[1..4]; cfg1 is the metric')
+    ap.add_argument('--config', default='cfg1', choices=sorted(CONFIGS), help='BASELINE.json configs[1..4] (cfg1 is the metric) or cfg243, the shipped 243-frame shape')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
     ap.add_argument('--channels', type=int, default=None)
     ap.add_argument('--overlap', action='store_true',
@@ -709,9 +738,9 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': args.dtype,
             'data': 'synthetic' if not dry else 'DRY RUN of the launcher on CPU (gloo, numpy op mirror): not a measurement',
-            'config': {'workload': 'BASELINE.json %s; SpatioTemporalModel J=%d arc %s (RF %d) channels=%d, '
+            'config': {'workload': '%s%s; SpatioTemporalModel J=%d arc %s (RF %d) channels=%d, '
                                    'B=%d/GPU x T=%d, dropout 0.05, step = zero_grad+fwd+mpjpe+bwd%s+Adam(amsgrad)%s'
-                                   % (cfg['what'], J, ','.join(map(str, arc)), T, C, B, T,
+                                   % ('BASELINE.json ' if cfg['what'].startswith('configs[') else '', cfg['what'], J, ','.join(map(str, arc)), T, C, B, T,
                                       '+RCCL grad all-reduce' if world > 1 else '', ' [torch loss/optimizer]' if args.torch_tail else ''),
                        'variant': args.variant, 'global_batch': world * B, 'parallelism': 'dp%d' % world,
                        'arithmetic': {'bf16x3': 'fp32 storage; GEMM / weight-gradient products as bf16 hi/lo split products on '
@@ -776,9 +805,11 @@ def main():
                     peak, unit = peak_tf, 'TFLOP/s'
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-                    pmc_name = 'r02_pmc_hbm_bytes_%s.json' % args.dtype      # counters of the committed kernels, one file per arithmetic
+                    pmc_name = next(n for n in ('r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
+                                    if os.path.exists(os.path.join(ROOT, 'profiles', n)))      # counters of the committed kernels, newest round first
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
-                    GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<')
+                    GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<',
+                              'splitk_finish_multi_kernel<')
                     fam = [v for k, v in pmc.items() if k.startswith(GEMM_K)]
                     # bytes of the family per step / gast_gemm(+_multi) API launches per step (a multi call may be two grids)
                     calls = pmc['_meta']['steps'] * gm['launches'] / tsteps
@@ -787,6 +818,32 @@ def main():
                             'kernels / %d gast_gemm launches, two rocprofv3 --pmc passes of `bench.py --dtype %s --no-graph`' % (pmc_name, calls, args.dtype))
                 except Exception:
                     pass
+                # ---- the family split by kernel, and the temporal-convolution launches of the north star's "conv path", each timed the same
+                # way (its launches alone in a hipGraph, 20 replays in one event pair)
+                def klass(pred, label):
+                    rs = [r for r in timer.calls if pred(r)]
+                    if not rs:
+                        return None
+                    msl = timer.replay_only('gemm', pred=pred)
+                    if not msl:
+                        return None
+                    nl = len(rs)
+                    byt, flo = sum(r[9] for r in rs) / nl, sum(r[8] for r in rs) / nl
+                    mult = 3.0 if args.dtype == 'bf16x3' else 1.0
+                    return {'what': label, 'launches_per_step': nl / tsteps, 'avg_launch_us': round(msl * 1e3, 2),
+                            'alg_mb_per_launch': round(byt / 1e6, 3), 'achieved_gb_s': round(byt / (msl * 1e-3) / 1e9, 1),
+                            'frac_of_hbm_peak': round(byt / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                            'mfma_tflops_eq': round(flo * mult / (msl * 1e-3) / 1e12, 1),
+                            'frac_of_mfma_peak': round(flo * mult / (msl * 1e-3) / 1e12 / (2500.0 if args.dtype != 'fp32' else 157.0), 4)}
+                by_kernel = {}
+                for key, pred, label in (('gemm_big_kernel', lambda r: r[6] == 'big', 'the large-M GAST_F32X3 kernel (csrc/gemm_big.hip): the single dominant kernel of the step'),
+                                         ('gemm_kernel+splitk_finish', lambda r: r[6] == 'small', 'the M = B*J stage and the 3-column output layer (csrc/gemm.hip, split-K + finish)'),
+                                         ('temporal_conv_fwd', lambda r: r[7] == 'conv_fwd', 'forward dilated temporal convolutions (k taps of one BatchNorm\'d tensor as K segments; reference gast_net.py:173)'),
+                                         ('temporal_conv_dgrad', lambda r: r[7] == 'conv_dgrad', 'their input gradients (gather GEMM / disjoint-tap scatter GEMMs)')):
+                    v = klass(pred, label)
+                    if v:
+                        by_kernel[key] = v
+                out['roofline_by_kernel'] = by_kernel
                 out['roofline'] = {'kernel': ('gemm_big_kernel (large-M GAST_F32X3) + gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; '
                                               'incl. split-K finish)' if args.dtype == 'bf16x3' else 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)') % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
                                    'peak': peak, 'unit': unit, 'frac': round(ach / peak, 4), 'traffic': traffic, 'traffic_source': tsrc,
@@ -797,7 +854,7 @@ def main():
                                    'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
             out['kernels_note'] = ('per-op durations from an EAGER pass with a HIP-event pair around every launch (events cannot be recorded inside a '
                                    'replayed graph): the GPU clocks down between eager launches, so the column sums to more than ms_per_step; '
-                                   'the replayed step itself is broken down in profiles/r02_*_step_summary.txt (rocprofv3 --kernel-trace)')
+                                   'the replayed step itself is broken down in profiles/r03_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
             out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
                                   'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)

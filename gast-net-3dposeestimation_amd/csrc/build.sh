@@ -9,6 +9,8 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
 # ABLATION=1: profiling build of gemm_big.hip with the GAST_GEMM_BIG_ABLATE run-time switches compiled in (scripts/gemm_big_ablate.py)
 if [ -n "$ABLATION" ]; then FLAGS="$FLAGS -DGAST_GEMM_BIG_ABLATION"; fi
+# EXTRA_FLAGS="-DGAST_..." : experiment switches of single kernels (scripts/ab_variants.sh builds and times several variants on the GPU box)
+if [ -n "$EXTRA_FLAGS" ]; then FLAGS="$FLAGS $EXTRA_FLAGS"; fi
 mkdir -p "$HERE/build"
 HDRS="$HERE/common.h $HERE/gemm_big.h $HERE/../../include/gast_hip.h"
 SRCS="gemm gemm_big wgrad graph_ops norm_ops pack_ops optim_ops data_ops"

@@ -607,25 +607,32 @@ __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, in
 // Several independent GEMMs of one plan step in ONE grid (gast_gemm_multi): the K <= 256 launches of a block (G2 / G3, the two
 // branch input gradients, ...) have 425-646 blocks each -- 1.7-2.5 per CU at an occupancy of 3 -- and end in a tail; launched
 // together they share one tail and one launch.
+// Round 3: split-K jobs (the M = B*J stage) ride in the same grid -- the three disjoint-tap input gradients of the last temporal
+// level, G2 | G3 and the two branch input gradients of the last block were one launch PAIR each (408 blocks + finish); together they
+// are one grid of ~1200 blocks and ONE finish launch (splitk_finish_multi_kernel).  ws_off = the job's slice of the workspace.
 struct GemmBatch {
     gast_gemm_args a[GAST_GEMM_MAX_BATCH];
     int first[GAST_GEMM_MAX_BATCH + 1];
     int M[GAST_GEMM_MAX_BATCH], gridM[GAST_GEMM_MAX_BATCH], gridN[GAST_GEMM_MAX_BATCH], vec_epi[GAST_GEMM_MAX_BATCH];
+    int splitk[GAST_GEMM_MAX_BATCH];
+    long ws_off[GAST_GEMM_MAX_BATCH];
+    float* ws;
     int n;
 };
-static_assert(sizeof(GemmBatch) <= 3584, "GemmBatch travels as a kernel argument (4 KB limit)");
+static_assert(sizeof(GemmBatch) <= 3712, "GemmBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO, bool X3 = false, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    gemm_body<T, TO, X3, F8>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], 1, nullptr, blockIdx.x - b.first[d]);
+    gemm_body<T, TO, X3, F8>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], b.splitk[d], b.splitk[d] > 1 ? b.ws + b.ws_off[d] : nullptr,
+                             blockIdx.x - b.first[d]);
 }
 
 template <typename T, typename TO>
-__global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args a, int M, int gridN, int splitk, const float* __restrict__ ws) {
+__device__ __forceinline__ void splitk_finish_body(const gast_gemm_args& a, int M, int gridN, int splitk, const float* __restrict__ ws, int blk) {
     __shared__ float sRed[8][BN][2];
     const int tid = threadIdx.x;
-    const int rg = blockIdx.x / gridN, nt = blockIdx.x - rg * gridN;
+    const int rg = blk / gridN, nt = blk - rg * gridN;
     const int cc = tid & 31, rq = tid >> 5;
     const int n0 = nt * BN + cc * 4;
     const int m = rg * 8 + rq;
@@ -689,6 +696,26 @@ __global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args
         }
     }
 }
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) splitk_finish_kernel(const gast_gemm_args a, int M, int gridN, int splitk, const float* __restrict__ ws) {
+    splitk_finish_body<T, TO>(a, M, gridN, splitk, ws, blockIdx.x);
+}
+// the finishes of the split-K jobs of one gast_gemm_multi call in one grid
+struct FinishBatch {
+    gast_gemm_args a[GAST_GEMM_MAX_BATCH];
+    int first[GAST_GEMM_MAX_BATCH + 1];
+    int M[GAST_GEMM_MAX_BATCH], gridN[GAST_GEMM_MAX_BATCH], splitk[GAST_GEMM_MAX_BATCH];
+    long ws_off[GAST_GEMM_MAX_BATCH];
+    const float* ws;
+    int n;
+};
+static_assert(sizeof(FinishBatch) <= 3712, "FinishBatch travels as a kernel argument (4 KB limit)");
+template <typename T, typename TO>
+__global__ void __launch_bounds__(256) splitk_finish_multi_kernel(const FinishBatch b) {
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    splitk_finish_body<T, TO>(b.a[d], b.M[d], b.gridN[d], b.splitk[d], b.ws + b.ws_off[d], blockIdx.x - b.first[d]);
+}
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
@@ -729,8 +756,9 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     for (int s2 = 0; s2 < a.nseg; ++s2) ntiles += (a.seg[s2].K + 8 * epc - 1) / (8 * epc);
     splitk = 1;
     static const int allow_splitk = getenv("GAST_GEMM_SPLITK") ? atoi(getenv("GAST_GEMM_SPLITK")) : 1;   // 0: bisecting aid
+    static const int splitk_blocks = getenv("GAST_GEMM_SPLITK_BLOCKS") ? atoi(getenv("GAST_GEMM_SPLITK_BLOCKS")) : 512;
     if (ws && gridM * gridN <= 160 && ntiles >= 4 && allow_splitk) {
-        splitk = 512 / (gridM * gridN);
+        splitk = splitk_blocks / (gridM * gridN);
         if (splitk > 8) splitk = 8;
         if (splitk > ntiles / 2) splitk = ntiles / 2;
         if (splitk < 1) splitk = 1;
@@ -794,6 +822,13 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     GemmBatch b;
     b.n = 0;
     b.first[0] = 0;
+    b.ws = (float*)ws;
+    FinishBatch fb;
+    fb.n = 0;
+    fb.first[0] = 0;
+    fb.ws = (const float*)ws;
+    long ws_used = 0;
+    bool deferred_after_own = false;
     gast_gemm_args big_a[GAST_GEMM_MAX_BATCH];
     BigPlan big_p[GAST_GEMM_MAX_BATCH];
     int nbig = 0;
@@ -803,16 +838,31 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
         if (gast_gemm_big_plan(args[d], big_p[nbig])) { big_a[nbig++] = args[d]; continue; }
-        if (splitk > 1) {                       // small-M job: its own split-K launch pair
-            rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
-            if (rc) return rc;
-            continue;
+        long off = 0;
+        if (splitk > 1) {                       // small-M job: its K ranges join the grid, its slice of the workspace follows the others'
+            off = ws_used;
+            const long need = (long)splitk * M * args[d].N;
+            static const int multi_splitk = getenv("GAST_GEMM_MULTI_SPLITK") ? atoi(getenv("GAST_GEMM_MULTI_SPLITK")) : 1;
+            if (!multi_splitk || (off + need) * (long)sizeof(float) > ws_bytes) {      // (0: bisecting aid) own split-K launch pair
+                rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
+                if (rc) return rc;
+                deferred_after_own = true;
+                continue;
+            }
+            ws_used += (need + 63) / 64 * 64;
         }
         const int k = b.n++;
         b.a[k] = args[d];
         b.M[k] = M; b.gridM[k] = gridM; b.gridN[k] = gridN; b.vec_epi[k] = vec_epi;
-        b.first[k + 1] = b.first[k] + gridM * gridN;
+        b.splitk[k] = splitk; b.ws_off[k] = off;
+        b.first[k + 1] = b.first[k] + gridM * gridN * splitk;
+        if (splitk > 1) {
+            const int f = fb.n++;
+            fb.a[f] = args[d]; fb.M[f] = M; fb.gridN[f] = gridN; fb.splitk[f] = splitk; fb.ws_off[f] = off;
+            fb.first[f + 1] = fb.first[f] + gridN * ((M + 7) / 8);
+        }
     }
+    (void)deferred_after_own;
     hipStream_t st = (hipStream_t)stream;
     if (nbig) {
         int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, st);
@@ -831,6 +881,16 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     else
         hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b);
     GAST_CHECK_LAUNCH();
+    if (fb.n) {
+        dim3 fgrid(fb.first[fb.n]);
+        if (args[0].dtype != GAST_BF16)
+            hipLaunchKernelGGL((splitk_finish_multi_kernel<float, float>), fgrid, block, 0, st, fb);
+        else if (args[0].out_f32)
+            hipLaunchKernelGGL((splitk_finish_multi_kernel<bf16_t, float>), fgrid, block, 0, st, fb);
+        else
+            hipLaunchKernelGGL((splitk_finish_multi_kernel<bf16_t, bf16_t>), fgrid, block, 0, st, fb);
+        GAST_CHECK_LAUNCH();
+    }
     return 0;
 }
 

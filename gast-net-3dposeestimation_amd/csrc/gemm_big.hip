@@ -515,7 +515,17 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
     // (the M = B*J stage stays on gemm.hip's split-K path: a split-K version of this kernel was built and measured slower on every
     // shape of that stage -- DESIGN.md, round 2b; it also cost the BNRELU_BWD variants 50 registers, and is gone)
-    if (Ml < min_rows || Ml > 0x7fffff00L || a.N < 32) return 0;
+    // Round 3: the short-K GEMMs of the M = B*J stage may take this kernel WITHOUT split-K (GAST_GEMM_BIG_SMALL_MIN_M rows and up, sum K
+    // <= GAST_GEMM_BIG_SMALL_MAX_K): a lone block needs ~0.6 us per 16-deep K step, so 32 steps cost what gemm.hip's split-K kernel +
+    // finish pair costs, without the partial-tile round trip
+    static const int small_min_m = getenv("GAST_GEMM_BIG_SMALL_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_SMALL_MIN_M")) : 0;
+    static const int small_max_k = getenv("GAST_GEMM_BIG_SMALL_MAX_K") ? atoi(getenv("GAST_GEMM_BIG_SMALL_MAX_K")) : 512;
+    if (Ml > 0x7fffff00L || a.N < 32) return 0;
+    if (Ml < min_rows) {
+        int ks = 0;
+        for (int s = 0; s < a.nseg; ++s) ks += a.seg[s].K;
+        if (!(small_min_m > 0 && Ml >= small_min_m && ks <= small_max_k)) return 0;
+    }
     // tile width, measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): 128 x 128 (NI = 2, 143-167 VGPRs, three blocks per
     // CU) for N <= 192 -- half of the wide tile would be empty -- and for every BNRELU_BWD epilogue (its X / addend values are
     // gathered per lane from the accumulator layout: at NI = 4 that epilogue spills 27-60 registers; at NI = 2 the short-K input

@@ -55,7 +55,31 @@ constexpr int FIN_COLS = 32, FIN_LANES = 8;          // the fused short-tensor k
 // The stand-alone finalizes run on 4..16 blocks, so their time is the serial chain of partial-row loads of one lane:
 // 16 columns x 16 lanes (a 128-byte row segment per load wave) and 8 loads in flight halve that chain again
 // (425 row blocks: 15 us -> 8 us).
-constexpr int FINS_COLS = 16, FINS_LANES = 16;
+// Round 3: 4 columns x 64 lanes (N / 4 blocks instead of N / 16: 64 .. 256 blocks on 256 CUs), every lane's <= 7 partial-row loads
+// (425 row blocks) all in flight at once, the 16 lanes of a column inside a wave combined with shuffles and the four waves through
+// LDS: the chain is ONE memory latency (5.7 us -> ~3 us per launch; 24 launches per step).
+constexpr int FINS_COLS = 4, FINS_LANES = 64;
+
+// thread = (column cx = tid & 3, lane ry = tid >> 2); sred: [4 waves][FINS_COLS][2]
+__device__ __forceinline__ void finalize_sums_wide(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
+                                                   double (*sred)[FINS_COLS][2], int cx, int ry, double& s1, double& s2) {
+    double a1 = 0.0, a2 = 0.0;
+    if (valid) {
+#pragma unroll 8
+        for (int b = ry; b < nblk; b += FINS_LANES) {
+            const float2 p = *(const float2*)(partials + ((long)b * ncol_total + col) * 2);
+            a1 += (double)p.x;
+            a2 += (double)p.y;
+        }
+    }
+#pragma unroll
+    for (int o = FINS_COLS; o < 64; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }      // lanes of equal cx inside the wave
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < FINS_COLS) { sred[w][cx][0] = a1; sred[w][cx][1] = a2; }
+    __syncthreads();
+    s1 = (sred[0][cx][0] + sred[1][cx][0]) + (sred[2][cx][0] + sred[3][cx][0]);
+    s2 = (sred[0][cx][1] + sred[1][cx][1]) + (sred[2][cx][1] + sred[3][cx][1]);
+}
 
 template <int COLS, int LANES>
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
@@ -78,7 +102,7 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
 }
 
 __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
-    __shared__ double sred[FINS_LANES][FINS_COLS][2];
+    __shared__ double sred[4][FINS_COLS][2];
     const float* __restrict__ partials = j.partials;
     const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N, centered = j.centered;
     const double count = j.count;
@@ -91,7 +115,7 @@ __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     const int n = blockIdx.x * FINS_COLS + cx;
     if ((int)blockIdx.x * FINS_COLS >= N) return;
     double s1, s2;
-    finalize_sums<FINS_COLS, FINS_LANES>(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    finalize_sums_wide(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
     double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -137,7 +161,7 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
 }
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& j) {
-    __shared__ double sred[FINS_LANES][FINS_COLS][2];
+    __shared__ double sred[4][FINS_COLS][2];
     const float* __restrict__ partials = j.partials;
     const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N;
     const double count = j.count;
@@ -150,7 +174,7 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& 
     const int n = blockIdx.x * FINS_COLS + cx;
     if ((int)blockIdx.x * FINS_COLS >= N) return;
     double s1, s2;
-    finalize_sums<FINS_COLS, FINS_LANES>(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
+    finalize_sums_wide(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
     double mu = mean[n], r = rstd[n], g = gamma[n];
     double dg = r * (s2 - mu * s1);   // sum dz * xhat

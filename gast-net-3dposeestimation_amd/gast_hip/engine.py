@@ -399,6 +399,11 @@ class Engine:
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
                     C=C, Tn=Tn, P=P, use_drop=use_drop)
 
+    def _gemm_multi_chunked(self, jobs):
+        """ops.gemm_multi for any number of independent jobs (GEMM_MAX_BATCH = 3 per launch)"""
+        for i in range(0, len(jobs), 3):
+            self.ops.gemm_multi(jobs[i:i + 3])
+
     def _gemm_chunked(self, dom, N, segs, out, cmap, addend=None, addmap=None, **epilogue):
         """ops.gemm for any number of K segments (the 7- and 19-tap convolutions of the dense=True ablation exceed the MAX_SEG
         segments of one launch): MAX_SEG segments per launch, each launch adding the previous partial result (`out` itself as
@@ -571,11 +576,12 @@ class Engine:
                 nbt = ops.gemm_row_blocks(P)
                 partO = za.take((k * nbt, C, 2))
                 res_tap = lv['resmap'].t_off
-                for tap in range(k):
-                    ops.gemm((B, Tn, J), C, [dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], dOp, RowMap(Tp, k, tap),
-                             addend=dX if tap == res_tap else None, addmap=ident(Tn) if tap == res_tap else None,
-                             epi=EPI_BNRELU_BWD, partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'],
-                             xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+                # (the k taps write disjoint rows of dOp: independent jobs of one grid -- and one split-K finish on the M = B*J stage)
+                self._gemm_multi_chunked([dict(dom=(B, Tn, J), N=C, segs=[dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], C_=dOp,
+                                               cmap=RowMap(Tp, k, tap), addend=dX if tap == res_tap else None,
+                                               addmap=ident(Tn) if tap == res_tap else None, epi=EPI_BNRELU_BWD,
+                                               partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'], xscale=prev['bnO'].scale,
+                                               xshift=prev['bnO'].shift) for tap in range(k)])
                 nbo = k * nbt
             elif Tn <= sp.tapstep[s] and any(tap * sp.tapstep[s] == lv['resmap'].t_off for tap in range(k)):
                 # disjoint taps (few output frames: Tn <= dilation, e.g. the last level where Tn = 1): every input frame receives
@@ -587,12 +593,11 @@ class Engine:
                 nbt = ops.gemm_row_blocks(P)
                 partO = za.take((k * nbt, C, 2))
                 res_off = lv['resmap'].t_off
-                for tap in range(k):
-                    hit = tap * d == res_off
-                    ops.gemm((B, Tn, J), C, [dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], dOp, RowMap(Tp, 1, tap * d),
-                             addend=dX if hit else None, addmap=ident(Tn) if hit else None,
-                             epi=EPI_BNRELU_BWD, partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'],
-                             xscale=prev['bnO'].scale, xshift=prev['bnO'].shift)
+                self._gemm_multi_chunked([dict(dom=(B, Tn, J), N=C, segs=[dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], C_=dOp,
+                                               cmap=RowMap(Tp, 1, tap * d), addend=dX if tap * d == res_off else None,
+                                               addmap=ident(Tn) if tap * d == res_off else None, epi=EPI_BNRELU_BWD,
+                                               partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'], xscale=prev['bnO'].scale,
+                                               xshift=prev['bnO'].shift) for tap in range(k)])
                 nbo = k * nbt
             else:
                 d = sp.tapstep[s]

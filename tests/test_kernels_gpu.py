@@ -194,8 +194,9 @@ def test_gemm(ops, case, mode):
 
 @pytest.mark.parametrize('mode', MM_MODES)
 def test_gemm_multi(ops, mode):
-    """Independent GEMMs with different domains, segment counts, prologues and epilogues as multi-job launches (4 per grid);
-    the split-K-eligible ones are peeled off into their own launch pair by the library."""
+    """Independent GEMMs with different domains, segment counts, prologues and epilogues as multi-job launches (3 per grid).  The
+    split-K-eligible ones (the M = B*J stage's shapes) ride in the same grid with their own slice of the workspace and share ONE
+    finish launch (round 3; three of them are consecutive in GEMM_CASES, i.e. one call of three split-K jobs)."""
     dt = MM_DT[mode]
     cases = [c for c in GEMM_CASES]
     built = [_gemm_case(c, dt) for c in cases]

@@ -32,8 +32,8 @@ TOL = {'fp32': {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch
 
 def compare(got, ref, size, arith='fp32', log=None):
     tol = TOL[arith][size]
-    m = {'train_loss_rel': abs(got['train_loss'] - ref['train_loss']) / abs(ref['train_loss']), 'mpjpe_mm': abs(got['e1'] - ref['e1']),
-         'p_mpjpe_mm': abs(got['e2'] - ref['e2']), 'pred_max_abs': float(np.abs(got['pred'] - ref['pred']).max())}
+    m = {'train_loss_rel': float(abs(got['train_loss'] - ref['train_loss']) / abs(ref['train_loss'])), 'mpjpe_mm': float(abs(got['e1'] - ref['e1'])),
+         'p_mpjpe_mm': float(abs(got['e2'] - ref['e2'])), 'pred_max_abs': float(np.abs(got['pred'] - ref['pred']).max())}
     keys = [k for k in ref if k.startswith('state/')]
     worst = ('', 0.0)
     for k in keys:
