@@ -462,6 +462,7 @@ def main():
     cls = SpatioTemporalModel if args.variant == 'dilated' else SpatioTemporalModelOptimized1f
     adj = adj_from_parents(PARENTS[J])
     model = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.05, channels=C).to(dev)
+    model._runner.graph_mode = False      # (the module's own hipGraph replay is measured explicitly in the `module_graph` leg below)
     if dry:
         from fake_backend import use_oracle_ops      # (dry run only: the host plan on the numpy mirror of the op set)
         use_oracle_ops(model)
@@ -478,6 +479,7 @@ def main():
     if rank == 0 and not args.no_parity:
         try:
             pm = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.0, channels=C)
+            pm._runner.graph_mode = False
             pm.load_state_dict(model.state_dict())
             pm.to(dev).train()
             sd = {k: v.clone() for k, v in pm.state_dict().items()}
@@ -693,6 +695,7 @@ def main():
             tcls = SpatioTemporalModelOptimized1f if args.variant == 'dilated' else SpatioTemporalModel
             torch.manual_seed(0)
             tm = tcls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.05, channels=C).to(dev).train()
+            tm._runner.graph_mode = False
             tsync = FlatGradAllReduce(tm.parameters(), model=tm, buckets=1)
             topt = FlatAdam(tm.parameters(), lr=1e-3, amsgrad=True, ops=tm._runner.engine.ops)
             tsync.attach(topt)
@@ -771,11 +774,12 @@ def main():
         if eager_ms is not None:
             if module_graph_ms is not None:
                 out['module_graph'] = {'ms_per_step': round(module_graph_ms, 4), 'sequences_per_s': round(B / module_graph_ms * 1e3, 1),
-                                       'note': 'GAST_HIP_GRAPH=1: the same eager loop, model(x) / loss.backward() replayed from the hipGraphs the '
-                                               'module captures by itself on the third call of a shape (loss and optimizer launched eagerly)'}
+                                       'note': 'what an UNCHANGED training loop gets (the default since round 3; GAST_HIP_GRAPH=0 turns it off): '
+                                               'model(x) / loss.backward() replayed from the hipGraphs the module captures by itself on the third '
+                                               'call of a shape, loss and optimizer launched eagerly'}
             out['eager_launch'] = {'ms_per_step': round(eager_ms, 4), 'sequences_per_s': round(B / eager_ms * 1e3, 1),
-                                   'note': 'the same step with every kernel launched eagerly from Python (ctypes), i.e. the speed of an '
-                                           'unchanged training loop around the drop-in module; `value` replays the step as one hipGraph'}
+                                   'note': 'the same step with every kernel launched eagerly from Python (ctypes; GAST_HIP_GRAPH=0); `value` '
+                                           'replays the whole step as one hipGraph'}
         if twin is not None:
             out['variants'] = {args.variant: {'ms_per_step': round(ms, 4), 'sequences_per_s': round(value, 1), 'headline': True},
                                twin.get('variant', 'twin'): twin}

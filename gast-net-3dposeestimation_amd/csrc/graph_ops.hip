@@ -1311,8 +1311,8 @@ static int agg_fwd_frame_blocks(int F, int C) {
 static int agg_fwd_joint_split(int F, int C) {
     const int CC = agg_fwd_cc(C);
     const int nblk = agg_fwd_frame_blocks(F, C) * ((C + CC - 1) / CC);
-    static const int env = getenv("GAST_AGG_FWD_JSPLIT") ? atoi(getenv("GAST_AGG_FWD_JSPLIT")) : 0;      // 0: the rule below
-    if (env > 0) return env;
+    // (round 3: splitting the joints further at the large stages -- more, shorter blocks -- is SLOWER: 3.87 / 3.89 vs 3.86 ms per step
+    //  with 2 / 4 parts forward, 3.92 / 3.95 backward; the rule stays)
     return nblk <= 128 ? 4 : nblk <= 512 ? 2 : 1;
 }
 extern "C" int gast_semch_agg_blocks(int F, int C) { return agg_fwd_frame_blocks(F, C) * agg_fwd_joint_split(F, C); }
@@ -1396,8 +1396,7 @@ extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void
     hipStream_t st = (hipStream_t)stream;
     dim3 grid(c.nfb * c.nchunk);
     // few frames (the M = B*J stage): split the joints / edges over 4 blocks so that the launch covers the chip
-    static const int jsplit_env = getenv("GAST_AGG_BWD_JSPLIT") ? atoi(getenv("GAST_AGG_BWD_JSPLIT")) : 0;      // 0: the rule below
-    dim3 grid_ell(c.nfb * c.nchunk, jsplit_env > 0 ? jsplit_env : (c.nfb * c.nchunk <= 128 ? 4 : 1));
+    dim3 grid_ell(c.nfb * c.nchunk, c.nfb * c.nchunk <= 128 ? 4 : 1);
 #define AGG_BWD_ELL(DS, DC)                                                                                                   \
     do {                                                                                                                      \
         if (dtype == GAST_F32) {                                                                                              \

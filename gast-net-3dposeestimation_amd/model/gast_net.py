@@ -22,6 +22,7 @@ import collections
 import contextlib
 import os
 import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -218,6 +219,16 @@ class _GraphEntry:
         self.x = self.pred = self.dpred = self.G = self.sink = None
         self.packer = None
         self.keep = None
+        self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
+
+    def busy(self):
+        """a replayed forward is still waiting for its backward (its autograd node is alive and unconsumed)"""
+        return self.token_ref is not None and self.token_ref() is not None
+
+
+class _Token:
+    """lives exactly as long as the autograd node of one replayed forward"""
+    __slots__ = ('__weakref__',)
 
 
 def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, need_grad):
@@ -270,6 +281,11 @@ class _GraphedFunction(torch.autograd.Function):
         entry.fwd.replay()
         entry.gen += 1
         ctx.entry, ctx.gen = entry, entry.gen
+        if entry.bwd is not None:
+            # the captured graphs keep ONE set of activations: until this call's backward has run (or its autograd node has been
+            # freed) further calls of the same shape take the eager path (SpatioTemporalModelBase.forward checks `busy()`)
+            ctx.token = _Token()
+            entry.token_ref = weakref.ref(ctx.token)
         return entry.pred.clone()
 
     @staticmethod
@@ -283,6 +299,7 @@ class _GraphedFunction(torch.autograd.Function):
                                'forward, or unset GAST_HIP_GRAPH)')
         e.dpred.copy_(dpred)
         e.bwd.replay()
+        e.token_ref = None          # the activations may be overwritten by the next forward of this shape
         if e.sink is not None:
             return (None, None) + (None,) * len(e.packer.params)
         return (None, None) + tuple(e.packer.grad_views(e.G.clone()))      # (a copy: the next replay rewrites G in place)
@@ -301,9 +318,12 @@ class _Runner:
         self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
         self.grad_sync = None     # optional gast_hip.dist.FlatGradAllReduce in bucketed mode: told when a bucket of grad_sink is complete
         self._seeds = {}
-        # GAST_HIP_GRAPH=1: forward / backward of every (shape, mode) replayed from hipGraphs captured on the third call, so an
-        # unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140 Python launches
-        self.graph_mode = os.environ.get('GAST_HIP_GRAPH', '0') not in ('0', '')
+        # Forward / backward of every (shape, mode, arithmetic, BatchNorm momentum, dropout p) are replayed from hipGraphs captured on
+        # the third call, so an unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140
+        # Python launches (3.9 vs 4.9 ms per step at B = 128).  ON by default since round 3 (GAST_HIP_GRAPH=0 turns it off): the
+        # cases a replay cannot serve fall back to the eager path by themselves -- a call inside somebody else's stream capture, a
+        # second forward of a shape whose previous forward still awaits its backward, DataParallel replicas, the bucketed exchange
+        self.graph_mode = os.environ.get('GAST_HIP_GRAPH', '1') not in ('0', '')
         # least-recently-used cache of (shape, mode, arithmetic) -> _GraphEntry, bounded: a captured entry pins its private memory
         # pool (every saved activation of that shape), and the reference's evaluate() feeds whole videos of many different lengths
         # (main.py:299-353) -- an unbounded cache would grow by one pool per video length.  The evicted entry's graphs and pool are
@@ -503,9 +523,12 @@ class SpatioTemporalModelBase(nn.Module):
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
             gs = runner.grad_sync
             if (runner.graph_mode and x.is_cuda and runner.ops_factory is None and not getattr(self, '_is_replica', False)
-                    and not (gs is not None and len(gs.ranges) > 1)):      # (the bucketed exchange hooks into the eager backward)
+                    and not (gs is not None and len(gs.ranges) > 1)       # (the bucketed exchange hooks into the eager backward)
+                    and not torch.cuda.is_current_stream_capturing()):    # (inside a caller's capture the kernels join THAT graph)
+                bufs_now = bn_buffers(self)
                 key = (tuple(x.shape), self.training, need_grad, str(x.device), runner.act_dtype, runner.x3, runner.f8, runner.centered,
-                       None if sink is None else sink.data_ptr())
+                       None if sink is None else sink.data_ptr(), runner.p_dropout if self.training else 0.0,
+                       tuple((b['momentum'], b['eps']) for b in bufs_now.values()))      # (baked into a capture: part of its identity)
                 entry = runner._graphs.get(key)
                 if entry is None:
                     entry = runner._graphs[key] = _GraphEntry()
@@ -514,9 +537,9 @@ class SpatioTemporalModelBase(nn.Module):
                 else:
                     runner._graphs.move_to_end(key)
                 entry.calls += 1
-                if entry.calls > _GraphEntry.WARMUP:
+                if entry.calls > _GraphEntry.WARMUP and not entry.busy():
                     if entry.fwd is None:
-                        _capture_graphs(entry, runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad)
+                        _capture_graphs(entry, runner, x, self.training, packer, st, bufs_now, engine, sink, need_grad)
                     return _GraphedFunction.apply(entry, x, *packer.params)
             return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)
 

@@ -170,14 +170,16 @@ def test_dropout_params_edge_cases():
 
 
 def test_graph_mode_leaves_the_cpu_mirror_path_alone(monkeypatch):
-    """GAST_HIP_GRAPH=1 is read by the runner at construction and only ever engages for CUDA inputs on the HIP op set: with the numpy
-    op mirror (or any call that cannot be captured) the module keeps its eager path and gives the same result."""
+    """The module's hipGraph replay (on by default since round 3, GAST_HIP_GRAPH=0 turns it off) is decided by the runner at
+    construction and only ever engages for CUDA inputs on the HIP op set: with the numpy op mirror (or any call that cannot be
+    captured) the module keeps its eager path and gives the same result."""
     from tests_helpers import PARENTS
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
     monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    monkeypatch.setenv('GAST_HIP_GRAPH', '0')
     torch.manual_seed(0)
     m0 = build(cfg)
-    monkeypatch.setenv('GAST_HIP_GRAPH', '1')
+    monkeypatch.delenv('GAST_HIP_GRAPH')
     torch.manual_seed(0)
     m1 = build(cfg)
     assert m1._runner.graph_mode and not m0._runner.graph_mode
