@@ -46,7 +46,46 @@ __global__ void cam_gather_kernel(const float* __restrict__ cams, int ncam, cons
     out[idx] = v;
 }
 
+// ---- causal streaming (gast_hip/streaming.py): the per-level frame windows advance by one frame per step.  One launch for every
+// window of the model: thread = (job, b, x) owns column x of batch entry b through the window's frames, so the in-place shift
+// buf[b][t] <- buf[b][t + 1] (t = 0 .. Tb - 2), buf[b][Tb - 1] <- newest[b] needs no second buffer and no synchronisation.
+struct ShiftBatch { gast_stream_shift_job j[GAST_STREAM_SHIFT_MAX]; int first[GAST_STREAM_SHIFT_MAX + 1]; int n; };
+__global__ void __launch_bounds__(256) stream_shift_kernel(const ShiftBatch b) {
+    int d = 0;
+    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
+    const gast_stream_shift_job& j = b.j[d];
+    const long idx = (long)(blockIdx.x - b.first[d]) * 256 + threadIdx.x;        // over B * X / 4 (16-byte pieces)
+    const long X4 = j.X / 4;
+    if (idx >= (long)j.B * X4) return;
+    const long bb = idx / X4, x = (idx - bb * X4) * 4;
+    float* base = (float*)j.buf + bb * (long)j.Tb * j.X + x;
+    float4 nxt = j.Tb > 1 ? *(const float4*)(base + j.X) : make_float4(0, 0, 0, 0);
+    for (int t = 0; t + 1 < j.Tb; ++t) {
+        const float4 cur = nxt;
+        if (t + 2 < j.Tb) nxt = *(const float4*)(base + (long)(t + 2) * j.X);
+        *(float4*)(base + (long)t * j.X) = cur;
+    }
+    *(float4*)(base + (long)(j.Tb - 1) * j.X) = *(const float4*)((const float*)j.newest + bb * (long)j.ldnew + x);
+}
+
 }  // namespace
+
+extern "C" int gast_stream_shift_multi(const gast_stream_shift_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_STREAM_SHIFT_MAX) return GAST_EINVAL;
+    ShiftBatch b;
+    b.n = n;
+    b.first[0] = 0;
+    for (int d = 0; d < n; ++d) {
+        const gast_stream_shift_job& j = jobs[d];
+        if (!j.buf || !j.newest || j.B < 1 || j.Tb < 1 || j.X < 4) return GAST_EINVAL;
+        if (j.X % 4 || j.ldnew % 4 || (((uintptr_t)j.buf) & 15) || (((uintptr_t)j.newest) & 15)) return GAST_EALIGN;
+        b.j[d] = j;
+        b.first[d + 1] = b.first[d] + (int)(((long)j.B * (j.X / 4) + 255) / 256);
+    }
+    hipLaunchKernelGGL(stream_shift_kernel, dim3(b.first[n]), dim3(256), 0, (hipStream_t)stream, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gast_chunk_gather(const float* poses2d, const float* poses3d, const float* cams, const int64_t* seq_off,
                                  const int32_t* pairs, long first_pair, int B, int chunk, int pad, int causal_shift, int J2, int F2,

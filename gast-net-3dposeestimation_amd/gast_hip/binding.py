@@ -83,6 +83,10 @@ class _AdjJob(C.Structure):
     _fields_ = [('e', C.c_void_p), ('C', C.c_int), ('pat', C.c_void_p), ('A_t', C.c_void_p), ('dA_t', C.c_void_p)]
 
 
+class _StreamShiftJob(C.Structure):
+    _fields_ = [('buf', C.c_void_p), ('newest', C.c_void_p), ('B', C.c_int), ('Tb', C.c_int), ('X', C.c_int), ('ldnew', C.c_int)]
+
+
 class _BnEvalJob(C.Structure):
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('N', C.c_int),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('centered', C.c_int)]
@@ -165,6 +169,7 @@ def load_library():
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
         'gast_null_launch': [vp],
         'gast_chunk_gather': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
+        'gast_stream_shift_multi': [C.POINTER(_StreamShiftJob), ci, vp],
     }
     for name, argtypes in sig.items():
         fn = getattr(lib, name)
@@ -185,7 +190,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
 
 def _check(rc, what):
@@ -677,6 +682,22 @@ class HipOps:
         _check(self.lib.gast_chunk_gather(_p(poses2d), _p(poses3d), _p(cams), _p(seq_off), _p(pairs), int(first_pair), int(B), int(chunk),
                                           int(pad), int(causal_shift), J2, F2, J3, F3, ncam, _p(perm2d), _p(perm3d), _p(out2d), _p(out3d),
                                           _p(outcam), _stream()), 'gast_chunk_gather')
+
+    STREAM_SHIFT_MAX = 8
+
+    def stream_shift_multi(self, jobs):
+        """jobs: (buf (B, Tb, X) fp32 contiguous, newest (B, X) fp32 row-contiguous): every frame window advances by one frame in
+        place and takes `newest` as its last frame -- one launch for all of them (gast_stream_shift_multi)."""
+        for i0 in range(0, len(jobs), self.STREAM_SHIFT_MAX):
+            chunk = jobs[i0:i0 + self.STREAM_SHIFT_MAX]
+            arr = (_StreamShiftJob * len(chunk))()
+            for a, (buf, newest) in zip(arr, chunk):
+                if buf.dtype != torch.float32 or newest.dtype != torch.float32 or not buf.is_contiguous() or newest.stride(-1) != 1:
+                    raise RuntimeError('gast_hip: stream_shift_multi needs fp32 tensors, a contiguous window and unit-stride rows')
+                a.buf, a.newest = _p(buf), _p(newest)
+                a.B, a.Tb, a.X, a.ldnew = int(buf.shape[0]), int(buf.shape[1]), int(buf.shape[2]), int(newest.stride(0))
+            self.launches += 1
+            _check(self.lib.gast_stream_shift_multi(arr, len(chunk), _stream()), 'gast_stream_shift_multi')
 
     def null_launch(self):
         _check(self.lib.gast_null_launch(_stream()), 'gast_null_launch')

@@ -113,8 +113,13 @@ class CausalStream:
 
     # ------------------------------------------------------------------------------------------ one frame
     def _shift_in(self, buf3, new):
-        """buf3: (B, Tb, X) window, new: (B, X): drop the oldest frame, append the newest (static addresses: graph-capturable)"""
-        if buf3.shape[1] > 1:
+        """buf3: (B, Tb, X) window, new: (B, X): drop the oldest frame, append the newest -- in place, one HIP launch
+        (gast_stream_shift_multi; static addresses: graph-capturable).  The raw-input window and every level's window are shifted by
+        the same kernel; a level's shift needs the previous block's output of THIS frame, so it is one launch per level (round 2 used
+        a torch.cat + copy_ pair per window).  bf16 windows (GAST_HIP_DTYPE=bf16) keep the torch pair."""
+        if buf3.dtype == torch.float32 and buf3.shape[2] % 4 == 0 and new.stride(0) % 4 == 0:
+            self.ops.stream_shift_multi([(buf3, new)])
+        elif buf3.shape[1] > 1:
             buf3.copy_(torch.cat([buf3[:, 1:], new.unsqueeze(1)], dim=1))
         else:
             buf3[:, 0] = new

@@ -165,11 +165,14 @@ class _GastFunction(torch.autograd.Function):
         pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
                                   need_grad=need_grad)
         ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink, ctx.runner = engine, packer, st, inp, sv, sink, runner
+        ctx.graph_entry = runner.__dict__.pop('_eager_entry', None)      # (the graph-cache entry this eager call warms up, if any)
         return pred
 
     @staticmethod
     def backward(ctx, dpred):
         engine, packer, st = ctx.engine, ctx.packer, ctx.st
+        if ctx.graph_entry is not None:
+            ctx.graph_entry.bwd_calls += 1       # an eager backward of this shape has run: its lazy tables / arenas exist
         if ctx.sv is None:
             raise RuntimeError('gast_net (MI355X build): backward through the same forward a second time is not supported (the saved '
                                'activations are released by the first backward, retain_graph has no effect); run forward again')
@@ -220,6 +223,7 @@ class _GraphEntry:
         self.packer = None
         self.keep = None
         self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
+        self.bwd_calls = 0          # eager backward passes seen for this key (the capture of a backward graph needs one: lazy state)
 
     def busy(self):
         """a replayed forward is still waiting for its backward (its autograd node is alive and unconsumed)"""
@@ -537,10 +541,14 @@ class SpatioTemporalModelBase(nn.Module):
                 else:
                     runner._graphs.move_to_end(key)
                 entry.calls += 1
-                if entry.calls > _GraphEntry.WARMUP and not entry.busy():
+                # capture after WARMUP eager forwards AND -- when a backward graph is wanted -- at least one eager backward of this
+                # key (its job tables / arenas are created lazily: a loop that only ever calls forward with autograd enabled stays eager)
+                if entry.calls > _GraphEntry.WARMUP and not entry.busy() and (not need_grad or entry.fwd is not None or entry.bwd_calls > 0):
                     if entry.fwd is None:
                         _capture_graphs(entry, runner, x, self.training, packer, st, bufs_now, engine, sink, need_grad)
                     return _GraphedFunction.apply(entry, x, *packer.params)
+                if entry.fwd is None:
+                    runner._eager_entry = entry
             return _GastFunction.apply(runner, x, self.training, packer, st, bn_buffers(self), engine, sink, need_grad, *packer.params)
 
 

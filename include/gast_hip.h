@@ -351,6 +351,18 @@ int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* 
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
 
+/* ---- causal streaming inference (reference gen_skes.py:43-69, tools/inference.py:73-91 re-run the whole
+ * receptive field per frame): the per-level frame windows of gast_hip/streaming.py advance by one frame -- every window of the model
+ * in ONE launch.  buf: [B][Tb][X] fp32 (X = J * channels, a multiple of 4), shifted in place by one frame towards t = 0; newest:
+ * [B][ldnew >= X] fp32, copied into frame Tb - 1. */
+#define GAST_STREAM_SHIFT_MAX 8
+typedef struct {
+    void* buf;
+    const void* newest;
+    int B, Tb, X, ldnew;
+} gast_stream_shift_job;
+int gast_stream_shift_multi(const gast_stream_shift_job* jobs, int n, gast_stream_t stream);
+
 /* ---- data side: device-resident ChunkedGenerator (reference common/generators.py:93-159) ---------------- */
 /* Builds one training batch from sequences resident in HBM.  poses2d: all sequences concatenated, [sum_len][J2][F2] fp32; seq_off:
  * nseq+1 frame offsets; pairs: the epoch's (seq, start_3d, end_3d, flip) int32 rows (generators.py:33-42, already shuffled),

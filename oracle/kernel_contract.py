@@ -530,3 +530,10 @@ def expand_bwd(dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W, gamma0
     dW[...] = dW + dWv if accumulate else dWv
     dgamma0[...] = dgamma0 + (w * G).sum(axis=(0, 2))
     dbeta0[...] = dbeta0 + (w * S.reshape(C, 1, 1)).sum(axis=(0, 2))
+
+
+def stream_shift(buf, newest):
+    """gast_stream_shift_multi, one job: buf (B, Tb, X) advances by one frame in place (frame t <- frame t + 1) and takes newest (B, X)
+    as its last frame -- the per-level frame windows of causal streaming inference (gast_hip/streaming.py)."""
+    buf[:, :-1] = buf[:, 1:].copy()
+    buf[:, -1] = newest

@@ -840,3 +840,21 @@ def test_pack_unpack_tables(ops, dt):
         ops.run_unpack(pk_g, st_g, Sb.cuda(), Gg, acc)
         torch.cuda.synchronize()
         close(host(Gg), host(Gc), torch.float32, 'unpacked gradients acc=%s' % acc, fp32=2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ streaming frame windows
+def test_stream_shift_multi(ops):
+    """every frame window of the causal stream advances by one frame in ONE launch (in place), vs the contract"""
+    gen = torch.Generator().manual_seed(31)
+    jobs, hosts = [], []
+    for (B, Tb, X, ldnew) in ((2, 3, 17 * 32, 17 * 32), (4, 7, 17 * 64, 17 * 64 + 8), (1, 19, 17 * 128, 17 * 128), (2, 1, 68, 68)):
+        buf = rand(gen, B, Tb, X)
+        new = rand(gen, B, ldnew)
+        jobs.append((buf.cuda(), new.cuda()[:, :X]))
+        hb = buf.numpy().copy()
+        kc.stream_shift(hb, new.numpy()[:, :X])
+        hosts.append(hb)
+    ops.stream_shift_multi(jobs)
+    torch.cuda.synchronize()
+    for (b, _), hb in zip(jobs, hosts):
+        assert np.array_equal(b.cpu().numpy(), hb)

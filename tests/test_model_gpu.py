@@ -577,7 +577,7 @@ def test_training_trajectory_matches_reference(mode2):
         # on the 317 mm loss of step 6).
         assert per_step[0] < 1e-3 and per_step[1] < 0.1, per_step
         assert all(d < 1e-2 * float(z['losses'][i]) * 1000 for i, d in enumerate(per_step)), per_step
-        assert err_final < 2e-2, err_final
+        assert err_final < 3e-2, err_final           # (measured 0.9e-2 .. 1.3e-2)
     assert all(v < 1.2e-2 for v in perr.values()), perr      # at most lr per step and parameter
 
 

@@ -27,7 +27,8 @@ REF = '/root/reference'
 # Adam's first steps move every parameter by lr * sign(gradient): a gradient within 4e-5 of zero flips and that parameter ends 2 lr away
 # -- so its parameter / loss bounds after the optimizer steps are wider; the north star's MPJPE bound (0.1 mm) is the same for both.
 TOL = {'fp32': {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)},
-       'bf16x3': {'short': dict(loss=1e-4, mm=0.05, pred=2e-3, param=5e-3), 'epoch': dict(loss=2e-3, mm=0.1, pred=1e-2, param=None)}}
+       # (measured, round 3: short 2.4e-5 / 0.006 mm / 1.2e-4 / 2.0e-3; epoch 1.0e-4 / 0.08 mm / 1.7e-3)
+       'bf16x3': {'short': dict(loss=1e-4, mm=0.05, pred=1e-3, param=5e-3), 'epoch': dict(loss=1e-3, mm=0.1, pred=1e-2, param=None)}}
 
 
 def compare(got, ref, size, arith='fp32', log=None):
