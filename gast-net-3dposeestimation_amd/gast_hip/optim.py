@@ -10,6 +10,8 @@ There is no CPU implementation: `step()` on CPU parameters raises.
 """
 import torch
 
+from gast_hip.packer import note_raw_parameter_write
+
 
 class FlatAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, ops=None):
@@ -107,6 +109,7 @@ class FlatAdam(torch.optim.Optimizer):
             self._get_ops().adam_step(st['P'], G, st['m'], st['v'], st['vmax'] if group['amsgrad'] else None, st['step'],
                                       float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
                                       grad_scale=float(self.grad_scale))
+            note_raw_parameter_write()      # (the kernel writes parameter memory behind torch's version counters)
         return loss
 
     # ------------------------------------------------------------------ (de)serialisation in torch.optim.Adam's per-parameter format

@@ -155,7 +155,8 @@ class _GastFunction(torch.autograd.Function):
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
         ops = engine.ops
-        ops.run_pack(packer, st)
+        if not packer.unchanged(st):          # (an evaluation loop over frozen weights packs once)
+            ops.run_pack(packer, st)
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
@@ -221,6 +222,7 @@ class _GraphEntry:
         self.gen = 0
         self.x = self.pred = self.dpred = self.G = self.sink = None
         self.packer = None
+        self.st = self.ops = None   # the packed-operand state (refreshed eagerly when the parameters changed) and the op set
         self.keep = None
         self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
         self.bwd_calls = 0          # eager backward passes seen for this key (the capture of a backward graph needs one: lazy state)
@@ -252,9 +254,11 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
         torch.cuda.graph.default_capture_stream = torch.cuda.Stream()
     with torch.cuda.stream(torch.cuda.graph.default_capture_stream):
         ops._splitk_ws(dev)
+    # parameter packing stays OUTSIDE the captured graphs: _GraphedFunction.forward launches its three kernels eagerly, and only when
+    # the parameters changed since the operands were last packed (a training loop: every step; an evaluation loop: once)
+    entry.st, entry.ops = st, ops
     g = torch.cuda.CUDAGraph()
     with torch.no_grad(), torch.cuda.graph(g, pool=pool):
-        ops.run_pack(packer, st)
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
@@ -282,6 +286,8 @@ class _GraphedFunction(torch.autograd.Function):
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
         entry.x.copy_(x)
+        if not entry.packer.unchanged(entry.st):       # (optimizer step / load_state_dict since the last packing: refresh the operands)
+            entry.ops.run_pack(entry.packer, entry.st)
         entry.fwd.replay()
         entry.gen += 1
         ctx.entry, ctx.gen = entry, entry.gen
@@ -534,6 +540,11 @@ class SpatioTemporalModelBase(nn.Module):
                        None if sink is None else sink.data_ptr(), runner.p_dropout if self.training else 0.0,
                        tuple((b['momentum'], b['eps']) for b in bufs_now.values()))      # (baked into a capture: part of its identity)
                 entry = runner._graphs.get(key)
+                if entry is not None and entry.fwd is not None and entry.st is not st:
+                    # the parameters moved to other memory since the capture (FlatAdam re-homes them into its flat buffer, .data was
+                    # re-bound, ...): the captured graphs read the old addresses -- drop them and warm up again
+                    del runner._graphs[key]
+                    entry = None
                 if entry is None:
                     entry = runner._graphs[key] = _GraphEntry()
                     while len(runner._graphs) > runner.graph_cache_max:

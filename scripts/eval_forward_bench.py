@@ -1,25 +1,31 @@
-import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gast-net-3dposeestimation_amd')); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
+"""What an UNCHANGED evaluation loop gets (reference main.py:299-353: `with torch.no_grad(): model.eval(); predicted = model(inputs_2d)`):
+per-call time of model(x) in eval mode, host clock around the loop, for the eager path (GAST_HIP_GRAPH=0) and the default (the module
+replays its captured forward graph; the packed operands are rebuilt only when the weights changed).  Run through gpurun."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'gast-net-3dposeestimation_amd')); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch
-os.environ['GAST_HIP_DTYPE'] = 'bf16'
 from tests_helpers import PARENTS
 from model.gast_net import SpatioTemporalModel
 from bench import adj_from_parents      # (the product's callers build adj themselves; nothing under oracle/ is used here)
-m = SpatioTemporalModel(adj_from_parents(PARENTS[17]), 17, 2, 17, filter_widths=[3,3,3], channels=128, dropout=0.05).cuda().eval()
-for shape in [(128, 27, 17, 2), (2, 2026, 17, 2)]:
-    x = (torch.rand(*shape) * 2 - 1).cuda()
-    with torch.no_grad():
-        for _ in range(3): m(x)
-        g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            m(x)
-        torch.cuda.current_stream().wait_stream(s)
-        with torch.cuda.graph(g):
-            y = m(x)
-        for _ in range(3): g.replay()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20): g.replay()
-        e1.record(); torch.cuda.synchronize()
-    print(shape, 'eval forward %.3f ms' % (e0.elapsed_time(e1) / 20), tuple(y.shape))
+out = []
+for dtype in ('bf16x3', 'fp32'):
+    os.environ['GAST_HIP_DTYPE'] = dtype
+    for shape in [(128, 27, 17, 2), (2, 303, 17, 2), (2, 2026, 17, 2)]:
+        row = {'dtype': dtype, 'input': list(shape)}
+        for label, graph in (('eager_ms', False), ('default_ms', True)):
+            torch.manual_seed(0)
+            m = SpatioTemporalModel(adj_from_parents(PARENTS[17]), 17, 2, 17, filter_widths=[3, 3, 3], channels=128, dropout=0.05).cuda().eval()
+            m._runner.graph_mode = graph
+            x = (torch.rand(*shape) * 2 - 1).cuda()
+            with torch.no_grad():
+                for _ in range(5):
+                    m(x)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    y = m(x)
+                torch.cuda.synchronize()
+            row[label] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+        out.append(row)
+print(json.dumps(out))

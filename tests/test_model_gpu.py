@@ -571,11 +571,11 @@ def test_training_trajectory_matches_reference(mode2):
         assert err_final < 1e-2, err_final           # eval prediction after 12 Adam steps (outputs of magnitude ~1; measured 2.6e-3)
     else:
         # bf16x3 starts from a 1e-5 instead of a 1e-7 round-off and Adam's first step moves every parameter by lr * sign(g): the
-        # first loss agrees to 1e-3 mm (measured 1.2e-4), the second to 0.1 mm (0.056), then the same amplifier as in fp32 runs
+        # first loss agrees to 1e-3 mm (measured 1.2e-4), the second to 0.25 mm (0.04 .. 0.11 over five runs), then the same amplifier as in fp32 runs
         # from the higher floor: measured <= 1.83 mm on losses of ~700 mm (0.26 %; 0.1 mm at the 45 mm operating point of a
         # trained model is 0.22 %), final eval prediction 8.9e-3.  Asserted: 1 % of the loss at every step (measured <= 0.5 %: 1.6 mm
         # on the 317 mm loss of step 6).
-        assert per_step[0] < 1e-3 and per_step[1] < 0.1, per_step
+        assert per_step[0] < 1e-3 and per_step[1] < 0.25, per_step      # (second step: 0.04 .. 0.11 mm over five runs)
         assert all(d < 1e-2 * float(z['losses'][i]) * 1000 for i, d in enumerate(per_step)), per_step
         assert err_final < 3e-2, err_final           # (measured 0.9e-2 .. 1.3e-2)
     assert all(v < 1.2e-2 for v in perr.values()), perr      # at most lr per step and parameter
@@ -843,3 +843,55 @@ def test_fp8_mixed_mode_configs4(monkeypatch):
     assert d_tr < 0.6 and d_ev < 5e-3, (d_tr, d_ev)
     assert c > 0.3, c
     assert res['fp8'][0] > res['bf16'][0]          # (sanity: the fp8 path really ran with coarser operands than the bf16 one)
+
+
+@pytest.mark.parametrize('graph', [False, True], ids=['eager', 'module_graphs'])
+def test_packed_operands_follow_parameter_changes(graph, monkeypatch):
+    """The packed GEMM operands are rebuilt only when the parameters changed (round 3: an evaluation loop over frozen weights packs
+    once).  Every way the values can change must be noticed: an in-place torch edit (version counter), load_state_dict, a torch
+    optimizer, and FlatAdam -- whose HIP kernel writes the flat buffer behind torch's version counters (gast_hip.packer.PARAM_EPOCH) --
+    on the eager path and when the module replays its captured graphs (the packing launches stay outside them)."""
+    from gast_hip.optim import FlatAdam
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    torch.manual_seed(4)
+    m = build(cfg).cuda().eval()
+    m._runner.graph_mode = graph
+    x = (torch.rand(3, 9, 17, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+
+    def fresh():          # the same weights through a model that has never packed anything
+        m2 = build(cfg).cuda().eval()
+        m2._runner.graph_mode = False
+        m2.load_state_dict(m.state_dict())
+        with torch.no_grad():
+            return m2(x)
+
+    def same(a, b):
+        return float((a - b).abs().max()) <= 1e-6 * max(1.0, float(b.abs().max()))
+
+    def now(n=4):         # (with graph=True the third call of the shape on is a replay)
+        with torch.no_grad():
+            return [m(x).clone() for _ in range(n)][-1]
+    y0 = now()
+    assert same(y0, fresh())
+    with torch.no_grad():
+        m.shrink.weight.mul_(2.0)                                     # in-place edit: version counter
+    y1 = now()
+    assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6) and same(y1, fresh())
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd['shrink.weight'] *= 0.25
+    m.load_state_dict(sd)                                             # copy_ into the parameters
+    y2 = now()
+    assert torch.allclose(y2, 0.5 * y0, rtol=1e-5, atol=1e-6) and same(y2, fresh())
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    for p in m.parameters():
+        p.grad = torch.ones_like(p) * 1e-2
+    opt.step()                                                        # torch optimizer
+    y3 = now()
+    assert float((y3 - y2).abs().max()) > 1e-4 and same(y3, fresh())
+    fopt = FlatAdam(m.parameters(), lr=1e-2, amsgrad=True)
+    for p in m.parameters():
+        p.grad.fill_(1e-2)
+    fopt.step()                                                       # raw write through the HIP kernel
+    y4 = now()
+    assert float((y4 - y3).abs().max()) > 1e-4 and same(y4, fresh())
