@@ -129,7 +129,9 @@ int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
  * enables every split the heuristic may pick; a smaller or null workspace simply disables splitting. */
 int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
 /* n <= GAST_GEMM_MAX_BATCH independent GEMMs (same dtype / out_f32) in ONE grid: one launch and one tail for the thin GEMMs of a
- * plan step.  Jobs the split-K heuristic picks (small M, long K) are launched on their own.  Per-job semantics of gast_gemm_ws. */
+ * plan step.  Jobs the split-K heuristic picks (small M, long K) ride in the same grid -- each with its own slice of the workspace --
+ * and share ONE finish launch (round 3; when the workspace cannot hold all their partial tiles the overflowing jobs are launched on
+ * their own, as before).  Per-job semantics of gast_gemm_ws. */
 #define GAST_GEMM_MAX_BATCH 3
 int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream);
 long gast_gemm_splitk_ws_bytes(long M, int N);
