@@ -21,6 +21,39 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
     return *(bf16_t*)&b;
 }
 
+// fp16 pairs (GAST_F32X3H): v_cvt_pk_f16_f32, round to nearest even; subnormal results are kept (the f16 MFMA honours them:
+// scripts/toolchain_smoke/f16_denorm_probe.hip)
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+    f32x2_t v = {lo, hi};
+    f16x2_t h = __builtin_convertvector(v, f16x2_t);
+    return *(uint32_t*)&h;
+}
+// x = hi + lo, both halves as packed pairs: PAIR = 1 bf16 (GAST_F32X3), 2 fp16 (GAST_F32X3H).  x - hi is exact in fp32.
+template <int PAIR>
+__device__ __forceinline__ void split_pair4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
+    if (PAIR == 2) {
+        hi.x = pack_f16x2(x0, x1);
+        hi.y = pack_f16x2(x2, x3);
+        const f16x2_t a = *(const f16x2_t*)&hi.x, b = *(const f16x2_t*)&hi.y;
+        lo.x = pack_f16x2(x0 - (float)a.x, x1 - (float)a.y);
+        lo.y = pack_f16x2(x2 - (float)b.x, x3 - (float)b.y);
+    } else {
+        hi.x = pack_bf16x2(x0, x1);
+        hi.y = pack_bf16x2(x2, x3);
+        lo.x = pack_bf16x2(x0 - __uint_as_float(hi.x << 16), x1 - __uint_as_float(hi.x & 0xffff0000u));
+        lo.y = pack_bf16x2(x2 - __uint_as_float(hi.y << 16), x3 - __uint_as_float(hi.y & 0xffff0000u));
+    }
+}
+// one 32x32x16 MFMA step on packed pairs held as 8 x 16 bit
+template <int PAIR>
+__device__ __forceinline__ f32x16 mfma_pair(const uint4& a, const uint4& b, const f32x16& c) {
+    if (PAIR == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const s16x8*)&a, *(const s16x8*)&b, c, 0, 0, 0);
+}
+
 template <typename T> struct Elem;
 template <> struct Elem<float> {
     static constexpr int EPC = 4;  // elements per 16-byte chunk

@@ -45,12 +45,11 @@ template <> struct Mma<bf16_t> {
 // fp32 storage, split-bf16 arithmetic (GAST_F32X3): x = hi + lo with hi = bf16(x), lo = bf16(x - hi) (the difference is exact in
 // fp32), and a*b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the dropped
 // a_lo*b_lo term and the rounding of lo are ~2^-17 relative, i.e. fp32-class products at 3/16 of the fp32 MFMA cost.
-__device__ __forceinline__ void split_bf16x4(const uint4& v, uint2& hi, uint2& lo) {
-    const float x0 = __uint_as_float(v.x), x1 = __uint_as_float(v.y), x2 = __uint_as_float(v.z), x3 = __uint_as_float(v.w);
-    hi.x = pack_bf16x2(x0, x1);
-    hi.y = pack_bf16x2(x2, x3);
-    lo.x = pack_bf16x2(x0 - __uint_as_float(hi.x << 16), x1 - __uint_as_float(hi.x & 0xffff0000u));
-    lo.y = pack_bf16x2(x2 - __uint_as_float(hi.y << 16), x3 - __uint_as_float(hi.y & 0xffff0000u));
+// GAST_F32X3H (X3 = 2): the same with fp16 pairs on v_mfma_f32_32x32x16_f16 -- 11 + 11 significand bits instead of 8 + 8 (~2^-22
+// per product) for operands inside fp16's range (activations, weights; NOT gradients): the forward GEMMs of the bf16x3 plan.
+template <int PAIR>
+__device__ __forceinline__ void split_x4(const uint4& v, uint2& hi, uint2& lo) {
+    split_pair4<PAIR>(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w), hi, lo);
 }
 
 // apply BN+ReLU(+dropout) to one 16-byte chunk of A held in registers
@@ -101,7 +100,7 @@ __device__ __forceinline__ uint2 to_fp8x8(const uint4& v, float s) {
     return make_uint2((uint32_t)q[0], (uint32_t)q[1]);
 }
 
-template <typename T, typename TO, bool X3 = false, bool F8 = false>
+template <typename T, typename TO, int X3 = 0, bool F8 = false>
 __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws, int blk) {
     static_assert(!X3 || sizeof(T) == 4, "the split-bf16 mode stores fp32");
     static_assert(!F8 || sizeof(T) == 2, "the fp8-operand mode stores bf16");
@@ -254,10 +253,10 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             } else if (X3) {
                 // row image: [hi plane: 32 bf16 = 64 B | lo plane: 64 B]; this thread's 4 k values are bytes chunk*8 .. +8 of each
                 uint2 h, l;
-                split_bf16x4(v, h, l);
+                split_x4<X3 == 2 ? 2 : 1>(v, h, l);
                 *(uint2*)(sA + r * LSTR + chunk * 8) = h;
                 *(uint2*)(sA + r * LSTR + 64 + chunk * 8) = l;
-                split_bf16x4(wv, h, l);
+                split_x4<X3 == 2 ? 2 : 1>(wv, h, l);
                 *(uint2*)(sB + r * LSTR + chunk * 8) = h;
                 *(uint2*)(sB + r * LSTR + 64 + chunk * 8) = l;
             } else {
@@ -289,31 +288,32 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             // accumulator, small terms first, consecutive MFMAs on different accumulators
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                union { uint4 u; s16x8 s; } ah[2], al[2], bh[2], bl[2];
+                constexpr int PAIR = X3 == 2 ? 2 : 1;
+                uint4 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
                     const unsigned char* p = sA + (wr * 64 + mi * 32 + li) * LSTR + (ks * 2 + lh) * 16;
-                    ah[mi].u = *(const uint4*)p;
-                    al[mi].u = *(const uint4*)(p + 64);
+                    ah[mi] = *(const uint4*)p;
+                    al[mi] = *(const uint4*)(p + 64);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni) {
                     const unsigned char* p = sB + (wc * 64 + ni * 32 + li) * LSTR + (ks * 2 + lh) * 16;
-                    bh[ni].u = *(const uint4*)p;
-                    bl[ni].u = *(const uint4*)(p + 64);
+                    bh[ni] = *(const uint4*)p;
+                    bl[ni] = *(const uint4*)(p + 64);
                 }
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_pair<PAIR>(al[mi], bh[ni], acc[mi][ni]);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[ni].s, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_pair<PAIR>(ah[mi], bl[ni], acc[mi][ni]);
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[ni].s, acc[mi][ni], 0, 0, 0);
+                    for (int ni = 0; ni < 2; ++ni) acc[mi][ni] = mfma_pair<PAIR>(ah[mi], bh[ni], acc[mi][ni]);
             }
             return;
         }
@@ -599,7 +599,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // ---- split-K finish: C = epi(sum_split ws + bias + addend), same epilogue semantics and partial-sum layout as gemm_kernel.
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
-template <typename T, typename TO, bool X3 = false, bool F8 = false>
+template <typename T, typename TO, int X3 = 0, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
     gemm_body<T, TO, X3, F8>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
@@ -620,7 +620,7 @@ struct GemmBatch {
     int n;
 };
 static_assert(sizeof(GemmBatch) <= 3712, "GemmBatch travels as a kernel argument (4 KB limit)");
-template <typename T, typename TO, bool X3 = false, bool F8 = false>
+template <typename T, typename TO, int X3 = 0, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
@@ -732,7 +732,7 @@ extern "C" int gast_gemm(const gast_gemm_args* args, gast_stream_t stream) { ret
 namespace {
 // validation + launch geometry shared by gast_gemm_ws / gast_gemm_multi
 int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gridM, int& gridN, int& vec_epi, int& splitk) {
-    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16 && a.dtype != GAST_F32X3) return GAST_EINVAL;
+    if (a.dtype != GAST_F32 && a.dtype != GAST_BF16 && a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H) return GAST_EINVAL;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.C || a.N < 1 || a.B < 1 || a.Tn < 1 || a.J < 1) return GAST_EINVAL;
     const int epc = a.dtype == GAST_BF16 ? 8 : 4;
     for (int s = 0; s < a.nseg; ++s) {
@@ -789,9 +789,11 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_kernel<float, float, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<float, float, 1>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+    else if (a.dtype == GAST_F32X3H)
+        hipLaunchKernelGGL((gemm_kernel<float, float, 2>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.f8_scale && !a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, false, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.out_f32)
         hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else
@@ -873,9 +875,11 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
     else if (args[0].dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float, true>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 1>), grid, block, 0, st, b);
+    else if (args[0].dtype == GAST_F32X3H)
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 2>), grid, block, 0, st, b);
     else if (args[0].f8_scale && !args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, false, true>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, b);
     else if (args[0].out_f32)
         hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
     else

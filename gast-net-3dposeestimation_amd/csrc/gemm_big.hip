@@ -59,7 +59,8 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived (compile-time: the
 // epilogue is straight-line code per element); ADD: an addend tensor is present
-template <int EPI, bool ADD, int NI, int MW>
+// PAIR: 1 = bf16 hi/lo pairs (GAST_F32X3), 2 = fp16 pairs (GAST_F32X3H: the forward GEMMs; weight images of the f16 kind)
+template <int EPI, bool ADD, int NI, int MW, int PAIR>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
     constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
     constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW);
@@ -209,10 +210,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             x2 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x2, tsc.z, tsh.z), 0.f) : x2);
             x3 = rz[i] ? 0.f : (pro ? fmaxf(fmaf(x3, tsc.w, tsh.w), 0.f) : x3);
             uint2 h, l;
-            h.x = pack_bf16x2(x0, x1);
-            h.y = pack_bf16x2(x2, x3);
-            l.x = pack_bf16x2(x0 - __uint_as_float(h.x << 16), x1 - __uint_as_float(h.x & 0xffff0000u));
-            l.y = pack_bf16x2(x2 - __uint_as_float(h.y << 16), x3 - __uint_as_float(h.y & 0xffff0000u));
+            split_pair4<PAIR>(x0, x1, x2, x3, h, l);
             *(uint2*)(sA + wa_hi + i * (TM / 2) * ROWB) = h;
             *(uint2*)(sA + wa_lo + i * (TM / 2) * ROWB) = l;
         }
@@ -261,7 +259,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     // One K step.  Order after the barrier: the fragment reads of tile t go out first (their LDS latency is covered by the VALU
     // work of write_a), then tile t+1's activations are written, the transfers of tiles t+2 / t+3 requested, and the MFMAs of
     // tile t issued; the second half of the weight fragments is read under the first half's MFMAs.
-    union Frag { uint4 u; s16x8 s; };
+    struct Frag { uint4 u; };
     auto mma3 = [&](int nh, const Frag (&ah)[2], const Frag (&al)[2], const Frag (&bh)[2], const Frag (&bl)[2]) {
         if (abl & 1) {      // keep the fragment reads alive without the matrix cores
 #pragma unroll
@@ -272,15 +270,15 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_pair<PAIR>(al[mi].u, bh[q].u, acc[mi][nh * 2 + q]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bl[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_pair<PAIR>(ah[mi].u, bl[q].u, acc[mi][nh * 2 + q]);
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mi].s, bh[q].s, acc[mi][nh * 2 + q], 0, 0, 0);
+            for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_pair<PAIR>(ah[mi].u, bh[q].u, acc[mi][nh * 2 + q]);
     };
     auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
         gload_wait_n<WPIECES + 2>();                           // (the newest step's DMA pieces + 2 activation loads stay in flight)
@@ -454,10 +452,10 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
     return e * 2 + (a.addend ? 1 : 0);
 }
 
-template <int EPI, bool ADD, int NI, int MW>
+template <int EPI, bool ADD, int NI, int MW, int PAIR>
 __global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD, NI, MW>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD, NI, MW, PAIR>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -468,12 +466,12 @@ struct BigBatch {
 };
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
-template <int EPI, bool ADD, int NI, int MW>
+template <int EPI, bool ADD, int NI, int MW, int PAIR>
 __global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD, NI, MW>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    big_body<EPI, ADD, NI, MW, PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -491,10 +489,8 @@ __global__ void __launch_bounds__(256) x3_image_kernel(const ImageBatch b) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (k < j.K) v = *(const float4*)(j.W + (long)r * j.ldw + k);
     uint2 h, l;
-    h.x = pack_bf16x2(v.x, v.y);
-    h.y = pack_bf16x2(v.z, v.w);
-    l.x = pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u));
-    l.y = pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u));
+    if (j.f16) split_pair4<2>(v.x, v.y, v.z, v.w, h, l);
+    else split_pair4<1>(v.x, v.y, v.z, v.w, h, l);
     bf16_t* o = (bf16_t*)j.img + (long)(k >> 4) * j.ldimg + (long)r * 32 + (k & 15);
     *(uint2*)o = h;
     *(uint2*)(o + 16) = l;
@@ -510,7 +506,10 @@ std::atomic<bool> big_setup_done[64];      // (zero-initialised: static storage)
 int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int enabled = getenv("GAST_GEMM_BIG") ? atoi(getenv("GAST_GEMM_BIG")) : 1;
     static const int min_rows = getenv("GAST_GEMM_BIG_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_MIN_M")) : 8192;
-    if (!enabled || a.dtype != GAST_F32X3) return 0;
+    if (!enabled || (a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H)) return 0;
+    // fp16 pairs: forward epilogues only (a gradient operand does not fit fp16's range; gemm.hip has every variant)
+    if (a.dtype == GAST_F32X3H && a.epi == GAST_EPI_BNRELU_BWD) return 0;
+    pl.pair = a.dtype == GAST_F32X3H ? 2 : 1;
     const long Ml = (long)a.B * a.Tn * a.J;
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
     // (the M = B*J stage stays on gemm.hip's split-K path: a split-K version of this kernel was built and measured slower on every
@@ -583,37 +582,57 @@ static int big_lds_bytes(int ntab, int ni, int mw) { return off_tab(ni, mw) + 2 
 
 typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
 template <int NI, int MW>
-static big_kernel_t big_kernel_ni(int v) {
+static big_kernel_t big_kernel_ni(int v, int pair) {
+    if (pair == 2) {                // (variants 0..3: gast_gemm_big_plan keeps the BNRELU_BWD epilogues on bf16 pairs)
+        switch (v) {
+            case 0: return gemm_big_kernel<0, false, NI, MW, 2>;
+            case 1: return gemm_big_kernel<0, true, NI, MW, 2>;
+            case 2: return gemm_big_kernel<1, false, NI, MW, 2>;
+            case 3: return gemm_big_kernel<1, true, NI, MW, 2>;
+            default: return nullptr;
+        }
+    }
     switch (v) {
-        case 0: return gemm_big_kernel<0, false, NI, MW>;
-        case 1: return gemm_big_kernel<0, true, NI, MW>;
-        case 2: return gemm_big_kernel<1, false, NI, MW>;
-        case 3: return gemm_big_kernel<1, true, NI, MW>;
-        case 4: return gemm_big_kernel<2, false, NI, MW>;
-        case 5: return gemm_big_kernel<2, true, NI, MW>;
-        case 6: return gemm_big_kernel<3, false, NI, MW>;
-        default: return gemm_big_kernel<3, true, NI, MW>;
+        case 0: return gemm_big_kernel<0, false, NI, MW, 1>;
+        case 1: return gemm_big_kernel<0, true, NI, MW, 1>;
+        case 2: return gemm_big_kernel<1, false, NI, MW, 1>;
+        case 3: return gemm_big_kernel<1, true, NI, MW, 1>;
+        case 4: return gemm_big_kernel<2, false, NI, MW, 1>;
+        case 5: return gemm_big_kernel<2, true, NI, MW, 1>;
+        case 6: return gemm_big_kernel<3, false, NI, MW, 1>;
+        default: return gemm_big_kernel<3, true, NI, MW, 1>;
     }
 }
 // (the 256-row block tile exists at the wide tile only)
-static big_kernel_t big_kernel(int v, int ni, int mw) { return mw == 4 ? big_kernel_ni<4, 4>(v) : ni == 2 ? big_kernel_ni<2, 2>(v) : big_kernel_ni<4, 2>(v); }
+static big_kernel_t big_kernel(int v, int ni, int mw, int pair) {
+    return mw == 4 ? big_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_kernel_ni<2, 2>(v, pair) : big_kernel_ni<4, 2>(v, pair);
+}
 
 typedef void (*big_multi_kernel_t)(const BigBatch);
 template <int NI, int MW>
-static big_multi_kernel_t big_multi_kernel_ni(int v) {
+static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
+    if (pair == 2) {
+        switch (v) {
+            case 0: return gemm_big_multi_kernel<0, false, NI, MW, 2>;
+            case 1: return gemm_big_multi_kernel<0, true, NI, MW, 2>;
+            case 2: return gemm_big_multi_kernel<1, false, NI, MW, 2>;
+            case 3: return gemm_big_multi_kernel<1, true, NI, MW, 2>;
+            default: return nullptr;
+        }
+    }
     switch (v) {
-        case 0: return gemm_big_multi_kernel<0, false, NI, MW>;
-        case 1: return gemm_big_multi_kernel<0, true, NI, MW>;
-        case 2: return gemm_big_multi_kernel<1, false, NI, MW>;
-        case 3: return gemm_big_multi_kernel<1, true, NI, MW>;
-        case 4: return gemm_big_multi_kernel<2, false, NI, MW>;
-        case 5: return gemm_big_multi_kernel<2, true, NI, MW>;
-        case 6: return gemm_big_multi_kernel<3, false, NI, MW>;
-        default: return gemm_big_multi_kernel<3, true, NI, MW>;
+        case 0: return gemm_big_multi_kernel<0, false, NI, MW, 1>;
+        case 1: return gemm_big_multi_kernel<0, true, NI, MW, 1>;
+        case 2: return gemm_big_multi_kernel<1, false, NI, MW, 1>;
+        case 3: return gemm_big_multi_kernel<1, true, NI, MW, 1>;
+        case 4: return gemm_big_multi_kernel<2, false, NI, MW, 1>;
+        case 5: return gemm_big_multi_kernel<2, true, NI, MW, 1>;
+        case 6: return gemm_big_multi_kernel<3, false, NI, MW, 1>;
+        default: return gemm_big_multi_kernel<3, true, NI, MW, 1>;
     }
 }
-static big_multi_kernel_t big_multi_kernel(int v, int ni, int mw) {
-    return mw == 4 ? big_multi_kernel_ni<4, 4>(v) : ni == 2 ? big_multi_kernel_ni<2, 2>(v) : big_multi_kernel_ni<4, 2>(v);
+static big_multi_kernel_t big_multi_kernel(int v, int ni, int mw, int pair) {
+    return mw == 4 ? big_multi_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_multi_kernel_ni<2, 2>(v, pair) : big_multi_kernel_ni<4, 2>(v, pair);
 }
 
 static void big_setup() {
@@ -623,19 +642,23 @@ static void big_setup() {
     if (big_setup_done[dev].load(std::memory_order_acquire)) return;      // (idempotent set-up: a racing first call repeats it)
     for (int c = 0; c < 3; ++c) {          // (NI, MW) = (2, 2), (4, 2), (4, 4)
         const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
-        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
-        for (int v = 0; v < 8; ++v) hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+        for (int pair = 1; pair <= 2; ++pair)
+            for (int v = 0; v < (pair == 2 ? 4 : 8); ++v) {
+                hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+            }
     }
     big_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BIG_DEBUG")) {
         for (int c = 0; c < 3; ++c) {
             const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
-            for (int v = 0; v < 8; v += 2) {
+            for (int pv = 0; pv < 12; pv += 2) {
+                const int pair = pv < 8 ? 1 : 2, v = pv < 8 ? pv : pv - 8;
                 int nb = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni, mw), nt_of(mw), big_lds_bytes(0, ni, mw));
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni, mw, pair), nt_of(mw), big_lds_bytes(0, ni, mw));
                 hipFuncAttributes fa;
-                (void)hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni, mw));
-                fprintf(stderr, "gemm_big variant %d NI %d MW %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, mw, nb, big_lds_bytes(0, ni, mw), fa.numRegs, (size_t)fa.localSizeBytes);
+                (void)hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni, mw, pair));
+                fprintf(stderr, "gemm_big variant %d NI %d MW %d pair %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, mw, pair, nb, big_lds_bytes(0, ni, mw), fa.numRegs, (size_t)fa.localSizeBytes);
             }
         }
     }
@@ -643,7 +666,7 @@ static void big_setup() {
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -653,13 +676,13 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
     bool done[GAST_GEMM_MAX_BATCH] = {};
     for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
-        const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw;
+        const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw, pair = pls[d0].pair;
         BigBatch b;
         b.n = 0;
         b.first[0] = 0;
         int ntab = 0;
         for (int d = d0; d < n; ++d) {
-            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni || pls[d].mw != mw) continue;
+            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni || pls[d].mw != mw || pls[d].pair != pair) continue;
             done[d] = true;
             const int k = b.n++;
             b.a[k] = args[d];
@@ -667,8 +690,8 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b.a[0], b.pl[0]);
-        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b);
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b);
         GAST_CHECK_LAUNCH();
     }
     return 0;

@@ -15,7 +15,7 @@ from gast_hip.packer import F8Weight, X3Weight
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libgast_hip.so')
 
-GAST_F32, GAST_BF16, GAST_F32X3 = 0, 1, 2
+GAST_F32, GAST_BF16, GAST_F32X3, GAST_F32X3H = 0, 1, 2, 3
 MAX_SEG = 8
 PRO_NONE, PRO_BNRELU, PRO_BNRELU_DROP = 0, 1, 2
 EPI_PLAIN, EPI_STATS, EPI_BNRELU_BWD = 0, 1, 2
@@ -53,7 +53,8 @@ class _GemmSeg(C.Structure):
 
 
 class _X3ImageJob(C.Structure):
-    _fields_ = [('W', C.c_void_p), ('R', C.c_int), ('K', C.c_int), ('ldw', C.c_int), ('img', C.c_void_p), ('ldimg', C.c_int)]
+    _fields_ = [('W', C.c_void_p), ('R', C.c_int), ('K', C.c_int), ('ldw', C.c_int), ('img', C.c_void_p), ('ldimg', C.c_int),
+                ('f16', C.c_int)]
 
 
 class _GemmArgs(C.Structure):
@@ -274,10 +275,12 @@ class HipOps:
         a.N = int(N)
         a.nseg = len(segs)
         f8_scales = []
+        nf16 = 0
         for i, s in enumerate(segs):
             g = a.seg[i]
             W, img = s['W'], None
             if isinstance(W, X3Weight):
+                nf16 += W.f16
                 W, img = W.t, W.img
             elif isinstance(W, F8Weight):
                 f8_scales.append(W.scale)
@@ -304,7 +307,10 @@ class HipOps:
         a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
         a.drop = _drop(drop)
         if self.x3 and st_dtype == GAST_F32:
-            a.dtype = GAST_F32X3
+            # fp16 pairs when the weight operands say so (the forward operands of the plan, gast_hip/packer.py); one GEMM, one kind
+            if nf16 not in (0, len(segs)):
+                raise RuntimeError('gast_hip: fp16-pair and bf16-pair weight operands in one gemm')
+            a.dtype = GAST_F32X3H if nf16 else GAST_F32X3
         if (self.f8 and st_dtype == GAST_BF16 and not a.out_f32 and len(f8_scales) == len(segs)
                 and all(sc.data_ptr() == f8_scales[0].data_ptr() for sc in f8_scales)):
             a.f8_scale = _p(f8_scales[0])
@@ -324,18 +330,19 @@ class HipOps:
         self._gemm_args(a, dom, N, segs, C_, cmap, **kw)
         return self.lib.gast_gemm_path(C.byref(a))
 
-    def x3_weight(self, W):
-        """fp32 [N][K] row-major operand -> X3Weight carrying a freshly built pre-split bf16 image (gast_x3_image_multi): what
-        Packer.inputs() hands the engine for every packed operand in GAST_F32X3 mode."""
+    def x3_weight(self, W, f16=False):
+        """fp32 [N][K] row-major operand -> X3Weight carrying a freshly built pre-split image (gast_x3_image_multi; bf16 pairs, or
+        fp16 pairs for a forward operand): what Packer.inputs() hands the engine for every packed operand in GAST_F32X3 mode."""
         if W.dtype != torch.float32:
             raise RuntimeError('gast_hip: x3_weight needs an fp32 operand')
         ld = int(self.lib.gast_x3_image_ld(int(W.shape[0])))
         img = torch.zeros((W.shape[1] + 15) // 16, ld // 32, 32, dtype=torch.bfloat16, device=W.device)
         job = (_X3ImageJob * 1)()
         job[0].W, job[0].R, job[0].K, job[0].ldw, job[0].img, job[0].ldimg = _p(W), W.shape[0], W.shape[1], _ld(W), _p(img), ld
+        job[0].f16 = int(bool(f16))
         self.launches += 1
         _check(self.lib.gast_x3_image_multi(job, 1, _stream()), 'gast_x3_image_multi')
-        return X3Weight(W, img)
+        return X3Weight(W, img, f16)
 
     def gemm_multi(self, jobs):
         """jobs: list of dicts with the arguments of gemm() (keys dom, N, segs, C_, cmap + keywords): independent GEMMs of one plan
@@ -726,8 +733,9 @@ class HipOps:
             if arr is None:
                 jobs = packer.image_jobs(st)
                 arr = (_X3ImageJob * len(jobs))()
-                for a, (wv, iv) in zip(arr, jobs):
+                for a, (wv, iv, f16) in zip(arr, jobs):
                     a.W, a.R, a.K, a.ldw, a.img, a.ldimg = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(iv), iv.stride(0)
+                    a.f16 = int(f16)
                 tb['x3img'] = arr
             self.launches += 1
             _check(self.lib.gast_x3_image_multi(arr, len(arr), _stream()), 'gast_x3_image_multi')

@@ -12,6 +12,8 @@ and runs each list with ONE launch (`ops.run_copy/run_fold/run_unfold`).  Addres
 pairs, so the tables survive buffers that move between calls (the gradient buffer).  The numpy mirror used by the CPU tests
 interprets the same python-level job descriptions through tensor views instead of raw addresses.
 """
+import os
+
 import torch
 
 NHEADS = 4
@@ -66,15 +68,26 @@ def x3_image_rows(R):
     return (R + 15) // 16 * 16 + X3_PAD_ROWS
 
 
-class X3Weight:
-    """An fp32 [N][K] GEMM operand together with its pre-split bf16 image (GAST_F32X3; `gast_x3_image_multi`, include/gast_hip.h):
-    img is the k-group-major 3-D view [ceil(K/16)][rows + zero padding][32].  Slices like the tensor it wraps (`w[r0:r1]`,
-    `w[:, k0:k1]`); a column slice that is not aligned to the 16-value groups drops the image (the GEMM then splits the fp32
-    operand itself)."""
-    __slots__ = ('t', 'img')
+def x3_forward_f16():
+    """GAST_X3_FWD = f16 (default) | bf16: the operand pairs of the FORWARD GEMMs in GAST_HIP_DTYPE=bf16x3.  f16: fp16 hi/lo pairs
+    (GAST_F32X3H, include/gast_hip.h -- 22 instead of 16 significand bits at the same matrix-core rate; post-BatchNorm activations
+    and weights live well inside fp16's range); input and weight gradients always run on bf16 pairs (fp32's exponent range)."""
+    v = os.environ.get('GAST_X3_FWD', 'f16').lower()
+    if v not in ('f16', 'fp16', 'bf16'):
+        raise ValueError('GAST_X3_FWD must be f16 or bf16, got %r' % v)
+    return v != 'bf16'
 
-    def __init__(self, t, img):
-        self.t, self.img = t, img
+
+class X3Weight:
+    """An fp32 [N][K] GEMM operand together with its pre-split image (GAST_F32X3 / GAST_F32X3H; `gast_x3_image_multi`,
+    include/gast_hip.h): img is the k-group-major 3-D view [ceil(K/16)][rows + zero padding][32].  f16: the GEMMs that read this
+    operand run on fp16 pairs (and the image, when present, holds fp16 halves) -- set on the forward operands, never on the
+    transposed twins the input gradients read.  Slices like the tensor it wraps (`w[r0:r1]`, `w[:, k0:k1]`); a column slice that is
+    not aligned to the 16-value groups drops the image (the GEMM then splits the fp32 operand itself)."""
+    __slots__ = ('t', 'img', 'f16')
+
+    def __init__(self, t, img, f16=False):
+        self.t, self.img, self.f16 = t, img, bool(f16)
 
     def __getitem__(self, idx):
         rs, cs = idx if isinstance(idx, tuple) else (idx, slice(None))
@@ -85,7 +98,7 @@ class X3Weight:
             r0, _, rstep = rs.indices(R)
             if step == 1 and rstep == 1 and a % 16 == 0 and (b % 16 == 0 or b == K):
                 img = self.img[a // 16:(b + 15) // 16, r0:]       # (keeps the rows behind the slice: tiles read 256 rows from r0)
-        return X3Weight(self.t[rs, cs], img)
+        return X3Weight(self.t[rs, cs], img, self.f16)
 
 
 class F8Weight:
@@ -251,7 +264,8 @@ class Packer:
     def state(self, dev, dt, x3=False, f8=False):
         """Per (device, dtype, x3) persistent buffers + device job tables.  x3 (GAST_F32X3): every packed fp32 operand also gets a
         pre-split bf16 image (`Xb`), refreshed by ops.run_pack after the copy / fold launches."""
-        key = (str(dev), dt, bool(x3), bool(f8))
+        f16fwd = bool(x3) and dt == torch.float32 and x3_forward_f16()
+        key = (str(dev), dt, bool(x3), bool(f8), f16fwd)
         st = self._dev.get(key)
         ptrs = tuple(p.data_ptr() for p in self.params)
         if st is None or st['ptrs'] != ptrs:
@@ -264,6 +278,7 @@ class Packer:
                 for n, (_, r, c) in self.W.regions.items():
                     X.add(n, (c + 15) // 16, x3_image_rows(r) * 32)
                 st['X'] = X
+                st['f16fwd'] = f16fwd
                 st['Xb'] = torch.zeros(X.size, dtype=torch.bfloat16, device=dev)
             self._dev[key] = st
         return st
@@ -286,8 +301,13 @@ class Packer:
         return False
 
     def image_jobs(self, st):
-        """(fp32 operand view, image view) per packed operand, for ops.run_pack."""
-        return [(self.W.view(st['Wb'], n), self._image(st, n)) for n in self.W.regions]
+        """(fp32 operand view, image view, fp16 pairs?) per packed operand, for ops.run_pack."""
+        return [(self.W.view(st['Wb'], n), self._image(st, n), self._f16(st, n)) for n in self.W.regions]
+
+    @staticmethod
+    def _f16(st, n):
+        """the forward operands (every packed region but the transposed twins of the input gradients) in fp16 pairs?"""
+        return bool(st.get('f16fwd')) and not n.endswith('T')
 
     def _image(self, st, n):
         g, per = st['X'].regions[n][1:]
@@ -297,7 +317,7 @@ class Packer:
         """engine `inp` dict: operand views (act dtype), fp32 packed views, raw parameters."""
         inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
         if st.get('Xb') is not None:
-            inp = {n: X3Weight(w, self._image(st, n)) for n, w in inp.items()}
+            inp = {n: X3Weight(w, self._image(st, n), self._f16(st, n)) for n, w in inp.items()}
         if st.get('F8s') is not None:
             for i, n in enumerate(self.f8_regions()):
                 inp[n] = F8Weight(inp[n], st['F8s'][i])

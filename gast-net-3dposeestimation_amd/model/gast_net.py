@@ -536,7 +536,8 @@ class SpatioTemporalModelBase(nn.Module):
                     and not (gs is not None and len(gs.ranges) > 1)       # (the bucketed exchange hooks into the eager backward)
                     and not torch.cuda.is_current_stream_capturing()):    # (inside a caller's capture the kernels join THAT graph)
                 bufs_now = bn_buffers(self)
-                key = (tuple(x.shape), self.training, need_grad, str(x.device), runner.act_dtype, runner.x3, runner.f8, runner.centered,
+                key = (tuple(x.shape), self.training, need_grad, str(x.device), runner.act_dtype, runner.x3, bool(st.get('f16fwd')), runner.f8,
+                       runner.centered,
                        None if sink is None else sink.data_ptr(), runner.p_dropout if self.training else 0.0,
                        tuple((b['momentum'], b['eps']) for b in bufs_now.values()))      # (baked into a capture: part of its identity)
                 entry = runner._graphs.get(key)

@@ -40,6 +40,11 @@ typedef void* gast_stream_t; /* hipStream_t */
  * registers and accumulate hi*hi + hi*lo + lo*hi on the bf16 matrix cores in fp32 ("bf16x3": ~2^-17 relative per product,
  * 3/16 of the fp32 MFMA cost).  Every other entry point treats it as GAST_F32. */
 #define GAST_F32X3 2
+/* fp32 storage like GAST_F32X3, products on FP16 hi/lo pairs (v_mfma_f32_32x32x16_f16): 11 + 11 significand bits instead of
+ * 8 + 8, ~2^-22 relative per product at the same matrix-core rate -- for operands inside fp16's range (|x| < 65504; parts below
+ * 6e-8 are lost), i.e. the FORWARD GEMMs (post-BatchNorm activations, weights), not gradient operands.  gast_gemm / gast_gemm_ws /
+ * gast_gemm_multi only (gast_wgrad* reject it); Wx images must be of the fp16 kind (gast_x3_image_job.f16). */
+#define GAST_F32X3H 3
 
 #define GAST_EINVAL (-1)   /* bad argument (null pointer, bad dtype, bad size) */
 #define GAST_EALIGN (-2)   /* pointer or leading dimension not 16-byte aligned */
@@ -146,13 +151,16 @@ int gast_gemm_path(const gast_gemm_args* args);
 /* Pre-split weight image for GAST_F32X3, k-group-major: for every group g of 16 K values and every row r of the fp32 operand
  * W[R][ldw] (K columns used), 16 bf16 "hi" = bf16(w) followed by 16 bf16 "lo" = bf16(w - hi):
  *   img[g * ldimg + r * 32 + (k & 15)] = hi,  img[... + 16] = lo,  g = k >> 4,  zero for K <= k < 16 * ceil(K / 16),
+ * (fp16 halves instead when the job's f16 flag is set: the image a GAST_F32X3H GEMM reads)
  * so the 256 x 16 weight tile of one K step of the large-M GEMM is ONE contiguous 16 KB block.  ldimg (bf16 elements per
  * k-group) >= gast_x3_image_ld(R) = 32 * (round_up(R, 16) + 256): the rows past R must exist and be ZERO-FILLED by the caller (a
  * tile may start at any row and always spans 256).  A row slice W[r0:] has the image img + 32 * r0, a column slice W[:, k0:]
  * with k0 % 16 == 0 the image img + (k0 / 16) * ldimg (same ldimg).  gast_gemm_seg.Wx / ldwx carry img / ldimg.
  * n jobs in one launch (GAST_X3_IMAGE_MAX_BATCH per launch). */
 #define GAST_X3_IMAGE_MAX_BATCH 64
-typedef struct { const float* W; int R, K, ldw; void* img; int ldimg; } gast_x3_image_job;
+typedef struct { const float* W; int R, K, ldw; void* img; int ldimg;
+                 int f16;   /* 0: bf16 hi/lo pairs (GAST_F32X3), 1: fp16 hi/lo pairs (GAST_F32X3H); same layout and size */
+} gast_x3_image_job;
 int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_stream_t stream);
 long gast_x3_image_ld(int R);
 /* number of row blocks (first dimension of `partials`) gast_gemm uses for a domain of M rows */

@@ -56,12 +56,16 @@ def _grad_cosines(m, ref, min_numel=64):
 
 
 FP32_GRAD_TOL = dict(grad=2e-4, gabs=2e-5)
-# GAST_HIP_DTYPE=bf16x3 (fp32 storage, split-bf16 products: ~2^-17 relative per product instead of fp32's 2^-24): the same
-# elementwise check as fp32 with a wider bound (measured values are logged by the GPU tests; see X3_GRAD_TOL's users)
-X3_GRAD_TOL = dict(grad=1e-3, gabs=1e-4)      # (measured on the goldens / mid-size cases: <= 0.36 of this bound)
+# GAST_HIP_DTYPE=bf16x3 (fp32 storage; forward GEMM products on fp16 hi/lo pairs, ~2^-22 relative per product; input / weight
+# gradients on bf16 pairs, ~2^-17): the same elementwise check as fp32 WITH FP32's BOUND -- measured on the goldens / mid-size cases
+# <= 0.29 of it (round 3, after the forward moved to fp16 pairs; with GAST_X3_FWD=bf16, the lever that restores bf16 pairs everywhere,
+# the old 5x wider bound applies: measured <= 0.36 of that)
+from gast_hip.packer import x3_forward_f16      # noqa: E402
+X3_FWD_F16 = x3_forward_f16()
+X3_GRAD_TOL = dict(grad=2e-4, gabs=2e-5) if X3_FWD_F16 else dict(grad=1e-3, gabs=1e-4)
 # largest |pre-activation| (BatchNorm-normalised units, O(1) scale) at which the path under test may decide a ReLU differently from
-# the float64 oracle: its own round-off on that quantity, with margin
-FLIP_EPS = {'fp32': 2e-5, 'bf16x3': 2e-3}
+# the float64 oracle: its own round-off on that quantity, with margin (bf16x3 measured <= 3.1e-5 over the BASELINE-size shapes)
+FLIP_EPS = {'fp32': 2e-5, 'bf16x3': 2e-4 if X3_FWD_F16 else 2e-3}
 
 
 def forced_oracle(run_oracle, decisions):

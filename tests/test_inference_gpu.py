@@ -120,11 +120,13 @@ def test_shape243_matches_reference(mode):
     loss = torch.mean(torch.norm(y - y3d, dim=-1))
     loss.backward()
     assert float((y_eval.cpu() - torch.from_numpy(z['y_eval'])).abs().max()) < TOL
-    # train mode (batch statistics): bf16x3's 16-bit operands are amplified ~2x per temporal level -- 4e-4 stated for five levels
-    # (measured 1.9e-4; tests/test_model_gpu.py::x3_depth_factor), fp32 1e-4 (measured 9e-6)
-    ttol = TOL if mode == 'fp32' else 4 * TOL
-    assert float((y.detach().cpu() - torch.from_numpy(z['y_train'])).abs().max()) < ttol
-    assert abs(loss.item() - float(z['loss'])) < (1e-5 if mode == 'fp32' else 4e-5)
+    # train mode (batch statistics): 1e-4 in both arithmetics (fp32 measured 9e-6; bf16x3, forward GEMMs on fp16 pairs, 1.7e-5).  With
+    # GAST_X3_FWD=bf16 the 16-bit operand halves are amplified ~2x per temporal level: 4e-4 stated for these five (measured 1.9e-4;
+    # tests/test_model_gpu.py::x3_depth_factor)
+    from parity_helpers import X3_FWD_F16
+    wide = mode != 'fp32' and not X3_FWD_F16
+    assert float((y.detach().cpu() - torch.from_numpy(z['y_train'])).abs().max()) < (4 * TOL if wide else TOL)
+    assert abs(loss.item() - float(z['loss'])) < (4e-5 if wide else 1e-5)
     dgen = torch.Generator().manual_seed(SHAPE243['seed'] + 2)
     # (norm / projection digests cannot be taken on the path's own ReLU branch: in bf16x3 ~2700 of the 1e8 ReLU inputs of this shape
     # are decided differently from the fp32 reference, each flipping one whole contribution -- hence 3e-2 here; the elementwise bound

@@ -16,15 +16,16 @@ pytestmark = pytest.mark.gpu
 DTYPES = [torch.float32, torch.bfloat16]
 # MFMA kernels (gast_gemm*, gast_wgrad*): fp32, bf16 and fp32 storage with split-bf16 products (GAST_F32X3); 'x3' runs the fp32
 # cases with HipOps.x3 set and a tolerance of 1e-4 of the result magnitude (three bf16 products carry ~2^-17 relative each)
-MM_MODES = ['f32', 'bf16', 'x3']
-MM_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'x3': torch.float32}
+# 'x3h' (GAST_F32X3H): the same with fp16 hi/lo pairs -- the weight operands carry the tag (X3Weight.f16), the tolerance is fp32's
+MM_MODES = ['f32', 'bf16', 'x3', 'x3h']
+MM_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'x3': torch.float32, 'x3h': torch.float32}
 
 
 class x3_mode:
     """with x3_mode(ops, mode): fp32 operands go through the split-bf16 MFMA path for the duration of the block"""
 
     def __init__(self, ops, mode):
-        self.ops, self.on = ops, mode == 'x3'
+        self.ops, self.on = ops, mode in ('x3', 'x3h')
 
     def __enter__(self):
         self.ops.x3 = self.on
@@ -170,6 +171,14 @@ def _gemm_case(case, dt):
     return jd, jh, (Cd, Ch, pd, ph)
 
 
+def _f16_pairs(jd):
+    """tag the weight operands of a gemm() job: its products run on fp16 pairs (what the packer does for the forward operands)"""
+    from gast_hip.packer import X3Weight
+    for s in jd['segs']:
+        s['W'] = X3Weight(s['W'], None, True)
+    return jd
+
+
 def _gemm_check(case, dt, bufs, mode='f32'):
     name, N, epi = case[0], case[2], case[4]
     Cd, Ch, pd, ph = bufs
@@ -185,6 +194,8 @@ def _gemm_check(case, dt, bufs, mode='f32'):
 def test_gemm(ops, case, mode):
     dt = MM_DT[mode]
     jd, jh, bufs = _gemm_case(case, dt)
+    if mode == 'x3h':
+        _f16_pairs(jd)
     with x3_mode(ops, mode):
         ops.gemm(**jd)
     kc.gemm(**jh)
@@ -200,6 +211,9 @@ def test_gemm_multi(ops, mode):
     dt = MM_DT[mode]
     cases = [c for c in GEMM_CASES]
     built = [_gemm_case(c, dt) for c in cases]
+    if mode == 'x3h':
+        for jd, _, _ in built:
+            _f16_pairs(jd)
     with x3_mode(ops, mode):
         ops.gemm_multi([jd for jd, _, _ in built])
     torch.cuda.synchronize()
@@ -223,43 +237,67 @@ GEMM_BIG_CASES = [
 ]
 
 
-def _with_images(ops, jd):
+def _with_images(ops, jd, f16=False):
     for s in jd['segs']:
-        s['W'] = ops.x3_weight(s['W'])
+        s['W'] = ops.x3_weight(s['W'], f16)
     return jd
 
 
+PAIRS = ['bf16', 'f16']      # GAST_F32X3 / GAST_F32X3H
+
+
+@pytest.mark.parametrize('pair', PAIRS)
 @pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
 @pytest.mark.parametrize('case', GEMM_BIG_CASES, ids=[c[0] for c in GEMM_BIG_CASES])
-def test_gemm_big_x3(ops, case, nodrop):
+def test_gemm_big_x3(ops, case, nodrop, pair):
     if nodrop and case[4] != 2:
         pytest.skip('only the BNRELU_BWD epilogue has a dropout variant')
     jd, jh, bufs = _gemm_case(case, torch.float32)
     if nodrop:
         jd['xdrop'] = jh['xdrop'] = False
+    f16 = pair == 'f16'
     with x3_mode(ops, 'x3'):
-        assert ops.gemm_path(**_with_images(ops, jd)) == 1, 'the large-M kernel (gemm_big.hip) was not selected'
+        # fp16 pairs: the forward epilogues run on the large-M kernel, a BNRELU_BWD epilogue falls to gemm.hip's fp16-pair variant
+        want = 0 if (f16 and case[4] == 2) else 1
+        assert ops.gemm_path(**_with_images(ops, jd, f16)) == want, 'kernel selection (gemm_big.hip = 1)'
         ops.gemm(**jd)
     kc.gemm(**jh)
     torch.cuda.synchronize()
-    _gemm_check(case, torch.float32, bufs, 'x3')
+    _gemm_check(case, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
+@pytest.mark.parametrize('pair', PAIRS)
 @pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
 @pytest.mark.parametrize('first', [0, 3, 6])
-def test_gemm_big_x3_multi(ops, first, nodrop):
+def test_gemm_big_x3_multi(ops, first, nodrop, pair):
     """every epilogue variant of the large-M kernel also inside a multi-job grid (3 jobs per launch)"""
     cases = (GEMM_BIG_CASES + GEMM_BIG_CASES[:1])[first:first + 3]
     built = [_gemm_case(c, torch.float32) for c in cases]
     if nodrop:
         for jd, jh, _ in built:
             jd['xdrop'] = jh['xdrop'] = False
+    f16 = pair == 'f16'
     with x3_mode(ops, 'x3'):
-        ops.gemm_multi([_with_images(ops, jd) for jd, _, _ in built])
+        ops.gemm_multi([_with_images(ops, jd, f16) for jd, _, _ in built])
     torch.cuda.synchronize()
     for c, (jd, jh, bufs) in zip(cases, built):
         kc.gemm(**jh)
-        _gemm_check(c, torch.float32, bufs, 'x3')
+        _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
+
+
+def test_gemm_pairs_do_not_mix(ops):
+    """one GEMM, one kind of operand pairs: fp16-tagged and untagged weight segments in one call are refused (binding), jobs of
+    different kinds in one multi call as well (C ABI: dtypes differ)"""
+    jd, _, _ = _gemm_case(GEMM_CASES[2], torch.float32)
+    from gast_hip.packer import X3Weight
+    jd['segs'][0]['W'] = X3Weight(jd['segs'][0]['W'], None, True)
+    with x3_mode(ops, 'x3'):
+        with pytest.raises(RuntimeError, match='fp16-pair and bf16-pair'):
+            ops.gemm(**jd)
+        a, _, _ = _gemm_case(GEMM_CASES[0], torch.float32)
+        b, _, _ = _gemm_case(GEMM_CASES[1], torch.float32)
+        with pytest.raises(RuntimeError):
+            ops.gemm_multi([_f16_pairs(a), b])
 
 
 GEMM_SMALL_X3_CASES = [
@@ -269,15 +307,16 @@ GEMM_SMALL_X3_CASES = [
 ]
 
 
+@pytest.mark.parametrize('pair', PAIRS)
 @pytest.mark.parametrize('case', GEMM_SMALL_X3_CASES, ids=[c[0] for c in GEMM_SMALL_X3_CASES])
-def test_gemm_small_x3_images(ops, case):
+def test_gemm_small_x3_images(ops, case, pair):
     """The M = B*J stage with pre-split weight images attached to its operands: gemm.hip's split-K path reads the fp32 weights."""
     jd, jh, bufs = _gemm_case(case, torch.float32)
     with x3_mode(ops, 'x3'):
-        ops.gemm(**_with_images(ops, jd))
+        ops.gemm(**_with_images(ops, jd, pair == 'f16'))
     kc.gemm(**jh)
     torch.cuda.synchronize()
-    _gemm_check(case, torch.float32, bufs, 'x3')
+    _gemm_check(case, torch.float32, bufs, 'x3h' if pair == 'f16' else 'x3')
 
 
 def test_x3_image_layout(ops):
@@ -297,6 +336,18 @@ def test_x3_image_layout(ops):
     assert not img[:, 37:].any()
     sl = xw[5:9, 32:72]                  # aligned column slice keeps its image, an unaligned one drops it
     assert sl.img is not None and sl.img.data_ptr() == xw.img[2:, 5:].data_ptr() and xw[:, 8:40].img is None
+    # the fp16 kind (GAST_F32X3H): same layout, fp16 halves (subnormal lo parts included); slices keep the tag
+    Ws = W * torch.logspace(-4, 0, 72, device='cuda')            # columns down to 1e-4: lo parts reach fp16's subnormals
+    xh = ops.x3_weight(Ws, True)
+    torch.cuda.synchronize()
+    imh = xh.img.view(torch.float16).float().cpu().numpy()
+    Wp[:, :72] = Ws.cpu().numpy()
+    hi = torch.from_numpy(Wp).to(torch.float16).float().numpy()
+    lo = torch.from_numpy(Wp - hi).to(torch.float16).float().numpy()
+    assert np.array_equal(imh[:, :37, :16].transpose(1, 0, 2).reshape(37, 80), hi)
+    assert np.array_equal(imh[:, :37, 16:].transpose(1, 0, 2).reshape(37, 80), lo)
+    assert (np.abs(lo[lo != 0]) < 6.1e-5).any(), 'the case is meant to exercise subnormal lo parts'
+    assert not imh[:, 37:].any() and xh.f16 and xh[5:9, 32:72].f16 and not xw.f16
 
 
 @pytest.mark.parametrize('case', [c for c in GEMM_CASES if c[0] in ('stats_two_tiles', 'dilated_taps', 'ktail', 'big', 'splitk_stats', 'concat3_drop')],
@@ -379,7 +430,7 @@ def _wgrad_case(case, dt):
     return jd, jh
 
 
-@pytest.mark.parametrize('mode', MM_MODES)
+@pytest.mark.parametrize('mode', MM_MODES[:3])      # (weight gradients: bf16 pairs only -- gradient operands need fp32's range)
 @pytest.mark.parametrize('case', WGRAD_CASES, ids=[c[0] for c in WGRAD_CASES])
 def test_wgrad(ops, case, mode):
     dt = MM_DT[mode]
@@ -391,7 +442,7 @@ def test_wgrad(ops, case, mode):
     close(host(jd['dW']), jh['dW'], dt, case[0], fp32=1e-4 if mode == 'x3' else 3e-5, bf16=2e-2)
 
 
-@pytest.mark.parametrize('mode', MM_MODES)
+@pytest.mark.parametrize('mode', MM_MODES[:3])      # (weight gradients: bf16 pairs only -- gradient operands need fp32's range)
 def test_wgrad_multi(ops, mode):
     """All WGRAD_CASES (different domains, segment counts, prologues) as ONE multi-job launch, accumulating into the 3.0 fill
     (zero_first=False) for the odd jobs and overwriting it for the even ones."""

@@ -23,12 +23,17 @@ import scenario as sc  # noqa: E402
 
 REF = '/root/reference'
 # after 2 optimizer steps the two implementations agree to fp32 round-off; over 7 steps Adam amplifies it (see scenario.py).
-# bf16x3 (fp32 storage, split-bf16 products: ~2^-17 per product, the arithmetic bench.py times) starts from a 100x larger round-off, and
-# Adam's first steps move every parameter by lr * sign(gradient): a gradient within 4e-5 of zero flips and that parameter ends 2 lr away
-# -- so its parameter / loss bounds after the optimizer steps are wider; the north star's MPJPE bound (0.1 mm) is the same for both.
+# bf16x3 (fp32 storage; forward GEMMs on fp16 hi/lo pairs, gradients on bf16 pairs -- the arithmetic bench.py times) behaves like fp32
+# here since the forward moved to fp16 pairs (measured, round 3: short 6.3e-7 / 0.002 mm / 1.3e-4 / 2.7e-5; epoch 7.8e-5 / 0.014 mm /
+# 1.2e-3), so it gets fp32's bounds except for the short prediction bound (5e-4: Adam's first steps move every parameter by
+# lr * sign(gradient), and a gradient within its 2e-5 round-off of zero flips).  With GAST_X3_FWD=bf16 (bf16 pairs in the forward too)
+# the round-off is ~20x larger and the round-2 bounds apply.  The north star's MPJPE bound (0.1 mm) is the same for all.
+from parity_helpers import X3_FWD_F16  # noqa: E402
 TOL = {'fp32': {'short': dict(loss=2e-6, mm=0.05, pred=2e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)},
-       # (measured, round 3: short 2.4e-5 / 0.006 mm / 1.2e-4 / 2.0e-3; epoch 1.0e-4 / 0.08 mm / 1.7e-3)
-       'bf16x3': {'short': dict(loss=1e-4, mm=0.05, pred=1e-3, param=5e-3), 'epoch': dict(loss=1e-3, mm=0.1, pred=1e-2, param=None)}}
+       'bf16x3': ({'short': dict(loss=5e-6, mm=0.05, pred=5e-4, param=2e-4), 'epoch': dict(loss=1e-3, mm=0.1, pred=5e-3, param=None)}
+                  if X3_FWD_F16 else
+                  # (measured with bf16 pairs: short 2.4e-5 / 0.006 mm / 1.2e-4 / 2.0e-3; epoch 1.0e-4 / 0.08 mm / 1.7e-3)
+                  {'short': dict(loss=1e-4, mm=0.05, pred=1e-3, param=5e-3), 'epoch': dict(loss=1e-3, mm=0.1, pred=1e-2, param=None)})}
 
 
 def compare(got, ref, size, arith='fp32', log=None):
