@@ -690,15 +690,61 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
 // [C | 2*nheads | nheads*J*J] that attn_bwd_finish_kernel reduces without atomics.
 __device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// unroll factor of the two J-long product loops of the JT kernels (full unrolling hoists all 17 row loads: 220 - 350 VGPRs in the backward)
+#ifndef GAST_ATTN_PROD_UNROLL
+#define GAST_ATTN_PROD_UNROLL 4
+#endif
 template <int CI4> struct AttnW {
     static constexpr int CI = CI4 * 4, GS = CI + 4, RG = 64 / CI4, NR = (JMAX + RG - 1) / RG;
     static constexpr int FWD_FLOATS = JMAX * JP + JMAX * GS + 32;
     static constexpr int BWD_FLOATS = 4 * JMAX * JP + 2 * JMAX * GS + 32;
 };
 
-// rows of att = softmax_j(leaky(a_i + c_j)) + C_k for lane i < J; optionally p and the LeakyReLU slopes
+// rows of att = softmax_j(leaky(a_i + c_j)) + C_k for lane i < J; optionally p and the LeakyReLU slopes.
+// JT = the skeleton's joint count as a compile-time constant (15 / 17 / 19: the shipped skeletons; 0 = run-time J).  A unit is ONE
+// wave's dependent instruction chain, so its length is the kernel's time: with JT the 17-lane row phases are straight-line code --
+// the exponentials stay in registers between the two passes, the row of c_j is read with 16-byte LDS loads, no loop branches.
+template <int JT>
 __device__ __forceinline__ void attn_row(int lane, int J, float a_i, const float* __restrict__ sc, const float* ckrow,
                                          float (*satt)[JP], float (*sp)[JP], float (*sslope)[JP]) {
+    if constexpr (JT > 0) {
+        if (lane < JT) {
+            constexpr int J4 = (JT + 3) / 4;
+            float s[J4 * 4], sl[J4 * 4];
+#pragma unroll
+            for (int q = 0; q < J4; ++q) {      // (sc has 32 floats: the tail of the last quad is finite garbage that is never used)
+                const float4 c4 = *(const float4*)(sc + 4 * q);
+                s[4 * q] = c4.x; s[4 * q + 1] = c4.y; s[4 * q + 2] = c4.z; s[4 * q + 3] = c4.w;
+            }
+            float mx = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                const float v = a_i + s[j];
+                sl[j] = v > 0.f ? 1.f : 0.2f;
+                s[j] = v * sl[j];
+                mx = fmaxf(mx, s[j]);
+            }
+            float sum = 0.f;
+#pragma unroll
+            for (int j = 0; j < JT; ++j) {
+                s[j] = expf(s[j] - mx);
+                sum += s[j];
+            }
+            const float inv = 1.f / sum;
+#pragma unroll
+            for (int j = JT; j < J4 * 4; ++j) { s[j] = 0.f; sl[j] = 0.f; }
+            // rows are JP = 20 floats (80 B, 16-byte aligned): whole quads; columns JT .. 4 J4 - 1 of a tile are padding nobody reads
+#pragma unroll
+            for (int q = 0; q < J4; ++q) {
+                const float4 pv = make_float4(s[4 * q] * inv, s[4 * q + 1] * inv, s[4 * q + 2] * inv, s[4 * q + 3] * inv);
+                if (sp) *(float4*)(&sp[lane][4 * q]) = pv;
+                if (sslope) *(float4*)(&sslope[lane][4 * q]) = make_float4(sl[4 * q], sl[4 * q + 1], sl[4 * q + 2], sl[4 * q + 3]);
+                *(float4*)(&satt[lane][4 * q]) = make_float4(pv.x + ckrow[4 * q], pv.y + ckrow[4 * q + 1], pv.z + ckrow[4 * q + 2],
+                                                             4 * q + 3 < JMAX ? pv.w + ckrow[4 * q + 3 < JMAX ? 4 * q + 3 : 0] : 0.f);
+            }
+        }
+        return;
+    }
     if (lane < J) {
         float mx = -3.0e38f;
         for (int j = 0; j < J; ++j) {
@@ -727,11 +773,12 @@ __device__ __forceinline__ void attn_row(int lane, int J, float a_i, const float
     }
 }
 
-template <typename T, int CI4>
+template <typename T, int CI4, int JT>
 __global__ void __launch_bounds__(256) attn_fwd_wave_kernel(const T* __restrict__ G, int ldg, const T* __restrict__ AC, int ldac,
-                                                            const float* __restrict__ Ck, int F, int J, int nheads,
+                                                            const float* __restrict__ Ck, int F, int Jrt, int nheads,
                                                             T* __restrict__ Y, int ldy) {
     using W = AttnW<CI4>;
+    const int J = JT ? JT : Jrt;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float* base = smem + w * W::FWD_FLOATS;
@@ -789,11 +836,12 @@ __global__ void __launch_bounds__(256) attn_fwd_wave_kernel(const T* __restrict_
             }
         }
         wave_lds_sync();
-        attn_row(lane, J, a_i, sc, ckrow, satt, nullptr, nullptr);
+        attn_row<JT>(lane, J, a_i, sc, ckrow, satt, nullptr, nullptr);
         wave_lds_sync();
         float4 acc[W::NR];
 #pragma unroll
         for (int q = 0; q < W::NR; ++q) acc[q] = make_float4(0, 0, 0, 0);
+#pragma unroll(JT ? GAST_ATTN_PROD_UNROLL : 1)
         for (int j = 0; j < J; ++j) {
             const float4 gv = *(const float4*)(sg + j * W::GS + c4 * 4);
 #pragma unroll
@@ -812,12 +860,13 @@ __global__ void __launch_bounds__(256) attn_fwd_wave_kernel(const T* __restrict_
     }
 }
 
-template <typename T, int CI4>
+template <typename T, int CI4, int JT>
 __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict__ dY, int lddy, const T* __restrict__ G, int ldg,
                                                             const T* __restrict__ AC, int ldac, const float* __restrict__ Ck,
-                                                            int F, int J, int nheads, T* __restrict__ dG, int lddg,
+                                                            int F, int Jrt, int nheads, T* __restrict__ dG, int lddg,
                                                             T* __restrict__ dAC, int lddac, float* __restrict__ ws, int ncol) {
     using W = AttnW<CI4>;
+    const int J = JT ? JT : Jrt;
     constexpr int NP = (JMAX * JMAX + 63) / 64;      // (i, j) pairs per lane
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -893,7 +942,7 @@ __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict_
             }
         }
         wave_lds_sync();
-        attn_row(lane, J, a_i, sc, ckrow, satt, sp, sds);
+        attn_row<JT>(lane, J, a_i, sc, ckrow, satt, sp, sds);
         // datt[i][j] = sum_c dy[i][c] * g[j][c]   (pairs t = lane + 64 q)
 #pragma unroll
         for (int q = 0; q < NP; ++q) {
@@ -915,6 +964,52 @@ __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict_
         }
         wave_lds_sync();
         // softmax + LeakyReLU backward, row i = lane: ds_ij = p_ij (datt_ij - <p_i, datt_i>) slope_ij;  da_i = sum_j ds_ij
+        if constexpr (JT > 0) {
+            // straight-line row phase: the rows of p / datt / slope come in with 16-byte loads, two partial sums break the FMA chain
+            if (lane < JT) {
+                constexpr int J4 = (JT + 3) / 4;
+                float pv[J4 * 4], dv[J4 * 4], sv[J4 * 4];
+#pragma unroll
+                for (int q = 0; q < J4; ++q) {
+                    const float4 a4 = *(const float4*)(&sp[lane][4 * q]), b4 = *(const float4*)(&sdat[lane][4 * q]), c4v = *(const float4*)(&sds[lane][4 * q]);
+                    pv[4 * q] = a4.x; pv[4 * q + 1] = a4.y; pv[4 * q + 2] = a4.z; pv[4 * q + 3] = a4.w;
+                    dv[4 * q] = b4.x; dv[4 * q + 1] = b4.y; dv[4 * q + 2] = b4.z; dv[4 * q + 3] = b4.w;
+                    sv[4 * q] = c4v.x; sv[4 * q + 1] = c4v.y; sv[4 * q + 2] = c4v.z; sv[4 * q + 3] = c4v.w;
+                }
+                float dot0 = 0.f, dot1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < JT; ++j) {
+                    if (j & 1) dot1 = fmaf(pv[j], dv[j], dot1);
+                    else dot0 = fmaf(pv[j], dv[j], dot0);
+                }
+                const float dot = dot0 + dot1;
+                float da0 = 0.f, da1 = 0.f;
+#pragma unroll
+                for (int j = 0; j < J4 * 4; ++j) {
+                    const float ds = j < JT ? pv[j] * (dv[j] - dot) * sv[j] : 0.f;
+                    sv[j] = ds;
+                    if (j & 1) da1 += ds;
+                    else da0 += ds;
+                }
+#pragma unroll
+                for (int q = 0; q < J4; ++q) *(float4*)(&sds[lane][4 * q]) = make_float4(sv[4 * q], sv[4 * q + 1], sv[4 * q + 2], sv[4 * q + 3]);
+                const float da = da0 + da1;
+                Elem<T>::st(dAC + ((long)f * J + lane) * lddac + h, da);
+                da_sum += da;
+            }
+            wave_lds_sync();
+            if (lane < JT) {
+                float dc0 = 0.f, dc1 = 0.f;
+#pragma unroll
+                for (int i = 0; i < JT; ++i) {
+                    if (i & 1) dc1 += sds[i][lane];
+                    else dc0 += sds[i][lane];
+                }
+                const float dc = dc0 + dc1;
+                Elem<T>::st(dAC + ((long)f * J + lane) * lddac + nheads + h, dc);
+                dc_sum += dc;
+            }
+        } else {
         if (lane < J) {
             float dot = 0.f;
             for (int j = 0; j < J; ++j) dot = fmaf(sp[lane][j], sdat[lane][j], dot);
@@ -934,10 +1029,12 @@ __global__ void __launch_bounds__(256) attn_bwd_wave_kernel(const T* __restrict_
             Elem<T>::st(dAC + ((long)f * J + lane) * lddac + nheads + h, dc);
             dc_sum += dc;
         }
+        }
         // dg[j][c] = sum_i att[i][j] * dy[i][c]
         float4 acc[W::NR];
 #pragma unroll
         for (int q = 0; q < W::NR; ++q) acc[q] = make_float4(0, 0, 0, 0);
+#pragma unroll(JT ? GAST_ATTN_PROD_UNROLL : 1)
         for (int i = 0; i < J; ++i) {
             const float4 dv = *(const float4*)(sdy + i * W::GS + c4 * 4);
 #pragma unroll
@@ -1501,9 +1598,9 @@ static bool attn_mfma_ok(int ld_a, const void* a, int ld_b, const void* b) {
     return on && ld_a % 8 == 0 && ld_b % 8 == 0 && ((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0;
 }
 
-template <typename T, int CI4>
-static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J, int nheads, void* Y,
-                                int ldy, hipStream_t st) {
+template <typename T, int CI4, int JT>
+static int launch_attn_fwd_wave_j(const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J, int nheads, void* Y,
+                                  int ldy, hipStream_t st) {
     if constexpr (sizeof(T) == 2) {
         if (attn_mfma_ok(ldg, G, ldg, G)) {
             constexpr int CI = CI4 * 4;
@@ -1520,23 +1617,41 @@ static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac
     }
     const size_t smem = (size_t)4 * AttnW<CI4>::FWD_FLOATS * sizeof(float);
     if (smem > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = hipFuncSetAttribute((const void*)attn_fwd_wave_kernel<T, CI4, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
     static AttnOcc occ;
-    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_fwd_wave_kernel<T, CI4>, smem) : 0;
-    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4>), dim3(attn_wave_grid(F, nheads, per_cu)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
+    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_fwd_wave_kernel<T, CI4, JT>, smem) : 0;
+    hipLaunchKernelGGL((attn_fwd_wave_kernel<T, CI4, JT>), dim3(attn_wave_grid(F, nheads, per_cu)), dim3(256), smem, st, (const T*)G, ldg, (const T*)AC,
                        ldac, C_k, F, J, nheads, (T*)Y, ldy);
     GAST_CHECK_LAUNCH();
     return 0;
 }
-
+// the shipped skeletons (Human3.6M 17, + toes 19, HumanEva 15) get the straight-line fp32 kernels, everything else the run-time-J ones
+// (GAST_ATTN_JT=0: run-time J everywhere, the A/B and bisecting switch)
+static bool attn_jt_enabled() {
+    static const int on = getenv("GAST_ATTN_JT") ? atoi(getenv("GAST_ATTN_JT")) : 1;
+    return on != 0;
+}
 template <typename T, int CI4>
-static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
-                                int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
-                                hipStream_t st) {
+static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J, int nheads, void* Y,
+                                int ldy, hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        if (attn_jt_enabled()) {
+            if (J == 17) return launch_attn_fwd_wave_j<T, CI4, 17>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, st);
+            if (J == 19) return launch_attn_fwd_wave_j<T, CI4, 19>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, st);
+            if (J == 15) return launch_attn_fwd_wave_j<T, CI4, 15>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, st);
+        }
+    }
+    return launch_attn_fwd_wave_j<T, CI4, 0>(G, ldg, AC, ldac, C_k, F, J, nheads, Y, ldy, st);
+}
+
+template <typename T, int CI4, int JT>
+static int launch_attn_bwd_wave_j(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
+                                  int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
+                                  hipStream_t st) {
     static AttnOcc occ;
-    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_bwd_wave_kernel<T, CI4>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
+    const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_bwd_wave_kernel<T, CI4, JT>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
     const int grid = attn_wave_grid(F, nheads, per_cu);
     const int C = nheads * CI4 * 4;
     const int nb = C + 2 * nheads, ncol = nb + nheads * J * J;
@@ -1557,16 +1672,29 @@ static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg
     } else {
         const size_t smem = (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float);
         if (smem > 48 * 1024) {
-            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_wave_kernel<T, CI4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+            hipError_t e = hipFuncSetAttribute((const void*)attn_bwd_wave_kernel<T, CI4, JT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
             if (e != hipSuccess) return (int)e;
         }
-        hipLaunchKernelGGL((attn_bwd_wave_kernel<T, CI4>), dim3(grid), dim3(256), smem, st, (const T*)dY, lddy, (const T*)G, ldg, (const T*)AC,
+        hipLaunchKernelGGL((attn_bwd_wave_kernel<T, CI4, JT>), dim3(grid), dim3(256), smem, st, (const T*)dY, lddy, (const T*)G, ldg, (const T*)AC,
                            ldac, C_k, F, J, nheads, (T*)dG, lddg, (T*)dAC, lddac, ws, ncol);
     }
     GAST_CHECK_LAUNCH();
     hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3((ncol + 31) / 32), dim3(256), 0, st, ws, grid * 4 / nheads, ncol, nb, dbias, dC_k);
     GAST_CHECK_LAUNCH();
     return 0;
+}
+template <typename T, int CI4>
+static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
+                                int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
+                                hipStream_t st) {
+    if constexpr (sizeof(T) == 4) {
+        if (attn_jt_enabled()) {
+#define GAST_BWD_J(JT_) if (J == JT_) return launch_attn_bwd_wave_j<T, CI4, JT_>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st);
+            GAST_BWD_J(17) GAST_BWD_J(19) GAST_BWD_J(15)
+#undef GAST_BWD_J
+        }
+    }
+    return launch_attn_bwd_wave_j<T, CI4, 0>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st);
 }
 
 extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
