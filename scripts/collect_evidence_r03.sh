@@ -5,10 +5,12 @@
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; cd "$R"
 O=$R/gpurun_out/r03_evidence; mkdir -p $O
+if [ "$ONLY" != trace ]; then
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json; echo
 for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-kernel-timer --no-eager --no-twin > $O/bench_repeat_$i.json 2>/dev/null; done
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --steps 6 --warmup 2 > $O/trace.log 2>&1
+fi
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --steps 8 --warmup 2 > $O/trace.log 2>&1
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 T=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python scripts/trace_step.py $T 3 > $O/step_summary.txt
@@ -23,7 +25,7 @@ segs = []
 for a, b in zip(marks[:-1], marks[1:]):
     if not any('expand_bwd_kernel' in rows[i]['Kernel_Name'] for i in range(a, b)):
         segs.append((a, b))
-segs = segs[-3:]
+segs = sorted(sorted(segs[-6:], key=lambda ab: int(rows[ab[1]]['Start_Timestamp']) - int(rows[ab[0]]['Start_Timestamp']))[:3])      # (the shortest: no tracer stalls)
 agg = collections.defaultdict(lambda: [0, 0]); busy = 0; wall = 0
 for a, b in segs:
     wall += int(rows[b]['Start_Timestamp']) - int(rows[a]['Start_Timestamp'])
@@ -38,6 +40,7 @@ for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     print('  %-40s n=%5.1f  us=%8.1f  avg=%7.1f us  %5.1f%%' % (k, c / n, t / 1e3 / n, t / 1e3 / c, 100.0 * t / busy))
 PY
 head -4 $O/forward_step_summary.txt
+if [ "$ONLY" = trace ]; then head -12 $O/step_summary.txt; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-timer --no-graph --no-twin > $O/pmc_$c.log 2>&1
 done

@@ -20,21 +20,27 @@ fills = [i for i, r in enumerate(rows) if 'expand_bwd_kernel' in r['Kernel_Name'
 nlast = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 if len(fills) < nlast + 1:
     print('could not delimit steps (fills=%d)' % len(fills)); sys.exit(1)
-i0, i1 = fills[-nlast - 1], fills[-1]
-seg = rows[i0:i1]
-t0, t1 = int(seg[0]['Start_Timestamp']), int(rows[i1]['Start_Timestamp'])
+# the nlast steps with the shortest wall span among the last nlast + 3 (the tracer occasionally stalls a replay for milliseconds while
+# it drains its buffers: such a step says nothing about the kernels)
+cand = [(fills[i], fills[i + 1]) for i in range(max(0, len(fills) - 1 - (nlast + 3)), len(fills) - 1)]
+cand.sort(key=lambda ab: int(rows[ab[1]]['Start_Timestamp']) - int(rows[ab[0]]['Start_Timestamp']))
+chosen = sorted(cand[:nlast])
+seg, wall, gaps, gap_list = [], 0, 0, []
+for i0, i1 in chosen:
+    part = rows[i0:i1]
+    seg += part
+    wall += int(rows[i1]['Start_Timestamp']) - int(part[0]['Start_Timestamp'])
+    prev_end = int(part[0]['End_Timestamp'])
+    for r in part[1:]:
+        s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+        if s > prev_end:
+            gaps += s - prev_end
+            gap_list.append((s - prev_end, short(r['Kernel_Name'])))
+        prev_end = max(prev_end, e)
+nlast = len(chosen)
 busy = sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in seg)
-gaps = 0
-prev_end = int(seg[0]['End_Timestamp'])
-gap_list = []
-for r in seg[1:]:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    if s > prev_end:
-        gaps += s - prev_end
-        gap_list.append((s - prev_end, short(r['Kernel_Name'])))
-    prev_end = max(prev_end, e)
-print('steps=%d kernels/step=%.0f wall/step=%.1f us  busy/step=%.1f us  idle gaps/step=%.1f us' % (
-    nlast, len(seg) / nlast, (t1 - t0) / 1e3 / nlast, busy / 1e3 / nlast, gaps / 1e3 / nlast))
+print('steps=%d (shortest of the last %d) kernels/step=%.0f wall/step=%.1f us  busy/step=%.1f us  idle gaps/step=%.1f us' % (
+    nlast, len(cand), len(seg) / nlast, wall / 1e3 / nlast, busy / 1e3 / nlast, gaps / 1e3 / nlast))
 agg = collections.defaultdict(lambda: [0, 0])
 for r in seg:
     k = short(r['Kernel_Name'])

@@ -9,12 +9,18 @@ delim = 'expand_fwd_kernel' if (len(sys.argv) > 3 and sys.argv[3] == 'fwd') else
 marks = [i for i, r in enumerate(rows) if delim in r['Kernel_Name']]
 if len(marks) < 2:
     print('could not delimit steps'); sys.exit(1)
-i0, i1 = marks[-2], marks[-1]
-if delim == 'expand_bwd_kernel':       # a step ends with expand_bwd (+ finish, wgrad flush, unpack, Adam): rotate to start at the first kernel after Adam
-    adam = [i for i in range(i0, i1) if 'adam_kernel' in rows[i]['Kernel_Name']]
-    if adam:
-        nxt = [i for i in range(i1, len(rows)) if 'adam_kernel' in rows[i]['Kernel_Name']]
-        i0, i1 = adam[-1] + 1, (nxt[0] + 1 if nxt else i1)
+# the shortest of the last four delimited steps (the tracer occasionally stalls a replay for milliseconds while it drains its buffers).
+# A training step runs from the first kernel after an Adam launch to the next Adam launch inclusive; a forward-only replay from one
+# expand_fwd to the next.
+def span(ab):
+    return int(rows[ab[1] - 1]['End_Timestamp']) - int(rows[ab[0]]['Start_Timestamp'])
+if delim == 'expand_bwd_kernel':
+    adam = [i for i, r in enumerate(rows) if 'adam_kernel' in r['Kernel_Name']]
+    pairs = [(a + 1, b + 1) for a, b in zip(adam[:-1], adam[1:])] if len(adam) >= 2 else list(zip(marks[:-1], marks[1:]))
+    pairs = [ab for ab in pairs if any(delim in rows[i]['Kernel_Name'] for i in range(ab[0], ab[1]))]      # (whole training steps only)
+else:
+    pairs = [ab for ab in zip(marks[:-1], marks[1:]) if not any('expand_bwd_kernel' in rows[i]['Kernel_Name'] for i in range(ab[0], ab[1]))]
+i0, i1 = min(pairs[-4:], key=span)
 seg = rows[i0:i1]
 def short(n):
     n = re.sub(r'\(anonymous namespace\)::', '', n)
