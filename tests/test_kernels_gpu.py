@@ -285,6 +285,37 @@ def test_gemm_big_x3_multi(ops, first, nodrop, pair):
         _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
+def test_gemm_fp16_pairs_range(ops):
+    """The documented range of GAST_F32X3H (include/gast_hip.h): operands up to fp16's largest finite value are exact-class, parts
+    below 2^-24 vanish (absolute, not relative, error floor), and an operand beyond 65504 is NOT representable -- the result is
+    non-finite, never silently wrong; the same inputs on bf16 pairs (GAST_F32X3, fp32's exponent range) stay fp32-class.  The forward
+    GEMMs of the plan read post-BatchNorm activations, their aggregates and weights: O(1e-3 .. 1e2)."""
+    from gast_hip.packer import X3Weight
+    gen = torch.Generator().manual_seed(5)
+    M, K, N = 17 * 8, 64, 32
+    A = torch.rand(M, K, generator=gen) + 0.5
+    W = (torch.rand(N, K, generator=gen) + 0.5) / K
+    dom, im = (8, 1, 17), kc.RowMap(1, 1, 0)
+
+    def run(scale_a, f16):
+        Cd = torch.empty(M, N).cuda()
+        with x3_mode(ops, 'x3'):
+            ops.gemm(dom, N, [dict(A=(A * scale_a).cuda(), K=K, map=im, W=X3Weight(W.cuda(), None, f16))], Cd, im)
+        torch.cuda.synchronize()
+        return Cd.cpu().double(), (A.double() * scale_a) @ W.double().t()
+    # (3e4 * 1.5 = 4.5e4 < 65504; at 1e-2 the lo halves (~5e-6) already sit in fp16's subnormals: absolute floor 3e-8 per element)
+    for scale, tol in ((1.0, 2e-6), (3.0e4, 2e-6), (1.0e-2, 1e-5)):
+        got, ref = run(scale, True)
+        assert float((got - ref).abs().max() / ref.abs().max()) < tol, scale
+    got, ref = run(1.0e-7, True)                              # lo parts (and most hi bits) below fp16's subnormals: ABSOLUTE floor ~6e-8 * |w| * K
+    assert float((got - ref).abs().max()) < 1e-7 and float((got - ref).abs().max() / ref.abs().max()) > 1e-4
+    got, _ = run(1.0e5, True)                                 # beyond fp16: loudly non-finite
+    assert not torch.isfinite(got).all()
+    for scale in (1.0e5, 1.0e-7, 1.0e20):                     # bf16 pairs keep fp32's range
+        got, ref = run(scale, False)
+        assert torch.isfinite(got).all() and float((got - ref).abs().max() / ref.abs().max()) < 1e-4, scale
+
+
 def test_gemm_pairs_do_not_mix(ops):
     """one GEMM, one kind of operand pairs: fp16-tagged and untagged weight segments in one call are refused (binding), jobs of
     different kinds in one multi call as well (C ABI: dtypes differ)"""
