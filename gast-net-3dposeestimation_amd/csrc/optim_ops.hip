@@ -11,8 +11,8 @@ namespace {
 
 struct AdamCoef { float step_size, inv_sqrt_bc2; };
 
-__device__ __forceinline__ AdamCoef adam_coef(const int* __restrict__ step, float lr, float beta1, float beta2) {
-    const double t = (double)*step;
+__device__ __forceinline__ AdamCoef adam_coef(int step, float lr, float beta1, float beta2) {
+    const double t = (double)step;
     const double bc1 = 1.0 - exp(t * log((double)beta1));
     const double bc2 = 1.0 - exp(t * log((double)beta2));
     AdamCoef c;
@@ -33,9 +33,13 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, float* __restrict__ vmax, long n, const int* __restrict__ step,
+                                                   float* __restrict__ v, float* __restrict__ vmax, long n, int* step,
                                                    float lr, float beta1, float beta2, float eps, float wd, float gscale) {
-    const AdamCoef c = adam_coef(step, lr, beta1, beta2);
+    // step[0] = optimizer steps taken so far, step[1] = blocks of this launch that have read it (zero between launches).  Every
+    // block uses t = step[0] + 1; the LAST block to arrive at the ticket (all others have read step[0] by then) stores t and clears
+    // the ticket -- the increment used to be a launch of its own (a 1-thread kernel costs a full ~4.7 us graph-node boundary).
+    const int t_now = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+    const AdamCoef c = adam_coef(t_now, lr, beta1, beta2);
     const bool ams = vmax != nullptr;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -55,9 +59,54 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
             if (ams) vmax[i] = x;
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = __hip_atomic_fetch_add(step + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == (int)gridDim.x - 1) {
+            __hip_atomic_store(step + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(step, t_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
-__global__ void step_inc_kernel(int* step) { *step += 1; }
+// ---- pass prologue ("prep"): everything a forward or backward pass needs before its first real kernel, as ONE launch -- the
+// zero fills of the accumulation arenas / gradient buffers (up to GAST_PREP_MAX_ZERO regions), the dropout seed bump + its
+// per-pass copy, and the 3 -> 8 column padding of d loss / d pred that the shrink layer's gradient GEMMs read.  These were 4 + 3
+// separate graph nodes per step (torch fills, an add, a clone, a slice copy) at ~4.7 us of boundary each.
+constexpr int PREP_CHUNK = 256 * 16 * 16;      // bytes one block zeroes: 256 threads x 16 B x 16 rounds
+struct PrepArgs {
+    gast_prep_args a;
+    int first[GAST_PREP_MAX_ZERO + 1];         // first block of every zero job; first[nzero] = first block of the pad job
+    int nblk_pad;
+};
+__global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p) {
+    const gast_prep_args& a = p.a;
+    const int blk = blockIdx.x, tid = threadIdx.x;
+    if (blk == 0 && tid == 0 && a.seed_ctr) {
+        const uint32_t s = *a.seed_ctr + 1u;
+        *a.seed_ctr = s;
+        if (a.seed_out) *a.seed_out = s;
+    }
+    if (blk < p.first[a.nzero]) {
+        int d = 0;
+        while (d + 1 < a.nzero && blk >= p.first[d + 1]) ++d;
+        char* base = (char*)a.zero[d].ptr;
+        const long off0 = (long)(blk - p.first[d]) * PREP_CHUNK, end = a.zero[d].bytes;
+        const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const long o = off0 + ((long)i * 256 + tid) * 16;
+            if (o < end) *(uint4*)(base + o) = z;
+        }
+        return;
+    }
+    // pad job: dst[r][c] = c < cols_src ? src[r][c] : 0, one thread per destination row
+    const long r = (long)(blk - p.first[a.nzero]) * 256 + tid;
+    if (r < a.pad_rows) {
+        for (int c = 0; c < a.pad_cols_dst; ++c)
+            a.pad_dst[r * a.pad_cols_dst + c] = c < a.pad_cols_src ? a.pad_src[r * a.pad_cols_src + c] : 0.f;
+    }
+}
 __global__ void null_kernel() {}
 
 // mpjpe (reference common/loss.py:5-11): mean over rows of ||pred[r,:] - target[r,:]||_2, D <= 4 components per row.
@@ -98,12 +147,39 @@ extern "C" int gast_adam_step(float* p, const float* g, float* m, float* v, floa
     if (!p || !g || !m || !v || !step || n < 1) return GAST_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return GAST_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
     long nb = ((n >> 2) + 255) / 256;
     if (nb > 256 * 16) nb = 256 * 16;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, weight_decay,
                        grad_scale);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_prep(const gast_prep_args* args, gast_stream_t stream) {
+    if (!args || args->nzero < 0 || args->nzero > GAST_PREP_MAX_ZERO) return GAST_EINVAL;
+    PrepArgs p;
+    p.a = *args;
+    int nb = 0;
+    for (int d = 0; d < args->nzero; ++d) {
+        const gast_zero_job& z = args->zero[d];
+        if (!z.ptr || z.bytes < 0) return GAST_EINVAL;
+        if (((uintptr_t)z.ptr & 15) || (z.bytes & 15)) return GAST_EALIGN;
+        p.first[d] = nb;
+        nb += (int)((z.bytes + PREP_CHUNK - 1) / PREP_CHUNK);
+    }
+    p.first[args->nzero] = nb;
+    p.nblk_pad = 0;
+    if (args->pad_rows > 0) {
+        if (!args->pad_src || !args->pad_dst || args->pad_cols_src < 1 || args->pad_cols_dst < args->pad_cols_src) return GAST_EINVAL;
+        p.nblk_pad = (int)((args->pad_rows + 255) / 256);
+    }
+    nb += p.nblk_pad;
+    if (nb == 0) {
+        if (!args->seed_ctr) return 0;
+        nb = 1;                                   // (seed bump only: block 0 falls through to an empty pad job)
+    }
+    hipLaunchKernelGGL(prep_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, p);
     GAST_CHECK_LAUNCH();
     return 0;
 }

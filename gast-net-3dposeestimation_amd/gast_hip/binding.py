@@ -88,6 +88,19 @@ class _StreamShiftJob(C.Structure):
     _fields_ = [('buf', C.c_void_p), ('newest', C.c_void_p), ('B', C.c_int), ('Tb', C.c_int), ('X', C.c_int), ('ldnew', C.c_int)]
 
 
+class _ZeroJob(C.Structure):
+    _fields_ = [('ptr', C.c_void_p), ('bytes', C.c_long)]
+
+
+PREP_MAX_ZERO = 6
+
+
+class _PrepArgs(C.Structure):
+    _fields_ = [('zero', _ZeroJob * PREP_MAX_ZERO), ('nzero', C.c_int), ('seed_ctr', C.c_void_p), ('seed_out', C.c_void_p),
+                ('pad_src', C.c_void_p), ('pad_dst', C.c_void_p), ('pad_rows', C.c_long), ('pad_cols_src', C.c_int),
+                ('pad_cols_dst', C.c_int)]
+
+
 class _BnEvalJob(C.Structure):
     _fields_ = [('gamma', C.c_void_p), ('beta', C.c_void_p), ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('N', C.c_int),
                 ('scale', C.c_void_p), ('shift', C.c_void_p), ('centered', C.c_int)]
@@ -169,6 +182,7 @@ def load_library():
         'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
         'gast_null_launch': [vp],
+        'gast_prep': [C.POINTER(_PrepArgs), vp],
         'gast_chunk_gather': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         'gast_stream_shift_multi': [C.POINTER(_StreamShiftJob), ci, vp],
     }
@@ -191,7 +205,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
 
 def _check(rc, what):
@@ -676,7 +690,10 @@ class HipOps:
         _check(self.lib.gast_mpjpe(_p(pred), _p(target), rows, D, _p(loss), _p(dirs), _stream()), 'gast_mpjpe')
 
     def adam_step(self, p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-        self.launches += 2
+        """step: int32[2] device tensor {steps taken, 0}; the launch advances step[0] itself"""
+        if step.numel() < 2:
+            raise RuntimeError('gast_hip: adam_step needs a 2-element int32 step tensor {steps taken, ticket}')
+        self.launches += 1
         _check(self.lib.gast_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
                                        weight_decay, grad_scale, _stream()), 'gast_adam_step')
 
@@ -705,6 +722,39 @@ class HipOps:
                 a.B, a.Tb, a.X, a.ldnew = int(buf.shape[0]), int(buf.shape[1]), int(buf.shape[2]), int(newest.stride(0))
             self.launches += 1
             _check(self.lib.gast_stream_shift_multi(arr, len(chunk), _stream()), 'gast_stream_shift_multi')
+
+    def prep(self, zero, seed=None, pad=None):
+        """Pass prologue (gast_prep): zero-fill the tensors of `zero` (contiguous device tensors), seed = (counter, per-pass copy):
+        *copy = ++*counter (int32 / uint32 one-element tensors), pad = (src, dst, rows, cols_src, cols_dst): contiguous fp32.  One
+        launch per PREP_MAX_ZERO regions; a region that is not 16-byte granular is zeroed by torch instead."""
+        jobs = []
+        for t in zero:
+            if not t.is_contiguous():
+                raise RuntimeError('gast_hip: prep needs contiguous tensors')
+            nbytes = t.numel() * t.element_size()
+            if t.data_ptr() % 16 or nbytes % 16:
+                t.zero_()
+                self.launches += 1
+            elif nbytes:
+                jobs.append((_p(t), nbytes))
+        first = True
+        while first or jobs:
+            a = _PrepArgs()
+            chunk, jobs = jobs[:PREP_MAX_ZERO], jobs[PREP_MAX_ZERO:]
+            for i, (ptr, nb) in enumerate(chunk):
+                a.zero[i].ptr, a.zero[i].bytes = ptr, nb
+            a.nzero = len(chunk)
+            if first and seed is not None:
+                a.seed_ctr, a.seed_out = _p(seed[0]), _p(seed[1])
+            if first and pad is not None:
+                src, dst, rows, cs, cd = pad
+                if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous():
+                    raise RuntimeError('gast_hip: prep pads contiguous fp32 tensors')
+                a.pad_src, a.pad_dst, a.pad_rows, a.pad_cols_src, a.pad_cols_dst = _p(src), _p(dst), int(rows), int(cs), int(cd)
+            if a.nzero or a.seed_ctr or a.pad_rows:
+                self.launches += 1
+                _check(self.lib.gast_prep(C.byref(a), _stream()), 'gast_prep')
+            first = False
 
     def null_launch(self):
         _check(self.lib.gast_null_launch(_stream()), 'gast_null_launch')

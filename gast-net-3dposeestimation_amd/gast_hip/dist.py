@@ -43,6 +43,7 @@ class FlatGradAllReduce:
         self.ranges = [(0, n)]      # completion order
         self._comm = None
         self._issued = 0
+        self._runner = model._runner if model is not None and hasattr(model, '_runner') else None
         if model is not None and hasattr(model, '_runner'):
             if [id(p) for p in model.parameters()] != [id(p) for p in self.params]:
                 raise ValueError('FlatGradAllReduce(model=...) needs params == list(model.parameters())')
@@ -81,8 +82,15 @@ class FlatGradAllReduce:
         self.scale_in_optimizer = True
         return self
 
-    def zero_(self):
-        self.flat.zero_()
+    def zero_(self, defer=False):
+        """defer=True (needs model=): the fill is not launched now but as part of the pass prologue of the model's NEXT forward
+        (one launch with its other zero fills, gast_prep) -- for loops that go zero_() -> forward -> backward -> step, where nothing
+        reads the gradients in between."""
+        if defer and self._runner is not None:
+            if not any(t is self.flat for t in self._runner.pending_zero):
+                self._runner.pending_zero.append(self.flat)
+        else:
+            self.flat.zero_()
         self._issued = 0
 
     def _active(self):

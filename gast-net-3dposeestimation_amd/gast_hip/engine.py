@@ -79,10 +79,13 @@ class ZeroArena:
         self.buf = None
         self.off = 0
 
-    def begin(self, key, dev):
+    def begin(self, key, dev, lazy=False):
+        """lazy: the buffer is handed back UNZEROED and the caller zero-fills it as part of its pass prologue (ops.prep: one launch
+        for this arena, the gradient buffers and the dropout-seed bump instead of a memset node each)."""
         self.key, self.dev, self.off = key, dev, 0
         n = self.totals.get(key)
-        self.buf = torch.zeros(n, dtype=torch.uint8, device=dev) if n else None
+        self.buf = (torch.empty if lazy else torch.zeros)(n, dtype=torch.uint8, device=dev) if n else None
+        return self.buf if lazy else None
 
     def take(self, shape, dtype=torch.float32):
         nbytes = 1
@@ -118,6 +121,15 @@ class Engine:
 
     def _ctr(self, bn):
         return bn['running_mean'] if self.centered else None
+
+    def _prep(self, arena_buf, prep, pad=None):
+        """Pass prologue: the arena's zero fill + whatever the caller wants zeroed before this pass (flat gradient buffer, packed
+        gradient scratch) + the dropout-seed bump (+ the padded copy of d loss / d pred) as ONE launch (gast_prep)."""
+        prep = prep or {}
+        zero = [t for t in [arena_buf] + list(prep.get('zero') or ()) if t is not None and t.numel()]
+        seed = prep.get('seed')
+        if zero or seed is not None or pad is not None:
+            self.ops.prep(zero, seed=seed, pad=pad)
 
     # ------------------------------------------------------------------------------------------ helpers
     def _new(self, rows, cols, dt, dev, zero=False):
@@ -223,8 +235,10 @@ class Engine:
             torch.cuda.current_stream(side.device).wait_stream(side)
 
     # ------------------------------------------------------------------------------------------ forward
-    def forward(self, x, inp, bufs, training, act_dtype, drop, need_grad=True):
+    def forward(self, x, inp, bufs, training, act_dtype, drop, need_grad=True, prep=None):
         """x: (B,T,J,F_in) fp32 contiguous device tensor.  inp: dict of packed fp32 tensors (see ModelSpec.pack).
+        prep: optional dict(zero=[tensors to zero-fill before the pass], seed=(counter, per-pass copy) of the dropout stream) --
+        merged with the arena's own zero fill into the pass prologue launch.
         bufs: dict of BN buffer dicts (+ momentum / eps of each module).  need_grad: a backward pass may follow (only matters in
         eval mode, where the BatchNorm states then also carry the running mean / rstd).
         Returns (pred (B,T',J,3) fp32, saved dict for backward)."""
@@ -236,7 +250,7 @@ class Engine:
         sv = {'B': B, 'T_in': T_in, 'dt': dt, 'drop': drop, 'training': training}
         use_drop = training and drop is not None and drop.thresh != 0
         za = self.za
-        za.begin(('fwd', tuple(x.shape), dt, training), dev)
+        self._prep(za.begin(('fwd', tuple(x.shape), dt, training), dev, lazy=True), prep)
         self._no_eval_grad = False
         self._pre = {} if training else self._eval_table(inp, bufs, dev, need_grad)
         sv['no_eval_grad'] = self._no_eval_grad
@@ -490,7 +504,7 @@ class Engine:
             ops.bn_bwd_apply(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n])
             o += n
 
-    def backward(self, sv, inp, dpred, gout, stage_done=None):
+    def backward(self, sv, inp, dpred, gout, stage_done=None, prep=None):
         """dpred: (B,T',J,3) fp32.  Every gradient is written into its destination `gout[key]` (packed fp32 scratch
         regions for the GEMM operands, views of the flat gradient buffer for directly-held parameters).  The destinations must
         arrive ZERO-FILLED: split-M weight gradients, column sums and dC_k accumulate into them with atomics.
@@ -509,7 +523,7 @@ class Engine:
         grads = gout
         f32 = torch.float32
         za = self.za
-        za.begin(('bwd', B, sv['T_in'], dt), dev)
+        arena = za.begin(('bwd', B, sv['T_in'], dt), dev, lazy=True)
         self._wq = []
         self._wside = None
         self._adjq = []
@@ -520,8 +534,13 @@ class Engine:
         TL = T[-1]
         PL = B * TL * J
         KP = 8
-        dp = za.take((PL, KP), dt)
-        dp[:, :3] = dpred.reshape(PL, 3).to(dt)
+        if dt == f32 and dpred.dtype == f32 and dpred.is_contiguous():
+            dp = torch.empty(PL, KP, dtype=f32, device=dev)       # written whole (3 columns + zero padding) by the pass prologue
+            self._prep(arena, prep, pad=(dpred, dp, PL, 3, KP))
+        else:
+            self._prep(arena, prep)
+            dp = za.take((PL, KP), dt)
+            dp[:, :3] = dpred.reshape(PL, 3).to(dt)
         self._wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
                                                         shift=last['bnO'].shift, wcol0=0)], gout['shrink'], zero_first=False)
         WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero

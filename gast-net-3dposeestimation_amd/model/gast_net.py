@@ -163,8 +163,10 @@ class _GastFunction(torch.autograd.Function):
         engine.centered = runner.centered
         ops.x3 = runner.x3
         ops.f8 = runner.f8
-        pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, x.device),
-                                  need_grad=need_grad)
+        drop, seed_job = runner.dropout_state(training, x.device)
+        # the pass prologue (ONE launch): zero arena, seed bump, and whatever a FlatGradAllReduce.zero_(defer=True) left pending
+        pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, drop, need_grad=need_grad,
+                                  prep={'seed': seed_job, 'zero': runner.take_pending_zero()})
         ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink, ctx.runner = engine, packer, st, inp, sv, sink, runner
         ctx.graph_entry = runner.__dict__.pop('_eager_entry', None)      # (the graph-cache entry this eager call warms up, if any)
         return pred
@@ -184,8 +186,10 @@ class _GastFunction(torch.autograd.Function):
         # (FlatGradAllReduce / FlatAdam), which then sums over backward calls like autograd's .grad does.  With such a sink the
         # gradients are NOT returned to autograd (hooks / torch.autograd.grad see None): they are already where p.grad points.
         with torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext():
-            G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
-            Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
+            # (zero-filled by the backward's pass prologue, together with its arena: engine.backward(prep=))
+            G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+            Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
+            prep = {'zero': [Sb] + ([G] if sink is None else [])}
             gout = packer.grad_outputs(G, Sb)
             gs = ctx.runner.grad_sync if sink is not None else None
             if gs is not None and len(gs.ranges) > 1 and gs.flat is sink:
@@ -196,13 +200,13 @@ class _GastFunction(torch.autograd.Function):
                     b = gs.bucket_of_stage(s_)
                     engine.ops.run_unpack(packer, st, Sb, G, True, bucket=b)
                     gs.bucket_ready(b)
-                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout, stage_done=stage_done)
+                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout, stage_done=stage_done, prep=prep)
                 ctx.sv = None
                 last = len(gs.ranges) - 1
                 engine.ops.run_unpack(packer, st, Sb, G, True, bucket=last)
                 gs.bucket_ready(last)
             else:
-                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout)
+                engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout, prep=prep)
                 ctx.sv = None
                 engine.ops.run_unpack(packer, st, Sb, G, True)
         if sink is not None:
@@ -221,7 +225,7 @@ class _GraphEntry:
         self.fwd = self.bwd = None
         self.gen = 0
         self.x = self.pred = self.dpred = self.G = self.sink = None
-        self.packer = None
+        self.packer = self.runner = None
         self.st = self.ops = None   # the packed-operand state (refreshed eagerly when the parameters changed) and the op set
         self.keep = None
         self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
@@ -243,7 +247,7 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     dev = x.device
     ops = engine.ops
     entry.x = x.clone()
-    entry.packer, entry.sink = packer, sink
+    entry.packer, entry.sink, entry.runner = packer, sink, runner
     pool = torch.cuda.graph_pool_handle()
     engine.centered = runner.centered
     ops.x3 = runner.x3
@@ -262,16 +266,17 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
-        pred, sv = engine.forward(entry.x, inp, bufs, training, runner.act_dtype, runner.dropout_state(training, dev), need_grad=need_grad)
+        drop, seed_job = runner.dropout_state(training, dev)
+        pred, sv = engine.forward(entry.x, inp, bufs, training, runner.act_dtype, drop, need_grad=need_grad, prep={'seed': seed_job})
     entry.fwd, entry.pred = g, pred
     entry.keep = (sv, inp, pool)
     if need_grad:
         entry.dpred = torch.zeros_like(pred)
         gb = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(gb, pool=pool):
-            G = sink if sink is not None else torch.zeros(packer.gsize, dtype=torch.float32, device=dev)
-            Sb = torch.zeros(packer.S.size, dtype=torch.float32, device=dev)
-            engine.backward(sv, inp, entry.dpred, packer.grad_outputs(G, Sb))
+            G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+            Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
+            engine.backward(sv, inp, entry.dpred, packer.grad_outputs(G, Sb), prep={'zero': [Sb] + ([G] if sink is None else [])})
             ops.run_unpack(packer, st, Sb, G, True)
         entry.bwd, entry.G = gb, G
         entry.keep += (Sb,)
@@ -286,6 +291,8 @@ class _GraphedFunction(torch.autograd.Function):
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
         entry.x.copy_(x)
+        for t in entry.runner.take_pending_zero():     # (a deferred FlatGradAllReduce.zero_(): not part of the captured forward)
+            t.zero_()
         if not entry.packer.unchanged(entry.st):       # (optimizer step / load_state_dict since the last packing: refresh the operands)
             entry.ops.run_pack(entry.packer, entry.st)
         entry.fwd.replay()
@@ -327,6 +334,7 @@ class _Runner:
         self._packer = None
         self.grad_sink = None     # optional flat fp32 buffer (model.parameters() order) that backward accumulates into directly
         self.grad_sync = None     # optional gast_hip.dist.FlatGradAllReduce in bucketed mode: told when a bucket of grad_sink is complete
+        self.pending_zero = []    # buffers whose zero fill rides in the next forward's pass prologue (FlatGradAllReduce.zero_(defer=True))
         self._seeds = {}
         # Forward / backward of every (shape, mode, arithmetic, BatchNorm momentum, dropout p) are replayed from hipGraphs captured on
         # the third call, so an unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140
@@ -346,7 +354,7 @@ class _Runner:
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode,
+                'grad_sync': None, 'pending_zero': [], '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode,
                 '_graphs': collections.OrderedDict(), 'graph_cache_max': self.graph_cache_max}
 
     def __setstate__(self, state):
@@ -406,10 +414,16 @@ class _Runner:
                 eng = self._engines[key] = self._new_engine()
         return eng
 
+    def take_pending_zero(self):
+        z, self.pending_zero = self.pending_zero, []
+        return z
+
     def dropout_state(self, training, dev):
-        """A fresh dropout stream per training forward: the seed lives on the device (graph-capture friendly)."""
+        """A fresh dropout stream per training forward: the seed lives on the device (graph-capture friendly).  Returns (Dropout
+        whose seed is this pass's copy -- NOT yet written --, (counter, copy)): the bump `*copy = ++*counter` is part of the
+        forward's pass prologue (engine.forward(prep=): one launch with the arena's zero fill instead of an add + a clone)."""
         if not training or self.p_dropout <= 0:
-            return None
+            return None, None
         from gast_hip.binding import Dropout, dropout_params
         thresh, inv_keep = dropout_params(self.p_dropout)
         key = str(dev)
@@ -418,8 +432,8 @@ class _Runner:
                 s = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
                 self._seeds[key] = torch.tensor([s], dtype=torch.int32, device=dev)
         seed = self._seeds[key]
-        seed.add_(1)
-        return Dropout(seed.clone(), thresh, inv_keep)
+        copy = torch.empty_like(seed)
+        return Dropout(copy, thresh, inv_keep), (seed, copy)
 
 
 class SpatioTemporalModelBase(nn.Module):

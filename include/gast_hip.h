@@ -356,10 +356,31 @@ int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases
  * dirs[r,:] = d loss / d pred[r,:] (zero where the difference vanishes).  All fp32, contiguous. */
 int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* loss, float* dirs, gast_stream_t stream);
 /* One Adam / AMSGrad step (torch.optim.Adam semantics, reference trainval.py:78) over flat fp32 buffers of n elements:
- * p, m, v (and vmax: non-null selects amsgrad) updated in place from g * grad_scale; *step (device int32) is incremented first
- * and supplies the bias corrections.  16-byte aligned buffers. */
+ * p, m, v (and vmax: non-null selects amsgrad) updated in place from g * grad_scale.  step: device int32[2] = {optimizer steps
+ * taken so far, 0}: the launch computes with step[0] + 1 and stores it back itself (the last block to finish does; step[1] is
+ * its ticket counter and is zero again when the launch ends) -- one launch per optimizer step.  16-byte aligned buffers. */
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
+
+/* Pass prologue, ONE launch: zero-fill up to GAST_PREP_MAX_ZERO regions (16-byte aligned, sizes multiples of 16: the accumulation
+ * arena of the pass, the flat gradient buffer, the packed-gradient scratch), optionally advance the dropout seed (*seed_out =
+ * ++*seed_ctr: the per-pass copy the kernels of this pass -- and its backward -- read) and optionally pad d loss / d pred from
+ * pad_cols_src to pad_cols_dst columns (pad_dst[r][c] = c < pad_cols_src ? pad_src[r][c] : 0, contiguous fp32, pad_rows rows;
+ * reference main.py:231-237: the 3 output coordinates, 8 columns for the shrink layer's gradient GEMMs).  Replaces the torch
+ * fill / add / clone / slice-copy nodes at the head of a forward and of a backward pass. */
+#define GAST_PREP_MAX_ZERO 6
+typedef struct { void* ptr; long bytes; } gast_zero_job;
+typedef struct {
+    gast_zero_job zero[GAST_PREP_MAX_ZERO];
+    int nzero;
+    uint32_t* seed_ctr;      /* nullable */
+    uint32_t* seed_out;      /* nullable */
+    const float* pad_src;    /* nullable (pad_rows == 0) */
+    float* pad_dst;
+    long pad_rows;
+    int pad_cols_src, pad_cols_dst;
+} gast_prep_args;
+int gast_prep(const gast_prep_args* args, gast_stream_t stream);
 
 /* ---- causal streaming inference (reference gen_skes.py:43-69, tools/inference.py:73-91 re-run the whole
  * receptive field per frame): the per-level frame windows of gast_hip/streaming.py advance by one frame -- every window of the model

@@ -537,3 +537,23 @@ def stream_shift(buf, newest):
     as its last frame -- the per-level frame windows of causal streaming inference (gast_hip/streaming.py)."""
     buf[:, :-1] = buf[:, 1:].copy()
     buf[:, -1] = newest
+
+
+def prep(zero, seed=None, pad=None):
+    """gast_prep (pass prologue): zero-fill every array of `zero`; seed = (counter, copy): copy[0] = counter[0] = counter[0] + 1
+    (mod 2^32); pad = (src, dst, rows, cols_src, cols_dst): dst[r, c] = src[r, c] for c < cols_src, 0 beyond."""
+    for z in zero:
+        z[...] = 0
+    if seed is not None:
+        ctr, copy = seed
+        v = (int(ctr.reshape(-1)[0]) + 1) & 0xffffffff
+        if ctr.dtype == np.int32 and v >= 2 ** 31:
+            v -= 2 ** 32
+        ctr.reshape(-1)[0] = v
+        copy.reshape(-1)[0] = v
+    if pad is not None:
+        src, dst, rows, cs, cd = pad
+        d = dst.reshape(rows, cd)
+        d[...] = 0
+        d[:, :cs] = src.reshape(rows, cs)
+

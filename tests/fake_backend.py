@@ -47,6 +47,11 @@ class OracleOps:
     def gemm_row_blocks(self, M):
         return kc.gemm_row_blocks(M)
 
+    def prep(self, zero, seed=None, pad=None):
+        self.launches += 1
+        kc.prep([_np(t) for t in zero], seed=None if seed is None else (_np(seed[0]), _np(seed[1])),
+                pad=None if pad is None else (_np(pad[0]), _np(pad[1])) + tuple(pad[2:]))
+
     def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, xscale=None,
              xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         self.launches += 1

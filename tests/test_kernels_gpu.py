@@ -77,6 +77,31 @@ def seed_tensor(v):
     return torch.tensor([v], dtype=torch.int32).cuda()
 
 
+# ------------------------------------------------------------------------------------------------ pass prologue
+def test_prep_matches_contract(ops):
+    """gast_prep: several zero fills (one longer than a block's share, one not 16-byte granular -> torch fill), the seed bump and
+    the 3 -> 8 column padding of d loss / d pred in one call; everything outside the regions untouched."""
+    gen = torch.Generator().manual_seed(3)
+    big = torch.randn(300001, generator=gen)             # 1.2 MB: many blocks, ragged last block
+    bufs = [big[:300000], torch.randn(4096, generator=gen), torch.randn(7, generator=gen), torch.randn(64, generator=gen),
+            torch.randn(128, generator=gen), torch.randn(256, generator=gen), torch.randn(512, generator=gen), torch.randn(1024, generator=gen)]
+    dev_big = big.cuda()
+    dbufs = [dev_big[:300000]] + [b.cuda() for b in bufs[1:]]
+    src = torch.randn(2176, 3, generator=gen)
+    ctr = torch.tensor([2 ** 31 - 1], dtype=torch.int32)     # wraps like the uint32 the kernels read
+    ctr_d, copy_d = ctr.cuda(), torch.zeros(1, dtype=torch.int32).cuda()
+    dst_d = torch.full((2176, 8), 7.0).cuda()
+    ops.prep(dbufs, seed=(ctr_d, copy_d), pad=(src.cuda(), dst_d, 2176, 3, 8))
+    ref_bufs = [b.numpy().copy() for b in bufs]
+    rc, rcopy, rdst = ctr.numpy().copy(), np.zeros(1, np.int32), np.full((2176, 8), 7.0, np.float32)
+    kc.prep(ref_bufs, seed=(rc, rcopy), pad=(src.numpy(), rdst, 2176, 3, 8))
+    for d, r in zip(dbufs, ref_bufs):
+        assert np.array_equal(d.cpu().numpy(), r)
+    assert float(dev_big[300000]) == float(big[300000]), 'the element past the zeroed region changed'
+    assert int(ctr_d.item()) == int(rc[0]) and int(copy_d.item()) == int(rcopy[0])
+    assert np.array_equal(dst_d.cpu().numpy(), rdst)
+
+
 # ------------------------------------------------------------------------------------------------ dropout stream
 def test_dropout_stream_matches_contract(ops):
     """bnrelu_bwd_mask with scale=1, shift=1 (always positive) exposes the keep mask exactly."""
