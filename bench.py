@@ -88,8 +88,7 @@ class KernelTimer:
         for name in ('gemm', 'gemm_multi', 'wgrad', 'wgrad_multi', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bn_bwd_apply',
                      'bnrelu_apply', 'bnrelu_bwd_mask', 'residual_fwd', 'expand_fwd', 'expand_bwd', 'colsum', 'bn_finalize',
                      'bn_finalize_multi', 'bn_bwd_finalize', 'bn_bwd_finalize_multi', 'bn_bwd_fused_multi', 'semch_adj_fwd_multi',
-                     'semch_adj_bwd_multi', 'input_stats', 'adam_step', 'run_pack', 'run_unpack', 'prep', 'bn_finalize_sums',
-                     'bn_bwd_apply_lazy'):
+                     'semch_adj_bwd_multi', 'input_stats', 'adam_step', 'run_pack', 'run_unpack'):
             self._wrap(name)
 
     def calibrate(self, n=200):
@@ -259,9 +258,6 @@ class KernelTimer:
 
     def cost_attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, *a, **k):
         return 4.0 * F * J * J * C_, F * J * (3.0 * C_ + 4 * nheads) * self._es(G)
-
-    def cost_bn_bwd_apply_lazy(self, dz, X, rows, jobs):
-        return self.cost_bn_bwd_apply(dz, X, rows, sum(j['n'] for j in jobs))
 
     def cost_bn_bwd_apply(self, dz, X, rows, N, *a):
         return 4.0 * rows * N, 3.0 * rows * N * self._es(dz)

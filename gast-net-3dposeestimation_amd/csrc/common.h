@@ -103,34 +103,6 @@ __device__ __forceinline__ float drop_mul(uint32_t key, uint32_t thresh, float i
     return bits >= thresh ? inv_keep : 0.f;
 }
 
-// ---------------------------------------------------------------- BatchNorm coefficients from column sums
-// ONE definition for gast_bn_finalize*, gast_bn_finalize_sums and every lazy consumer (gast_bn_lazy), written with explicit fused
-// operations so that no context-dependent contraction can make two instantiations disagree: the forward consumers' scale / shift
-// and the tables the backward pass reads must be the same bits (the backward re-derives ReLU masks from them).
-struct BnCoef { float scale, shift, mean, rstd; double var; };
-__device__ __forceinline__ BnCoef bn_coef(double s1, double s2, double count, float eps, float gamma, float beta) {
-    BnCoef c;
-    const double mean = s1 / count;
-    double var = fma(-mean, mean, s2 / count);
-    if (var < 0.0) var = 0.0;
-    c.var = var;
-    c.rstd = (float)(1.0 / sqrt(var + (double)eps));
-    c.mean = (float)mean;
-    c.scale = gamma * c.rstd;
-    c.shift = fmaf(-c.mean, c.scale, beta);
-    return c;
-}
-__device__ __forceinline__ void bn_lazy_coef(const gast_bn_lazy& lz, int k, float& sc, float& sh) {
-    const BnCoef c = bn_coef(lz.sums[2 * k], lz.sums[2 * k + 1], lz.count, lz.eps, lz.gamma[k], lz.beta[k]);
-    sc = c.scale;
-    sh = c.shift;
-}
-// a block's column sums -> the slab (one double atomic per value; the slab is zero-filled by the pass prologue)
-__device__ __forceinline__ void bn_sums_add(double* sums, int n, float s1, float s2) {
-    atomicAdd(sums + 2 * n, (double)s1);
-    atomicAdd(sums + 2 * n + 1, (double)s2);
-}
-
 // ---------------------------------------------------------------- row maps
 // m in [0, B*Tn*J) -> (b, t, j);  mapped row or -1
 __device__ __forceinline__ long map_row(const gast_rowmap& mp, int b, int t, int j, int J) {

@@ -525,14 +525,9 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
             if (tid < BN) {
                 const int n = nt * BN + tid;
                 if (n < a.N) {
-                    const float v1 = sRed[0][tid][0] + sRed[1][tid][0] + sRed[2][tid][0] + sRed[3][tid][0];
-                    const float v2 = sRed[0][tid][1] + sRed[1][tid][1] + sRed[2][tid][1] + sRed[3][tid][1];
-                    if (a.stat_sums) bn_sums_add(a.stat_sums, n, v1, v2);
-                    else {
-                        float* pp = a.partials + ((long)mt * a.N + n) * 2;
-                        pp[0] = v1;
-                        pp[1] = v2;
-                    }
+                    float* pp = a.partials + ((long)mt * a.N + n) * 2;
+                    pp[0] = sRed[0][tid][0] + sRed[1][tid][0] + sRed[2][tid][0] + sRed[3][tid][0];
+                    pp[1] = sRed[0][tid][1] + sRed[1][tid][1] + sRed[2][tid][1] + sRed[3][tid][1];
                 }
             }
         }
@@ -593,13 +588,9 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
         if (tid < BN) {
             int n = nt * BN + tid;
             if (n < a.N) {
-                const float v1 = sRed[0][tid][0] + sRed[1][tid][0], v2 = sRed[0][tid][1] + sRed[1][tid][1];
-                if (a.stat_sums) bn_sums_add(a.stat_sums, n, v1, v2);
-                else {
-                    float* p = a.partials + ((long)mt * a.N + n) * 2;
-                    p[0] = v1;
-                    p[1] = v2;
-                }
+                float* p = a.partials + ((long)mt * a.N + n) * 2;
+                p[0] = sRed[0][tid][0] + sRed[1][tid][0];
+                p[1] = sRed[0][tid][1] + sRed[1][tid][1];
             }
         }
     }
@@ -628,7 +619,7 @@ struct GemmBatch {
     float* ws;
     int n;
 };
-static_assert(sizeof(GemmBatch) <= 6144, "GemmBatch travels by value in the HSA kernarg segment (gfx950: no 4 KB limit)");
+static_assert(sizeof(GemmBatch) <= 3712, "GemmBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO, int X3 = 0, bool F8 = false>
 __global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
@@ -698,12 +689,9 @@ __device__ __forceinline__ void splitk_finish_body(const gast_gemm_args& a, int 
                 float t1 = 0.f, t2 = 0.f;
 #pragma unroll
                 for (int r = 0; r < 8; ++r) { t1 += sRed[r][tid][0]; t2 += sRed[r][tid][1]; }
-                if (a.stat_sums) bn_sums_add(a.stat_sums, n, t1, t2);
-                else {
-                    float* pp = a.partials + ((long)((rg * 8) / BM) * a.N + n) * 2;
-                    atomicAdd(pp, t1);
-                    atomicAdd(pp + 1, t2);
-                }
+                float* pp = a.partials + ((long)((rg * 8) / BM) * a.N + n) * 2;
+                atomicAdd(pp, t1);
+                atomicAdd(pp + 1, t2);
             }
         }
     }
@@ -721,7 +709,7 @@ struct FinishBatch {
     const float* ws;
     int n;
 };
-static_assert(sizeof(FinishBatch) <= 6144, "FinishBatch travels by value in the HSA kernarg segment (gfx950: no 4 KB limit)");
+static_assert(sizeof(FinishBatch) <= 3712, "FinishBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO>
 __global__ void __launch_bounds__(256) splitk_finish_multi_kernel(const FinishBatch b) {
     int d = 0;
@@ -753,11 +741,10 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
         if (g.K % epc || g.lda % epc || g.ldw % epc || !aligned16(g.A) || !aligned16(g.W)) return GAST_EALIGN;
         if (g.pro != GAST_PRO_NONE && (!g.scale || !g.shift || !aligned16(g.scale) || !aligned16(g.shift))) return GAST_EINVAL;
         if (g.pro < 0 || g.pro > GAST_PRO_BNRELU_DROP) return GAST_EINVAL;
-        if (g.pro != GAST_PRO_NONE && g.lazy.sums && (!g.lazy.gamma || !g.lazy.beta || !(g.lazy.count > 0))) return GAST_EINVAL;
     }
     if (a.epi < 0 || a.epi > GAST_EPI_BNRELU_BWD) return GAST_EINVAL;
     if (a.f8_scale && (a.dtype != GAST_BF16 || a.out_f32)) return GAST_EINVAL;
-    if (a.epi != GAST_EPI_PLAIN && !a.partials && !a.stat_sums) return GAST_EINVAL;
+    if (a.epi != GAST_EPI_PLAIN && !a.partials) return GAST_EINVAL;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return GAST_EINVAL;
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
@@ -787,16 +774,6 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
     return 0;
 }
-// lazy BatchNorm segments (gast_bn_lazy) are a feature of the large-M kernel only: the 128x128-tile kernel runs at the 168-register
-// limit of three blocks per CU, and a double-precision coefficient prologue inside it spilled 39 registers of its K loop (and a
-// kernel with scratch costs ~6 us more per dispatch).  Callers finalize such a BatchNorm first (gast_bn_finalize_sums) when
-// gast_gemm_path() says 0.
-static bool has_lazy_seg(const gast_gemm_args& a) {
-    for (int s = 0; s < a.nseg; ++s)
-        if (a.seg[s].pro != GAST_PRO_NONE && a.seg[s].lazy.sums) return true;
-    return false;
-}
-
 }  // namespace
 
 extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream) {
@@ -808,7 +785,6 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     hipStream_t st = (hipStream_t)stream;
     BigPlan bp;
     if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
-    if (has_lazy_seg(a)) return GAST_EINVAL;
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
         hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
@@ -864,7 +840,6 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
         if (gast_gemm_big_plan(args[d], big_p[nbig])) { big_a[nbig++] = args[d]; continue; }
-        if (has_lazy_seg(args[d])) return GAST_EINVAL;
         long off = 0;
         if (splitk > 1) {                       // small-M job: its K ranges join the grid, its slice of the workspace follows the others'
             off = ws_used;

@@ -242,14 +242,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         load_a(d1, ra1, rz1);
         for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
             if (pl.taboff[s] >= 0) {
-                const gast_bn_lazy& lz = a.seg[s].lazy;
-                if (lz.sums) {                                 // lazy BatchNorm: no finalize launch ran; derive the table from the producers' sums
-                    for (int k = tid; k < a.seg[s].K; k += NT) bn_lazy_coef(lz, k, sSc[pl.taboff[s] + k], sSh[pl.taboff[s] + k]);
-                } else {
-                    const float* sc = a.seg[s].scale;
-                    const float* sh = a.seg[s].shift;
-                    for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
-                }
+                const float* sc = a.seg[s].scale;
+                const float* sh = a.seg[s].shift;
+                for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
             }
         }
         gload_wait_n<0>();
@@ -434,13 +429,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         if constexpr (MW == 2) {
             const int n = n0 + tid;
             if (tid < TN && n < N) {
-                const float v1 = sRed[tid * 2] + sRed[(TN + tid) * 2], v2 = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
-                if (a.stat_sums) bn_sums_add(a.stat_sums, n, v1, v2);
-                else {
-                    float* pp = a.partials + ((long)mt * N + n) * 2;
-                    pp[0] = v1;
-                    pp[1] = v2;
-                }
+                float* pp = a.partials + ((long)mt * N + n) * 2;
+                pp[0] = sRed[tid * 2] + sRed[(TN + tid) * 2];
+                pp[1] = sRed[tid * 2 + 1] + sRed[(TN + tid) * 2 + 1];
             }
         } else {
             // a 256-row block is two 128-row statistics blocks (wave rows 0-1 and 2-3)
@@ -448,14 +439,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             const int n = n0 + cl;
             const int sblk = mt * (MW / 2) + hb;
             if (hb < MW / 2 && n < N && (long)sblk * 128 < M) {
-                const float v1 = sRed[((2 * hb) * TN + cl) * 2] + sRed[((2 * hb + 1) * TN + cl) * 2];
-                const float v2 = sRed[((2 * hb) * TN + cl) * 2 + 1] + sRed[((2 * hb + 1) * TN + cl) * 2 + 1];
-                if (a.stat_sums) bn_sums_add(a.stat_sums, n, v1, v2);
-                else {
-                    float* pp = a.partials + ((long)sblk * N + n) * 2;
-                    pp[0] = v1;
-                    pp[1] = v2;
-                }
+                float* pp = a.partials + ((long)sblk * N + n) * 2;
+                pp[0] = sRed[((2 * hb) * TN + cl) * 2] + sRed[((2 * hb + 1) * TN + cl) * 2];
+                pp[1] = sRed[((2 * hb) * TN + cl) * 2 + 1] + sRed[((2 * hb + 1) * TN + cl) * 2 + 1];
             }
         }
     }
@@ -478,7 +464,7 @@ struct BigBatch {
     int first[GAST_GEMM_MAX_BATCH + 1];
     int n;
 };
-static_assert(sizeof(BigBatch) <= 6144, "BigBatch travels by value in the HSA kernarg segment (no 4 KB CUDA-style limit on gfx950: the weight-gradient batch has been 4.4 KB since round 1)");
+static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
 template <int EPI, bool ADD, int NI, int MW, int PAIR>
 __global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
@@ -570,16 +556,14 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
         if (g.pro == GAST_PRO_BNRELU_DROP) return 0;
         pl.taboff[s] = -1;
         if (g.pro == GAST_PRO_BNRELU) {
-            if (g.lazy.sums ? (!g.lazy.gamma || !g.lazy.beta || !(g.lazy.count > 0)) : (!g.scale || !g.shift)) return 0;
+            if (!g.scale || !g.shift) return 0;
             for (int q = 0; q < s; ++q)
-                if (pl.taboff[q] >= 0 && a.seg[q].scale == g.scale && a.seg[q].shift == g.shift && a.seg[q].K == g.K &&
-                    a.seg[q].lazy.sums == g.lazy.sums && a.seg[q].lazy.gamma == g.lazy.gamma)
-                    pl.taboff[s] = pl.taboff[q];
+                if (pl.taboff[q] >= 0 && a.seg[q].scale == g.scale && a.seg[q].shift == g.shift && a.seg[q].K == g.K) pl.taboff[s] = pl.taboff[q];
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
     if (ntab > max_tab(pl.ni, pl.mw)) return 0;
-    if (a.epi != GAST_EPI_PLAIN && !a.partials && !a.stat_sums) return 0;
+    if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;

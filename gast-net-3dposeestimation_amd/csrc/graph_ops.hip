@@ -96,8 +96,7 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
                                                             const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                             const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
                                                             T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB,
-                                                            const float* __restrict__ ctr_s, const float* __restrict__ ctr_c,
-                                                            double* __restrict__ sums) {
+                                                            const float* __restrict__ ctr_s, const float* __restrict__ ctr_c) {
     __shared__ float sred[256][8];
     const int tid = threadIdx.x;
     const int slot = tid / TPF, ct = tid - slot * TPF;
@@ -151,14 +150,9 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_kernel(const T* __restrict_
                 for (int sl = 0; sl < FB; ++sl)
 #pragma unroll
                     for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
-                if (sums) {
+                float* pp = partials + ((long)blockIdx.x * 2 * C + g * C + c) * 2;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) bn_sums_add(sums, g * C + c + q, t[q], t[4 + q]);
-                } else {
-                    float* pp = partials + ((long)blockIdx.x * 2 * C + g * C + c) * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
-                }
+                for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
             }
         }
     }
@@ -203,7 +197,7 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
                                                                 T* __restrict__ Y, int ldy, float* __restrict__ partials, int TPF, int FB,
                                                                 const float* __restrict__ ctr_s, const float* __restrict__ ctr_c,
-                                                                int nchunk, int CC, double* __restrict__ sums) {
+                                                                int nchunk, int CC) {
     extern __shared__ __attribute__((aligned(16))) float sAgg[];      // [nnz_s + 1][CC] | [nnz_c + 1][CC]
     __shared__ float sred[256][8];
     const int tid = threadIdx.x;
@@ -251,14 +245,9 @@ __global__ void __launch_bounds__(256) semch_agg_fwd_ell_kernel(const T* __restr
             for (int sl = 0; sl < FB; ++sl)
 #pragma unroll
                 for (int q = 0; q < 8; ++q) t[q] += sred[sl * TPF + ct][q];
-            if (sums) {          // lazy BatchNorm: the block's column sums go straight into the slab (gast_bn_lazy)
+            float* pp = partials + (((long)blockIdx.y * nfb + fb) * 2 * C + g * C + c) * 2;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) bn_sums_add(sums, g * C + c + q, t[q], t[4 + q]);
-            } else {
-                float* pp = partials + (((long)blockIdx.y * nfb + fb) * 2 * C + g * C + c) * 2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
-            }
+            for (int q = 0; q < 4; ++q) { pp[2 * q] = t[q]; pp[2 * q + 1] = t[4 + q]; }
         }
     }
 }
@@ -1425,11 +1414,11 @@ static int agg_fwd_joint_split(int F, int C) {
 }
 extern "C" int gast_semch_agg_blocks(int F, int C) { return agg_fwd_frame_blocks(F, C) * agg_fwd_joint_split(F, C); }
 
-static int semch_agg_fwd_impl(int dtype, const void* H, int ldh, int F, int J, int C,
-                              const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
-                              const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials,
-                              const float* center_sym, const float* center_con, double* sums, gast_stream_t stream) {
-    if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || (!partials && !sums)) return GAST_EINVAL;
+extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
+                                  const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
+                                  const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials,
+                                  const float* center_sym, const float* center_con, gast_stream_t stream) {
+    if (!H || !A_sym || !A_con || !pat_sym || !pat_con || !Y || !partials) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || J < 1 || J > JMAX || F < 1) return GAST_EALIGN;
     const int CC = agg_fwd_cc(C), nchunk = (C + CC - 1) / CC;
@@ -1443,10 +1432,10 @@ static int semch_agg_fwd_impl(int dtype, const void* H, int ldh, int F, int J, i
     do {                                                                                                                     \
         if (dtype == GAST_F32)                                                                                               \
             hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<float, DS, DC>), grid_ell, dim3(256), smem, st, (const float*)H, ldh, F, J, C, \
-                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC, sums); \
+                               A_sym, pat_sym, A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC); \
         else                                                                                                                 \
             hipLaunchKernelGGL((semch_agg_fwd_ell_kernel<bf16_t, DS, DC>), grid_ell, dim3(256), smem, st, (const bf16_t*)H, ldh, F, J, \
-                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC, sums); \
+                               C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con, nchunk, CC); \
     } while (0)
     // the fixed-degree kernels walk exactly DS / DC padded slots per row: the pattern tables must have been built with
     // these degrees, which is the case for deg_sym == 2 (every supported skeleton) and deg_con in {5, 6}
@@ -1454,36 +1443,20 @@ static int semch_agg_fwd_impl(int dtype, const void* H, int ldh, int F, int J, i
     else if (deg_sym == 2 && deg_con == 6) AGG_FWD_ELL(2, 6);
     else {
         // generic CSR kernel: it fills the first nb partial rows only; the joint-split rows stay zero
-        if (jsplit > 1 && !sums) {
+        if (jsplit > 1) {
             hipError_t e = hipMemsetAsync(partials + (size_t)nb * 2 * C * 2, 0, (size_t)nb * (jsplit - 1) * 2 * C * 2 * sizeof(float), st);
             if (e != hipSuccess) return (int)e;
         }
         if (dtype == GAST_F32)
             hipLaunchKernelGGL((semch_agg_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)H, ldh, F, J, C, A_sym, pat_sym,
-                               A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con, sums);
+                               A_con, pat_con, (float*)Y, ldy, partials, TPF, FB, center_sym, center_con);
         else
             hipLaunchKernelGGL((semch_agg_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)H, ldh, F, J, C, A_sym,
-                               pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con, sums);
+                               pat_sym, A_con, pat_con, (bf16_t*)Y, ldy, partials, TPF, FB, center_sym, center_con);
     }
 #undef AGG_FWD_ELL
     GAST_CHECK_LAUNCH();
     return 0;
-}
-
-extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
-                                  const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
-                                  const int32_t* pat_con, int deg_con, void* Y, int ldy, float* partials,
-                                  const float* center_sym, const float* center_con, gast_stream_t stream) {
-    if (!partials) return GAST_EINVAL;
-    return semch_agg_fwd_impl(dtype, H, ldh, F, J, C, A_sym, pat_sym, deg_sym, A_con, pat_con, deg_con, Y, ldy, partials, center_sym,
-                              center_con, nullptr, stream);
-}
-extern "C" int gast_semch_agg_fwd_sums(int dtype, const void* H, int ldh, int F, int J, int C,
-                                       const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con,
-                                       const int32_t* pat_con, int deg_con, void* Y, int ldy, double* sums, gast_stream_t stream) {
-    if (!sums) return GAST_EINVAL;
-    return semch_agg_fwd_impl(dtype, H, ldh, F, J, C, A_sym, pat_sym, deg_sym, A_con, pat_con, deg_con, Y, ldy, nullptr, nullptr, nullptr,
-                              sums, stream);
 }
 
 struct AggBwdCfg { int CC, nchunk, TPF, FB, nfb; };

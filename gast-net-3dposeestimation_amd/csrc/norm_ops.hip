@@ -10,19 +10,6 @@ namespace {
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 
-// Lazy BatchNorm (gast_bn_lazy): up to two descriptors covering adjacent column ranges (bn_1 | bn_2, lcat_bn | gcat_bn); n = 0: the
-// scale / shift tables are read instead
-struct Lazy2 { gast_bn_lazy d[2]; int n; };
-__device__ __forceinline__ void lazy_coef4(const Lazy2& lz, int c, float4& s, float4& h) {
-    const bool second = lz.n > 1 && c >= lz.d[0].n;           // (column ranges are multiples of 4)
-    const gast_bn_lazy& d = second ? lz.d[1] : lz.d[0];
-    const int k = second ? c - lz.d[0].n : c;
-    bn_lazy_coef(d, k, s.x, h.x);
-    bn_lazy_coef(d, k + 1, s.y, h.y);
-    bn_lazy_coef(d, k + 2, s.z, h.z);
-    bn_lazy_coef(d, k + 3, s.w, h.w);
-}
-
 struct RowCfg { int TPR, RB; };
 inline RowCfg row_cfg(int N) {
     RowCfg c;
@@ -114,19 +101,6 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
     for (int r = 0; r < LANES; ++r) { s1 += sred[r][cx][0]; s2 += sred[r][cx][1]; }
 }
 
-// nn.BatchNorm2d's train-mode buffer update for channel n (momentum, unbiased variance; num_batches_tracked by channel 0)
-__device__ __forceinline__ void bn_running_update(const BnCoef& cf, double count, float momentum, int centered, float* running_mean,
-                                                  float* running_var, int64_t* nbt, int n) {
-    if (running_mean) {
-        const double unb = count > 1.0 ? cf.var * (count / (count - 1.0)) : cf.var;
-        // centred storage: the statistics are those of x - running_mean, so the true batch mean is running_mean + mean
-        running_mean[n] = centered ? running_mean[n] + momentum * cf.mean
-                                   : (1.f - momentum) * running_mean[n] + momentum * cf.mean;
-        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unb;
-    }
-    if (n == 0 && nbt) *nbt += 1;
-}
-
 __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     __shared__ double sred[4][FINS_COLS][2];
     const float* __restrict__ partials = j.partials;
@@ -143,12 +117,23 @@ __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     double s1, s2;
     finalize_sums_wide(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
     if (ry != 0 || n >= N) return;
-    const BnCoef cf = bn_coef(s1, s2, count, eps, gamma[n], beta[n]);
-    scale[n] = cf.scale;
-    shift[n] = cf.shift;
-    mean_out[n] = cf.mean;
-    rstd_out[n] = cf.rstd;
-    bn_running_update(cf, count, momentum, centered, running_mean, running_var, nbt, n);
+    double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    float sc = gamma[n] * rstd;
+    scale[n] = sc;
+    shift[n] = beta[n] - (float)mean * sc;
+    mean_out[n] = (float)mean;
+    rstd_out[n] = rstd;
+    if (running_mean) {
+        double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
+        // centred storage: the statistics are those of x - running_mean, so the true batch mean is running_mean + mean
+        running_mean[n] = centered ? running_mean[n] + momentum * (float)mean
+                                   : (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unb;
+    }
+    if (n == 0 && nbt) *nbt += 1;
 }
 
 // up to GAST_BN_MAX_BATCH independent finalizes in one launch: blockIdx.y = job
@@ -228,60 +213,6 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, i
     }
 }
 
-// Lazy form (gast_bn_bwd_apply_lazy): no finalize launch -- every thread derives the three coefficients of its 4 channels from the
-// slab {sum dz, sum dz*x} (the arithmetic of bn_bwd_finalize_body), block 0 accumulates dgamma / dbeta.
-struct BnBwdLazy2 { gast_bn_bwd_lazy_job j[2]; int n; };
-template <typename T>
-__global__ void __launch_bounds__(256) bn_bwd_apply_lazy_kernel(T* __restrict__ dz, int lddz, const T* __restrict__ X, int ldx, long rows,
-                                                                int N, int TPR, int RB, const BnBwdLazy2 b) {
-    const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
-    if (slot >= RB) return;
-    const int N4 = N >> 2;
-    for (int cg = ct; cg < N4; cg += TPR) {
-        const int c = cg * 4;
-        const bool second = b.n > 1 && c >= b.j[1].col0;
-        const gast_bn_bwd_lazy_job& j = second ? b.j[1] : b.j[0];
-        const int k0 = c - j.col0;
-        float ka[4], kb[4], kc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int k = k0 + q;
-            const double s1 = j.sums[2 * k], s2 = j.sums[2 * k + 1];
-            const double mu = j.mean[k], r = j.rstd[k], g = j.gamma[k];
-            const double dg = r * (s2 - mu * s1);   // sum dz * xhat
-            const double db = s1;
-            const double a_ = g * r;
-            const double b_ = -g * r * r * dg / j.count;
-            ka[q] = (float)a_;
-            kb[q] = (float)b_;
-            kc[q] = (float)(-b_ * mu - a_ * db / j.count);
-            if (blockIdx.x == 0 && slot == 0) { j.dgamma[k] += (float)dg; j.dbeta[k] += (float)db; }      // one owner per channel
-        }
-        for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
-            float4 d = ld4(dz + r * lddz + c), x = ld4(X + r * ldx + c);
-            d.x = fmaf(ka[0], d.x, fmaf(kb[0], x.x, kc[0]));
-            d.y = fmaf(ka[1], d.y, fmaf(kb[1], x.y, kc[1]));
-            d.z = fmaf(ka[2], d.z, fmaf(kb[2], x.z, kc[2]));
-            d.w = fmaf(ka[3], d.w, fmaf(kb[3], x.w, kc[3]));
-            st4(dz + r * lddz + c, d);
-        }
-    }
-}
-
-// End of a lazy forward pass: every BatchNorm of the model in one launch (blockIdx.y = job, one thread per channel)
-struct BnSumsBatch { gast_bn_sums_job j[GAST_BN_SUMS_MAX_BATCH]; };
-__global__ void __launch_bounds__(256) bn_finalize_sums_kernel(const BnSumsBatch b) {
-    const gast_bn_sums_job& j = b.j[blockIdx.y];
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= j.N) return;
-    const BnCoef cf = bn_coef(j.sums[2 * n], j.sums[2 * n + 1], j.count, j.eps, j.gamma[n], j.beta[n]);
-    j.scale[n] = cf.scale;
-    j.shift[n] = cf.shift;
-    if (j.mean) j.mean[n] = cf.mean;
-    if (j.rstd) j.rstd[n] = cf.rstd;
-    bn_running_update(cf, j.count, j.momentum, 0, j.running_mean, j.running_var, j.num_batches_tracked, n);
-}
-
 // BatchNorm backward for SHORT tensors (the M = B*J rows of the last stage, small models): finalize and apply in ONE launch.
 // A block owns 32 columns of one job: it reduces the partial column sums (as bn_bwd_finalize), keeps the three coefficients in
 // LDS and rewrites FUSED_ROWS rows of its columns (dz <- ka*dz + kb*x + kc; grid.z walks the rows, every split redoes the cheap
@@ -337,7 +268,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                            T* __restrict__ Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop,
-                                                           int TPR, int RB, const Lazy2 lz) {
+                                                           int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -345,9 +276,7 @@ __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__
     const uint32_t key = dr ? drop_key(drop, salt) : 0u;
     for (int cg = ct; cg < N4; cg += TPR) {
         const int c = cg * 4;
-        float4 s, h;
-        if (lz.n) lazy_coef4(lz, c, s, h);
-        else { s = *(const float4*)(scale + c); h = *(const float4*)(shift + c); }
+        const float4 s = *(const float4*)(scale + c), h = *(const float4*)(shift + c);
         for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
             float4 x = ld4(X + r * ldx + c);
             x.x = fmaxf(fmaf(x.x, s.x, h.x), 0.f);
@@ -371,7 +300,7 @@ __global__ void __launch_bounds__(256) bnrelu_bwd_mask_kernel(const T* dY, int l
                                                               long rows, int N, const float* __restrict__ scale,
                                                               const float* __restrict__ shift, int use_drop, uint32_t salt,
                                                               gast_dropout drop, T* dz, int lddz,
-                                                              float* __restrict__ partials, int TPR, int RB, double* __restrict__ sums) {
+                                                              float* __restrict__ partials, int TPR, int RB) {
     __shared__ float sred[256][8];
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int N4 = N >> 2;
@@ -406,14 +335,9 @@ __global__ void __launch_bounds__(256) bnrelu_bwd_mask_kernel(const T* dY, int l
         }
         slot_reduce<2>(acc, sred, tid, slot, ct, TPR, RB);
         if (slot == 0 && cg < N4) {
-            if (sums) {
-                bn_sums_add(sums, c, acc[0].x, acc[1].x); bn_sums_add(sums, c + 1, acc[0].y, acc[1].y);
-                bn_sums_add(sums, c + 2, acc[0].z, acc[1].z); bn_sums_add(sums, c + 3, acc[0].w, acc[1].w);
-            } else {
-                float* pp = partials + ((long)blockIdx.x * N + c) * 2;
-                pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
-                pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
-            }
+            float* pp = partials + ((long)blockIdx.x * N + c) * 2;
+            pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
+            pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
         }
     }
 }
@@ -424,17 +348,8 @@ __global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__
                                                            const T* __restrict__ T2, int ldt, const float* __restrict__ sc2,
                                                            const float* __restrict__ sh2, int use_drop, uint32_t salt,
                                                            gast_dropout drop, int Tn, int J, long rows, int N,
-                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB, const Lazy2 lz) {
-    extern __shared__ __attribute__((aligned(16))) float sLz[];      // lazy BatchNorm: [scO | shO | sc2 | sh2][N], else unused (0 bytes)
+                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
-    if (lz.n) {          // d[0]: the BatchNorm of O, d[1]: the BatchNorm of T2 (both over all N channels)
-        for (int k = tid; k < N; k += 256) {
-            bn_lazy_coef(lz.d[0], k, sLz[k], sLz[N + k]);
-            bn_lazy_coef(lz.d[1], k, sLz[2 * N + k], sLz[3 * N + k]);
-        }
-        __syncthreads();
-    }
-    const bool lzn = lz.n != 0;
     if (slot >= RB) return;
     const int N4 = N >> 2;
     const bool dr = use_drop && drop.thresh != 0;
@@ -450,14 +365,12 @@ __global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__
             float4 res = make_float4(0, 0, 0, 0);
             if (orow >= 0) {
                 float4 o = ld4(O + orow * ldo + c);
-                const float4 s = lzn ? *(const float4*)(sLz + c) : *(const float4*)(scO + c);
-                const float4 h = lzn ? *(const float4*)(sLz + N + c) : *(const float4*)(shO + c);
+                const float4 s = *(const float4*)(scO + c), h = *(const float4*)(shO + c);
                 res.x = fmaxf(fmaf(o.x, s.x, h.x), 0.f); res.y = fmaxf(fmaf(o.y, s.y, h.y), 0.f);
                 res.z = fmaxf(fmaf(o.z, s.z, h.z), 0.f); res.w = fmaxf(fmaf(o.w, s.w, h.w), 0.f);
             }
             float4 x = ld4(T2 + r * ldt + c);
-            const float4 s = lzn ? *(const float4*)(sLz + 2 * N + c) : *(const float4*)(sc2 + c);
-            const float4 h = lzn ? *(const float4*)(sLz + 3 * N + c) : *(const float4*)(sh2 + c);
+            const float4 s = *(const float4*)(sc2 + c), h = *(const float4*)(sh2 + c);
             x.x = fmaxf(fmaf(x.x, s.x, h.x), 0.f); x.y = fmaxf(fmaf(x.y, s.y, h.y), 0.f);
             x.z = fmaxf(fmaf(x.z, s.z, h.z), 0.f); x.w = fmaxf(fmaf(x.w, s.w, h.w), 0.f);
             if (dr) {
@@ -501,8 +414,7 @@ __global__ void __launch_bounds__(256) colsum_kernel(const T* __restrict__ X, in
 // ------------------------------------------------------------------------------------------------ input side
 constexpr int IN_ROWS_PER_BLOCK = 1024;      // 4 rows per thread: 58 blocks on the B=128 window batch (15 blocks of 4096 rows took 12 us)
 
-__global__ void __launch_bounds__(256) input_stats_kernel(const float* __restrict__ x, long rows, int F_in, float* __restrict__ partials,
-                                                          double* __restrict__ sums) {
+__global__ void __launch_bounds__(256) input_stats_kernel(const float* __restrict__ x, long rows, int F_in, float* __restrict__ partials) {
     // partials[blk][f][2]; F_in <= 8
     __shared__ float sred[256][16];
     const int tid = threadIdx.x;
@@ -523,8 +435,7 @@ __global__ void __launch_bounds__(256) input_stats_kernel(const float* __restric
     if (tid < 2 * F_in) {
         float t = 0.f;
         for (int i = 0; i < 256; ++i) t += sred[i][tid];
-        if (sums) atomicAdd(sums + tid, (double)t);            // (slab layout [f][2] == this thread index)
-        else partials[(long)blockIdx.x * F_in * 2 + tid] = t;
+        partials[(long)blockIdx.x * F_in * 2 + tid] = t;
     }
 }
 
@@ -535,16 +446,11 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
                                                          int t_stride, int T_out, const float* __restrict__ W,
                                                          const float* __restrict__ sc0, const float* __restrict__ sh0, int C,
                                                          T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB,
-                                                         const float* __restrict__ center, const Lazy2 lz, double* __restrict__ sums) {
+                                                         const float* __restrict__ center) {
     extern __shared__ __attribute__((aligned(16))) float sW[];  // [K0][C] then sred
     __shared__ float sred[256][8];
-    __shared__ float s0tab[2][16];                              // init_bn scale / shift of the F_in <= KMAX input features
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
-    if (tid < F_in) {
-        if (lz.n) bn_lazy_coef(lz.d[0], tid, s0tab[0][tid], s0tab[1][tid]);
-        else { s0tab[0][tid] = sc0[tid]; s0tab[1][tid] = sh0[tid]; }
-    }
     for (int t = tid; t < K0 * C; t += 256) {
         int c = t / K0, kk = t - c * K0;     // W is [c][f][tap] = [c][kk]
         sW[kk * C + c] = W[t];
@@ -565,7 +471,7 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
                 int t = rem / J, j = rem - t * J;
                 float4 e = make_float4(0, 0, 0, 0);
                 for (int f = 0; f < F_in; ++f) {
-                    float s = s0tab[0][f], h = s0tab[1][f];
+                    float s = sc0[f], h = sh0[f];
                     for (int tap = 0; tap < k0; ++tap) {
                         long xr = ((long)b * T_in + t * t_stride + tap) * J + j;
                         float xv = fmaf(x[xr * F_in + f], s, h);
@@ -583,14 +489,9 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
         }
         slot_reduce<2>(acc, sred, tid, slot, ct, TPR, RB);
         if (slot == 0 && cg < C4) {
-            if (sums) {
-                bn_sums_add(sums, c, acc[0].x, acc[1].x); bn_sums_add(sums, c + 1, acc[0].y, acc[1].y);
-                bn_sums_add(sums, c + 2, acc[0].z, acc[1].z); bn_sums_add(sums, c + 3, acc[0].w, acc[1].w);
-            } else {
-                float* pp = partials + ((long)blockIdx.x * C + c) * 2;
-                pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
-                pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
-            }
+            float* pp = partials + ((long)blockIdx.x * C + c) * 2;
+            pp[0] = acc[0].x; pp[1] = acc[1].x; pp[2] = acc[0].y; pp[3] = acc[1].y;
+            pp[4] = acc[0].z; pp[5] = acc[1].z; pp[6] = acc[0].w; pp[7] = acc[1].w;
         }
     }
 }
@@ -848,170 +749,56 @@ extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, i
     return 0;
 }
 
-// descriptors covering columns [0, N) in order; every range a multiple of 4
-static int make_lazy2(const gast_bn_lazy* lazy, int nlazy, int N, Lazy2& lz) {
-    lz.n = 0;
-    if (!lazy || nlazy < 1 || nlazy > 2) return GAST_EINVAL;
-    int tot = 0;
-    for (int i = 0; i < nlazy; ++i) {
-        if (!lazy[i].sums || !lazy[i].gamma || !lazy[i].beta || !(lazy[i].count > 0) || lazy[i].n < 1) return GAST_EINVAL;
-        if (lazy[i].n % 4) return GAST_EALIGN;
-        lz.d[i] = lazy[i];
-        tot += lazy[i].n;
-    }
-    if (tot != N) return GAST_EINVAL;
-    lz.n = nlazy;
-    return 0;
-}
-
-static int bnrelu_apply_impl(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                             void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, const Lazy2& lz, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !X || !Y || rows < 1) return GAST_EINVAL;
+extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1) return GAST_EINVAL;
     if (N % 4 || ldx % 4 || ldy % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bnrelu_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)X, ldx, rows, N, scale,
-                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
+                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
-                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
-    GAST_CHECK_LAUNCH();
-    return 0;
-}
-extern "C" int gast_bn_bwd_apply_lazy(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, const gast_bn_bwd_lazy_job* jobs,
-                                      int njobs, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !dz || !X || !jobs || njobs < 1 || njobs > 2 || rows < 1) return GAST_EINVAL;
-    BnBwdLazy2 b;
-    b.n = njobs;
-    int N = 0;
-    for (int i = 0; i < njobs; ++i) {
-        const gast_bn_bwd_lazy_job& j = jobs[i];
-        if (!j.sums || !j.gamma || !j.mean || !j.rstd || !j.dgamma || !j.dbeta || !(j.count > 0) || j.n < 1 || j.col0 != N) return GAST_EINVAL;
-        if (j.n % 4) return GAST_EALIGN;
-        b.j[i] = j;
-        N += j.n;
-    }
-    if (lddz % 4 || ldx % 4) return GAST_EALIGN;
-    RowCfg c = row_cfg(N);
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == GAST_F32)
-        hipLaunchKernelGGL((bn_bwd_apply_lazy_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (float*)dz, lddz, (const float*)X,
-                           ldx, rows, N, c.TPR, c.RB, b);
-    else
-        hipLaunchKernelGGL((bn_bwd_apply_lazy_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz,
-                           (const bf16_t*)X, ldx, rows, N, c.TPR, c.RB, b);
+                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
-extern "C" int gast_bn_finalize_sums(const gast_bn_sums_job* jobs, int n, gast_stream_t stream) {
-    if (!jobs || n < 1 || n > GAST_BN_SUMS_MAX_BATCH) return GAST_EINVAL;
-    BnSumsBatch b;
-    int maxN = 0;
-    for (int d = 0; d < n; ++d) {
-        const gast_bn_sums_job& j = jobs[d];
-        if (!j.sums || !j.gamma || !j.beta || !j.scale || !j.shift || j.N < 1 || !(j.count > 0)) return GAST_EINVAL;
-        if ((j.running_mean == nullptr) != (j.running_var == nullptr)) return GAST_EINVAL;
-        b.j[d] = j;
-        if (j.N > maxN) maxN = j.N;
-    }
-    hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3((maxN + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, b);
-    GAST_CHECK_LAUNCH();
-    return 0;
-}
-
-extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
-    if (!scale || !shift) return GAST_EINVAL;
-    Lazy2 lz;
-    lz.n = 0;
-    return bnrelu_apply_impl(dtype, X, ldx, rows, N, scale, shift, Y, ldy, use_drop, salt, drop, lz, stream);
-}
-extern "C" int gast_bnrelu_apply_lazy(int dtype, const void* X, int ldx, long rows, int N, const gast_bn_lazy* lazy, int nlazy,
-                                      void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
-    Lazy2 lz;
-    if (int rc = make_lazy2(lazy, nlazy, N, lz)) return rc;
-    return bnrelu_apply_impl(dtype, X, ldx, rows, N, nullptr, nullptr, Y, ldy, use_drop, salt, drop, lz, stream);
-}
-
-static int bnrelu_bwd_mask_impl(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
-                                const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
-                                void* dz, int lddz, float* partials, double* sums, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !dY || !X || !scale || !shift || !dz || (!partials && !sums) || rows < 1) return GAST_EINVAL;
+extern "C" int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
+                                    const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
+                                    void* dz, int lddz, float* partials, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dY || !X || !scale || !shift || !dz || !partials || rows < 1) return GAST_EINVAL;
     if (N % 4 || lddy % 4 || ldx % 4 || lddz % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bnrelu_bwd_mask_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)dY, lddy,
-                           (const float*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (float*)dz, lddz, partials, c.TPR, c.RB, sums);
+                           (const float*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (float*)dz, lddz, partials, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((bnrelu_bwd_mask_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)dY, lddy,
-                           (const bf16_t*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (bf16_t*)dz, lddz, partials, c.TPR, c.RB, sums);
+                           (const bf16_t*)X, ldx, rows, N, scale, shift, use_drop, salt, drop, (bf16_t*)dz, lddz, partials, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
-}
-extern "C" int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
-                                    const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
-                                    void* dz, int lddz, float* partials, gast_stream_t stream) {
-    if (!partials) return GAST_EINVAL;
-    return bnrelu_bwd_mask_impl(dtype, dY, lddy, X, ldx, rows, N, scale, shift, use_drop, salt, drop, dz, lddz, partials, nullptr, stream);
-}
-extern "C" int gast_bnrelu_bwd_mask_sums(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
-                                         const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
-                                         void* dz, int lddz, double* sums, gast_stream_t stream) {
-    if (!sums) return GAST_EINVAL;
-    return bnrelu_bwd_mask_impl(dtype, dY, lddy, X, ldx, rows, N, scale, shift, use_drop, salt, drop, dz, lddz, nullptr, sums, stream);
 }
 
-static int residual_fwd_impl(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
-                             const void* T2, int ldt, const float* sc2, const float* sh2,
-                             int use_drop, uint32_t salt, gast_dropout drop,
-                             int B, int Tn, int J, int N, void* Xn, int ldxn, const Lazy2& lz, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !O || !T2 || !Xn || B < 1 || Tn < 1 || J < 1) return GAST_EINVAL;
-    if (N % 4 || ldo % 4 || ldt % 4 || ldxn % 4) return GAST_EALIGN;
-    long rows = (long)B * Tn * J;
-    RowCfg c = row_cfg(N);
-    hipStream_t st = (hipStream_t)stream;
-    const size_t smem = lz.n ? (size_t)4 * N * sizeof(float) : 0;       // the lazy scale / shift tables of both BatchNorms
-    if (smem > 64 * 1024) return GAST_ERANGE;
-    if (smem > 48 * 1024) {
-        hipError_t e = dtype == GAST_F32
-            ? hipFuncSetAttribute((const void*)residual_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-            : hipFuncSetAttribute((const void*)residual_fwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (dtype == GAST_F32)
-        hipLaunchKernelGGL((residual_fwd_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), smem, st, (const float*)O, ldo, omap, scO, shO,
-                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB, lz);
-    else
-        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), smem, st, (const bf16_t*)O, ldo, omap, scO, shO,
-                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB, lz);
-    GAST_CHECK_LAUNCH();
-    return 0;
-}
 extern "C" int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
                                  const void* T2, int ldt, const float* sc2, const float* sh2,
                                  int use_drop, uint32_t salt, gast_dropout drop,
                                  int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream) {
-    if (!scO || !shO || !sc2 || !sh2) return GAST_EINVAL;
-    Lazy2 lz;
-    lz.n = 0;
-    return residual_fwd_impl(dtype, O, ldo, omap, scO, shO, T2, ldt, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, ldxn, lz, stream);
-}
-extern "C" int gast_residual_fwd_lazy(int dtype, const void* O, int ldo, gast_rowmap omap, const gast_bn_lazy* lazyO,
-                                      const void* T2, int ldt, const gast_bn_lazy* lazy2, int use_drop, uint32_t salt, gast_dropout drop,
-                                      int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream) {
-    if (!lazyO || !lazy2) return GAST_EINVAL;
-    Lazy2 lz;
-    const gast_bn_lazy both[2] = {*lazyO, *lazy2};
-    for (int i = 0; i < 2; ++i)
-        if (!both[i].sums || !both[i].gamma || !both[i].beta || !(both[i].count > 0) || both[i].n != N) return GAST_EINVAL;
-    lz.d[0] = both[0];
-    lz.d[1] = both[1];
-    lz.n = 2;
-    return residual_fwd_impl(dtype, O, ldo, omap, nullptr, nullptr, T2, ldt, nullptr, nullptr, use_drop, salt, drop, B, Tn, J, N, Xn, ldxn,
-                             lz, stream);
+    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1) return GAST_EINVAL;
+    if (N % 4 || ldo % 4 || ldt % 4 || ldxn % 4) return GAST_EALIGN;
+    long rows = (long)B * Tn * J;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((residual_fwd_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)O, ldo, omap, scO, shO,
+                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB);
+    else
+        hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)O, ldo, omap, scO, shO,
+                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out, int zero_first, gast_stream_t stream) {
@@ -1039,24 +826,17 @@ extern "C" int gast_input_stats(const float* x, long rows, int F_in, float* part
     if (!x || !partials || rows < 1 || F_in < 1 || F_in > 8) return GAST_EINVAL;
     int nb = gast_input_stats_blocks(rows);
     if (nblk_out) *nblk_out = nb;
-    hipLaunchKernelGGL(input_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, F_in, partials, (double*)nullptr);
-    GAST_CHECK_LAUNCH();
-    return 0;
-}
-extern "C" int gast_input_stats_sums(const float* x, long rows, int F_in, double* sums, gast_stream_t stream) {
-    if (!x || !sums || rows < 1 || F_in < 1 || F_in > 8) return GAST_EINVAL;
-    hipLaunchKernelGGL(input_stats_kernel, dim3(gast_input_stats_blocks(rows)), dim3(256), 0, (hipStream_t)stream, x, rows, F_in,
-                       (float*)nullptr, sums);
+    hipLaunchKernelGGL(input_stats_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, rows, F_in, partials);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
 static inline int conv_t_out(int T_in, int k0, int t_stride) { return (T_in - k0) / t_stride + 1; }
 
-static int expand_fwd_impl(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                           const float* W, const float* sc0, const float* sh0, int C,
-                           void* E, int lde, float* partials, const float* center, const Lazy2& lz, double* sums, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !x || !W || !E || (!partials && !sums)) return GAST_EINVAL;
+extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
+                               const float* W, const float* sc0, const float* sh0, int C,
+                               void* E, int lde, float* partials, const float* center, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials) return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || lde % 4) return GAST_EALIGN;
     size_t smem = (size_t)F_in * k0 * C * sizeof(float);
@@ -1074,28 +854,12 @@ static int expand_fwd_impl(int dtype, const float* x, int B, int T_in, int J, in
     }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
-                           C, (float*)E, lde, partials, c.TPR, c.RB, center, lz, sums);
+                           C, (float*)E, lde, partials, c.TPR, c.RB, center);
     else
         hipLaunchKernelGGL((expand_fwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0,
-                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center, lz, sums);
+                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center);
     GAST_CHECK_LAUNCH();
     return 0;
-}
-extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                               const float* W, const float* sc0, const float* sh0, int C,
-                               void* E, int lde, float* partials, const float* center, gast_stream_t stream) {
-    if (!sc0 || !sh0 || !partials) return GAST_EINVAL;
-    Lazy2 lz;
-    lz.n = 0;
-    return expand_fwd_impl(dtype, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, lde, partials, center, lz, nullptr, stream);
-}
-extern "C" int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                                    const float* W, const gast_bn_lazy* lazy0, int C, void* E, int lde, double* sums, gast_stream_t stream) {
-    if (!lazy0 || !lazy0->sums || !lazy0->gamma || !lazy0->beta || !(lazy0->count > 0) || lazy0->n != F_in || !sums) return GAST_EINVAL;
-    Lazy2 lz;
-    lz.d[0] = *lazy0;
-    lz.n = 1;
-    return expand_fwd_impl(dtype, x, B, T_in, J, F_in, k0, t_stride, W, nullptr, nullptr, C, E, lde, nullptr, nullptr, lz, sums, stream);
 }
 
 static int expand_bwd_blocks(long rows, int C) {

@@ -994,12 +994,6 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     long chunk = (tile_rows + tgt - 1) / tgt;
     chunk = (chunk + bkm - 1) / bkm * bkm;
     if (chunk < 4 * bkm) chunk = 4 * bkm;
-    // GAST_WGRAD_MIN_CHUNK (rows): lower bound of the chunk length.  The M = B*J stage (2176 rows, ~340 output tiles) gets 3 chunks
-    // per tile from the block budget above, i.e. every output element is added three times with atomics (79 MB of them) by 1200
-    // blocks in 2.3 rounds of the 512 resident slots; with the whole reduction in one chunk it is 400 blocks, one round, a third of
-    // the atomics.  Large stages are unaffected (their chunks are ~3000 rows).
-    static const int min_chunk = getenv("GAST_WGRAD_MIN_CHUNK") ? atoi(getenv("GAST_WGRAD_MIN_CHUNK")) : 0;
-    if (min_chunk > 0 && chunk < min_chunk) chunk = ((long)min_chunk + bkm - 1) / bkm * bkm;
     const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS");
     if (ring2) {
         // two blocks per CU: the block count is quantised against 512 slots (518 blocks run 1.33x slower than 444), so pick

@@ -47,28 +47,9 @@ class _Dropout(C.Structure):
     _fields_ = [('seed', C.c_void_p), ('thresh', C.c_uint32), ('inv_keep', C.c_float)]
 
 
-class BnLazy(namedtuple('BnLazy', 'sums gamma beta count eps n')):
-    """gast_bn_lazy: a training-mode BatchNorm read straight from its producers' column sums.  sums: float64 [n][2] device view
-    (zero-filled before the producers ran), gamma / beta: fp32 [n], count: rows the statistics cover."""
-    __slots__ = ()
-
-
-class _BnLazy(C.Structure):
-    _fields_ = [('sums', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('count', C.c_double), ('eps', C.c_float),
-                ('n', C.c_int)]
-
-
-def _fill_lazy(dst, lz):
-    if lz.sums.dtype != torch.float64 or not lz.sums.is_contiguous() or lz.sums.numel() != 2 * lz.n:
-        raise RuntimeError('gast_hip: a lazy BatchNorm needs a contiguous float64 [n][2] slab')
-    dst.sums, dst.gamma, dst.beta = _p(lz.sums), _p(lz.gamma), _p(lz.beta)
-    dst.count, dst.eps, dst.n = float(lz.count), float(lz.eps), int(lz.n)
-
-
 class _GemmSeg(C.Structure):
     _fields_ = [('A', C.c_void_p), ('lda', C.c_int), ('K', C.c_int), ('map', _RowMap), ('W', C.c_void_p), ('ldw', C.c_int),
-                ('pro', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('salt', C.c_uint32), ('Wx', C.c_void_p), ('ldwx', C.c_int),
-                ('lazy', _BnLazy)]
+                ('pro', C.c_int), ('scale', C.c_void_p), ('shift', C.c_void_p), ('salt', C.c_uint32), ('Wx', C.c_void_p), ('ldwx', C.c_int)]
 
 
 class _X3ImageJob(C.Structure):
@@ -81,19 +62,7 @@ class _GemmArgs(C.Structure):
                 ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
                 ('bias', C.c_void_p), ('bias_neg', C.c_int), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
                 ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
-                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('stat_sums', C.c_void_p), ('f8_scale', C.c_void_p)]
-
-
-class _BnBwdLazyJob(C.Structure):
-    _fields_ = [('sums', C.c_void_p), ('col0', C.c_int), ('n', C.c_int), ('count', C.c_double), ('gamma', C.c_void_p),
-                ('mean', C.c_void_p), ('rstd', C.c_void_p), ('dgamma', C.c_void_p), ('dbeta', C.c_void_p)]
-
-
-class _BnSumsJob(C.Structure):
-    _fields_ = [('sums', C.c_void_p), ('N', C.c_int), ('count', C.c_double), ('gamma', C.c_void_p), ('beta', C.c_void_p),
-                ('running_mean', C.c_void_p), ('running_var', C.c_void_p), ('num_batches_tracked', C.c_void_p),
-                ('momentum', C.c_float), ('eps', C.c_float), ('scale', C.c_void_p), ('shift', C.c_void_p), ('mean', C.c_void_p),
-                ('rstd', C.c_void_p)]
+                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('f8_scale', C.c_void_p)]
 
 
 class _F8ScaleJob(C.Structure):
@@ -214,15 +183,6 @@ def load_library():
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
         'gast_null_launch': [vp],
         'gast_prep': [C.POINTER(_PrepArgs), vp],
-        'gast_bnrelu_apply_lazy': [ci, vp, ci, cl, ci, C.POINTER(_BnLazy), ci, vp, ci, ci, cu, _Dropout, vp],
-        'gast_residual_fwd_lazy': [ci, vp, ci, _RowMap, C.POINTER(_BnLazy), vp, ci, C.POINTER(_BnLazy), ci, cu, _Dropout, ci, ci, ci, ci, vp,
-                                   ci, vp],
-        'gast_bnrelu_bwd_mask_sums': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
-        'gast_bn_bwd_apply_lazy': [ci, vp, ci, vp, ci, cl, C.POINTER(_BnBwdLazyJob), ci, vp],
-        'gast_bn_finalize_sums': [C.POINTER(_BnSumsJob), ci, vp],
-        'gast_input_stats_sums': [vp, cl, ci, vp, vp],
-        'gast_expand_fwd_lazy': [ci, vp, ci, ci, ci, ci, ci, ci, vp, C.POINTER(_BnLazy), ci, vp, ci, vp, vp],
-        'gast_semch_agg_fwd_sums': [ci, vp, ci, ci, ci, ci, vp, vp, ci, vp, vp, ci, vp, ci, vp, vp],
         'gast_chunk_gather': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
         'gast_stream_shift_multi': [C.POINTER(_StreamShiftJob), ci, vp],
     }
@@ -245,9 +205,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_prep', 'gast_bnrelu_apply_lazy', 'gast_residual_fwd_lazy', 'gast_bnrelu_bwd_mask_sums',
-                    'gast_bn_bwd_apply_lazy', 'gast_bn_finalize_sums', 'gast_input_stats_sums', 'gast_expand_fwd_lazy', 'gast_semch_agg_fwd_sums',
-                    'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
 
 def _check(rc, what):
@@ -323,7 +281,7 @@ class HipOps:
         return self.lib.gast_gemm_row_blocks(int(M))
 
     def _gemm_args(self, a, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, stat_sums=None):
+                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         a.dtype = _dt(segs[0]['A'])
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
         st_dtype = a.dtype
@@ -350,8 +308,6 @@ class HipOps:
             g.pro = int(s.get('pro', PRO_NONE))
             g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
             g.salt = int(s.get('salt', 0))
-            if s.get('lazy') is not None:       # lazy BatchNorm: scale / shift from the producers' sums (large-M kernel only)
-                _fill_lazy(g.lazy, s['lazy'])
         a.C, a.ldc, a.cmap = _p(C_), _ld(C_), _rm(cmap)
         a.bias = _p(bias)
         a.bias_neg = int(bool(bias_neg))
@@ -359,10 +315,6 @@ class HipOps:
             a.addend, a.ldadd, a.addmap = _p(addend), _ld(addend), _rm(addmap)
         a.epi = int(epi)
         a.partials = _p(partials)
-        if stat_sums is not None:
-            if stat_sums.dtype != torch.float64 or not stat_sums.is_contiguous() or stat_sums.numel() != 2 * int(N):
-                raise RuntimeError('gast_hip: stat_sums must be a contiguous float64 [N][2] slab')
-            a.stat_sums = _p(stat_sums)
         if X is not None:
             a.X, a.ldx = _p(X), _ld(X)
         a.xscale, a.xshift = _p(xscale), _p(xshift)
@@ -490,15 +442,10 @@ class HipOps:
     def semch_agg_blocks(self, F, C_):
         return self.lib.gast_semch_agg_blocks(int(F), int(C_))
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None), sums=None):
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
         """A_*: [nnz+1][C] (row nnz all zero); deg = (Dr_sym, Dr_con) of the pattern tables selects the unrolled kernels;
-        center = (bn_1.running_mean, bn_2.running_mean) or Nones: subtracted from the stored outputs.
-        sums (float64 [2C][2], zero-filled): lazy-BatchNorm form, the column sums are accumulated there and `partials` is unused."""
+        center = (bn_1.running_mean, bn_2.running_mean) or Nones: subtracted from the stored outputs."""
         self.launches += 1
-        if sums is not None:
-            _check(self.lib.gast_semch_agg_fwd_sums(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), int(deg[0]), _p(A_con),
-                                                    _p(pat_con), int(deg[1]), _p(Y), _ld(Y), _p(sums), _stream()), 'gast_semch_agg_fwd_sums')
-            return
         _check(self.lib.gast_semch_agg_fwd(_dt(H), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym), int(deg[0]), _p(A_con),
                                            _p(pat_con), int(deg[1]), _p(Y), _ld(Y), _p(partials), _p(center[0]), _p(center[1]),
                                            _stream()), 'gast_semch_agg_fwd')
@@ -615,80 +562,28 @@ class HipOps:
                                              _p(rstd), _p(dgamma), _p(dbeta), _p(ka), _p(kb), _p(kc), _stream()),
                'gast_bn_bwd_finalize')
 
-    def bn_bwd_apply_lazy(self, dz, X, rows, jobs):
-        """jobs: <= 2 dicts(sums (float64 [n][2]), col0, n, count, gamma, mean, rstd, dgamma, dbeta) over adjacent column ranges of
-        dz / X starting at 0: dz <- dx in place with the coefficients derived from the sums; dgamma / dbeta += (gast_bn_bwd_apply_lazy)."""
-        arr = (_BnBwdLazyJob * len(jobs))()
-        for a, j in zip(arr, jobs):
-            a.sums, a.col0, a.n, a.count = _p(j['sums']), int(j['col0']), int(j['n']), float(j['count'])
-            a.gamma, a.mean, a.rstd, a.dgamma, a.dbeta = _p(j['gamma']), _p(j['mean']), _p(j['rstd']), _p(j['dgamma']), _p(j['dbeta'])
-        self.launches += 1
-        _check(self.lib.gast_bn_bwd_apply_lazy(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), int(rows), arr, len(jobs), _stream()),
-               'gast_bn_bwd_apply_lazy')
-
-    BN_SUMS_MAX_BATCH = 24
-
-    def bn_finalize_sums(self, jobs):
-        """jobs: dicts(sums, N, count, gamma, beta, running_mean, running_var, nbt, momentum, eps, scale, shift, mean, rstd): the tables
-        and running statistics of every lazily handled BatchNorm of a forward pass, BN_SUMS_MAX_BATCH per launch."""
-        for i0 in range(0, len(jobs), self.BN_SUMS_MAX_BATCH):
-            chunk = jobs[i0:i0 + self.BN_SUMS_MAX_BATCH]
-            arr = (_BnSumsJob * len(chunk))()
-            for a, j in zip(arr, chunk):
-                a.sums, a.N, a.count = _p(j['sums']), int(j['N']), float(j['count'])
-                a.gamma, a.beta = _p(j['gamma']), _p(j['beta'])
-                a.running_mean, a.running_var, a.num_batches_tracked = _p(j['running_mean']), _p(j['running_var']), _p(j['nbt'])
-                a.momentum, a.eps = j['momentum'], j['eps']
-                a.scale, a.shift, a.mean, a.rstd = _p(j['scale']), _p(j['shift']), _p(j['mean']), _p(j['rstd'])
-            self.launches += 1
-            _check(self.lib.gast_bn_finalize_sums(arr, len(chunk), _stream()), 'gast_bn_finalize_sums')
-
     def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc):
         self.launches += 1
         _check(self.lib.gast_bn_bwd_apply(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _stream()),
                'gast_bn_bwd_apply')
 
-    @staticmethod
-    def _lazy_array(lazy):
-        arr = (_BnLazy * len(lazy))()
-        for d, lz in zip(arr, lazy):
-            _fill_lazy(d, lz)
-        return arr
-
-    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None, lazy=None):
-        """Y = drop(relu(scale*X + shift)); the dropout stream `salt` is indexed by the element offset in X.
-        lazy: list of <= 2 BnLazy covering the N columns in order -- scale / shift (then unused) come from the producers' sums."""
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
+        """Y = drop(relu(scale*X + shift)); the dropout stream `salt` is indexed by the element offset in X."""
         self.launches += 1
-        if lazy is not None:
-            _check(self.lib.gast_bnrelu_apply_lazy(_dt(X), _p(X), _ld(X), rows, N, self._lazy_array(lazy), len(lazy), _p(Y), _ld(Y),
-                                                   int(bool(use_drop)), int(salt), _drop(drop), _stream()), 'gast_bnrelu_apply_lazy')
-            return
         _check(self.lib.gast_bnrelu_apply(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), int(bool(use_drop)),
                                           int(salt), _drop(drop), _stream()), 'gast_bnrelu_apply')
 
     def rowwise_blocks(self, rows, N):
         return self.lib.gast_rowwise_blocks(int(rows), int(N))
 
-    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials, sums=None):
+    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials):
         self.launches += 1
-        if sums is not None:
-            _check(self.lib.gast_bnrelu_bwd_mask_sums(_dt(X), _p(dY), _ld(dY), _p(X), _ld(X), rows, N, _p(scale), _p(shift),
-                                                      int(bool(use_drop)), int(salt), _drop(drop), _p(dz), _ld(dz), _p(sums), _stream()),
-                   'gast_bnrelu_bwd_mask_sums')
-            return
         _check(self.lib.gast_bnrelu_bwd_mask(_dt(X), _p(dY), _ld(dY), _p(X), _ld(X), rows, N, _p(scale), _p(shift),
                                              int(bool(use_drop)), int(salt), _drop(drop), _p(dz), _ld(dz), _p(partials), _stream()),
                'gast_bnrelu_bwd_mask')
 
-    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, lazyO=None, lazy2=None):
+    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
         self.launches += 1
-        if lazyO is not None or lazy2 is not None:
-            if lazyO is None or lazy2 is None:
-                raise RuntimeError('gast_hip: residual_fwd takes both BatchNorms lazy or neither')
-            _check(self.lib.gast_residual_fwd_lazy(_dt(O), _p(O), _ld(O), _rm(omap), self._lazy_array([lazyO]), _p(T2), _ld(T2),
-                                                   self._lazy_array([lazy2]), int(bool(use_drop)), int(salt), _drop(drop), B, Tn, J, N,
-                                                   _p(Xn), _ld(Xn), _stream()), 'gast_residual_fwd_lazy')
-            return
         _check(self.lib.gast_residual_fwd(_dt(O), _p(O), _ld(O), _rm(omap), _p(scO), _p(shO), _p(T2), _ld(T2), _p(sc2), _p(sh2),
                                           int(bool(use_drop)), int(salt), _drop(drop), B, Tn, J, N, _p(Xn), _ld(Xn), _stream()),
                'gast_residual_fwd')
@@ -701,19 +596,12 @@ class HipOps:
     def input_stats_blocks(self, rows):
         return self.lib.gast_input_stats_blocks(int(rows))
 
-    def input_stats(self, x, rows, F_in, partials, sums=None):
+    def input_stats(self, x, rows, F_in, partials):
         self.launches += 1
-        if sums is not None:
-            _check(self.lib.gast_input_stats_sums(_p(x), rows, F_in, _p(sums), _stream()), 'gast_input_stats_sums')
-            return
         _check(self.lib.gast_input_stats(_p(x), rows, F_in, _p(partials), None, _stream()), 'gast_input_stats')
 
-    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None, lazy0=None, sums=None):
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
         self.launches += 1
-        if lazy0 is not None:
-            _check(self.lib.gast_expand_fwd_lazy(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), self._lazy_array([lazy0]), C_, _p(E),
-                                                 _ld(E), _p(sums), _stream()), 'gast_expand_fwd_lazy')
-            return
         _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
                                         _p(partials), _p(center), _stream()), 'gast_expand_fwd')
 

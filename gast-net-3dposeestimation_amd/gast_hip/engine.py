@@ -46,7 +46,7 @@ def ident(T):
 
 class BNState:
     """scale/shift (+ mean/rstd in training) of one BatchNorm2d for the current batch."""
-    __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count', 'lz', 'jobs')
+    __slots__ = ('scale', 'shift', 'mean', 'rstd', 'count')
 
     EVAL_COUNT = 1e300     # "infinitely many rows": the batch-statistics terms of the BatchNorm backward vanish
 
@@ -55,11 +55,6 @@ class BNState:
         may follow): nothing to compute for this state.  Eval-mode BatchNorm is the fixed affine map y = scale*x + shift, whose
         backward is dx = gamma*rstd*dz, dgamma = sum dz*(x-mean)*rstd, dbeta = sum dz with the RUNNING statistics -- exactly what
         the training-mode backward kernels compute for count -> infinity."""
-        # lazy training-mode BatchNorm (Engine._bn_lazy): `lz` = [(column offset, BnLazy)] of the BatchNorms this state spans -- consumers
-        # derive scale / shift from the producers' sums themselves -- and `jobs` = their still pending table / running-statistics
-        # updates (Engine._bn_flush at the end of the forward pass, or _bn_materialize for a consumer that needs the tables now)
-        self.lz = None
-        self.jobs = None
         self.scale = pre[0] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
         self.shift = pre[1] if pre is not None else torch.empty(n, dtype=torch.float32, device=dev)
         if pre is not None and pre[2] is not None:
@@ -121,13 +116,6 @@ class Engine:
         self.centered = bool(centered)
         self.za = ZeroArena()
         self._pre = {}           # eval mode: pre-filled (scale, shift) views per BNState name
-        # Lazy BatchNorm (include/gast_hip.h: gast_bn_lazy; GAST_BN_LAZY=0 restores the finalize launches): training-mode producers
-        # accumulate their column sums into zero-filled float64 slabs with atomics and the consumers derive scale / shift themselves,
-        # so the 24 finalize launches of a training step (~5 us of graph-node boundary each) disappear; the tables the backward pass
-        # reads and the running statistics are written by ONE launch at the end of the forward pass.
-        self.lazy_bn = os.environ.get('GAST_BN_LAZY', '1') not in ('0', '')
-        self._lazy = False       # ... in effect for the current pass
-        self._bnq = []           # pending gast_bn_finalize_sums jobs of the current forward pass
         self._side = {}          # device -> side stream for independent branches of the plan
         self._keep = []          # operands of side-stream launches, kept alive until the join
 
@@ -153,94 +141,6 @@ class Engine:
         attention kernels that read it in 256-byte pieces."""
         per = 128 // torch.empty((), dtype=dt).element_size()
         return torch.empty(rows, (cols + per - 1) // per * per, dtype=dt, device=dev)[:, :cols]
-
-    # ------------------------------------------------------------------------------------------ lazy BatchNorm
-    def _stat_dst(self, nb, ncol, arena=True):
-        """Where a producer leaves its column statistics: (partials, sums) -- the float64 slab of the lazy scheme (zero-filled by the
-        arena) or the per-row-block partial rows of the two-phase scheme; the other one is None."""
-        if self._lazy:
-            return None, self.za.take((ncol, 2), torch.float64)
-        dev = self.za.dev
-        return (self.za.take((nb, ncol, 2)) if arena else torch.empty(nb, ncol, 2, dtype=torch.float32, device=dev)), None
-
-    def _bn_lazy(self, st, parts, count):
-        """parts: [(sums view [n][2], column offset in st, n, bn dict)] -- register a lazily finalized training-mode BatchNorm state."""
-        from gast_hip.binding import BnLazy
-        if st.lz is None:
-            st.lz, st.jobs = [], []
-            self._bnq.append(st)
-        for sums, off, n, bn in parts:
-            eps = bn.get('eps', BN_EPS)
-            st.lz.append((off, BnLazy(sums, bn['weight'], bn['bias'], count, eps, n)))
-            sl = slice(off, off + n)
-            st.jobs.append(dict(sums=sums, N=n, count=count, gamma=bn['weight'], beta=bn['bias'], running_mean=bn['running_mean'],
-                                running_var=bn['running_var'], nbt=bn['num_batches_tracked'], momentum=bn.get('momentum', BN_MOMENTUM),
-                                eps=eps, scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl], rstd=st.rstd[sl]))
-
-    def _bn_materialize(self, st):
-        """The tables of a lazy state are needed NOW (a consumer on the 128x128-tile GEMM kernel, which has no registers to spare for
-        the coefficient prologue): run its finalize job(s) as a launch of their own and drop the lazy descriptors."""
-        if st.jobs:
-            self.ops.bn_finalize_sums(st.jobs)
-        st.jobs, st.lz = None, None
-
-    def _bn_flush(self):
-        """End of the forward pass: tables (for the backward pass) and running statistics of every state still lazy -- one launch."""
-        jobs = [j for st in self._bnq if st.jobs for j in st.jobs]
-        if jobs:
-            self.ops.bn_finalize_sums(jobs)
-        for st in self._bnq:
-            st.jobs = None          # (st.lz stays: a later consumer of the same pass may still derive its coefficients itself)
-        self._bnq = []
-
-    @staticmethod
-    def _lz1(st):
-        """the single BnLazy of a state that spans one BatchNorm (None when not lazy)"""
-        return st.lz[0][1] if st.lz else None
-
-    def _pro(self, st, off=0, n=None):
-        """Prologue keywords of a GEMM K segment that reads columns [off, off + n) of a tensor through relu(bn(.)) of state `st`: the
-        tables, plus -- while the state is lazy and the range is exactly one of its BatchNorms -- the BnLazy descriptor.  (A lazy state
-        that spans two BatchNorms must be read as one segment per BatchNorm: see `_bn_ranges`.)"""
-        n = st.scale.numel() if n is None else n
-        d = dict(pro=PRO_BNRELU, scale=st.scale[off:off + n], shift=st.shift[off:off + n])
-        if st.lz:
-            hit = [lz for o, lz in st.lz if o == off and lz.n == n]
-            if not hit:
-                raise RuntimeError('engine: a lazy BatchNorm state is read over a column range that is not one of its BatchNorms')
-            d['lazy'], d['_st'] = hit[0], st
-        return d
-
-    @staticmethod
-    def _bn_ranges(st, cols):
-        """column ranges a consumer has to read the state in: one per BatchNorm while it is lazy, else the whole width"""
-        return [(o, lz.n) for o, lz in st.lz] if st.lz else [(0, cols)]
-
-    def _settle(self, jobs):
-        """jobs: dicts with the keyword arguments of ops.gemm.  Lazy K segments are a feature of the large-M GEMM kernel only: a job
-        that would run on the 128x128-tile kernel gets the BatchNorm states it reads materialised first (their finalize as a launch of
-        its own) and reads the tables."""
-        for j in jobs:
-            lazy = [sg for sg in j['segs'] if 'lazy' in sg]
-            if lazy and not self.ops.gemm_path(**j):
-                for sg in lazy:
-                    if sg['_st'].lz:
-                        self._bn_materialize(sg['_st'])
-                    del sg['lazy']
-            for sg in j['segs']:
-                sg.pop('_st', None)
-        return jobs
-
-    def _lzkw(self, st):
-        """keyword of an elementwise consumer (bnrelu_apply) that reads all columns of `st`: its BnLazy list while the state is lazy"""
-        return {'lazy': [lz for _, lz in st.lz]} if st.lz else {}
-
-    def _bn_stats(self, partials, sums, nblk, col0, n, count, bn, st, training, off=0, centered=False):
-        """A producer's statistics are complete: lazy -> register the state (nothing is launched), else the finalize launch."""
-        if training and sums is not None:
-            self._bn_lazy(st, [(sums[col0:col0 + n], off, n, bn)], count)
-        else:
-            self._bn_forward(partials, nblk, col0, n, count, bn, st, training, off=off, centered=centered)
 
     def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0, centered=False):
         """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n)."""
@@ -300,10 +200,6 @@ class Engine:
             for partials, nblk, col0, n, count, bn, st, off in items:
                 self._bn_forward(partials, nblk, col0, n, count, bn, st, False, off=off, centered=centered)
             return
-        if self._lazy:           # (`partials` is then the float64 slab of the producer: Engine._stat_dst)
-            for sums, nblk, col0, n, count, bn, st, off in items:
-                self._bn_lazy(st, [(sums[col0:col0 + n], off, n, bn)], count)
-            return
         jobs = []
         for partials, nblk, col0, n, count, bn, st, off in items:
             sl = slice(off, off + n)
@@ -354,9 +250,7 @@ class Engine:
         sv = {'B': B, 'T_in': T_in, 'dt': dt, 'drop': drop, 'training': training}
         use_drop = training and drop is not None and drop.thresh != 0
         za = self.za
-        self._lazy = bool(training and self.lazy_bn and not self.centered and hasattr(ops, 'bn_finalize_sums'))
-        self._bnq = []
-        self._prep(za.begin(('fwd', tuple(x.shape), dt, training, self._lazy), dev, lazy=True), prep)
+        self._prep(za.begin(('fwd', tuple(x.shape), dt, training), dev, lazy=True), prep)
         self._no_eval_grad = False
         self._pre = {} if training else self._eval_table(inp, bufs, dev, need_grad)
         sv['no_eval_grad'] = self._no_eval_grad
@@ -369,27 +263,26 @@ class Engine:
             raise RuntimeError('input has %d frames, receptive field needs at least %d' % (T_in, sp.receptive_field))
         T = [(T_in - k0) // s0 + 1]
         rows_in = B * T_in * J
-        lazy = self._lazy
         bn0 = BNState(F_in, dev, rows_in, pre('bn0'))
         if training:
             nb = ops.input_stats_blocks(rows_in)
-            part, sums = self._stat_dst(nb, F_in, arena=False)
-            ops.input_stats(x, rows_in, F_in, part, **({'sums': sums} if lazy else {}))
-            self._bn_stats(part, sums, nb, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, True)
+            part = torch.empty(nb, F_in, 2, dtype=torch.float32, device=dev)
+            ops.input_stats(x, rows_in, F_in, part)
+            self._bn_forward(part, nb, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, True)
         else:
             self._bn_forward(None, 0, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, False)
         C0 = sp.channels
         P0 = B * T[0] * J
         E = self._new(P0, C0, dt, dev)
         nbE = ops.rowwise_blocks(P0, C0)
-        partE, sumsE = self._stat_dst(nbE, C0, arena=False)
+        partE = torch.empty(nbE, C0, 2, dtype=torch.float32, device=dev)
         cen = self.centered
         ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE,
-                       center=self._ctr(bufs['expand_bn']), **({'lazy0': self._lz1(bn0), 'sums': sumsE} if lazy else {}))
+                       center=self._ctr(bufs['expand_bn']))
         bnE = BNState(C0, dev, P0, pre('bnE'))
-        self._bn_stats(partE, sumsE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen)
+        self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen)
         X = self._new(P0, C0, dt, dev)
-        ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X, **self._lzkw(bnE))
+        ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
         sv.update(x=x, bn0=bn0, E=E, bnE=bnE, T=T)
 
         # ---- masked-softmax adjacencies of every block (parameters only; local_attention.py:40-42): one launch for all of them
@@ -427,25 +320,22 @@ class Engine:
                 W1 = inp['l%d.conv1' % s]       # [C][C]
                 nb = ops.gemm_row_blocks(P)
                 T1 = self._new(P, C, dt, dev)
-                part1, sums1 = self._stat_dst(nb, C)
-                segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], **self._pro(prev['bnO'])) for tap in range(k)]
-                self._gemm_chunked((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1, stat_sums=sums1,
+                part1 = za.take((nb, C, 2))
+                segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
+                             scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
+                self._gemm_chunked((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
                                    bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
                 bn1 = BNState(C, dev, P, pre('l%d.bn1' % s))
-                self._bn_stats(part1, sums1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
+                self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
-                part2, sums2 = self._stat_dst(nb, C)
-                self._gemm_chunked((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, **self._pro(bn1))], T2, ident(Tn), epi=EPI_STATS,
-                                   partials=part2, stat_sums=sums2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
+                part2 = za.take((nb, C, 2))
+                ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
+                         T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
                 bn2 = BNState(C, dev, P, pre('l%d.bn2' % s))
-                self._bn_stats(part2, sums2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen)
+                self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen)
                 X = self._new(P, C, dt, dev)
-                lzO, lz2 = self._lz1(prev['bnO']), self._lz1(bn2)
-                if (lzO is None) != (lz2 is None):      # (one of the two was materialised for a GEMM on the small-tile kernel)
-                    self._bn_materialize(prev['bnO'] if lzO is not None else bn2)
-                    lzO = lz2 = None
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
-                                 use_drop, 3 * s, drop, B, Tn, J, C, X, **({'lazyO': lzO, 'lazy2': lz2} if lzO is not None else {}))
+                                 use_drop, 3 * s, drop, B, Tn, J, C, X)
                 levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, k=k))
             stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, adjs[s]))
 
@@ -455,8 +345,8 @@ class Engine:
         PL = B * T[-1] * J
         Wsh = inp['shrink']   # [3][CL]
         pred = torch.empty(PL, 3, dtype=torch.float32, device=dev)
-        self._gemm_chunked((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, **self._pro(last['bnO']))], pred, ident(T[-1]))
-        self._bn_flush()          # lazy BatchNorm: the tables the backward pass reads + the running statistics, one launch
+        ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
+                                         scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
         sv.update(stages=stages, levels=levels)
         za.end()
         return pred.view(B, T[-1], J, 3), sv
@@ -483,16 +373,15 @@ class Engine:
         A_s, A_c = adj
         Y = self._new(P, 2 * C, dt, dev)
         nba = ops.semch_agg_blocks(F, C)
-        lazy = self._lazy
-        partY, sumsY = self._stat_dst(nba, 2 * C, arena=False)
+        partY = torch.empty(nba, 2 * C, 2, dtype=torch.float32, device=dev)
         bnY = BNState(2 * C, dev, P, self._pre.get(g + 'bnY'))
         # the local and the global branch write the two column halves of ONE tensor LG = [Lpre | Gpre] (and one BNState): their
         # post-activation drop(relu(bn(.))) is materialised once as ZLG, so the G4 GEMM / its weight gradient read a plain operand
         # (the dropout hash in their load prologues was 3/4 of the VALU stream of those kernels, 250 of 345 instructions per K tile)
         LG = self._new(P, 2 * C, dt, dev)
         Lp, Gp = LG[:, :C], LG[:, C:]
-        partL, sumsL = self._stat_dst(nb, C)
-        partG, sumsG = self._stat_dst(nb, C)
+        partL = za.take((nb, C, 2))
+        partG = za.take((nb, C, 2))
         bnLG = BNState(2 * C, dev, P, self._pre.get(g + 'bnLG'))
         Ya = self._new(P, C, dt, dev)
         ZLG = self._new(P, 2 * C, dt, dev)
@@ -502,33 +391,25 @@ class Engine:
             ops.attn_fwd(H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, Ya)
         # ---- local branch: neighbour aggregation + bn_1/bn_2 statistics (one finalize launch for both)
         ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
-                          center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])), **({'sums': sumsY} if lazy else {}))
-        statY = sumsY if lazy else partY
-        self._bn_forward_group([(statY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
-                                (statY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, C)], training, centered=cen)
+                          center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
+        self._bn_forward_group([(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
+                                (partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, C)], training, centered=cen)
         self._join(side)
         # ---- G2 (local cat conv) and G3 (global cat conv) are independent: one grid, then one finalize for lcat_bn + gcat_bn
-        # (a lazy bnY is read as one K segment per BatchNorm: bn_1 | bn_2 have their own gamma / beta)
-        skw = {'stat_sums': sumsL} if lazy else {}
-        gkw = {'stat_sums': sumsG} if lazy else {}
-        ops.gemm_multi(self._settle([
-            dict(dom=dom, N=C, segs=[dict(A=Y[:, o:o + n], K=n, map=im, W=Wlc[:, o:o + n], **self._pro(bnY, o, n))
-                                     for o, n in self._bn_ranges(bnY, 2 * C)],
-                 C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen, **skw),
-            dict(dom=dom, N=C, segs=[dict(A=Ya, K=C, map=im, W=Wgc)], C_=Gp, cmap=im, epi=EPI_STATS, partials=partG,
-                 bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen, **gkw)]))
-        self._bn_forward_group([(sumsL if lazy else partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnLG, 0),
-                                (sumsG if lazy else partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnLG, C)],
-                               training, centered=cen)
-        ops.bnrelu_apply(LG, P, 2 * C, bnLG.scale, bnLG.shift, ZLG, use_drop=use_drop, salt=3 * s + 1, drop=drop, **self._lzkw(bnLG))
+        ops.gemm_multi([dict(dom=dom, N=C, segs=[dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)],
+                             C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen),
+                        dict(dom=dom, N=C, segs=[dict(A=Ya, K=C, map=im, W=Wgc)], C_=Gp, cmap=im, epi=EPI_STATS, partials=partG,
+                             bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)])
+        self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnLG, 0),
+                                (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnLG, C)], training, centered=cen)
+        ops.bnrelu_apply(LG, P, 2 * C, bnLG.scale, bnLG.shift, ZLG, use_drop=use_drop, salt=3 * s + 1, drop=drop)
         # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised: two K segments
         O = self._new(P, 2 * C, dt, dev)
-        partO, sumsO = self._stat_dst(nb, 2 * C)
+        partO = za.take((nb, 2 * C, 2))
         segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C]), dict(A=ZLG, K=2 * C, map=im, W=Wbc[:, C:3 * C])]
-        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen,
-                 **({'stat_sums': sumsO} if lazy else {}))
+        ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
         bnO = BNState(2 * C, dev, P, self._pre.get(g + 'bnO'))
-        self._bn_stats(partO, sumsO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
+        self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
                     C=C, Tn=Tn, P=P, use_drop=use_drop)
 
@@ -542,17 +423,12 @@ class Engine:
         segments of one launch): MAX_SEG segments per launch, each launch adding the previous partial result (`out` itself as
         the addend: every element is read and rewritten by the same thread), the caller's addend in the first and its epilogue
         (bias, statistics, ReLU/BN backward) in the last."""
-        if epilogue.get('stat_sums') is None:
-            epilogue.pop('stat_sums', None)
         if len(segs) <= MAX_SEG:
-            (job,) = self._settle([dict(dom=dom, N=N, segs=segs, C_=out, cmap=cmap, addend=addend, addmap=addmap, **epilogue)])
-            return self.ops.gemm(**job)
+            return self.ops.gemm(dom, N, segs, out, cmap, addend=addend, addmap=addmap, **epilogue)
         chunks = [segs[i:i + MAX_SEG] for i in range(0, len(segs), MAX_SEG)]
         for ci, ch in enumerate(chunks):
             a, am = (addend, addmap) if ci == 0 else (out, cmap)
-            (job,) = self._settle([dict(dom=dom, N=N, segs=ch, C_=out, cmap=cmap, addend=a, addmap=am,
-                                        **(epilogue if ci == len(chunks) - 1 else {}))])
-            self.ops.gemm(**job)
+            self.ops.gemm(dom, N, ch, out, cmap, addend=a, addmap=am, **(epilogue if ci == len(chunks) - 1 else {}))
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=False):
@@ -574,18 +450,6 @@ class Engine:
             self._wside = side
             self._wq = []
 
-    def _bstat(self, nb, ncol, rows, arena=True):
-        """Where a backward producer leaves {sum dz, sum dz*x}: the float64 slab [ncol][2] of the lazy scheme (large tensors: the
-        BatchNorm backward then needs no finalize launch) or per-row-block partial rows.  The consumers tell them apart by dtype."""
-        if self._lazy_b and rows > FUSED_BN_BWD_ROWS:
-            return self.za.take((ncol, 2), torch.float64)
-        return self.za.take((nb, ncol, 2)) if arena else torch.empty(nb, ncol, 2, dtype=torch.float32, device=self.za.dev)
-
-    @staticmethod
-    def _skw(t):
-        """the producer keyword of a statistics destination made by _bstat"""
-        return {'stat_sums': t} if t.dtype == torch.float64 else {'partials': t}
-
     def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
         """finalize {sum dz, sum dz*x} -> dgamma/dbeta (ACCUMULATED into their destinations: the gradient buffers arrive zeroed or
         hold a running sum) + coefficients, then dz <- dx in place."""
@@ -602,23 +466,6 @@ class Engine:
         dev = items[0]['gamma'].device
         ntot = sum(it['n'] for it in items)
         rows_max = one_apply[2] if one_apply is not None else max(it['rows'] for it in items)
-        if items[0]['partials'].dtype == torch.float64:
-            # lazy scheme (Engine._bstat): the apply kernel derives its coefficients from the slab, block 0 adds dgamma / dbeta
-            def job(it, c0):
-                n, st, off = it['n'], it['st'], it.get('off', 0)
-                sl = slice(off, off + n)
-                return dict(sums=it['partials'][it['col0']:it['col0'] + n], col0=c0, n=n, count=st.count, gamma=it['gamma'],
-                            mean=st.mean[sl], rstd=st.rstd[sl], dgamma=gout[it['key'] + '.weight'], dbeta=gout[it['key'] + '.bias'])
-            if one_apply is not None:
-                jobs, o = [], 0
-                for it in items:
-                    jobs.append(job(it, o))
-                    o += it['n']
-                ops.bn_bwd_apply_lazy(one_apply[0], one_apply[1], one_apply[2], jobs)
-            else:
-                for it in items:
-                    ops.bn_bwd_apply_lazy(it['dz'], it['X'], it['rows'], [job(it, 0)])
-            return
         if rows_max <= FUSED_BN_BWD_ROWS:
             # short tensors (the M = B*J stage, small models): finalize + apply in ONE launch for the whole group
             jobs, o = [], 0
@@ -676,8 +523,7 @@ class Engine:
         grads = gout
         f32 = torch.float32
         za = self.za
-        self._lazy_b = bool(self.lazy_bn and sv['training'] and not self.centered and hasattr(ops, 'bn_bwd_apply_lazy'))
-        arena = za.begin(('bwd', B, sv['T_in'], dt, self._lazy_b), dev, lazy=True)
+        arena = za.begin(('bwd', B, sv['T_in'], dt), dev, lazy=True)
         self._wq = []
         self._wside = None
         self._adjq = []
@@ -700,8 +546,8 @@ class Engine:
         WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
         dO = self._new(PL, CL, dt, dev)
         nb = ops.gemm_row_blocks(PL)
-        part = self._bstat(nb, CL, PL)
-        ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, **self._skw(part),
+        part = za.take((nb, CL, 2))
+        ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, partials=part,
                  X=last['O'], xscale=last['bnO'].scale, xshift=last['bnO'].shift)
         g = 'g%d.' % (L - 1)
         self._bn_backward(part, nb, 0, CL, last['bnO'], inp[g + 'cat_bn.weight'], grads, g + 'cat_bn', dO, last['O'], PL)
@@ -721,20 +567,19 @@ class Engine:
             use_drop = sv['training'] and drop is not None and drop.thresh != 0
             # branch 2: drop(relu(bn(T2pre)))
             nbr = ops.rowwise_blocks(P, C)
-            part2 = self._bstat(nbr, C, P, arena=False)
+            part2 = torch.empty(nbr, C, 2, dtype=f32, device=dev)
             dT2 = self._new(P, C, dt, dev)
-            ops.bnrelu_bwd_mask(dX, lv['T2'], P, C, lv['bn2'].scale, lv['bn2'].shift, use_drop, 3 * s, drop, dT2,
-                                *((None, part2) if part2.dtype == torch.float64 else (part2,)))
+            ops.bnrelu_bwd_mask(dX, lv['T2'], P, C, lv['bn2'].scale, lv['bn2'].shift, use_drop, 3 * s, drop, dT2, part2)
             lk = 'l%d.' % s
             self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
             # 1x1 conv
             self._wgrad((B, Tn, J), dT2, C, ident(Tn), [dict(Q=lv['T1'], S=C, map=ident(Tn), pro=PRO_BNRELU, scale=lv['bn1'].scale,
                                                             shift=lv['bn1'].shift, wcol0=0)], gout[lk + 'conv1'], zero_first=False)
             nbg = ops.gemm_row_blocks(P)
-            part1 = self._bstat(nbg, C, P)
+            part1 = za.take((nbg, C, 2))
             dT1 = self._new(P, C, dt, dev)
             W1T = inp[lk + 'conv1T']
-            ops.gemm((B, Tn, J), C, [dict(A=dT2, K=C, map=ident(Tn), W=W1T)], dT1, ident(Tn), epi=EPI_BNRELU_BWD, **self._skw(part1),
+            ops.gemm((B, Tn, J), C, [dict(A=dT2, K=C, map=ident(Tn), W=W1T)], dT1, ident(Tn), epi=EPI_BNRELU_BWD, partials=part1,
                      X=lv['T1'], xscale=lv['bn1'].scale, xshift=lv['bn1'].shift)
             self._bn_backward(part1, nbg, 0, C, lv['bn1'], inp[lk + 'bn0.weight'], grads, lk + 'bn0', dT1, lv['T1'], P)
             # temporal conv: weight gradient (k K-segments) ...
@@ -748,15 +593,14 @@ class Engine:
                 covered = k * Tn == Tp
                 dOp = self._new(Pp, C, dt, dev) if covered else za.take((Pp, C), dt)
                 nbt = ops.gemm_row_blocks(P)
-                partO = self._bstat(k * nbt, C, Pp)
-                lzb = partO.dtype == torch.float64     # (lazy: the k jobs accumulate into ONE slab)
+                partO = za.take((k * nbt, C, 2))
                 res_tap = lv['resmap'].t_off
                 # (the k taps write disjoint rows of dOp: independent jobs of one grid -- and one split-K finish on the M = B*J stage)
                 self._gemm_multi_chunked([dict(dom=(B, Tn, J), N=C, segs=[dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], C_=dOp,
                                                cmap=RowMap(Tp, k, tap), addend=dX if tap == res_tap else None,
                                                addmap=ident(Tn) if tap == res_tap else None, epi=EPI_BNRELU_BWD,
-                                               **self._skw(partO if lzb else partO[tap * nbt:(tap + 1) * nbt]), X=prev['O'],
-                                               xscale=prev['bnO'].scale, xshift=prev['bnO'].shift) for tap in range(k)])
+                                               partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'], xscale=prev['bnO'].scale,
+                                               xshift=prev['bnO'].shift) for tap in range(k)])
                 nbo = k * nbt
             elif Tn <= sp.tapstep[s] and any(tap * sp.tapstep[s] == lv['resmap'].t_off for tap in range(k)):
                 # disjoint taps (few output frames: Tn <= dilation, e.g. the last level where Tn = 1): every input frame receives
@@ -766,23 +610,22 @@ class Engine:
                 d = sp.tapstep[s]
                 dOp = za.take((Pp, C), dt)
                 nbt = ops.gemm_row_blocks(P)
-                partO = self._bstat(k * nbt, C, Pp)
-                lzb = partO.dtype == torch.float64
+                partO = za.take((k * nbt, C, 2))
                 res_off = lv['resmap'].t_off
                 self._gemm_multi_chunked([dict(dom=(B, Tn, J), N=C, segs=[dict(A=dT1, K=C, map=ident(Tn), W=WcT[tap])], C_=dOp,
                                                cmap=RowMap(Tp, 1, tap * d), addend=dX if tap * d == res_off else None,
                                                addmap=ident(Tn) if tap * d == res_off else None, epi=EPI_BNRELU_BWD,
-                                               **self._skw(partO if lzb else partO[tap * nbt:(tap + 1) * nbt]), X=prev['O'],
-                                               xscale=prev['bnO'].scale, xshift=prev['bnO'].shift) for tap in range(k)])
+                                               partials=partO[tap * nbt:(tap + 1) * nbt], X=prev['O'], xscale=prev['bnO'].scale,
+                                               xshift=prev['bnO'].shift) for tap in range(k)])
                 nbo = k * nbt
             else:
                 d = sp.tapstep[s]
                 dOp = self._new(Pp, C, dt, dev)
                 nbo = ops.gemm_row_blocks(Pp)
-                partO = self._bstat(nbo, C, Pp)
+                partO = za.take((nbo, C, 2))
                 segs = [dict(A=dT1, K=C, map=RowMap(Tn, 1, -tap * d), W=WcT[tap]) for tap in range(k)]
                 self._gemm_chunked((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
-                                   epi=EPI_BNRELU_BWD, **self._skw(partO), X=prev['O'], xscale=prev['bnO'].scale,
+                                   epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale,
                                    xshift=prev['bnO'].shift)
             self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
             dO = dOp
@@ -796,10 +639,9 @@ class Engine:
         # ---- expand conv + init_bn backward (dX is the gradient w.r.t. relu(expand_bn(E)))
         P0 = B * T[0] * J
         nbr = ops.rowwise_blocks(P0, C0)
-        partE = self._bstat(nbr, C0, P0, arena=False)
+        partE = torch.empty(nbr, C0, 2, dtype=f32, device=dev)
         dE = self._new(P0, C0, dt, dev)
-        ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE,
-                            *((None, partE) if partE.dtype == torch.float64 else (partE,)))
+        ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE, partE)
         self._bn_backward(partE, nbr, 0, C0, sv['bnE'], inp['expand_bn.weight'], grads, 'expand_bn', dE, sv['E'], P0)
         x = sv['x']
         F_in = x.shape[-1]
@@ -838,9 +680,9 @@ class Engine:
         # launch for lcat_bn + gcat_bn and one in-place apply over both halves
         dLG = self._new(P, 2 * C, dt, dev)
         dL, dG = dLG[:, :C], dLG[:, C:]
-        partLG = self._bstat(nb, 2 * C, P)
+        partLG = za.take((nb, 2 * C, 2))
         bnLG = st['bnLG']
-        ops.gemm(dom, 2 * C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:3 * C])], dLG, im, epi=EPI_BNRELU_BWD, **self._skw(partLG), X=st['LG'],
+        ops.gemm(dom, 2 * C, [dict(A=dO, K=2 * C, map=im, W=WbcT[C:3 * C])], dLG, im, epi=EPI_BNRELU_BWD, partials=partLG, X=st['LG'],
                  xscale=bnLG.scale, xshift=bnLG.shift, xdrop=xdrop, xsalt=3 * s + 1, drop=drop)
         self._bn_backward_group([dict(partials=partLG, nblk=nb, col0=0, n=C, st=bnLG, off=0, gamma=inp[g + 'lcat_bn.weight'],
                                       key=g + 'lcat_bn'),
@@ -853,10 +695,10 @@ class Engine:
         WlcT = inp[g + 'BlcT']       # [2C][C]
         WgcT = inp[g + 'BgcT']
         dY = self._new(P, 2 * C, dt, dev)
-        partY = self._bstat(nb, 2 * C, P)
+        partY = za.take((nb, 2 * C, 2))
         dYa = self._new(P, C, dt, dev)
         ops.gemm_multi([dict(dom=dom, N=2 * C, segs=[dict(A=dL, K=C, map=im, W=WlcT)], C_=dY, cmap=im, epi=EPI_BNRELU_BWD,
-                             **self._skw(partY), X=st['Y'], xscale=st['bnY'].scale, xshift=st['bnY'].shift),
+                             partials=partY, X=st['Y'], xscale=st['bnY'].scale, xshift=st['bnY'].shift),
                         dict(dom=dom, N=C, segs=[dict(A=dG, K=C, map=im, W=WgcT)], C_=dYa, cmap=im)])
         self._bn_backward_group([dict(partials=partY, nblk=nb, col0=0, n=C, st=st['bnY'], off=0, gamma=inp[g + 'bn_1.weight'],
                                       key=g + 'bn_1'),

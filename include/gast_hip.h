@@ -76,23 +76,6 @@ typedef struct {
     float inv_keep;
 } gast_dropout;
 
-/* "Lazy" training-mode BatchNorm (round 4).  Producers accumulate the per-channel column sums {sum x, sum x^2} (backward: {sum dz,
- * sum dz*x}) with double-precision atomics into a ZERO-FILLED slab sums[n][2] instead of writing per-row-block partial rows, and
- * every consumer derives scale / shift from the slab in its own prologue,
- *   mean = s1 / count, var = max(s2 / count - mean^2, 0), rstd = (float)(1 / sqrt(var + eps)), scale = gamma * rstd,
- *   shift = beta - (float)mean * scale                                     (double arithmetic: exactly gast_bn_finalize's),
- * so the ~5 us finalize launch between a producer and its consumer disappears (24 graph nodes per training step); ONE
- * gast_bn_finalize_sums launch at the end of the forward pass writes the tables the backward pass reads (scale, shift, mean, rstd)
- * and updates the running statistics of every BatchNorm.  sums == null: not lazy, the scale / shift tables are read as before. */
-typedef struct {
-    const double* sums;   /* [n][2] */
-    const float* gamma;   /* [n] */
-    const float* beta;    /* [n] */
-    double count;         /* rows the statistics were taken over */
-    float eps;
-    int n;                /* channels covered (column range of an elementwise consumer; GEMM segments: = K) */
-} gast_bn_lazy;
-
 typedef struct {
     const void* A;       /* [rows][lda]  activation operand of this K segment */
     int lda;
@@ -107,10 +90,6 @@ typedef struct {
     const void* Wx;      /* optional (GAST_F32X3): pre-split bf16 image of W made by gast_x3_image_multi, [N][ldwx]; lets the GEMM
                           * take the large-M path (gemm_big.hip) whose weight tiles stream global -> LDS without passing registers */
     int ldwx;
-    gast_bn_lazy lazy;   /* pro != NONE and lazy.sums != null: scale / shift of this segment come from the slab (scale / shift are
-                          * then unused).  Large-M kernel only (gast_gemm_path() == 1): the 128x128-tile kernel has no registers
-                          * to spare for the coefficient prologue and rejects such a segment with GAST_EINVAL -- finalize that
-                          * BatchNorm first (gast_bn_finalize_sums) and pass its tables */
 } gast_gemm_seg;
 
 /* gast_gemm: the channel-mixing GEMM family on MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_32x32x16_bf16).
@@ -143,8 +122,6 @@ typedef struct {
     int xdrop;            /* forward applied dropout to relu(bn(X)) */
     uint32_t xsalt;
     gast_dropout drop;
-    double* stat_sums;    /* epi != PLAIN, optional: accumulate the column sums into this zero-filled slab [N][2] with double atomics
-                           * (gast_bn_lazy) instead of writing `partials` (which may then be null) */
     const float* f8_scale; /* optional (GAST_BF16, bf16 output): run this GEMM's operands as OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8
                             * ("mixed fp8", BASELINE.json configs[4]).  Device pointer to {s, 1/s}: every weight is multiplied by s
                             * (a power of two, gast_f8_scale_multi) before the conversion, the accumulators by 1/s; activations are
@@ -256,10 +233,6 @@ int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int J, int C,
                        int deg_con, void* Y, int ldy, float* partials, const float* center_sym, const float* center_con,
                        gast_stream_t stream);   /* deg_* = Dr of the tables; center_* (nullable, [C]) are subtracted from the outputs */
 int gast_semch_agg_blocks(int F, int C);
-/* as gast_semch_agg_fwd, the bn_1 / bn_2 column sums accumulated into the zero-filled slab sums[2C][2] (gast_bn_lazy) */
-int gast_semch_agg_fwd_sums(int dtype, const void* H, int ldh, int F, int J, int C,
-                            const float* A_sym, const int32_t* pat_sym, int deg_sym, const float* A_con, const int32_t* pat_con,
-                            int deg_con, void* Y, int ldy, double* sums, gast_stream_t stream);
 /* Backward: dH columns [0,4C) and dA = [dA_sym (nnz_sym rows) ; dA_con (nnz_con rows)] x C, fully written (no zero-fill
  * needed).  ws: workspace of gast_semch_agg_bwd_ws_floats() floats for the per-block partial rows. */
 int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
@@ -334,30 +307,6 @@ int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int
                          const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
                          void* dz, int lddz, float* partials, gast_stream_t stream);
 int gast_rowwise_blocks(long rows, int N);
-/* ---- lazy-BatchNorm forms (gast_bn_lazy above).  `lazy`: nlazy <= 2 descriptors covering columns [0, n_0), [n_0, n_0 + n_1) of the
- * N columns (bn_1 | bn_2, lcat_bn | gcat_bn); `sums` outputs: zero-filled [N][2] double slabs accumulated into with atomics. */
-int gast_bnrelu_apply_lazy(int dtype, const void* X, int ldx, long rows, int N, const gast_bn_lazy* lazy, int nlazy,
-                           void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream);
-int gast_residual_fwd_lazy(int dtype, const void* O, int ldo, gast_rowmap omap, const gast_bn_lazy* lazyO,
-                           const void* T2, int ldt, const gast_bn_lazy* lazy2, int use_drop, uint32_t salt, gast_dropout drop,
-                           int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream);
-int gast_bnrelu_bwd_mask_sums(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
-                              const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
-                              void* dz, int lddz, double* sums, gast_stream_t stream);
-/* BatchNorm backward without a finalize launch: per job (columns [col0, col0 + n) of dz / X) the coefficients of dx = ka*dz + kb*x + kc
- * are derived from the slab {sum dz, sum dz*x} in the prologue of every block, block 0 accumulates dgamma / dbeta (+=); njobs <= 2. */
-typedef struct { const double* sums; int col0, n; double count; const float* gamma; const float* mean; const float* rstd;
-                 float* dgamma; float* dbeta; } gast_bn_bwd_lazy_job;
-int gast_bn_bwd_apply_lazy(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, const gast_bn_bwd_lazy_job* jobs,
-                           int njobs, gast_stream_t stream);
-/* End of a lazy forward pass, ONE launch for every BatchNorm of the model (n <= GAST_BN_SUMS_MAX_BATCH per launch): tables scale /
- * shift / mean / rstd from the slabs + the running-statistics update of nn.BatchNorm2d (momentum, unbiased variance,
- * num_batches_tracked += 1), exactly as gast_bn_finalize. */
-#define GAST_BN_SUMS_MAX_BATCH 24
-typedef struct { const double* sums; int N; double count; const float* gamma; const float* beta; float* running_mean;
-                 float* running_var; int64_t* num_batches_tracked; float momentum, eps; float* scale; float* shift; float* mean;
-                 float* rstd; } gast_bn_sums_job;
-int gast_bn_finalize_sums(const gast_bn_sums_job* jobs, int n, gast_stream_t stream);
 /* Residual of a temporal block (gast_net.py:170-174 / :243-247):
  * Xn[m] = relu(scO*O[omap(m)] + shO) + keep/(1-p) * relu(sc2*T2[m] + sh2) */
 int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
@@ -369,11 +318,6 @@ int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const
 /* partial sums {sum x, sum x^2} of the (rows, F_in) fp32 network input: partials[nblk][F_in][2] */
 int gast_input_stats(const float* x, long rows, int F_in, float* partials, int* nblk_out, gast_stream_t stream);
 int gast_input_stats_blocks(long rows);
-/* lazy forms: column sums of x into the zero-filled slab sums[F_in][2]; expand conv reading init_bn from `lazy0` (F_in channels) and
- * accumulating expand_bn's column sums into sums[C][2] */
-int gast_input_stats_sums(const float* x, long rows, int F_in, double* sums, gast_stream_t stream);
-int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                         const float* W, const gast_bn_lazy* lazy0, int C, void* E, int lde, double* sums, gast_stream_t stream);
 /* E[(b,t,j), c] = sum_{f,tap} W[c][f][tap] * (sc0[f]*x[(b, t*t_stride+tap, j), f] + sh0[f]) + partial sums for expand_bn */
 int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                     const float* W, const float* sc0, const float* sh0, int C,

@@ -27,31 +27,9 @@ def _segs(segs, a_key):
             d['W'] = _np(d['W'])
         d['scale'] = _np(s.get('scale'))
         d['shift'] = _np(s.get('shift'))
-        if d.pop('lazy', None) is not None:
-            d['scale'], d['shift'] = _lazy_tables(s['lazy'])
-        d.pop('_st', None)
         d['map'] = kc.RowMap(*s['map'])
         out.append(d)
     return out
-
-
-def _lazy_tables(lz):
-    """scale / shift (fp32-rounded, as the kernels hold them) of a gast_hip.binding.BnLazy: gast_bn_lazy's arithmetic"""
-    n = lz.n
-    sc, sh, mu, r = (np.zeros(n) for _ in range(4))
-    kc.bn_finalize(_np(lz.sums)[None], 1, 0, n, lz.count, _np(lz.gamma), _np(lz.beta), None, None, None, 0.0, lz.eps, sc, sh, mu, r)
-    return sc.astype(np.float32).astype(np.float64), sh.astype(np.float32).astype(np.float64)
-
-
-def _tables_of(lazy_list):
-    """concatenated scale / shift of a list of BnLazy covering adjacent column ranges"""
-    t = [_lazy_tables(lz) for lz in lazy_list]
-    return np.concatenate([a for a, _ in t]), np.concatenate([b for _, b in t])
-
-
-def _add_sums(sums, partials):
-    """a producer's per-block partial rows [nblk][N][2] accumulated into the float64 slab [N][2] (the kernels use double atomics)"""
-    _np(sums)[...] += np.asarray(partials, np.float64).sum(axis=0)
 
 
 def _drop(d):
@@ -74,26 +52,12 @@ class OracleOps:
         kc.prep([_np(t) for t in zero], seed=None if seed is None else (_np(seed[0]), _np(seed[1])),
                 pad=None if pad is None else (_np(pad[0]), _np(pad[1])) + tuple(pad[2:]))
 
-    # rows from which the mirror's "large-M kernel" takes a GEMM -- the only kernel that accepts lazy K segments (the real rule:
-    # gast_gemm_path).  Tests set it to 0 / a huge value to drive the engine through both of its paths.
-    BIG_MIN_M = 8192
-
-    def gemm_path(self, dom, N, segs, C_, cmap, **kw):
-        return 1 if dom[0] * dom[1] * dom[2] >= self.BIG_MIN_M else 0
-
     def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, xscale=None,
-             xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, stat_sums=None):
+             xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
         self.launches += 1
-        if any(sg.get('lazy') is not None for sg in segs) and not self.gemm_path(dom, N, segs, C_, cmap):
-            raise RuntimeError('mirror: a lazy K segment reached the small-tile GEMM kernel (GAST_EINVAL on the device)')
-        part = _np(partials)
-        if stat_sums is not None and epi != 0:
-            part = np.zeros((kc.gemm_row_blocks(dom[0] * dom[1] * dom[2]), N, 2), np.float32)
         kc.gemm(dom, N, _segs(segs, 'A'), _np(C_), kc.RowMap(*cmap), _np(bias), _np(addend),
-                kc.RowMap(*addmap) if addmap is not None else None, epi, part, _np(X), _np(xscale), _np(xshift),
+                kc.RowMap(*addmap) if addmap is not None else None, epi, _np(partials), _np(X), _np(xscale), _np(xshift),
                 xdrop, xsalt, _drop(drop), bias_neg=bias_neg)
-        if stat_sums is not None and epi != 0:
-            _add_sums(stat_sums, part)
 
     def gemm_multi(self, jobs):
         for j in jobs:
@@ -124,12 +88,9 @@ class OracleOps:
         for dA_t, A_t, pat, de in jobs:
             kc.semch_adj_bwd(_np(dA_t), _np(A_t), _np(pat), _np(de), accumulate=accumulate)
 
-    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None), sums=None):
-        part = _np(partials) if sums is None else np.zeros((kc.semch_agg_blocks(F, C_), 2 * C_, 2), np.float32)
-        kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), part,
+    def semch_agg_fwd(self, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, Y, partials, deg=(0, 0), center=(None, None)):
+        kc.semch_agg_fwd(_np(H), F, J, C_, _np(A_sym), _np(pat_sym), _np(A_con), _np(pat_con), _np(Y), _np(partials),
                          center_sym=_np(center[0]), center_con=_np(center[1]))
-        if sums is not None:
-            _add_sums(sums, part)
 
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return 1
@@ -184,40 +145,17 @@ class OracleOps:
     def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc_):
         kc.bn_bwd_apply(_np(dz), _np(X), rows, N, _np(ka), _np(kb), _np(kc_))
 
-    def bn_bwd_apply_lazy(self, dz, X, rows, jobs):
-        for j in jobs:
-            n, c0 = j['n'], j['col0']
-            ka, kb, kc_ = np.zeros(n), np.zeros(n), np.zeros(n)
-            kc.bn_bwd_finalize(_np(j['sums'])[None], 1, 0, n, j['count'], _np(j['gamma']), _np(j['mean']), _np(j['rstd']),
-                               _np(j['dgamma']), _np(j['dbeta']), ka, kb, kc_, accumulate=True)
-            kc.bn_bwd_apply(_np(dz)[:, c0:c0 + n], _np(X)[:, c0:c0 + n], rows, n, ka, kb, kc_)
-
-    def bn_finalize_sums(self, jobs):
-        self.launches += 1
-        for j in jobs:
-            kc.bn_finalize(_np(j['sums'])[None], 1, 0, j['N'], j['count'], _np(j['gamma']), _np(j['beta']), _np(j['running_mean']),
-                           _np(j['running_var']), _np(j['nbt']), j['momentum'], j['eps'], _np(j['scale']), _np(j['shift']),
-                           _np(j['mean']), _np(j['rstd']))
-
-    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None, lazy=None):
-        sc, sh = _tables_of(lazy) if lazy is not None else (_np(scale), _np(shift))
-        kc.bnrelu_apply(_np(X), rows, N, sc, sh, _np(Y), use_drop=use_drop, salt=salt, drop=_drop(drop))
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
+        kc.bnrelu_apply(_np(X), rows, N, _np(scale), _np(shift), _np(Y), use_drop=use_drop, salt=salt, drop=_drop(drop))
 
     def rowwise_blocks(self, rows, N):
         return kc.rowwise_blocks(rows, N)
 
-    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials, sums=None):
-        part = _np(partials) if sums is None else np.zeros((kc.rowwise_blocks(rows, N), N, 2), np.float32)
-        kc.bnrelu_bwd_mask(_np(dY), _np(X), rows, N, _np(scale), _np(shift), use_drop, salt, _drop(drop), _np(dz), part)
-        if sums is not None:
-            _add_sums(sums, part)
+    def bnrelu_bwd_mask(self, dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, partials):
+        kc.bnrelu_bwd_mask(_np(dY), _np(X), rows, N, _np(scale), _np(shift), use_drop, salt, _drop(drop), _np(dz), _np(partials))
 
-    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, lazyO=None, lazy2=None):
-        if lazyO is not None:
-            (scO_, shO_), (sc2_, sh2_) = _lazy_tables(lazyO), _lazy_tables(lazy2)
-        else:
-            scO_, shO_, sc2_, sh2_ = _np(scO), _np(shO), _np(sc2), _np(sh2)
-        kc.residual_fwd(_np(O), kc.RowMap(*omap), scO_, shO_, _np(T2), sc2_, sh2_, use_drop, salt, _drop(drop),
+    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
+        kc.residual_fwd(_np(O), kc.RowMap(*omap), _np(scO), _np(shO), _np(T2), _np(sc2), _np(sh2), use_drop, salt, _drop(drop),
                         B, Tn, J, N, _np(Xn))
 
     def colsum(self, X, rows, N, out, zero_first=True):
@@ -226,19 +164,11 @@ class OracleOps:
     def input_stats_blocks(self, rows):
         return kc.input_stats_blocks(rows)
 
-    def input_stats(self, x, rows, F_in, partials, sums=None):
-        part = _np(partials) if sums is None else np.zeros((kc.input_stats_blocks(rows), F_in, 2), np.float32)
-        kc.input_stats(_np(x), rows, F_in, part)
-        if sums is not None:
-            _add_sums(sums, part)
+    def input_stats(self, x, rows, F_in, partials):
+        kc.input_stats(_np(x), rows, F_in, _np(partials))
 
-    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None, lazy0=None, sums=None):
-        sc, sh = _lazy_tables(lazy0) if lazy0 is not None else (_np(sc0), _np(sh0))
-        T_out = (T_in - k0) // t_stride + 1
-        part = _np(partials) if sums is None else np.zeros((kc.rowwise_blocks(B * T_out * J, C_), C_, 2), np.float32)
-        kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), sc, sh, C_, _np(E), part, center=_np(center))
-        if sums is not None:
-            _add_sums(sums, part)
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
+        kc.expand_fwd(_np(x), B, T_in, J, F_in, k0, t_stride, _np(W), _np(sc0), _np(sh0), C_, _np(E), _np(partials), center=_np(center))
 
     def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0, accumulate=False):
         kc.expand_bwd(_np(dE), _np(x), B, T_in, J, F_in, k0, t_stride, _np(mean0), _np(rstd0), C_, _np(W), _np(gamma0), _np(beta0),

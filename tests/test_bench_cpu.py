@@ -45,7 +45,7 @@ def test_kernel_timer_cost_models_cover_the_engine_calls(monkeypatch):
     y.sum().backward()
     agg = timer.summary()
     for name in ('gemm', 'gemm_multi', 'wgrad_multi', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bnrelu_apply',
-                 'bn_finalize_sums', 'prep', 'expand_bwd'):
+                 'bn_finalize_multi', 'expand_bwd'):
         assert name in agg and agg[name]['launches'] > 0, name
     assert agg['gemm']['bytes'] > 0 and agg['gemm_multi']['flops'] > 0 and agg['wgrad_multi']['bytes'] > 0
 
