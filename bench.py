@@ -88,7 +88,7 @@ class KernelTimer:
         for name in ('gemm', 'gemm_multi', 'wgrad', 'wgrad_multi', 'semch_agg_fwd', 'semch_agg_bwd', 'attn_fwd', 'attn_bwd', 'bn_bwd_apply',
                      'bnrelu_apply', 'bnrelu_bwd_mask', 'residual_fwd', 'expand_fwd', 'expand_bwd', 'colsum', 'bn_finalize',
                      'bn_finalize_multi', 'bn_bwd_finalize', 'bn_bwd_finalize_multi', 'bn_bwd_fused_multi', 'semch_adj_fwd_multi',
-                     'semch_adj_bwd_multi', 'input_stats', 'adam_step', 'run_pack', 'run_unpack'):
+                     'semch_adj_bwd_multi', 'input_stats', 'adam_step', 'run_pack', 'run_unpack', 'prep'):
             self._wrap(name)
 
     def calibrate(self, n=200):

@@ -33,13 +33,12 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
-                                                   float* __restrict__ v, float* __restrict__ vmax, long n, int* step,
+                                                   float* __restrict__ v, float* __restrict__ vmax, long n, const int* __restrict__ step,
                                                    float lr, float beta1, float beta2, float eps, float wd, float gscale) {
-    // step[0] = optimizer steps taken so far, step[1] = blocks of this launch that have read it (zero between launches).  Every
-    // block uses t = step[0] + 1; the LAST block to arrive at the ticket (all others have read step[0] by then) stores t and clears
-    // the ticket -- the increment used to be a launch of its own (a 1-thread kernel costs a full ~4.7 us graph-node boundary).
-    const int t_now = __hip_atomic_load(step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
-    const AdamCoef c = adam_coef(t_now, lr, beta1, beta2);
+    // (Round 4 tried to fold the step increment into this kernel -- every block computing with step + 1 and the last block to take a
+    // ticket storing it back: 4096 device-scope atomics on ONE address cost 194 us (~47 ns each, serialised at the memory side), against
+    // 4.6 us for the one-thread increment kernel.  Same-address atomics from every block of a grid are never cheap on this chip.)
+    const AdamCoef c = adam_coef(*step, lr, beta1, beta2);
     const bool ams = vmax != nullptr;
     const long n4 = n >> 2;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -59,15 +58,9 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
             if (ams) vmax[i] = x;
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(step + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == (int)gridDim.x - 1) {
-            __hip_atomic_store(step + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(step, t_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
+
+__global__ void step_inc_kernel(int* step) { *step += 1; }
 
 // ---- pass prologue ("prep"): everything a forward or backward pass needs before its first real kernel, as ONE launch -- the
 // zero fills of the accumulation arenas / gradient buffers (up to GAST_PREP_MAX_ZERO regions), the dropout seed bump + its
@@ -147,6 +140,7 @@ extern "C" int gast_adam_step(float* p, const float* g, float* m, float* v, floa
     if (!p || !g || !m || !v || !step || n < 1) return GAST_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return GAST_EALIGN;
     hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
     long nb = ((n >> 2) + 255) / 256;
     if (nb > 256 * 16) nb = 256 * 16;
     if (nb < 1) nb = 1;

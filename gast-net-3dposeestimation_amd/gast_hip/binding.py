@@ -690,10 +690,7 @@ class HipOps:
         _check(self.lib.gast_mpjpe(_p(pred), _p(target), rows, D, _p(loss), _p(dirs), _stream()), 'gast_mpjpe')
 
     def adam_step(self, p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
-        """step: int32[2] device tensor {steps taken, 0}; the launch advances step[0] itself"""
-        if step.numel() < 2:
-            raise RuntimeError('gast_hip: adam_step needs a 2-element int32 step tensor {steps taken, ticket}')
-        self.launches += 1
+        self.launches += 2
         _check(self.lib.gast_adam_step(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
                                        weight_decay, grad_scale, _stream()), 'gast_adam_step')
 

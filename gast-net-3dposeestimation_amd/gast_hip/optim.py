@@ -42,7 +42,7 @@ class FlatAdam(torch.optim.Optimizer):
             st = dict(params=ps, offs=offs, n=n, P=P, G=None,
                       m=torch.zeros(n, dtype=torch.float32, device=dev), v=torch.zeros(n, dtype=torch.float32, device=dev),
                       vmax=torch.zeros(n, dtype=torch.float32, device=dev) if group['amsgrad'] else None,
-                      step=torch.zeros(2, dtype=torch.int32, device=dev))       # {steps taken, ticket of the update kernel (0 between launches)}
+                      step=torch.zeros(1, dtype=torch.int32, device=dev))
             self._flat.append(st)
 
     # ------------------------------------------------------------------ gradients
@@ -119,7 +119,7 @@ class FlatAdam(torch.optim.Optimizer):
         for group, st in zip(self.param_groups, self._flat):
             ids = []
             if st is not None:
-                step = st['step'][0].to(torch.float32).reshape(()).clone()
+                step = st['step'].to(torch.float32).reshape(()).clone()
                 for p, o in zip(st['params'], st['offs']):
                     n = p.numel()
                     ent = {'step': step.clone(), 'exp_avg': st['m'][o:o + n].view(p.shape).clone(),
@@ -152,4 +152,4 @@ class FlatAdam(torch.optim.Optimizer):
                     if st['vmax'] is None:
                         st['vmax'] = torch.zeros_like(st['v'])
                     st['vmax'][o:o + n].copy_(ent['max_exp_avg_sq'].reshape(-1))
-                st['step'][0] = int(ent['step'])
+                st['step'].fill_(int(ent['step']))

@@ -55,10 +55,15 @@ class Layout:
 # are views of) bump this epoch; together with the parameters' `_version`s it tells `Packer.unchanged()` whether the packed operands
 # still match the parameters -- an inference / evaluation loop then skips the three packing launches (95 us per forward at C = 128).
 PARAM_EPOCH = [0]
+# ... but a raw writer that was CAPTURED into a hipGraph (the whole training step of bench.py / a user's torch.cuda.graph) writes the
+# parameters on every replay with no host-side trace at all: from then on the skip is off for good.
+CAPTURED_WRITER = [False]
 
 
 def note_raw_parameter_write():
     PARAM_EPOCH[0] += 1
+    if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        CAPTURED_WRITER[0] = True
 
 
 X3_PAD_ROWS = 256      # zero rows behind every pre-split weight image (a GEMM tile spans 256 weight rows from any start row)
@@ -288,10 +293,15 @@ class Packer:
         load_state_dict, manual edits) + the epoch of raw writers (FlatAdam)"""
         return (PARAM_EPOCH[0],) + tuple(p._version for p in self.params)
 
-    def unchanged(self, st):
-        """True if the packed operands in `st` were built from the parameters' current values (never inside a stream capture: a
-        replayed graph must refresh them itself)."""
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+    def unchanged(self, st, frozen=False):
+        """True if the packed operands in `st` may be reused instead of being rebuilt from the parameters.  Only ever under
+        `frozen` -- the caller vouches that this is an inference call (eval mode, no gradient wanted): a training loop repacks on
+        every forward, whatever the host believes about the parameters -- and only while the host-visible signature (version
+        counters + the epoch of raw writers) is unchanged and no raw writer lives inside a captured graph.  What the signature
+        cannot see are in-place writes through `.data` (`p.data.mul_()`, `dist.broadcast(p.data)`): after such a write in an
+        inference loop call `model.invalidate_packed()`.  Never inside a stream capture: a replayed graph must refresh the operands
+        itself."""
+        if not frozen or CAPTURED_WRITER[0] or (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             st['packed_sig'] = None
             return False
         sig = self.signature()
@@ -299,6 +309,11 @@ class Packer:
             return True
         st['packed_sig'] = sig           # (the caller packs now)
         return False
+
+    def invalidate(self):
+        """forget what the packed operands were built from: the next forward repacks (after a `.data` write in an inference loop)"""
+        for st in self._dev.values():
+            st['packed_sig'] = None
 
     def image_jobs(self, st):
         """(fp32 operand view, image view, fp16 pairs?) per packed operand, for ops.run_pack."""

@@ -155,7 +155,7 @@ class _GastFunction(torch.autograd.Function):
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
         ops = engine.ops
-        if not packer.unchanged(st):          # (an evaluation loop over frozen weights packs once)
+        if not packer.unchanged(st, frozen=not training and not need_grad):      # (an evaluation loop over frozen weights packs once)
             ops.run_pack(packer, st)
         inp = st.get('inp')
         if inp is None:
@@ -226,6 +226,7 @@ class _GraphEntry:
         self.gen = 0
         self.x = self.pred = self.dpred = self.G = self.sink = None
         self.packer = self.runner = None
+        self.frozen = False
         self.st = self.ops = None   # the packed-operand state (refreshed eagerly when the parameters changed) and the op set
         self.keep = None
         self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
@@ -248,6 +249,7 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     ops = engine.ops
     entry.x = x.clone()
     entry.packer, entry.sink, entry.runner = packer, sink, runner
+    entry.frozen = not training and not need_grad
     pool = torch.cuda.graph_pool_handle()
     engine.centered = runner.centered
     ops.x3 = runner.x3
@@ -293,7 +295,8 @@ class _GraphedFunction(torch.autograd.Function):
         entry.x.copy_(x)
         for t in entry.runner.take_pending_zero():     # (a deferred FlatGradAllReduce.zero_(): not part of the captured forward)
             t.zero_()
-        if not entry.packer.unchanged(entry.st):       # (optimizer step / load_state_dict since the last packing: refresh the operands)
+        # (a training / gradient-enabled entry repacks on every call; an inference entry when the parameters changed: Packer.unchanged)
+        if not entry.packer.unchanged(entry.st, frozen=entry.frozen):
             entry.ops.run_pack(entry.packer, entry.st)
         entry.fwd.replay()
         entry.gen += 1
@@ -487,6 +490,15 @@ class SpatioTemporalModelBase(nn.Module):
         spec = ModelSpec(adj, filter_widths, channels, causal, strided, self.in_features, dense=dense)
         # kept out of nn.Module's registries (no parameters / buffers of its own -> state_dict is untouched)
         object.__setattr__(self, '_runner', _Runner(spec, dropout))
+
+    def invalidate_packed(self):
+        """Force the next forward to rebuild the GEMM-ready operands from the parameters.  Needed only in an INFERENCE loop (eval mode
+        under torch.no_grad(), where the operands are packed once and reused) after the parameters were written through `.data`
+        in place (`p.data.mul_()`, `dist.broadcast(p.data)`, an EMA swap by `p.data.copy_()`): such writes leave no trace the host
+        could see.  Optimizer steps, load_state_dict and tracked in-place edits are noticed by themselves; training-mode and
+        gradient-enabled forwards always repack."""
+        if self._runner._packer is not None:
+            self._runner._packer.invalidate()
 
     def receptive_field(self):
         """

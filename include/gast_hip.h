@@ -356,9 +356,8 @@ int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases
  * dirs[r,:] = d loss / d pred[r,:] (zero where the difference vanishes).  All fp32, contiguous. */
 int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* loss, float* dirs, gast_stream_t stream);
 /* One Adam / AMSGrad step (torch.optim.Adam semantics, reference trainval.py:78) over flat fp32 buffers of n elements:
- * p, m, v (and vmax: non-null selects amsgrad) updated in place from g * grad_scale.  step: device int32[2] = {optimizer steps
- * taken so far, 0}: the launch computes with step[0] + 1 and stores it back itself (the last block to finish does; step[1] is
- * its ticket counter and is zero again when the launch ends) -- one launch per optimizer step.  16-byte aligned buffers. */
+ * p, m, v (and vmax: non-null selects amsgrad) updated in place from g * grad_scale; *step (device int32) is incremented first
+ * and supplies the bias corrections.  16-byte aligned buffers. */
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
 

@@ -922,3 +922,41 @@ def test_packed_operands_follow_parameter_changes(graph, monkeypatch):
     fopt.step()                                                       # raw write through the HIP kernel
     y4 = now()
     assert float((y4 - y3).abs().max()) > 1e-4 and same(y4, fresh())
+    # writes through .data leave no trace the host could see: in an INFERENCE loop the documented remedy is
+    # invalidate_packed(); a training-mode or gradient-enabled forward repacks on every call and needs nothing
+    m.shrink.weight.data.mul_(2.0)
+    m.invalidate_packed()
+    y5 = now()
+    assert torch.allclose(y5, 2 * y4, rtol=1e-5, atol=1e-6) and same(y5, fresh())
+    m.shrink.weight.data.mul_(0.5)
+    y6 = m(x).detach()                                                # autograd enabled: never skips
+    assert torch.allclose(y6, y4, rtol=1e-5, atol=1e-6)
+    m.invalidate_packed()
+
+
+def test_training_forward_always_repacks(monkeypatch):
+    """`.data` writes and a graph-captured optimizer change the parameters without touching a version counter.
+    Train-mode forwards therefore never reuse packed operands, and once a raw writer has been captured into a graph the reuse is
+    off for inference too."""
+    from gast_hip import packer as pk
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'fp32')
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3], channels=16, causal=False, variant='dilated')
+    torch.manual_seed(5)
+    m = build(cfg).cuda().train()
+    m._runner.graph_mode = False
+    x = (torch.rand(3, 9, 17, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.momentum = 0.0                                        # (keep the running statistics out of the comparison)
+    with torch.no_grad():
+        y0 = m(x).clone()
+        m.shrink.weight.data.mul_(2.0)                                # no version bump
+        y1 = m(x).clone()
+    assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
+    m.eval()
+    monkeypatch.setattr(pk, 'CAPTURED_WRITER', [True])
+    with torch.no_grad():
+        y2 = m(x).clone()
+        m.shrink.weight.data.mul_(0.5)
+        y3 = m(x).clone()
+    assert torch.allclose(y3, 0.5 * y2, rtol=1e-5, atol=1e-6)
