@@ -6,31 +6,54 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef uint16_t bf16_t;  // raw bits of the 16-bit STORAGE type of this build (GAST_BF16): bfloat16 -- or IEEE binary16, see below
 
-// ---------------------------------------------------------------- bf16 <-> f32 (round to nearest even)
-__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-// hardware conversions (gfx950): v_cvt_pk_bf16_f32, round to nearest even
+// hardware conversions (gfx950): v_cvt_pk_bf16_f32, round to nearest even.  pack_bf16x2 is ALWAYS bfloat16: the hi/lo operand pairs of
+// the GAST_F32X3 arithmetic are built with it whatever the storage flavour of the build.
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     bf16x2_t v = {(__bf16)lo, (__bf16)hi};
     return *(uint32_t*)&v;
 }
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    __bf16 b = (__bf16)f;
-    return *(bf16_t*)&b;
-}
-
-// fp16 pairs (GAST_F32X3H): v_cvt_pk_f16_f32, round to nearest even; subnormal results are kept (the f16 MFMA honours them:
-// scripts/toolchain_smoke/f16_denorm_probe.hip)
 typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {
+__device__ __forceinline__ uint32_t pack_f16x2(float lo, float hi) {      // v_cvt_pk_f16_f32, round to nearest even, subnormals kept
     f32x2_t v = {lo, hi};
     f16x2_t h = __builtin_convertvector(v, f16x2_t);
     return *(uint32_t*)&h;
 }
+
+// ---------------------------------------------------------------- the 16-bit storage flavour of the build
+// The sources are compiled twice (build.sh): libgast_hip.so stores GAST_BF16 tensors as bfloat16 (8 significand bits, fp32's range),
+// libgast_hip_f16.so (-DGAST_H16_F16) as IEEE binary16 (11 significand bits, |x| <= 65504: GAST_HIP_DTYPE=f16, the 16-bit mode that
+// meets the north star's 1e-2 bound; gradients travel multiplied by a power-of-two loss scale).  Same ABI, same kernels: only the
+// four conversions below and the matrix instruction of the 16-bit operands (mfma_h16) differ.
+//   h16_to_f / f_to_h16: one value;  h16x2_unpack / pack_h16x2: the two halves of a 32-bit word (low half = lower address)
+#ifdef GAST_H16_F16
+__device__ __forceinline__ float bf2f(bf16_t h) { return (float)*(const _Float16*)&h; }
+__device__ __forceinline__ bf16_t f2bf(float f) { const _Float16 h = (_Float16)f; return *(const bf16_t*)&h; }
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) { return pack_f16x2(lo, hi); }
+__device__ __forceinline__ void h16x2_unpack(uint32_t w, float& lo, float& hi) {
+    const f16x2_t h = *(const f16x2_t*)&w;
+    lo = (float)h.x;
+    hi = (float)h.y;
+}
+#else
+__device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = (__bf16)f;
+    return *(bf16_t*)&b;
+}
+__device__ __forceinline__ uint32_t pack_h16x2(float lo, float hi) { return pack_bf16x2(lo, hi); }
+__device__ __forceinline__ void h16x2_unpack(uint32_t w, float& lo, float& hi) {
+    lo = __uint_as_float(w << 16);
+    hi = __uint_as_float(w & 0xffff0000u);
+}
+#endif
+
+// fp16 pairs (GAST_F32X3H): pack_f16x2 above; subnormal results are kept (the f16 MFMA honours them:
+// scripts/toolchain_smoke/f16_denorm_probe.hip)
 // x = hi + lo, both halves as packed pairs: PAIR = 1 bf16 (GAST_F32X3), 2 fp16 (GAST_F32X3H).  x - hi is exact in fp32.
 template <int PAIR>
 __device__ __forceinline__ void split_pair4(float x0, float x1, float x2, float x3, uint2& hi, uint2& lo) {
@@ -53,6 +76,14 @@ __device__ __forceinline__ f32x16 mfma_pair(const uint4& a, const uint4& b, cons
     if (PAIR == 2) return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const s16x8*)&a, *(const s16x8*)&b, c, 0, 0, 0);
 }
+// one 32x32x16 MFMA step on 8 values of the 16-bit STORAGE type per lane and operand
+__device__ __forceinline__ f32x16 mfma_h16(const uint4& a, const uint4& b, const f32x16& c) {
+#ifdef GAST_H16_F16
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(*(const f16x8*)&a, *(const f16x8*)&b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*(const s16x8*)&a, *(const s16x8*)&b, c, 0, 0, 0);
+#endif
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -72,14 +103,16 @@ template <> struct Elem<bf16_t> {
 __device__ __forceinline__ float4 ld4(const float* p) { return *(const float4*)p; }
 __device__ __forceinline__ float4 ld4(const bf16_t* p) {
     uint2 u = *(const uint2*)p;
-    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
-                       __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    float4 v;
+    h16x2_unpack(u.x, v.x, v.y);
+    h16x2_unpack(u.y, v.z, v.w);
+    return v;
 }
 __device__ __forceinline__ void st4(float* p, float4 v) { *(float4*)p = v; }
 __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
     uint2 u;
-    u.x = pack_bf16x2(v.x, v.y);
-    u.y = pack_bf16x2(v.z, v.w);
+    u.x = pack_h16x2(v.x, v.y);
+    u.y = pack_h16x2(v.z, v.w);
     *(uint2*)p = u;
 }
 __device__ __forceinline__ float4 rnd4(float4 v, const float*) { return v; }

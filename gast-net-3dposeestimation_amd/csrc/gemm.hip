@@ -36,9 +36,7 @@ template <> struct Mma<float> {
 };
 template <> struct Mma<bf16_t> {
     __device__ static __forceinline__ void run(f32x16& acc, const uint4& a, const uint4& b) {
-        union { uint4 u; s16x8 s; } ua, ub;
-        ua.u = a; ub.u = b;
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.s, ub.s, acc, 0, 0, 0);
+        acc = mfma_h16(a, b, acc);      // (bfloat16 or binary16: the storage flavour of the build, common.h)
     }
 };
 
@@ -74,14 +72,15 @@ __device__ __forceinline__ uint4 prologue<bf16_t>(uint4 v, const float* sc, cons
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        float lo = __uint_as_float(w[p] << 16), hi = __uint_as_float(w[p] & 0xffff0000u);
+        float lo, hi;
+        h16x2_unpack(w[p], lo, hi);
         lo = fmaxf(fmaf(lo, sc[2 * p], sh[2 * p]), 0.f);
         hi = fmaxf(fmaf(hi, sc[2 * p + 1], sh[2 * p + 1]), 0.f);
         if (drop) {
             lo *= drop_mul(key, thresh, inv_keep, e0 + 2 * p);
             hi *= drop_mul(key, thresh, inv_keep, e0 + 2 * p + 1);
         }
-        w[p] = pack_bf16x2(lo, hi);
+        w[p] = pack_h16x2(lo, hi);
     }
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
@@ -94,7 +93,10 @@ __device__ __forceinline__ uint2 to_fp8x8(const uint4& v, float s) {
     int q[2] = {0, 0};
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        const float lo = __uint_as_float(w[p] << 16) * s, hi = __uint_as_float(w[p] & 0xffff0000u) * s;
+        float lo, hi;
+        h16x2_unpack(w[p], lo, hi);
+        lo *= s;
+        hi *= s;
         q[p >> 1] = (p & 1) ? __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, q[p >> 1], true) : __builtin_amdgcn_cvt_pk_fp8_f32(lo, hi, q[p >> 1], false);
     }
     return make_uint2((uint32_t)q[0], (uint32_t)q[1]);
@@ -453,7 +455,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                 } else {
                     const uint32_t w4[4] = {raw.x, raw.y, raw.z, raw.w};
 #pragma unroll
-                    for (int p2 = 0; p2 < 4; ++p2) { v[(2 * p2) % EPO] = __uint_as_float(w4[p2] << 16); v[(2 * p2 + 1) % EPO] = __uint_as_float(w4[p2] & 0xffff0000u); }
+                    for (int p2 = 0; p2 < 4; ++p2) h16x2_unpack(w4[p2], v[(2 * p2) % EPO], v[(2 * p2 + 1) % EPO]);
                 }
                 if (Addv) {
                     const int arow = sAddRow[ml];
@@ -464,7 +466,12 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                         } else {
                             const uint32_t w4[4] = {ar.x, ar.y, ar.z, ar.w};
 #pragma unroll
-                            for (int p2 = 0; p2 < 4; ++p2) { v[(2 * p2) % EPO] += __uint_as_float(w4[p2] << 16); v[(2 * p2 + 1) % EPO] += __uint_as_float(w4[p2] & 0xffff0000u); }
+                            for (int p2 = 0; p2 < 4; ++p2) {
+                                float a0, a1;
+                                h16x2_unpack(w4[p2], a0, a1);
+                                v[(2 * p2) % EPO] += a0;
+                                v[(2 * p2 + 1) % EPO] += a1;
+                            }
                         }
                     }
                 }
@@ -476,7 +483,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                     } else {
                         const uint32_t w4[4] = {xr.x, xr.y, xr.z, xr.w};
 #pragma unroll
-                        for (int p2 = 0; p2 < 4; ++p2) { x[(2 * p2) % EPO] = __uint_as_float(w4[p2] << 16); x[(2 * p2 + 1) % EPO] = __uint_as_float(w4[p2] & 0xffff0000u); }
+                        for (int p2 = 0; p2 < 4; ++p2) h16x2_unpack(w4[p2], x[(2 * p2) % EPO], x[(2 * p2 + 1) % EPO]);
                     }
                     const uint32_t e0 = (uint32_t)((long)crow * a.ldx + n0);
 #pragma unroll
@@ -502,8 +509,8 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                 if (sizeof(TO) == 4) {
                     o = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
                 } else {
-                    o = make_uint4(pack_bf16x2(v[0], v[1 % EPO]), pack_bf16x2(v[2 % EPO], v[3 % EPO]), pack_bf16x2(v[4 % EPO], v[5 % EPO]),
-                                   pack_bf16x2(v[6 % EPO], v[7 % EPO]));
+                    o = make_uint4(pack_h16x2(v[0], v[1 % EPO]), pack_h16x2(v[2 % EPO], v[3 % EPO]), pack_h16x2(v[4 % EPO], v[5 % EPO]),
+                                   pack_h16x2(v[6 % EPO], v[7 % EPO]));
                 }
                 *(uint4*)(Cv + (long)crow * a.ldc + n0) = o;
             }

@@ -1091,9 +1091,7 @@ template <int CI> struct AttnM {
 };
 
 __device__ __forceinline__ f32x16 mfma_bf16(const uint4& a, const uint4& b, f32x16 c) {
-    union { uint4 u; s16x8 s; } ua, ub;
-    ua.u = a; ub.u = b;
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua.s, ub.s, c, 0, 0, 0);
+    return mfma_h16(a, b, c);       // (the 16-bit storage flavour of the build: common.h)
 }
 // 8 bf16 of a fragment register -> column `col` of rows c0 .. c0+7 of a [*][32] bf16 tile
 __device__ __forceinline__ void scatter8_bf16(bf16_t* __restrict__ tile, int c0, int col, const uint4& v) {

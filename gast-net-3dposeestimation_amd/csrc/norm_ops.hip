@@ -898,4 +898,8 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
     return 0;
 }
 
-extern "C" const char* gast_version(void) { return "gast_hip 0.1 gfx950"; }
+#ifdef GAST_H16_F16
+extern "C" const char* gast_version(void) { return "gast_hip 0.2 gfx950 (16-bit storage: IEEE binary16)"; }
+#else
+extern "C" const char* gast_version(void) { return "gast_hip 0.2 gfx950 (16-bit storage: bfloat16)"; }
+#endif

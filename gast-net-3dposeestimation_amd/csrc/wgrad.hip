@@ -714,14 +714,15 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
                 uint32_t e0 = (uint32_t)((long)row * ld + col);
 #pragma unroll
                 for (int p = 0; p < 4; ++p) {
-                    float lo = __uint_as_float(wv[p] << 16), hi = __uint_as_float(wv[p] & 0xffff0000u);
+                    float lo, hi;
+                    h16x2_unpack(wv[p], lo, hi);
                     lo = fmaxf(fmaf(lo, sc[2 * p], sh[2 * p]), 0.f);
                     hi = fmaxf(fmaf(hi, sc[2 * p + 1], sh[2 * p + 1]), 0.f);
                     if (drop) {
                         lo *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p);
                         hi *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e0 + 2 * p + 1);
                     }
-                    wv[p] = pack_bf16x2(lo, hi);
+                    wv[p] = pack_h16x2(lo, hi);
                 }
                 rl[i] = u32x4{wv[0], wv[1], wv[2], wv[3]};
             }
@@ -746,7 +747,7 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mi].s, fb[ni].s, acc[mi][ni], 0, 0, 0);
+                    acc[mi][ni] = mfma_h16(fa[mi].u, fb[ni].u, acc[mi][ni]);
         }
     };
 

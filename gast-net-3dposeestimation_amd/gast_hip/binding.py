@@ -123,18 +123,37 @@ class _BnBwdJob(C.Structure):
     _fields_ = [('f', _BnBwdFinJob), ('dz', C.c_void_p), ('lddz', C.c_int), ('X', C.c_void_p), ('ldx', C.c_int), ('rows', C.c_long)]
 
 
-_lib = None
+# The library exists in two 16-bit STORAGE flavours built from the same sources (csrc/build.sh, csrc/common.h): libgast_hip.so keeps
+# GAST_BF16 tensors as bfloat16, libgast_hip_f16.so as IEEE binary16 (GAST_HIP_DTYPE=f16).  Same ABI; the process-wide flavour
+# (`set_h16`) decides which one the op set calls and which 16-bit torch dtype `_dt` accepts -- a tensor of the other kind raises.
+LIB_PATH_F16 = os.path.join(_HERE, 'libgast_hip_f16.so')
+_libs = {}
+_H16 = {'dtype': torch.bfloat16}
 
 
-def load_library():
-    """Load libgast_hip.so or raise -- the HIP path is the only path."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    if not os.path.exists(LIB_PATH):
+def set_h16(dtype):
+    """Select the 16-bit storage flavour for every following call: torch.bfloat16 (default) or torch.float16."""
+    if dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError('gast_hip: the 16-bit storage type is torch.bfloat16 or torch.float16, got %r' % (dtype,))
+    if dtype == torch.float16:
+        load_library(torch.float16)        # (fail here, loudly, if the flavour was not built)
+    _H16['dtype'] = dtype
+
+
+def h16_dtype():
+    return _H16['dtype']
+
+
+def load_library(h16=torch.bfloat16):
+    """Load libgast_hip.so (or its binary16 flavour) or raise -- the HIP path is the only path."""
+    lib = _libs.get(h16)
+    if lib is not None:
+        return lib
+    path = LIB_PATH_F16 if h16 == torch.float16 else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError('gast_hip: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
-                           '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+                           '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % path)
+    lib = C.CDLL(path)
     vp, ci, cl, cf, cd, cu = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double, C.c_uint32
     sig = {
         'gast_gemm': [C.POINTER(_GemmArgs), vp],
@@ -196,7 +215,7 @@ def load_library():
     lib.gast_expand_bwd_ws_floats.restype = C.c_long
     lib.gast_version.restype = C.c_char_p
     lib.gast_version.argtypes = []
-    _lib = lib
+    _libs[h16] = lib
     return lib
 
 
@@ -231,8 +250,11 @@ def _ld(t):
 def _dt(t):
     if t.dtype == torch.float32:
         return GAST_F32
-    if t.dtype == torch.bfloat16:
-        return GAST_BF16
+    if t.dtype in (torch.bfloat16, torch.float16):
+        if t.dtype != _H16['dtype']:
+            raise RuntimeError('gast_hip: %s tensor, but the selected 16-bit storage flavour is %s (gast_hip.binding.set_h16)'
+                               % (t.dtype, _H16['dtype']))
+        return GAST_BF16          # ("the 16-bit storage type of the loaded flavour")
     raise RuntimeError('gast_hip: unsupported dtype %s' % t.dtype)
 
 
@@ -255,8 +277,14 @@ class HipOps:
     CPU tensors with the numpy oracle (tests only)."""
     name = 'hip'
 
+    @property
+    def lib(self):
+        return load_library(_H16['dtype'])
+
+    set_h16 = staticmethod(set_h16)
+
     def __init__(self):
-        self.lib = load_library()
+        load_library()
         self.launches = 0
         # fp32 tensors: run the MFMA GEMMs / weight gradients on split-bf16 products (GAST_F32X3, include/gast_hip.h) instead of
         # the fp32 matrix instruction.  Set by the model runner from GAST_HIP_DTYPE=bf16x3; storage stays fp32 everywhere.

@@ -122,6 +122,18 @@ class Engine:
     def _ctr(self, bn):
         return bn['running_mean'] if self.centered else None
 
+    @staticmethod
+    def loss_scale(dt):
+        """GAST_HIP_DTYPE=f16: d loss / d prediction is multiplied by this power of two before the backward pass (every gradient is
+        linear in it), so that the activation gradients -- 1e-7 .. 1e-3 at B = 128, i.e. subnormal or zero in binary16 -- are stored with
+        full precision; the caller divides the parameter gradients by it again (model/gast_net.py).  GAST_F16_LOSS_SCALE overrides."""
+        if dt != torch.float16:
+            return 1.0
+        v = float(os.environ.get('GAST_F16_LOSS_SCALE', '4096'))
+        if v <= 0 or (v != 1.0 and (v < 1.0 or (int(v) & (int(v) - 1)))):
+            raise ValueError('GAST_F16_LOSS_SCALE must be a power of two >= 1')
+        return v
+
     def _prep(self, arena_buf, prep, pad=None):
         """Pass prologue: the arena's zero fill + whatever the caller wants zeroed before this pass (flat gradient buffer, packed
         gradient scratch) + the dropout-seed bump (+ the padded copy of d loss / d pred) as ONE launch (gast_prep)."""
@@ -515,6 +527,8 @@ class Engine:
         if sv.get('no_eval_grad'):
             raise NotImplementedError('gradients of an eval-mode forward are not available with GAST_HIP_CENTER=1')
         B, dt, drop = sv['B'], sv['dt'], sv['drop']
+        if dt != torch.float32 and hasattr(ops, 'set_h16'):
+            ops.set_h16(dt)
         J = sp.J
         T = sv['T']
         L = len(sp.fw)
@@ -540,7 +554,8 @@ class Engine:
         else:
             self._prep(arena, prep)
             dp = za.take((PL, KP), dt)
-            dp[:, :3] = dpred.reshape(PL, 3).to(dt)
+            ls = self.loss_scale(dt)
+            dp[:, :3] = (dpred.reshape(PL, 3) * ls if ls != 1.0 else dpred.reshape(PL, 3)).to(dt)
         self._wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
                                                         shift=last['bnO'].shift, wcol0=0)], gout['shrink'], zero_first=False)
         WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero

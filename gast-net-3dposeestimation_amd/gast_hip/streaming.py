@@ -74,6 +74,8 @@ class CausalStream:
         sp, ops, dev = self.spec, self.ops, self.dev
         self.dt = self.runner.act_dtype
         ops.x3 = self.runner.x3
+        if self.dt != torch.float32 and hasattr(ops, 'set_h16'):
+            ops.set_h16(self.dt)          # (bfloat16 or binary16 flavour of the library for every launch of this stream)
         with torch.cuda.device(dev):
             self.st = self.packer.state(dev, self.dt, x3=self.runner.x3)
             ops.run_pack(self.packer, self.st)

@@ -187,11 +187,18 @@ class _GastFunction(torch.autograd.Function):
         # gradients are NOT returned to autograd (hooks / torch.autograd.grad see None): they are already where p.grad points.
         with torch.cuda.device(dev) if dev.type == 'cuda' else contextlib.nullcontext():
             # (zero-filled by the backward's pass prologue, together with its arena: engine.backward(prep=))
-            G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+            # f16 mode: every gradient of this pass comes out multiplied by the loss scale (engine.backward) -- into a private buffer,
+            # unscaled as it is added to its destination
+            scale = engine.loss_scale(ctx.sv['dt'])
+            priv = sink is None or scale != 1.0
+            G = torch.empty(packer.gsize, dtype=torch.float32, device=dev) if priv else sink
             Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
-            prep = {'zero': [Sb] + ([G] if sink is None else [])}
+            prep = {'zero': [Sb] + ([G] if priv else [])}
             gout = packer.grad_outputs(G, Sb)
             gs = ctx.runner.grad_sync if sink is not None else None
+            if gs is not None and len(gs.ranges) > 1 and gs.flat is sink and scale != 1.0:
+                raise NotImplementedError('gast_net (MI355X build): the bucketed gradient exchange is not available in GAST_HIP_DTYPE=f16 '
+                                          '(loss-scaled gradients are unscaled in one pass at the end of backward); use buckets=1')
             if gs is not None and len(gs.ranges) > 1 and gs.flat is sink:
                 # bucketed exchange (gast_hip/dist.py): complete and hand over each bucket of the flat buffer as soon as its stage is done
                 packer.set_buckets(gs.ranges)
@@ -209,6 +216,11 @@ class _GastFunction(torch.autograd.Function):
                 engine.backward(ctx.sv, ctx.inp, dpred.contiguous(), gout, prep=prep)
                 ctx.sv = None
                 engine.ops.run_unpack(packer, st, Sb, G, True)
+                if scale != 1.0:
+                    if sink is not None:
+                        sink.add_(G, alpha=1.0 / scale)
+                    else:
+                        G.mul_(1.0 / scale)
         if sink is not None:
             return (None,) * 9 + (None,) * len(packer.params)
         return (None,) * 9 + tuple(packer.grad_views(G))
@@ -276,10 +288,17 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
         entry.dpred = torch.zeros_like(pred)
         gb = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(gb, pool=pool):
-            G = sink if sink is not None else torch.empty(packer.gsize, dtype=torch.float32, device=dev)
+            scale = engine.loss_scale(sv['dt'])
+            priv = sink is None or scale != 1.0
+            G = torch.empty(packer.gsize, dtype=torch.float32, device=dev) if priv else sink
             Sb = torch.empty(packer.S.size, dtype=torch.float32, device=dev)
-            engine.backward(sv, inp, entry.dpred, packer.grad_outputs(G, Sb), prep={'zero': [Sb] + ([G] if sink is None else [])})
+            engine.backward(sv, inp, entry.dpred, packer.grad_outputs(G, Sb), prep={'zero': [Sb] + ([G] if priv else [])})
             ops.run_unpack(packer, st, Sb, G, True)
+            if scale != 1.0:          # (f16 mode: loss-scaled gradients, see _GastFunction.backward)
+                if sink is not None:
+                    sink.add_(G, alpha=1.0 / scale)
+                else:
+                    G.mul_(1.0 / scale)
         entry.bwd, entry.G = gb, G
         entry.keep += (Sb,)
 
@@ -371,7 +390,12 @@ class _Runner:
             return torch.float32
         if v in ('bf16', 'bfloat16', 'fp8'):
             return torch.bfloat16
-        raise ValueError('GAST_HIP_DTYPE must be fp32, bf16x3, bf16 or fp8, got %r' % v)
+        if v in ('f16', 'fp16', 'float16', 'half'):
+            # IEEE binary16 storage and matrix operands (libgast_hip_f16.so; fp32 accumulate, statistics, softmax, master weights and
+            # parameter gradients as in bf16 mode): 11 significand bits instead of 8 -- the 16-bit mode that meets the north star's
+            # 1e-2 bound (bf16 cannot: tests/test_bf16_floor_cpu.py); gradients travel multiplied by a power-of-two loss scale
+            return torch.float16
+        raise ValueError('GAST_HIP_DTYPE must be fp32, bf16x3, bf16, f16 or fp8, got %r' % v)
 
     @property
     def x3(self):
@@ -553,6 +577,8 @@ class SpatioTemporalModelBase(nn.Module):
                     runner._graphs = collections.OrderedDict()          # (captured graphs hold the old parameters' addresses)
                 packer = runner._packer
                 engine, sink = runner.engine, runner.grad_sink
+            if runner.act_dtype != torch.float32 and hasattr(engine.ops, 'set_h16'):
+                engine.ops.set_h16(runner.act_dtype)        # (which flavour of the library the launches of this call go to)
             st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None,
                               f8=runner.f8 and runner.ops_factory is None)
             # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)

@@ -101,7 +101,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), sym
     assert sorted(EXPORTED_SYMBOLS) == declared
     lib.gast_version.restype = ctypes.c_char_p
-    assert b'gfx950' in lib.gast_version()
+    assert b'gfx950' in lib.gast_version() and b'bfloat16' in lib.gast_version()
+    # the binary16 storage flavour (same sources, -DGAST_H16_F16: GAST_HIP_DTYPE=f16) has the same ABI
+    from gast_hip.binding import LIB_PATH_F16
+    assert os.path.exists(LIB_PATH_F16), 'run __graft_entry__.build() first'
+    lib16 = ctypes.CDLL(LIB_PATH_F16)
+    for sym in declared:
+        assert hasattr(lib16, sym), sym
+    lib16.gast_version.restype = ctypes.c_char_p
+    assert b'gfx950' in lib16.gast_version() and b'binary16' in lib16.gast_version()
     # size helpers are pure host functions: callable without a GPU
     assert lib.gast_gemm_row_blocks(54400) == 425
 

@@ -13,12 +13,16 @@ from tests_helpers import PARENTS
 
 pytestmark = pytest.mark.gpu
 
-DTYPES = [torch.float32, torch.bfloat16]
+# The 16-bit STORAGE flavour under test (csrc/common.h: the library is built twice): bfloat16, or -- GAST_TEST_H16=f16, set by
+# tests/test_f16_gpu.py for a child run of the "bf16" parametrisations of this file -- IEEE binary16 through libgast_hip_f16.so.
+import os as _os
+H16 = torch.float16 if _os.environ.get('GAST_TEST_H16') == 'f16' else torch.bfloat16
+DTYPES = [torch.float32, H16]
 # MFMA kernels (gast_gemm*, gast_wgrad*): fp32, bf16 and fp32 storage with split-bf16 products (GAST_F32X3); 'x3' runs the fp32
 # cases with HipOps.x3 set and a tolerance of 1e-4 of the result magnitude (three bf16 products carry ~2^-17 relative each)
 # 'x3h' (GAST_F32X3H): the same with fp16 hi/lo pairs -- the weight operands carry the tag (X3Weight.f16), the tolerance is fp32's
 MM_MODES = ['f32', 'bf16', 'x3', 'x3h']
-MM_DT = {'f32': torch.float32, 'bf16': torch.bfloat16, 'x3': torch.float32, 'x3h': torch.float32}
+MM_DT = {'f32': torch.float32, 'bf16': H16, 'x3': torch.float32, 'x3h': torch.float32}
 
 
 class x3_mode:
@@ -38,7 +42,8 @@ class x3_mode:
 def ops():
     import os
     os.environ.setdefault('GAST_GEMM_BIG_ALL', '1')     # kernel tests: every eligible shape on the large-M kernel (read once by the library)
-    from gast_hip.binding import HipOps
+    from gast_hip.binding import HipOps, set_h16
+    set_h16(H16)
     return HipOps()
 
 
@@ -58,8 +63,9 @@ def rand(gen, *shape, scale=1.0):
 
 
 def tol(dt, ref, fp32=2e-5, bf16=2e-2):
+    """bf16: the bound for bfloat16 storage; binary16 carries three more significand bits and is held to a quarter of it"""
     mag = max(1e-6, float(np.abs(ref).max()))
-    return (fp32 if dt == torch.float32 else bf16) * mag
+    return (fp32 if dt == torch.float32 else bf16 / 4 if dt == torch.float16 else bf16) * mag
 
 
 def close(a, ref, dt, what, fp32=2e-5, bf16=2e-2):
@@ -184,7 +190,7 @@ def _gemm_case(case, dt):
     X = rand(gen, B * cT * J, N).to(dt) if epi == 2 else None
     xs = (torch.rand(N, generator=gen) + 0.5) if epi == 2 else None
     xh = rand(gen, N, scale=0.3) if epi == 2 else None
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     jd = dict(dom=dom, N=N, segs=segs_d, C_=Cd[:, :N], cmap=cmap, bias=bias.cuda() if use_bias else None,
               addend=add.cuda() if use_add else None, addmap=addmap, epi=epi, partials=pd, X=X.cuda() if X is not None else None,
               xscale=xs.cuda() if xs is not None else None, xshift=xh.cuda() if xh is not None else None,
@@ -441,8 +447,8 @@ def test_gemm_out_f32_from_bf16(ops):
     gen = torch.Generator().manual_seed(5)
     dom, N, K = (2, 4, 17), 3, 64
     M = 2 * 4 * 17
-    A = rand(gen, M, K).to(torch.bfloat16)
-    W = rand(gen, N, K).to(torch.bfloat16)
+    A = rand(gen, M, K).to(H16)
+    W = rand(gen, N, K).to(H16)
     C = torch.zeros(M, N).cuda()
     ops.gemm(dom, N, [dict(A=A.cuda(), K=K, map=kc.RowMap(4, 1, 0), W=W.cuda())], C, kc.RowMap(4, 1, 0))
     ref = host(A) @ host(W).T
@@ -602,7 +608,7 @@ def test_semch_agg(ops, J, C, F, dt):
                       center=tuple(c.cuda() if c is not None else None for c in ctr))
     Yh = np.zeros((P, 2 * C))
     ph = np.zeros((nb, 2 * C, 2))
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     kc.semch_agg_fwd(host(H), F, J, C, host(As)[:-1], ps, host(Ac)[:-1], pc, Yh, ph, round_fn=rnd,
                      center_sym=host(ctr[0]) if ctr[0] is not None else None, center_con=host(ctr[1]) if ctr[1] is not None else None)
     close(host(Y), Yh, dt, 'agg fwd')
@@ -645,7 +651,7 @@ def test_attention(ops, J, C, F, generic, dt):
     ops.attn_fwd(G, AC, Ck.cuda(), F, J, C, nh, Y[:, :C])
     Hh = host(Hx)
     Yh = np.zeros((P, C))
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     kc.attn_fwd(Hh[:, :C], Hh[:, C:C + 2 * nh], host(Ck), F, J, C, nh, Yh, round_fn=rnd)
     got = host(Y)
     close(got[:, :C], Yh, dt, 'attn fwd')
@@ -783,7 +789,7 @@ def test_bn_finalize_multi(ops):
         assert np.all(np.abs(host(bd['kc']) - bh['kc']) <= 1e-5 * terms + 1e-12)
     # fused finalize + apply (short tensors): same jobs, dgamma / dbeta accumulated onto a fill, dz rewritten in place
     for dt in DTYPES:
-        rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+        rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
         fj, refs = [], []
         for bd, bh in zip(bwd_dev, bwd_host):
             N, rows = bd['N'], 301
@@ -812,7 +818,7 @@ def test_bn_finalize_multi(ops):
 def test_rowwise_kernels(ops, rows, N, dt):
     from gast_hip.binding import Dropout, dropout_params
     gen = torch.Generator().manual_seed(rows + N)
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     ld = N + 8
     X = rand(gen, rows, ld).to(dt)
     sc, sh = torch.rand(N, generator=gen) + 0.5, rand(gen, N, scale=0.5)
@@ -855,7 +861,7 @@ def test_rowwise_kernels(ops, rows, N, dt):
 def test_residual_fwd(ops, dt):
     from gast_hip.binding import Dropout, dropout_params
     gen = torch.Generator().manual_seed(8)
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     B, Tp, Tn, J, N = 3, 11, 5, 17, 64
     O = rand(gen, B * Tp * J, N).to(dt)
     T2 = rand(gen, B * Tn * J, N).to(dt)
@@ -877,7 +883,7 @@ def test_residual_fwd(ops, dt):
 @pytest.mark.parametrize('B,T,J,k0,ts,C', [(3, 29, 17, 3, 1, 16), (5, 27, 17, 3, 3, 128), (2, 17, 19, 5, 1, 32), (2, 15, 15, 5, 5, 8)])
 def test_input_side(ops, B, T, J, k0, ts, C, dt):
     gen = torch.Generator().manual_seed(B * T)
-    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(torch.bfloat16)))
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
     F_in = 2
     x = torch.rand(B, T, J, F_in, generator=gen) * 2 - 1
     rows = B * T * J
