@@ -361,12 +361,13 @@ def cpu_reference_forward(state, adj, fw, channels, x, y3d):
     return p, float(torch.mean(torch.norm(p - y3d.cpu(), dim=-1)))
 
 
-def stock_gpu_baseline():
+def stock_gpu_baseline(full=False):
     """SURVEY.md section 8(d) "extra comparator": the same model through stock PyTorch-ROCm operators on this GPU (what
-    `model.cuda()` of the reference gives a user): eager launches, fp32 and autocast-bf16."""
+    `model.cuda()` of the reference gives a user): eager launches, fp32 (3 steps after a warm-up: part of the default N = 1 line) and,
+    with --stock-baseline, autocast-bf16 and a longer sample."""
     out = {}
-    for tag, ac in (('fp32', False), ('autocast_bf16', True)):
-        n, dt = _stock_steps('cuda', ac, 128, 10.0, 10)
+    for tag, ac in ((('fp32', False), ('autocast_bf16', True)) if full else (('fp32', False),)):
+        n, dt = _stock_steps('cuda', ac, 128, 10.0 if full else 0.0, 10 if full else 3, min_steps=3)
         out[tag] = dict(ms_per_step=round(dt / n * 1e3, 2), sequences_per_s=round(128 * n / dt, 1), steps=n)
     out['note'] = ('oracle restatement on stock ATen/MIOpen/rocBLAS operators (oracle/torch_ops.py), eager, '
                    'zero_grad+fwd+mpjpe+bwd+Adam(amsgrad), B=128 T=27 J=17 C=128, dropout 0.05')
@@ -390,7 +391,8 @@ def main():
     ap.add_argument('--no-parity', action='store_true', help='skip the parity object (timed arithmetic vs fp32 HIP path vs CPU restatement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--stock-baseline', action='store_true',
-                    help='also time the same model through stock PyTorch-ROCm operators on this GPU (SURVEY 8d comparator)')
+                    help='the stock PyTorch-ROCm comparator (SURVEY 8d; fp32, 3 steps by default) also in autocast-bf16 and with a longer sample')
+    ap.add_argument('--no-stock-baseline', action='store_true', help='skip the stock PyTorch-ROCm comparator')
     ap.add_argument('--no-graph', action='store_true', help='run the step eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--timer-steps', type=int, default=3, help='eager, event-instrumented steps for the per-kernel roofline')
     ap.add_argument('--no-kernel-timer', action='store_true')
@@ -411,7 +413,7 @@ def main():
     args = ap.parse_args()
     dry = args.dry_run_cpu
     if dry:
-        args.no_graph = args.no_parity = args.no_cpu_baseline = args.no_kernel_timer = args.no_eager = args.no_twin = args.no_f16 = True
+        args.no_graph = args.no_parity = args.no_cpu_baseline = args.no_kernel_timer = args.no_eager = args.no_twin = args.no_f16 = args.no_stock_baseline = True
         args.torch_tail = True        # (the fused loss / flat Adam are HIP launches without a CPU form)
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -899,7 +901,7 @@ def main():
                     peak, unit = peak_tf, 'TFLOP/s'
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-                    pmc_name = next(n for n in ('r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
+                    pmc_name = next(n for n in ('r04_pmc_hbm_bytes_%s.json' % args.dtype, 'r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
                                     if os.path.exists(os.path.join(ROOT, 'profiles', n)))      # counters of the committed kernels, newest round first
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
                     GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<',
@@ -924,7 +926,12 @@ def main():
                     nl = len(rs)
                     byt, flo = sum(r[9] for r in rs) / nl, sum(r[8] for r in rs) / nl
                     mult = 3.0 if args.dtype == 'bf16x3' else 1.0
-                    return {'what': label, 'launches_per_step': nl / tsteps, 'avg_launch_us': round(msl * 1e3, 2),
+                    nmulti = sum(1 for r in rs if r[0] == 'gemm_multi')
+                    return {'what': label, 'launches_per_step': nl / tsteps, 'multi_job_calls_per_step': nmulti / tsteps,
+                            'grids_note': 'launches = gast_gemm / gast_gemm_multi API calls; a multi-job call is one grid (gemm_big_multi_kernel / '
+                                          'gemm_multi_kernel in a kernel trace; one more grid per extra epilogue variant among its jobs, and '
+                                          'one shared split-K finish grid)',
+                            'avg_launch_us': round(msl * 1e3, 2),
                             'alg_mb_per_launch': round(byt / 1e6, 3), 'achieved_gb_s': round(byt / (msl * 1e-3) / 1e9, 1),
                             'frac_of_hbm_peak': round(byt / (msl * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                             'mfma_tflops_eq': round(flo * mult / (msl * 1e-3) / 1e12, 1),
@@ -966,10 +973,15 @@ def main():
                                            + ('' if args.variant == 'dilated' else ' (dilated-model figure; the strided twin does 0.31x the work)')}
         if cpu is not None:
             out['cpu_baseline'] = cpu
-        if args.stock_baseline and world == 1:
-            del model, opt, sync, graphs
-            torch.cuda.empty_cache()
-            out['stock_pytorch_rocm'] = stock_gpu_baseline()
+        if world == 1 and not dry and not args.no_stock_baseline and args.config == 'cfg1':
+            try:
+                del model, opt, sync, graphs
+                torch.cuda.empty_cache()
+                out['stock_pytorch_rocm'] = stock_gpu_baseline(full=args.stock_baseline)
+                sp_ = out['stock_pytorch_rocm']['fp32']['sequences_per_s']
+                out['stock_pytorch_rocm']['this_path_over_stock_fp32'] = round(value / sp_, 1) if sp_ else None
+            except Exception as e:   # noqa: BLE001 -- never lose the bench line to this leg
+                out['stock_pytorch_rocm'] = {'error': str(e).splitlines()[0][:200]}
         if collective:
             # RCCL prints its version banner through C stdio, which would otherwise be flushed at exit, AFTER the JSON line
             import ctypes

@@ -119,7 +119,10 @@ class CausalStream:
         (gast_stream_shift_multi; static addresses: graph-capturable).  The raw-input window and every level's window are shifted by
         the same kernel; a level's shift needs the previous block's output of THIS frame, so it is one launch per level (round 2 used
         a torch.cat + copy_ pair per window).  bf16 windows (GAST_HIP_DTYPE=bf16) keep the torch pair."""
-        if buf3.dtype == torch.float32 and buf3.shape[2] % 4 == 0 and new.stride(0) % 4 == 0:
+        # (the kernel wants an fp32, contiguous window and 16-byte aligned unit-stride rows; anything else takes the torch pair below
+        #  instead of raising from the binding -- ADVICE round 3)
+        if (buf3.dtype == torch.float32 and new.dtype == torch.float32 and buf3.shape[2] % 4 == 0 and new.stride(0) % 4 == 0
+                and buf3.is_contiguous() and new.stride(-1) == 1 and buf3.data_ptr() % 16 == 0 and new.data_ptr() % 16 == 0):
             self.ops.stream_shift_multi([(buf3, new)])
         elif buf3.shape[1] > 1:
             buf3.copy_(torch.cat([buf3[:, 1:], new.unsqueeze(1)], dim=1))

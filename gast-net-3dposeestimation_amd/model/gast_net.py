@@ -239,6 +239,7 @@ class _GraphEntry:
         self.x = self.pred = self.dpred = self.G = self.sink = None
         self.packer = self.runner = None
         self.frozen = False
+        self.buf_ptrs = None        # addresses of the BatchNorm buffers the captured kernels update
         self.st = self.ops = None   # the packed-operand state (refreshed eagerly when the parameters changed) and the op set
         self.keep = None
         self.token_ref = None       # weak reference to the token of the forward whose backward has not run yet
@@ -344,6 +345,19 @@ class _GraphedFunction(torch.autograd.Function):
         return (None, None) + tuple(e.packer.grad_views(e.G.clone()))      # (a copy: the next replay rewrites G in place)
 
 
+_SEAM = [None]      # the resolved `gast_test_seam` module, False when there is none (the product), None before the first look-up
+
+
+def _test_seam():
+    if _SEAM[0] is None:
+        try:
+            import gast_test_seam as seam        # exists only under tests/
+        except ImportError:
+            seam = False
+        _SEAM[0] = seam
+    return _SEAM[0]
+
+
 class _Runner:
     """Per-model glue: op set, activation dtype, dropout stream."""
 
@@ -370,18 +384,23 @@ class _Runner:
         # released with it; a shape that keeps being evicted before its third call simply stays on the eager path.
         self._graphs = collections.OrderedDict()
         self.graph_cache_max = max(1, int(os.environ.get('GAST_HIP_GRAPH_MAX', '8')))
-        # TEST SEAM ONLY: tests/fake_backend.py injects a numpy mirror of the op set to check the host plan on CPU.
-        # Product code never sets it; with it unset the only op set is HipOps and CPU tensors are rejected.
-        self.ops_factory = None
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, 'pending_zero': [], '_seeds': {}, 'ops_factory': None, 'graph_mode': self.graph_mode,
+                'grad_sync': None, 'pending_zero': [], '_seeds': {}, 'graph_mode': self.graph_mode,
                 '_graphs': collections.OrderedDict(), 'graph_cache_max': self.graph_cache_max}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._lock = threading.Lock()
+
+    @property
+    def ops_factory(self):
+        """TEST SEAM.  The product has ONE op set, gast_hip.binding.HipOps (device tensors, HIP kernels, no fallback).  The test-suite
+        checks the host plan on CPU through a numpy mirror of that op set; it registers a model for the mirror in `gast_test_seam`, a
+        module that exists only under tests/ -- outside the test tree the import fails and this is always None."""
+        seam = _test_seam()
+        return seam.factory_for(self) if seam else None
 
     @property
     def act_dtype(self):
@@ -593,13 +612,21 @@ class SpatioTemporalModelBase(nn.Module):
                        None if sink is None else sink.data_ptr(), runner.p_dropout if self.training else 0.0,
                        tuple((b['momentum'], b['eps']) for b in bufs_now.values()))      # (baked into a capture: part of its identity)
                 entry = runner._graphs.get(key)
-                if entry is not None and entry.fwd is not None and entry.st is not st:
+                buf_ptrs = tuple(t.data_ptr() for b in bufs_now.values() for t in (b['running_mean'], b['running_var'], b['num_batches_tracked']))
+                if entry is not None and entry.fwd is not None and (entry.st is not st or entry.buf_ptrs != buf_ptrs):
                     # the parameters moved to other memory since the capture (FlatAdam re-homes them into its flat buffer, .data was
-                    # re-bound, ...): the captured graphs read the old addresses -- drop them and warm up again
+                    # re-bound, ...) or a BatchNorm buffer was re-bound (the captured finalize kernels update running statistics at the
+                    # captured addresses -- ADVICE round 3): the captured graphs are stale -- drop them and warm up again
                     del runner._graphs[key]
                     entry = None
                 if entry is None:
+                    # a key that differs from a cached one ONLY in what is baked into the capture besides shape and mode (BatchNorm
+                    # momentum / eps, dropout p, the gradient sink) supersedes it: a momentum schedule would otherwise strand one
+                    # activation pool per value until the LRU bound is reached
+                    for k_old in [k for k in runner._graphs if k[:9] == key[:9]]:
+                        del runner._graphs[k_old]
                     entry = runner._graphs[key] = _GraphEntry()
+                    entry.buf_ptrs = buf_ptrs
                     while len(runner._graphs) > runner.graph_cache_max:
                         runner._graphs.popitem(last=False)       # least recently used: its graphs, static buffers and pool go with it
                 else:

@@ -4,7 +4,8 @@ The reference ships this module next to local_attention.py; gast_net.py does not
 one), but checkpoints and scripts written against the SemGCN-style layer can.  Same constructor signatures, parameter names,
 shapes and initialisers (sem_graph_conv.py:15-33, 59-128).  The adjacency is ONE masked softmax shared by all channels
 (e: (1, nnz)), i.e. the channel-wise kernels of the fused plan with `e` broadcast over the channels; bias defaults to True.
-Forward-only plan over the HIP kernels: gast_hip/modules.py.
+Fused forward-only plan under torch.no_grad() and a trainable path (forward kernel + the fused plan's backward kernels as
+autograd.Functions) otherwise: gast_hip/modules.py, gast_hip/autograd_ops.py.
 """
 from __future__ import absolute_import, division
 

@@ -315,3 +315,16 @@ def mpjpe(pred, target):
         pred.acc(g * d / safe[..., None] / nrm.size)
     out.bw = bw
     return out
+
+
+def forced_oracle(run_oracle, decisions):
+    """run_oracle() with every relu / leaky_relu decision taken from `decisions` (oracle/plan_decisions.py: what the path under test
+    decided).  Returns (result, number of decisions that differ from the oracle's own, largest |input| among those)."""
+    TIES.update(forced=list(decisions), pos=0, flips=0, flip_max=0.0)
+    try:
+        out = run_oracle()
+        used, flips, fmax = TIES['pos'], TIES['flips'], TIES['flip_max']
+    finally:
+        TIES.update(forced=None, pos=0, flips=0, flip_max=0.0)
+    assert used == len(decisions), ('the oracle made %d relu calls, %d decisions were supplied' % (used, len(decisions)))
+    return out, flips, fmax

@@ -3,7 +3,7 @@
 It lets the product's host-side plan (gast_hip/engine.py) run on CPU so that its *composition* of ops can be pinned
 against the reference-generated golden fixtures without a GPU (tests/test_plan_cpu.py).  Every op forwards to
 oracle/kernel_contract.py.  It lives under tests/ and is injected through the model's documented test seam
-(`model._runner.ops_factory`); nothing in the product imports it.
+(tests/gast_test_seam.py, looked up by `model._runner.ops_factory`); nothing in the product imports it.
 """
 import numpy as np
 import torch
@@ -225,6 +225,7 @@ OracleOps.run_unpack = _run_unpack
 
 def use_oracle_ops(model):
     """Route a model instance through the numpy mirror (CPU tensors allowed)."""
-    model._runner.ops_factory = OracleOps
+    import gast_test_seam
+    gast_test_seam.register(model._runner, OracleOps)
     model._runner._engine = None
     return model

@@ -65,21 +65,10 @@ X3_FWD_F16 = x3_forward_f16()
 X3_GRAD_TOL = dict(grad=2e-4, gabs=2e-5) if X3_FWD_F16 else dict(grad=1e-3, gabs=1e-4)
 # largest |pre-activation| (BatchNorm-normalised units, O(1) scale) at which the path under test may decide a ReLU differently from
 # the float64 oracle: its own round-off on that quantity, with margin (bf16x3 measured <= 3.1e-5 over the BASELINE-size shapes)
-FLIP_EPS = {'fp32': 2e-5, 'bf16x3': 2e-4 if X3_FWD_F16 else 2e-3}
+FLIP_EPS = {'fp32': 2e-5, 'bf16x3': 1e-4 if X3_FWD_F16 else 2e-3}
 
 
-def forced_oracle(run_oracle, decisions):
-    """run_oracle() with every relu / leaky_relu decision taken from `decisions` (tests/plan_decisions.py: what the path under test
-    decided).  Returns (result, number of decisions that differ from the oracle's own, largest |input| among those)."""
-    from oracle import np_autograd as ag
-    ag.TIES.update(forced=list(decisions), pos=0, flips=0, flip_max=0.0)
-    try:
-        out = run_oracle()
-        used, flips, fmax = ag.TIES['pos'], ag.TIES['flips'], ag.TIES['flip_max']
-    finally:
-        ag.TIES.update(forced=None, pos=0, flips=0, flip_max=0.0)
-    assert used == len(decisions), ('the oracle made %d relu calls, %d decisions were supplied' % (used, len(decisions)))
-    return out, flips, fmax
+from oracle.np_autograd import forced_oracle      # noqa: E402,F401  (lives next to the oracle: __graft_entry__.smoke() uses it too)
 
 
 def _check_fp32_grads(m, ref, run_oracle, FP32_GRAD_TOL=FP32_GRAD_TOL, decisions=None, flip_eps=FLIP_EPS['fp32']):
