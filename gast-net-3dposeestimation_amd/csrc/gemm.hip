@@ -476,6 +476,13 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                     }
                 }
                 if (epi == GAST_EPI_BNRELU_BWD) {
+                    if (a.C2) {          // second output: the value before the mask
+                        uint4 o2;
+                        if (sizeof(TO) == 4) o2 = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+                        else o2 = make_uint4(pack_h16x2(v[0], v[1 % EPO]), pack_h16x2(v[2 % EPO], v[3 % EPO]), pack_h16x2(v[4 % EPO], v[5 % EPO]),
+                                             pack_h16x2(v[6 % EPO], v[7 % EPO]));
+                        *(uint4*)((TO*)a.C2 + (long)crow * a.ldc2 + n0) = o2;
+                    }
                     const uint4 xr = *(const uint4*)(Xv + (long)crow * a.ldx + n0);
                     float x[EPO];
                     if (sizeof(TO) == 4) {
@@ -566,6 +573,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
                     if (arow >= 0) v += Elem<T>::ld(Addb + (long)arow * a.ldadd + n);
                 }
                 if (epi == GAST_EPI_BNRELU_BWD) {
+                    if (a.C2) Elem<TO>::st((TO*)a.C2 + (long)crow * a.ldc2 + n, v);
                     float x = Elem<T>::ld(Xb + (long)crow * a.ldx + n);
                     if (!(fmaf(x, xs, xh) > 0.f)) v = 0.f;
                     if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)((long)crow * a.ldx + n));
@@ -671,6 +679,7 @@ __device__ __forceinline__ void splitk_finish_body(const gast_gemm_args& a, int 
                 if (a.bias) v += a.bias_neg ? -a.bias[n] : a.bias[n];
                 if (arow >= 0) v += Elem<T>::ld((const T*)a.addend + arow * a.ldadd + n);
                 if (epi == GAST_EPI_BNRELU_BWD) {
+                    if (a.C2) Elem<TO>::st((TO*)a.C2 + crow * a.ldc2 + n, v);
                     const float x = Elem<T>::ld((const T*)a.X + crow * a.ldx + n);
                     if (!(fmaf(x, a.xscale[n], a.xshift[n]) > 0.f)) v = 0.f;
                     if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(crow * a.ldx + n));
@@ -753,6 +762,7 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     if (a.f8_scale && (a.dtype != GAST_BF16 || a.out_f32)) return GAST_EINVAL;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return GAST_EINVAL;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return GAST_EINVAL;
+    if (a.C2 && a.epi != GAST_EPI_BNRELU_BWD) return GAST_EINVAL;
     long Ml = (long)a.B * a.Tn * a.J;
     if (Ml > 0x7fffff00L) return GAST_ERANGE;
     M = (int)Ml;
@@ -779,6 +789,7 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     vec_epi = !(a.dtype == GAST_BF16 && a.out_f32) && a.N % epc == 0 && a.ldc % epc == 0 && aligned16(a.C);
     if (a.addend && (a.ldadd % epc || !aligned16(a.addend))) vec_epi = 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (a.ldx % epc || !aligned16(a.X))) vec_epi = 0;
+    if (a.C2 && (a.ldc2 % epc || !aligned16(a.C2))) vec_epi = 0;
     return 0;
 }
 }  // namespace

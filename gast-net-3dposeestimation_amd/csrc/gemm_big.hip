@@ -340,6 +340,12 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
     const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * 4), RSRC3);
     const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * 4) : 0, RSRC3);
+    // second output of the BNRELU_BWD epilogues: the value before the mask (a null C2 gets a zero-sized descriptor: its stores are dropped).
+    // Only in the variants WITHOUT an addend (what the plan needs: gast_gemm_big_plan): with one the extra descriptor and store push the
+    // narrow-tile kernel from 167 to 173 registers, i.e. from three to two blocks per CU.
+    constexpr bool C2OK = bwd && !ADD;
+    const bool has2 = C2OK && a.C2 != nullptr;
+    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(has2 ? a.C2 : a.C, 0, has2 ? (int)(((rowsC - 1) * a.ldc2 + N) * 4) : 0, RSRC3);
     const long rowsAdd = ADD ? (long)a.B * a.addmap.T_total * a.J : 1;
     const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(ADD ? a.addend : a.C), 0, ADD ? (int)(((rowsAdd - 1) * a.ldadd + N) * 4) : 0, RSRC3);
     const int col0 = n0 + wc * (TN / 2) + li;          // the lane's first column; the others are + 32 ni
@@ -398,6 +404,8 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
                 float v = acc[mi][ni][4 * q + r] + bias[ni];
                 if (ADD) v += av[buf][ni][r];
                 if (bwd) {
+                    if constexpr (C2OK)
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rC2, ok ? (uint32_t)(cr * a.ldc2 + col0) * 4u + 128 * ni : OOB, 0, 0);
                     const float x = xv[buf][ni][r];
                     v = fmaf(x, xs[ni], xh[ni]) > 0.f ? v : 0.f;
                     if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(cr * a.ldx + col0 + 32 * ni));
@@ -568,6 +576,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
     if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
+    if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || a.addend || rowsC * a.ldc2 * 4 >= 0x7fffffffL)) return 0;
     if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
     static const int ablate = getenv("GAST_GEMM_BIG_ABLATE") ? atoi(getenv("GAST_GEMM_BIG_ABLATE")) : 0;
     pl.ablate = ablate;

@@ -62,7 +62,7 @@ class _GemmArgs(C.Structure):
                 ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
                 ('bias', C.c_void_p), ('bias_neg', C.c_int), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
                 ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
-                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('f8_scale', C.c_void_p)]
+                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('C2', C.c_void_p), ('ldc2', C.c_int), ('f8_scale', C.c_void_p)]
 
 
 class _F8ScaleJob(C.Structure):
@@ -309,7 +309,7 @@ class HipOps:
         return self.lib.gast_gemm_row_blocks(int(M))
 
     def _gemm_args(self, a, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
+                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, C2=None):
         a.dtype = _dt(segs[0]['A'])
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
         st_dtype = a.dtype
@@ -348,6 +348,10 @@ class HipOps:
         a.xscale, a.xshift = _p(xscale), _p(xshift)
         a.xdrop, a.xsalt = int(bool(xdrop)), int(xsalt)
         a.drop = _drop(drop)
+        if C2 is not None:          # BNRELU_BWD: second output, the value before the mask (same row map as C_)
+            if C2.dtype != C_.dtype or C2.shape[0] != C_.shape[0]:
+                raise RuntimeError('gast_hip: gemm C2 must have the dtype and rows of C_')
+            a.C2, a.ldc2 = _p(C2), _ld(C2)
         if self.x3 and st_dtype == GAST_F32:
             # fp16 pairs when the weight operands say so (the forward operands of the plan, gast_hip/packer.py); one GEMM, one kind
             if nf16 not in (0, len(segs)):

@@ -567,9 +567,26 @@ class Engine:
         g = 'g%d.' % (L - 1)
         self._bn_backward(part, nb, 0, CL, last['bnO'], inp[g + 'cat_bn.weight'], grads, g + 'cat_bn', dO, last['O'], PL)
 
+        # The input gradient dX of a block has two consumers: the residual path takes it as it is, the branch through
+        # drop(relu(bn(T2pre))) (level s >= 1) or relu(expand_bn(E)) (the input side) takes it masked, with the BatchNorm-backward column
+        # sums.  Fused (default): the block's last GEMM writes both -- masked value + sums through its BNRELU_BWD epilogue, the plain
+        # value through the epilogue's second output (gast_gemm_args.C2) -- and the stand-alone gast_bnrelu_bwd_mask pass (3 launches,
+        # 45 us per step at B = 128, a re-read of dX) is gone.  GAST_FUSE_MASK=0: the separate pass (bisecting aid).
+        fuse_mask = os.environ.get('GAST_FUSE_MASK', '1') not in ('0', '')
+        use_drop = sv['training'] and drop is not None and drop.thresh != 0
+        P0 = B * T[0] * J
         for s in range(L - 1, -1, -1):
             st = stages[s]
-            dX = self._gab_backward(s, st, dO, B, J, inp, grads, dt, drop)
+            mask = None
+            if fuse_mask:
+                Pm, Cm = B * T[s] * J, st['C']
+                mask = dict(dz=self._new(Pm, Cm, dt, dev), partials=za.take((ops.gemm_row_blocks(Pm), Cm, 2)), nblk=ops.gemm_row_blocks(Pm))
+                if s > 0:
+                    lv = levels[s - 1]
+                    mask.update(X=lv['T2'], scale=lv['bn2'].scale, shift=lv['bn2'].shift, xdrop=use_drop, xsalt=3 * s, plain=True)
+                else:
+                    mask.update(X=sv['E'], scale=sv['bnE'].scale, shift=sv['bnE'].shift, xdrop=False, xsalt=0, plain=False)
+            dX = self._gab_backward(s, st, dO, B, J, inp, grads, dt, drop, mask=mask)
             if s == 0:
                 break
             # ---- temporal level s backward
@@ -579,12 +596,14 @@ class Engine:
             Tn, Tp = T[s], T[s - 1]
             P, Pp = B * Tn * J, B * Tp * J
             k = lv['k']
-            use_drop = sv['training'] and drop is not None and drop.thresh != 0
             # branch 2: drop(relu(bn(T2pre)))
-            nbr = ops.rowwise_blocks(P, C)
-            part2 = torch.empty(nbr, C, 2, dtype=f32, device=dev)
-            dT2 = self._new(P, C, dt, dev)
-            ops.bnrelu_bwd_mask(dX, lv['T2'], P, C, lv['bn2'].scale, lv['bn2'].shift, use_drop, 3 * s, drop, dT2, part2)
+            if mask is not None:
+                dT2, part2, nbr = mask['dz'], mask['partials'], mask['nblk']
+            else:
+                nbr = ops.rowwise_blocks(P, C)
+                part2 = torch.empty(nbr, C, 2, dtype=f32, device=dev)
+                dT2 = self._new(P, C, dt, dev)
+                ops.bnrelu_bwd_mask(dX, lv['T2'], P, C, lv['bn2'].scale, lv['bn2'].shift, use_drop, 3 * s, drop, dT2, part2)
             lk = 'l%d.' % s
             self._bn_backward(part2, nbr, 0, C, lv['bn2'], inp[lk + 'bn1.weight'], grads, lk + 'bn1', dT2, lv['T2'], P)
             # 1x1 conv
@@ -652,11 +671,13 @@ class Engine:
                 stage_done(s)
 
         # ---- expand conv + init_bn backward (dX is the gradient w.r.t. relu(expand_bn(E)))
-        P0 = B * T[0] * J
-        nbr = ops.rowwise_blocks(P0, C0)
-        partE = torch.empty(nbr, C0, 2, dtype=f32, device=dev)
-        dE = self._new(P0, C0, dt, dev)
-        ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE, partE)
+        if mask is not None:
+            dE, partE, nbr = mask['dz'], mask['partials'], mask['nblk']
+        else:
+            nbr = ops.rowwise_blocks(P0, C0)
+            partE = torch.empty(nbr, C0, 2, dtype=f32, device=dev)
+            dE = self._new(P0, C0, dt, dev)
+            ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE, partE)
         self._bn_backward(partE, nbr, 0, C0, sv['bnE'], inp['expand_bn.weight'], grads, 'expand_bn', dE, sv['E'], P0)
         x = sv['x']
         F_in = x.shape[-1]
@@ -673,8 +694,10 @@ class Engine:
         self._keep = []
         za.end()
 
-    def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop):
-        """dO: gradient w.r.t. Opre (pre-BN output of the block's cat_conv), (P x 2C).  Returns dX (P x C)."""
+    def _gab_backward(self, s, st, dO, B, J, inp, grads, dt, drop, mask=None):
+        """dO: gradient w.r.t. Opre (pre-BN output of the block's cat_conv), (P x 2C).  Returns dX (P x C).
+        mask (see Engine.backward): the block's last GEMM also produces the masked gradient of the NEXT consumer's BatchNorm'd branch
+        (mask['dz'], with its column sums in mask['partials']); dX itself is then only written when mask['plain']."""
         sp, ops, za = self.spec, self.ops, self.za
         dev = dO.device
         f32 = torch.float32
@@ -738,7 +761,12 @@ class Engine:
         self._wgrad(dom, dH, N1, im, [dict(Q=st['X'], S=C, map=im, wcol0=0)], grads[g + 'Bg1'], zero_first=False)
         Wg1T = inp[g + 'Bg1T']       # [C][N1]
         dX = self._new(P, C, dt, dev)
-        ops.gemm(dom, C, [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])], dX, im)
+        segs = [dict(A=dH, K=N1, map=im, W=Wg1T), dict(A=dO, K=2 * C, map=im, W=WbcT[0:C])]
+        if mask is None:
+            ops.gemm(dom, C, segs, dX, im)
+        else:
+            ops.gemm(dom, C, segs, mask['dz'], im, epi=EPI_BNRELU_BWD, partials=mask['partials'], X=mask['X'], xscale=mask['scale'],
+                     xshift=mask['shift'], xdrop=mask['xdrop'], xsalt=mask['xsalt'], drop=drop, C2=dX if mask['plain'] else None)
         return dX
 
 

@@ -122,6 +122,11 @@ typedef struct {
     int xdrop;            /* forward applied dropout to relu(bn(X)) */
     uint32_t xsalt;
     gast_dropout drop;
+    void* C2;             /* epi == BNRELU_BWD, optional: a second output [rows][ldc2] addressed with cmap that receives the value BEFORE the
+                           * mask, acc (+bias) (+addend).  The input gradient of a block feeds two consumers -- the residual path takes it
+                           * as it is, the branch through drop(relu(bn(T2))) takes it masked, with the BatchNorm-backward sums: one GEMM
+                           * writes both, the stand-alone gast_bnrelu_bwd_mask pass (reference gast_net.py:174 backward) disappears */
+    int ldc2;
     const float* f8_scale; /* optional (GAST_BF16, bf16 output): run this GEMM's operands as OCP e4m3 on v_mfma_f32_32x32x16_fp8_fp8
                             * ("mixed fp8", BASELINE.json configs[4]).  Device pointer to {s, 1/s}: every weight is multiplied by s
                             * (a power of two, gast_f8_scale_multi) before the conversion, the accumulators by 1/s; activations are

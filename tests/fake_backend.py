@@ -53,8 +53,12 @@ class OracleOps:
                 pad=None if pad is None else (_np(pad[0]), _np(pad[1])) + tuple(pad[2:]))
 
     def gemm(self, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=0, partials=None, X=None, xscale=None,
-             xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False):
+             xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, C2=None):
         self.launches += 1
+        if C2 is not None:        # second output of the BNRELU_BWD epilogue: the value before the mask = the same GEMM with the PLAIN epilogue
+            assert epi == 2
+            kc.gemm(dom, N, _segs(segs, 'A'), _np(C2), kc.RowMap(*cmap), _np(bias), _np(addend),
+                    kc.RowMap(*addmap) if addmap is not None else None, 0, None, None, None, None, False, 0, None, bias_neg=bias_neg)
         kc.gemm(dom, N, _segs(segs, 'A'), _np(C_), kc.RowMap(*cmap), _np(bias), _np(addend),
                 kc.RowMap(*addmap) if addmap is not None else None, epi, _np(partials), _np(X), _np(xscale), _np(xshift),
                 xdrop, xsalt, _drop(drop), bias_neg=bias_neg)

@@ -316,6 +316,42 @@ def test_gemm_big_x3_multi(ops, first, nodrop, pair):
         _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
+BWD_CASES = [c for c in GEMM_CASES + GEMM_BIG_CASES if c[4] == 2]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16', 'x3'])
+@pytest.mark.parametrize('case', BWD_CASES, ids=[c[0] for c in BWD_CASES])
+def test_gemm_bwd_second_output(ops, case, mode):
+    """gast_gemm_args.C2: the BNRELU_BWD epilogue also stores the value BEFORE the mask (acc + bias + addend) -- bit-equal to the same
+    GEMM with the PLAIN epilogue -- while C, the masked value, and the column sums are unchanged by it.  Both kernels, split-K finish."""
+    dt = MM_DT[mode]
+    jd, jh, bufs = _gemm_case(case, dt)
+    big = case in GEMM_BIG_CASES
+    with x3_mode(ops, mode):
+        if big and mode == 'x3':
+            _with_images(ops, jd)
+        ops.gemm(**jd)
+        torch.cuda.synchronize()
+        C_ref, part_ref = bufs[0].clone(), bufs[2].clone()
+        plain = torch.full_like(bufs[0], 7.0)
+        jp = dict(jd, C_=plain[:, :case[2]], epi=0, partials=None, X=None, xscale=None, xshift=None, xdrop=False)
+        ops.gemm(**jp)
+        bufs[0].fill_(7.0)
+        bufs[2].zero_()
+        C2 = torch.full_like(bufs[0], 7.0)
+        ops.gemm(**dict(jd, C2=C2[:, :case[2]]))
+        torch.cuda.synchronize()
+    if big and mode == 'x3' and jd.get('addend') is not None:
+        # (the large-M kernel carries the second output in its addend-free variants only: with an addend this call takes the 128x128-tile
+        #  kernel -- another summation order than the large-M run it is compared with)
+        close(host(bufs[0]), host(C_ref), dt, 'masked output', fp32=1e-4)
+        close(host(C2), host(plain), dt, 'C2', fp32=1e-4)
+    else:
+        assert torch.equal(bufs[0], C_ref), 'the masked output changed'
+        assert torch.equal(C2, plain), 'C2 differs from the PLAIN epilogue of the same GEMM'
+    close(host(bufs[2]).sum(axis=0), host(part_ref).sum(axis=0), dt, 'sums', fp32=1e-5, bf16=1e-5)
+
+
 def test_gemm_fp16_pairs_range(ops):
     """The documented range of GAST_F32X3H (include/gast_hip.h): operands up to fp16's largest finite value are exact-class, parts
     below 2^-24 vanish (absolute, not relative, error floor), and an operand beyond 65504 is NOT representable -- the result is
