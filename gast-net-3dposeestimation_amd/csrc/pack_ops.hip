@@ -19,13 +19,16 @@ __device__ __forceinline__ float load_any(const void* p, long idx, int is_bf16) 
     return is_bf16 ? bf2f(((const bf16_t*)p)[idx]) : ((const float*)p)[idx];
 }
 
-// one block = one 32x32 tile of one job; 256 threads = 32 x 8
-__global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restrict__ jobs, const int* __restrict__ tiles,
-                                                           const Bases bs) {
-    const long* bases = bs.v;
-    __shared__ float tile[TILE][TILE + 1];
-    const int* t = tiles + (long)blockIdx.x * 3;
-    const long* j = jobs + (long)t[0] * CJ_WORDS;
+// one block = one 32x32 tile of one job; 256 threads = 32 x 8.
+// CJ: 10 words per job (gast_strided_copy) or 16 (gast_pack_all: + the pre-split image of the packed operand the tile lands in --
+// words 10..15 = image word, ldimg (16-bit elements per k-group), element offset of the job's (0, 0) inside the operand, columns K
+// of the operand, fp16-pair flag, reserved; image word 0 = none): the tile is then ALSO written as 16-bit hi/lo pairs in the
+// k-group-major layout of gast_x3_image_multi, so the large-M GEMM's weight images no longer need a pass of their own over the
+// packed fp32 operands (x3_image_kernel: 30 us per step + its graph-node boundary).
+constexpr int CJ_WORDS_X = 16;
+template <int CJ>
+__device__ __forceinline__ void copy_tile(const long* __restrict__ jobs, const int* __restrict__ t, const long* bases, float (*tile)[TILE + 1]) {
+    const long* j = jobs + (long)t[0] * CJ;
     const char* src = (const char*)(bases[j[0] & 7] + (j[0] >> 4));     // (element-size independent) byte address
     char* dst = (char*)(bases[j[1] & 7] + (j[1] >> 4));
     const int R = (int)j[2], S = (int)j[3];
@@ -58,21 +61,81 @@ __global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restric
             else ((float*)dst)[o] = v;
         }
     }
+    if constexpr (CJ == CJ_WORDS_X) {
+        if (j[10] == 0) return;
+        // image: thread = (line along the operand's row direction, quad of 4 consecutive K values).  The operand's K runs along the
+        // job's s when dcs == 1 and along its r when drs == 1 (a transposed twin); 4-aligned quads stay inside one 16-value k-group.
+        bf16_t* img = (bf16_t*)(bases[j[10] & 7] + (j[10] >> 4));
+        const long ldimg = j[11], rel = j[12];
+        const int Kop = (int)j[13], f16 = (int)j[14];
+        const int line = threadIdx.x >> 3, quad = threadIdx.x & 7;
+        const bool k_on_s = dcs == 1;
+        float x[4];
+        bool in[4];
+        long o0 = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int rl = k_on_s ? line : quad * 4 + q, cl = k_on_s ? quad * 4 + q : line;
+            in[q] = r0 + rl < R && c0 + cl < S;
+            x[q] = in[q] ? tile[rl][cl] : 0.f;
+            if (q == 0) o0 = rel + (long)(r0 + rl) * drs + (long)(c0 + cl) * dcs;
+        }
+        if (!in[0]) return;          // (validity is monotone along the quad)
+        const long row = o0 / Kop;
+        const int k = (int)(o0 - row * Kop);
+        uint2 h, l;
+        if (f16) split_pair4<2>(x[0], x[1], x[2], x[3], h, l);
+        else split_pair4<1>(x[0], x[1], x[2], x[3], h, l);
+        bf16_t* o = img + (long)(k >> 4) * ldimg + row * 32 + (k & 15);
+        if (in[3] && (k & 3) == 0) {
+            *(uint2*)o = h;
+            *(uint2*)(o + 16) = l;
+        } else {
+            // ragged quad (a 2-row head block of an 8-channel model, a K offset that is not a multiple of 4): value by value -- the
+            // neighbouring K positions belong to other jobs
+            const bf16_t* hp = (const bf16_t*)&h;
+            const bf16_t* lp = (const bf16_t*)&l;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!in[q]) break;
+                const int kq = k + q;
+                bf16_t* oq = img + (long)(kq >> 4) * ldimg + row * 32 + (kq & 15);
+                oq[0] = hp[q];
+                oq[16] = lp[q];
+            }
+        }
+    }
+}
+__global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restrict__ jobs, const int* __restrict__ tiles,
+                                                           const Bases bs) {
+    __shared__ float tile[TILE][TILE + 1];
+    copy_tile<CJ_WORDS>(jobs, tiles + (long)blockIdx.x * 3, bs.v, tile);
 }
 
 // fold: v[k] = sum_m W[m][k] * w[m]  (k < C, m < Ci), a = sum_m w[m] * b[m]
 //   -> dst_row[k * ds_row]  and dst_col[k * ds_col] (activation dtype), bias_dst (fp32)
 // grid = (njobs, ceil(C/32)); 256 threads = 32 columns x 8 m-lanes (each lane sums every 8th m, LDS combine)
+// FJ: 12 words per job (gast_fold) or 18 (gast_pack_all: + words 12..17 = image word of the row destination's first element,
+// its ldimg, image word of the column destination's first element, its ldimg, fp16-pair flags (bit 0 row, bit 1 column), reserved:
+// element k of the row destination is K position k0r + k of one operand row, element k of the column destination is K position
+// (fixed) of operand row k -- see gast_hip/binding.py)
 constexpr int FJ_WORDS = 12;
-__global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs, const Bases bs) {
-    const long* bases = bs.v;
-    __shared__ float sred[8][32];
-    const long* j = jobs + (long)blockIdx.x * FJ_WORDS;
+constexpr int FJ_WORDS_X = 18;
+__device__ __forceinline__ void split1(float v, int f16, bf16_t& hi, bf16_t& lo) {
+    uint2 h, l;
+    if (f16) split_pair4<2>(v, 0.f, 0.f, 0.f, h, l);
+    else split_pair4<1>(v, 0.f, 0.f, 0.f, h, l);
+    hi = (bf16_t)(h.x & 0xffffu);
+    lo = (bf16_t)(l.x & 0xffffu);
+}
+template <int FJ>
+__device__ __forceinline__ void fold_body(const long* __restrict__ jobs, const long* bases, int job, int by, float (*sred)[32]) {
+    const long* j = jobs + (long)job * FJ;
     const float* W = (const float*)(bases[j[0] & 7] + (j[0] >> 4));
     const float* w = (const float*)(bases[j[1] & 7] + (j[1] >> 4));
     const float* b = (const float*)(bases[j[2] & 7] + (j[2] >> 4));
     const int Ci = (int)j[3], C = (int)j[4];
-    if ((int)blockIdx.y * 32 >= C) return;
+    if (by * 32 >= C) return;
     char* d_row = (char*)(bases[j[5] & 7] + (j[5] >> 4));
     const long ds_row = j[6];
     char* d_col = (char*)(bases[j[7] & 7] + (j[7] >> 4));
@@ -80,7 +143,7 @@ __global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs
     float* d_bias = (float*)(bases[j[9] & 7] + (j[9] >> 4));
     const int dst_bf16 = (int)j[10];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
-    const int k = blockIdx.y * 32 + cx;
+    const int k = by * 32 + cx;
     float acc = 0.f;
     if (k < C) {
 #pragma unroll 4
@@ -94,12 +157,48 @@ __global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs
         for (int r = 0; r < 8; ++r) v += sred[r][cx];
         if (dst_bf16) { ((bf16_t*)d_row)[k * ds_row] = f2bf(v); ((bf16_t*)d_col)[k * ds_col] = f2bf(v); }
         else { ((float*)d_row)[k * ds_row] = v; ((float*)d_col)[k * ds_col] = v; }
+        if constexpr (FJ == FJ_WORDS_X) {
+            if (j[12]) {         // images: the row destination is K positions k0 + k of one operand row ...
+                bf16_t* ir = (bf16_t*)(bases[j[12] & 7] + (j[12] >> 4));      // (address of K position 0 of that row in k-group 0)
+                bf16_t hi, lo;
+                split1(v, (int)j[16] & 1, hi, lo);
+                bf16_t* o = ir + (long)(k >> 4) * j[13] + (k & 15);
+                o[0] = hi;
+                o[16] = lo;
+            }
+            if (j[14]) {         // ... the column destination one K position of operand row k
+                bf16_t* ic = (bf16_t*)(bases[j[14] & 7] + (j[14] >> 4));      // (address of that K position in operand row 0)
+                bf16_t hi, lo;
+                split1(v, ((int)j[16] >> 1) & 1, hi, lo);
+                bf16_t* o = ic + (long)k * 32;
+                o[0] = hi;
+                o[16] = lo;
+            }
+        }
     }
-    if (blockIdx.y == 0 && threadIdx.x == 0) {
+    if (by == 0 && threadIdx.x == 0) {
         float a = 0.f;
         for (int m = 0; m < Ci; ++m) a = fmaf(w[m], b[m], a);
         *d_bias = a;
     }
+}
+__global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs, const Bases bs) {
+    __shared__ float sred[8][32];
+    fold_body<FJ_WORDS>(jobs, bs.v, blockIdx.x, blockIdx.y, sred);
+}
+
+// gast_pack_all: every copy tile (with its image) and every fold block (with its images) of a step in ONE grid -- the three
+// launches of the parameter packing (strided_copy, fold, x3_image: 68 us + three graph-node boundaries per step) as one.  The jobs
+// are independent: a copy tile and a fold block never write the same element (operand or image).
+__global__ void __launch_bounds__(256) pack_all_kernel(const long* __restrict__ cjobs, const int* __restrict__ tiles, int ntiles,
+                                                       const long* __restrict__ fjobs, int fold_by, const Bases bs) {
+    __shared__ float smem[TILE][TILE + 1];
+    if ((int)blockIdx.x < ntiles) {
+        copy_tile<CJ_WORDS_X>(cjobs, tiles + (long)blockIdx.x * 3, bs.v, smem);
+        return;
+    }
+    const int fb = blockIdx.x - ntiles;
+    fold_body<FJ_WORDS_X>(fjobs, bs.v, fb / fold_by, fb % fold_by, (float (*)[32])smem);
 }
 
 // unfold (gradient of fold): given dv[k] (fp32, stride 1) and da (fp32 scalar):
@@ -146,6 +245,20 @@ extern "C" int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int 
     Bases b;
     for (int i = 0; i < 8; ++i) b.v[i] = bases[i];
     hipLaunchKernelGGL(strided_copy_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, tiles, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_pack_all(const int64_t* cjobs, const int32_t* tiles, int ntiles, const int64_t* fjobs, int nfold, int max_C,
+                             const int64_t* bases, gast_stream_t stream) {
+    if (!bases || ntiles < 0 || nfold < 0 || (ntiles && (!cjobs || !tiles)) || (nfold && (!fjobs || max_C < 1))) return GAST_EINVAL;
+    const int fold_by = nfold ? (max_C + 31) / 32 : 1;
+    const long nblk = (long)ntiles + (long)nfold * fold_by;
+    if (nblk == 0) return 0;
+    Bases b;
+    for (int i = 0; i < 8; ++i) b.v[i] = bases[i];
+    hipLaunchKernelGGL(pack_all_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const long*)cjobs, tiles, ntiles,
+                       (const long*)fjobs, fold_by, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

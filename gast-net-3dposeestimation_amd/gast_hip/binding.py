@@ -197,6 +197,7 @@ def load_library(h16=torch.bfloat16):
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
         'gast_fold': [vp, ci, ci, vp, vp],
+        'gast_pack_all': [vp, vp, ci, vp, ci, ci, vp, vp],
         'gast_unfold': [vp, ci, ci, vp, vp],
         'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
@@ -223,7 +224,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
-                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_fold',
+                    'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
 
@@ -687,6 +688,54 @@ class HipOps:
             st['tables'] = tb
         return tb
 
+    def _packx_tables(self, packer, st, dev):
+        """gast_pack_all tables (GAST_F32X3 states): the copy jobs with the pre-split image of the operand each one lands in, the
+        fold jobs with the images of their two destinations -- one launch packs operands AND images."""
+        from gast_hip.packer import BASE_W
+        wsize = st['Wb'].element_size()
+        regions = sorted((off, r, c, n) for n, (off, r, c) in packer.W.regions.items())
+
+        def region_of(off):
+            for o, r, c, n in regions:
+                if o <= off < o + r * c:
+                    return o, c, n
+            raise RuntimeError('gast_hip: packed destination outside every operand region')
+        words, tiles = [], []
+        for ji, job in enumerate(packer.copy_jobs):
+            src, dst, R, S = job[0], job[1], job[2], job[3]
+            src_size = wsize if src.base == BASE_W else 4
+            dst_size = wsize if dst.base == BASE_W else 4
+            flags = (1 if src_size == 2 else 0) | (2 if dst_size == 2 else 0)
+            ext = [0, 0, 0, 0, 0, 0]
+            if dst.base == BASE_W:
+                roff, K, name = region_of(dst.off)
+                if dst.rs != 1 and dst.cs != 1:
+                    raise RuntimeError('gast_hip: an operand destination must be K-contiguous or a transposed twin')
+                img = packer._image(st, name)
+                ext = [(img.data_ptr() << 4) | 0, img.stride(0), dst.off - roff, K, int(packer._f16(st, name)), 0]
+            words += [self._word(src, src_size), self._word(dst, dst_size), R, S, src.rs, src.cs, dst.rs, dst.cs, flags, 0] + ext
+            for tr in range((R + 31) // 32):
+                for tc in range((S + 31) // 32):
+                    tiles += [ji, tr, tc]
+        fw = []
+        for j in packer.fold_jobs:
+            wt = j['w']
+            roff_r, K_r, name_r = region_of(j['row'].off)
+            roff_c, K_c, name_c = region_of(j['col'].off)
+            img_r, img_c = packer._image(st, name_r), packer._image(st, name_c)
+            row_r, k0_r = divmod(j['row'].off - roff_r, K_r)          # the row destination: operand row, first K position (0)
+            row_c, k_c = divmod(j['col'].off - roff_c, K_c)           # the column destination: first operand row (0), K position
+            if k0_r != 0 or row_c != 0 or j['row'].cs != 1 or j['col'].cs != K_c:
+                raise RuntimeError('gast_hip: unexpected fold destination layout')
+            ir = img_r.data_ptr() + 2 * (row_r * 32)
+            ic = img_c.data_ptr() + 2 * ((k_c >> 4) * img_c.stride(0) + (k_c & 15))
+            fw += [(j['W'].data_ptr() << 4), ((wt.data_ptr() + j['woff'] * 4) << 4), (j['b'].data_ptr() << 4), j['Ci'], j['C'],
+                   self._word(j['row'], wsize), j['row'].cs, self._word(j['col'], wsize), j['col'].cs, self._word(j['bias'], 4),
+                   1 if wsize == 2 else 0, 0,
+                   (ir << 4), img_r.stride(0), (ic << 4), 0, int(packer._f16(st, name_r)) | (int(packer._f16(st, name_c)) << 1), 0]
+        return (torch.tensor(words, dtype=torch.int64).to(dev), torch.tensor(tiles, dtype=torch.int32).to(dev), len(tiles) // 3,
+                torch.tensor(fw, dtype=torch.int64).to(dev) if fw else None, len(packer.fold_jobs))
+
     def _unpack_tables(self, packer, st, dev, accumulate, bucket=None):
         tb = self._tables(packer, st, dev)
         key = 'unpack%d' % int(accumulate) + ('' if bucket is None else ':%d' % bucket)
@@ -792,6 +841,17 @@ class HipOps:
         dev = st['Wb'].device
         tb = self._tables(packer, st, dev)
         bases = self._bases(W=st['Wb'], F=st['Fb'])
+        if st.get('Xb') is not None and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
+            # GAST_F32X3: operands, folds and their pre-split images in ONE launch (gast_pack_all; GAST_PACK_FUSED=0: the three
+            # launches of rounds 2-3)
+            px = tb.get('packx')
+            if px is None:
+                px = tb['packx'] = self._packx_tables(packer, st, dev)
+            jt, tt, nt, ft, nf = px
+            self.launches += 1
+            _check(self.lib.gast_pack_all(_p(jt), _p(tt), nt, _p(ft), nf, max((j['C'] for j in packer.fold_jobs), default=1),
+                                          C.cast(bases, C.c_void_p), _stream()), 'gast_pack_all')
+            return
         jt, tt, nt = tb['pack']
         self.launches += 2
         _check(self.lib.gast_strided_copy(_p(jt), _p(tt), nt, C.cast(bases, C.c_void_p), _stream()), 'gast_strided_copy')

@@ -352,6 +352,14 @@ int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out,
  *   (theta/phi folding of the additive attention, global_attention.py:60-74).
  * unfold job (12 int64): dv word, da word, W, w, b, dW, dw, db words, Ci, C, accumulate, reserved. */
 int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int ntiles, const int64_t* bases, gast_stream_t stream);
+/* The whole parameter packing of a step in ONE launch (round 4; was gast_strided_copy + gast_fold + gast_x3_image_multi): copy jobs of
+ * 16 int64 = the 10 words above + {image word (0: none), ldimg, element offset of the job's element (0, 0) inside its packed operand,
+ * columns K of that operand, fp16-pair flag, reserved} -- the tile is also written into the operand's pre-split image (layout of
+ * gast_x3_image_multi; the destination must be K-contiguous or a transposed twin, i.e. one of its strides 1) -- and fold jobs of 18
+ * int64 = the 12 words above + {image word of K position 0 of the destination row (k-group 0), its ldimg, image word of the
+ * destination column's K position in operand row 0, reserved, fp16-pair flags (bit 0 row, bit 1 column), reserved}. */
+int gast_pack_all(const int64_t* cjobs, const int32_t* tiles, int ntiles, const int64_t* fjobs, int nfold, int max_C,
+                  const int64_t* bases, gast_stream_t stream);
 int gast_fold(const int64_t* jobs, int njobs, int max_C, const int64_t* bases, gast_stream_t stream);      /* max_C  = largest C of the jobs */
 int gast_unfold(const int64_t* jobs, int njobs, int max_Ci, const int64_t* bases, gast_stream_t stream);  /* max_Ci = largest Ci */
 

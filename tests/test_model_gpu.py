@@ -960,3 +960,34 @@ def test_training_forward_always_repacks(monkeypatch):
         m.shrink.weight.data.mul_(0.5)
         y3 = m(x).clone()
     assert torch.allclose(y3, 0.5 * y2, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('ch,arc,variant', [(16, [3, 3], 'dilated'), (8, [3, 3, 3], 'dilated'), (32, [3, 3], 'strided')])
+def test_fused_parameter_packing_equals_the_three_launch_path(ch, arc, variant, monkeypatch):
+    """gast_pack_all (round 4: copy jobs + fold jobs + the pre-split weight images of the bf16x3 arithmetic in ONE launch) writes
+    exactly what gast_strided_copy + gast_fold + gast_x3_image_multi wrote: packed operands, packed fp32 values and every image, bit
+    for bit -- including the ragged cases (2-row head blocks of an 8-channel model, transposed twins)."""
+    from gast_hip.packer import Packer
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'bf16x3')
+    cfg = dict(J=17, parents=PARENTS[17], arc=arc, channels=ch, causal=False, variant=variant)
+    torch.manual_seed(11)
+    m = build(cfg).cuda()
+    gen = torch.Generator().manual_seed(2)
+    _random_state(m, gen)
+    ops = m._runner.engine.ops
+    packer = Packer(m, m._runner.spec)
+    got = {}
+    for fused in ('0', '1'):
+        monkeypatch.setenv('GAST_PACK_FUSED', fused)
+        st = packer.state(torch.device('cuda', 0), torch.float32, x3=True)
+        for k in ('Wb', 'Fb', 'Xb'):
+            st[k].zero_()
+        st['tables'] = None
+        ops.run_pack(packer, st)
+        torch.cuda.synchronize()
+        got[fused] = {k: st[k].clone() for k in ('Wb', 'Fb', 'Xb')}
+    for k in ('Wb', 'Fb'):
+        assert torch.equal(got['0'][k], got['1'][k]), k
+    assert torch.equal(got['0']['Xb'].view(torch.int16), got['1']['Xb'].view(torch.int16)), 'weight images differ'
+    assert got['1']['Xb'].view(torch.int16).ne(0).any()
+
