@@ -1353,8 +1353,48 @@ __global__ void __launch_bounds__(256) attn_bwd_finish_kernel(const float* __res
     }
 }
 
+// gast_rowsum_multi: the deferred finishes of a backward pass (attention: dbias / dC_k += column sums of the per-wave partial rows;
+// aggregation: dA = column sums of the per-block partial rows) as ONE launch, blockIdx.y = job -- they were six launches per step
+// (256 threads = 32 columns x 8 row lanes, as the two kernels above)
+struct RowsumBatch { gast_rowsum_job j[GAST_ROWSUM_MAX_BATCH]; };
+__global__ void __launch_bounds__(256) rowsum_multi_kernel(const RowsumBatch b) {
+    __shared__ float sred[8][32];
+    const gast_rowsum_job& j = b.j[blockIdx.y];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const long n = (long)blockIdx.x * 32 + cx;
+    if ((long)blockIdx.x * 32 >= j.ncol) return;
+    float a = 0.f;
+    if (n < j.ncol) {
+#pragma unroll 4
+        for (int r = ry; r < j.nrow; r += 8) a += j.ws[(long)r * j.ncol + n];
+    }
+    sred[ry][cx] = a;
+    __syncthreads();
+    if (ry == 0 && n < j.ncol) {
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) t += sred[r][cx];
+        float* o = n < j.nb ? (j.out0 ? j.out0 + n : nullptr) : (j.out1 ? j.out1 + (n - j.nb) : nullptr);
+        if (o) *o = j.accumulate ? *o + t : t;
+    }
+}
 
 }  // namespace
+
+extern "C" int gast_rowsum_multi(const gast_rowsum_job* jobs, int n, gast_stream_t stream) {
+    if (!jobs || n < 1 || n > GAST_ROWSUM_MAX_BATCH) return GAST_EINVAL;
+    RowsumBatch b;
+    long maxcol = 0;
+    for (int d = 0; d < n; ++d) {
+        const gast_rowsum_job& j = jobs[d];
+        if (!j.ws || j.nrow < 1 || j.ncol < 1 || j.nb < 0 || j.nb > j.ncol || (!j.out0 && !j.out1)) return GAST_EINVAL;
+        b.j[d] = j;
+        if (j.ncol > maxcol) maxcol = j.ncol;
+    }
+    hipLaunchKernelGGL(rowsum_multi_kernel, dim3((unsigned)((maxcol + 31) / 32), n), dim3(256), 0, (hipStream_t)stream, b);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int gast_semch_adj_fwd(const float* e, int C, const int32_t* pat, float* A_t, gast_stream_t stream) {
     if (!e || !pat || !A_t || C < 1) return GAST_EINVAL;
@@ -1477,10 +1517,10 @@ extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_
     return (long)c.nfb * (nnz_sym + nnz_con) * C;
 }
 
-extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
-                                  const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
-                                  const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
-                                  gast_stream_t stream) {
+static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                              const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                              const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                              gast_rowsum_job* finish, gast_stream_t stream) {
     if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA || !ws) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
@@ -1516,6 +1556,10 @@ extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void
     if (fast) {
         GAST_CHECK_LAUNCH();
         long ncol_f = (long)nnz_t * C;
+        if (finish) {            // deferred: the caller sums the partial rows later (gast_rowsum_multi)
+            *finish = gast_rowsum_job{ws, c.nfb, ncol_f, ncol_f, dA, nullptr, 0};
+            return 0;
+        }
         hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol_f + 31) / 32)), dim3(256), 0, st, ws, c.nfb, ncol_f, dA);
         GAST_CHECK_LAUNCH();
         return 0;
@@ -1535,9 +1579,29 @@ extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void
                            J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk, c.CC, c.TPF, c.FB);
     GAST_CHECK_LAUNCH();
     long ncol = (long)nnz_t * C;
+    if (finish) {
+        *finish = gast_rowsum_job{ws, c.nfb, ncol, ncol, dA, nullptr, 0};
+        return 0;
+    }
     hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)((ncol + 31) / 32)), dim3(256), 0, st, ws, c.nfb, ncol, dA);
     GAST_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int gast_semch_agg_bwd(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                                  const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                                  const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                                  gast_stream_t stream) {
+    return semch_agg_bwd_impl(dtype, dY, ldy, H, ldh, F, J, C, A_sym, pat_sym, nnz_sym, cdeg_sym, A_con, pat_con, nnz_con, cdeg_con, dH, lddh,
+                              dA, ws, nullptr, stream);
+}
+extern "C" int gast_semch_agg_bwd_deferred(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                                           const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                                           const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                                           gast_rowsum_job* finish, gast_stream_t stream) {
+    if (!finish) return GAST_EINVAL;
+    finish->ws = nullptr;
+    return semch_agg_bwd_impl(dtype, dY, ldy, H, ldh, F, J, C, A_sym, pat_sym, nnz_sym, cdeg_sym, A_con, pat_con, nnz_con, cdeg_con, dH, lddh,
+                              dA, ws, finish, stream);
 }
 
 static int attn_grid(int F, int nheads, int ub) {
@@ -1647,7 +1711,7 @@ static int launch_attn_fwd_wave(const void* G, int ldg, const void* AC, int ldac
 template <typename T, int CI4, int JT>
 static int launch_attn_bwd_wave_j(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                   int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
-                                  hipStream_t st) {
+                                  hipStream_t st, gast_rowsum_job* finish) {
     static AttnOcc occ;
     const int per_cu = sizeof(T) == 4 ? occ.get((const void*)attn_bwd_wave_kernel<T, CI4, JT>, (size_t)4 * AttnW<CI4>::BWD_FLOATS * sizeof(float)) : 0;
     const int grid = attn_wave_grid(F, nheads, per_cu);
@@ -1677,6 +1741,10 @@ static int launch_attn_bwd_wave_j(const void* dY, int lddy, const void* G, int l
                            ldac, C_k, F, J, nheads, (T*)dG, lddg, (T*)dAC, lddac, ws, ncol);
     }
     GAST_CHECK_LAUNCH();
+    if (finish) {            // deferred: dbias / dC_k += column sums of the partial rows, later (gast_rowsum_multi)
+        *finish = gast_rowsum_job{ws, grid * 4 / nheads, (long)ncol, (long)nb, dbias, dC_k, 1};
+        return 0;
+    }
     hipLaunchKernelGGL(attn_bwd_finish_kernel, dim3((ncol + 31) / 32), dim3(256), 0, st, ws, grid * 4 / nheads, ncol, nb, dbias, dC_k);
     GAST_CHECK_LAUNCH();
     return 0;
@@ -1684,15 +1752,15 @@ static int launch_attn_bwd_wave_j(const void* dY, int lddy, const void* G, int l
 template <typename T, int CI4>
 static int launch_attn_bwd_wave(const void* dY, int lddy, const void* G, int ldg, const void* AC, int ldac, const float* C_k, int F, int J,
                                 int nheads, void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws,
-                                hipStream_t st) {
+                                hipStream_t st, gast_rowsum_job* finish) {
     if constexpr (sizeof(T) == 4) {
         if (attn_jt_enabled()) {
-#define GAST_BWD_J(JT_) if (J == JT_) return launch_attn_bwd_wave_j<T, CI4, JT_>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st);
+#define GAST_BWD_J(JT_) if (J == JT_) return launch_attn_bwd_wave_j<T, CI4, JT_>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st, finish);
             GAST_BWD_J(17) GAST_BWD_J(19) GAST_BWD_J(15)
 #undef GAST_BWD_J
         }
     }
-    return launch_attn_bwd_wave_j<T, CI4, 0>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st);
+    return launch_attn_bwd_wave_j<T, CI4, 0>(dY, lddy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, st, finish);
 }
 
 extern "C" int gast_attn_fwd(int dtype, const void* G, int ldg, const void* AC, int ldac, const float* C_k,
@@ -1743,9 +1811,10 @@ extern "C" long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads) {
     return (g * 4 / nheads + 1) * (long)(C + 2 * nheads + nheads * J * J);
 }
 
-extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
-                             const float* C_k, int F, int J, int C, int nheads,
-                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_stream_t stream) {
+static int attn_bwd_impl(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                         const float* C_k, int F, int J, int C, int nheads,
+                         void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_rowsum_job* finish,
+                         gast_stream_t stream) {
     if (!dY || !G || !AC || !C_k || !dG || !dAC || !dC_k) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (J < 1 || J > JMAX || nheads < 1 || C % nheads || F < 1) return GAST_EINVAL;
@@ -1754,9 +1823,9 @@ extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, 
 #define GAST_BWD_WAVE(CI4_)                                                                                                         \
             case CI4_: return dtype == GAST_F32                                                                                     \
                 ? launch_attn_bwd_wave<float, CI4_>(dY, ldy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, \
-                                                    (hipStream_t)stream)                                                            \
+                                                    (hipStream_t)stream, finish)                                                    \
                 : launch_attn_bwd_wave<bf16_t, CI4_>(dY, ldy, G, ldg, AC, ldac, C_k, F, J, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, \
-                                                     (hipStream_t)stream);
+                                                     (hipStream_t)stream, finish);
             GAST_BWD_WAVE(8) GAST_BWD_WAVE(16) GAST_BWD_WAVE(32)
 #undef GAST_BWD_WAVE
             default: break;
@@ -1789,3 +1858,16 @@ extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, 
     if (dbias) return gast_colsum(dtype, dG, lddg, (long)F * J, C, dbias, 0, stream);      // g-bias part: column sums of dG
     return 0;
 }
+extern "C" int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                             const float* C_k, int F, int J, int C, int nheads,
+                             void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_stream_t stream) {
+    return attn_bwd_impl(dtype, dY, ldy, G, ldg, AC, ldac, C_k, F, J, C, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, nullptr, stream);
+}
+extern "C" int gast_attn_bwd_deferred(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                                      const float* C_k, int F, int J, int C, int nheads, void* dG, int lddg, void* dAC, int lddac,
+                                      float* dC_k, float* dbias, float* ws, gast_rowsum_job* finish, gast_stream_t stream) {
+    if (!finish) return GAST_EINVAL;
+    finish->ws = nullptr;         // (stays null when a generic kernel, which needs no finish, took the call)
+    return attn_bwd_impl(dtype, dY, ldy, G, ldg, AC, ldac, C_k, F, J, C, nheads, dG, lddg, dAC, lddac, dC_k, dbias, ws, finish, stream);
+}
+

@@ -88,6 +88,11 @@ class _StreamShiftJob(C.Structure):
     _fields_ = [('buf', C.c_void_p), ('newest', C.c_void_p), ('B', C.c_int), ('Tb', C.c_int), ('X', C.c_int), ('ldnew', C.c_int)]
 
 
+class _RowsumJob(C.Structure):
+    _fields_ = [('ws', C.c_void_p), ('nrow', C.c_int), ('ncol', C.c_long), ('nb', C.c_long), ('out0', C.c_void_p), ('out1', C.c_void_p),
+                ('accumulate', C.c_int)]
+
+
 class _ZeroJob(C.Structure):
     _fields_ = [('ptr', C.c_void_p), ('bytes', C.c_long)]
 
@@ -177,6 +182,9 @@ def load_library(h16=torch.bfloat16):
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
         'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, vp],
         'gast_attn_bwd_ws_floats': [ci, ci, ci, ci],
+        'gast_rowsum_multi': [C.POINTER(_RowsumJob), ci, vp],
+        'gast_attn_bwd_deferred': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, C.POINTER(_RowsumJob), vp],
+        'gast_semch_agg_bwd_deferred': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, C.POINTER(_RowsumJob), vp],
         'gast_bn_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp, vp, ci, vp],
         'gast_bn_eval': [vp, vp, vp, vp, cf, ci, vp, vp, ci, vp],
         'gast_bn_finalize_multi': [C.POINTER(_BnFinJob), ci, vp],
@@ -221,7 +229,7 @@ def load_library(h16=torch.bfloat16):
 
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_f8_scale_multi', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
-                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats',
+                    'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats', 'gast_rowsum_multi', 'gast_attn_bwd_deferred', 'gast_semch_agg_bwd_deferred',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
@@ -486,9 +494,32 @@ class HipOps:
     def semch_agg_bwd_ws(self, F, C_, nnz_sym, nnz_con):
         return self.lib.gast_semch_agg_bwd_ws_floats(int(F), int(C_), int(nnz_sym), int(nnz_con))
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0)):
+    ROWSUM_MAX_BATCH = 8
+
+    def rowsum_multi(self, jobs):
+        """jobs: the (job struct, tensors kept alive) pairs the deferred forms of attn_bwd / semch_agg_bwd appended: their finishes
+        (dbias / dC_k += column sums of the partial rows, dA = column sums) as one launch per ROWSUM_MAX_BATCH."""
+        for i0 in range(0, len(jobs), self.ROWSUM_MAX_BATCH):
+            chunk = jobs[i0:i0 + self.ROWSUM_MAX_BATCH]
+            arr = (_RowsumJob * len(chunk))()
+            for a, (j, _keep) in zip(arr, chunk):
+                a.ws, a.nrow, a.ncol, a.nb, a.out0, a.out1, a.accumulate = j.ws, j.nrow, j.ncol, j.nb, j.out0, j.out1, j.accumulate
+            self.launches += 1
+            _check(self.lib.gast_rowsum_multi(arr, len(chunk), _stream()), 'gast_rowsum_multi')
+
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0), defer=None):
         """dA: [nnz_sym + nnz_con][C] fp32 (sym rows first), fully written; ws: workspace of semch_agg_bwd_ws() floats;
-        cdeg = (Dc_sym, Dc_con)."""
+        cdeg = (Dc_sym, Dc_con).  defer: a list -- the final row reduction into dA is not launched but appended to it (rowsum_multi)."""
+        if defer is not None:
+            job = _RowsumJob()
+            self.launches += 1
+            _check(self.lib.gast_semch_agg_bwd_deferred(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym),
+                                                        A_sym.shape[0] - 1, int(cdeg[0]), _p(A_con), _p(pat_con), A_con.shape[0] - 1,
+                                                        int(cdeg[1]), _p(dH), _ld(dH), _p(dA), _p(ws), C.byref(job), _stream()),
+                   'gast_semch_agg_bwd_deferred')
+            if job.ws:
+                defer.append((job, (ws, dA)))
+            return
         self.launches += 2
         _check(self.lib.gast_semch_agg_bwd(_dt(H), _p(dY), _ld(dY), _p(H), _ld(H), F, J, C_, _p(A_sym), _p(pat_sym),
                                            A_sym.shape[0] - 1, int(cdeg[0]), _p(A_con), _p(pat_con), A_con.shape[0] - 1, int(cdeg[1]),
@@ -500,12 +531,22 @@ class HipOps:
         _check(self.lib.gast_attn_fwd(_dt(G), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads, _p(Y), _ld(Y), _stream()),
                'gast_attn_fwd')
 
-    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias=None, generic=False):
-        """dC_k and dbias ([C + 2*nheads]: column sums of [dG | dAC]) are accumulated into (zero-filled by the caller)."""
+    def attn_bwd(self, dY, G, AC, C_k, F, J, C_, nheads, dG, dAC, dC_k, dbias=None, generic=False, defer=None):
+        """dC_k and dbias ([C + 2*nheads]: column sums of [dG | dAC]) are accumulated into (zero-filled by the caller).
+        defer: a list -- the reduction of the per-wave partial rows into dbias / dC_k is appended to it instead of launched."""
         self.launches += 2
         ws = None
         if not generic:
             ws = torch.empty(max(1, self.lib.gast_attn_bwd_ws_floats(F, J, C_, nheads)), dtype=torch.float32, device=G.device)
+        if defer is not None:
+            job = _RowsumJob()
+            self.launches -= 1
+            _check(self.lib.gast_attn_bwd_deferred(_dt(G), _p(dY), _ld(dY), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads,
+                                                   _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _p(dbias), _p(ws), C.byref(job), _stream()),
+                   'gast_attn_bwd_deferred')
+            if job.ws:
+                defer.append((job, (ws, dC_k, dbias)))
+            return
         _check(self.lib.gast_attn_bwd(_dt(G), _p(dY), _ld(dY), _p(G), _ld(G), _p(AC), _ld(AC), _p(C_k), F, J, C_, nheads,
                                       _p(dG), _ld(dG), _p(dAC), _ld(dAC), _p(dC_k), _p(dbias), _p(ws), _stream()), 'gast_attn_bwd')
 

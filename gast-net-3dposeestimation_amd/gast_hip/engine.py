@@ -462,6 +462,11 @@ class Engine:
             self._wside = side
             self._wq = []
 
+    def _fin_flush(self):
+        if self._finq:
+            self.ops.rowsum_multi(self._finq)
+            self._finq = []
+
     def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
         """finalize {sum dz, sum dz*x} -> dgamma/dbeta (ACCUMULATED into their destinations: the gradient buffers arrive zeroed or
         hold a running sum) + coefficients, then dz <- dx in place."""
@@ -541,6 +546,9 @@ class Engine:
         self._wq = []
         self._wside = None
         self._adjq = []
+        # the small reductions that end attn_bwd / semch_agg_bwd (partial rows -> dbias, dC_k, dA) are collected and run as ONE launch
+        # in front of the adjacency-softmax backward, the only kernel that waits for them (6 launches per step -> 1)
+        self._finq = [] if hasattr(ops, 'rowsum_multi') else None
 
         # ---- shrink backward
         last = stages[-1]
@@ -665,6 +673,7 @@ class Engine:
             dO = dOp
             self._wgrad_flush()
             if stage_done is not None:
+                self._fin_flush()
                 ops.semch_adj_bwd_multi(self._adjq, accumulate=True)     # (otherwise: one launch for all blocks at the end)
                 self._adjq = []
                 self._join(self._wside)
@@ -688,6 +697,7 @@ class Engine:
                        inp['init_bn.weight'], inp['init_bn.bias'], gout['expand_w'], gout['init_bn.weight'], gout['init_bn.bias'],
                        accumulate=True)
         self._wgrad_flush()
+        self._fin_flush()
         ops.semch_adj_bwd_multi(self._adjq, accumulate=True)
         self._adjq = []
         self._join(self._wside)
@@ -747,13 +757,14 @@ class Engine:
         dH = self._new_rows128(P, N1, dt, dev)
         dCk = grads[g + 'C_k']          # accumulated with atomics: gradient destinations arrive zeroed (see backward())
         # (+ the bias gradients of g / theta / phi = column sums of these dH columns, reduced in the same pass)
+        dkw = {'defer': self._finq} if self._finq is not None else {}
         ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], inp[g + 'C_k'], F, J, C, NHEADS, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk,
-                     dbias=grads[g + 'bias1'][4 * C:])
+                     dbias=grads[g + 'bias1'][4 * C:], **dkw)
         nnz_s, nnz_c = sp.nnz_sym, sp.nnz_con
         dA = torch.empty(nnz_s + nnz_c, C, dtype=f32, device=dev)
         ws = torch.empty(max(1, ops.semch_agg_bwd_ws(F, C, nnz_s, nnz_c)), dtype=f32, device=dev)
         ops.semch_agg_bwd(dY, H, F, J, C, st['A_s'], sp.pat_sym(dev), st['A_c'], sp.pat_con(dev), dH, dA, ws,
-                          cdeg=(sp.deg_sym[1], sp.deg_con[1]))
+                          cdeg=(sp.deg_sym[1], sp.deg_con[1]), **dkw)
         # softmax backward of the adjacencies: queued, one launch for all blocks at the end of backward()
         self._adjq += [(dA[:nnz_s], st['A_s'], sp.pat_sym(dev), grads[g + 'e_sym']),
                        (dA[nnz_s:], st['A_c'], sp.pat_con(dev), grads[g + 'e_con'])]

@@ -260,6 +260,22 @@ int gast_attn_bwd(int dtype, const void* dY, int ldy, const void* G, int ldg, co
                   void* dG, int lddg, void* dAC, int lddac, float* dC_k, float* dbias, float* ws, gast_stream_t stream);
 long gast_attn_bwd_ws_floats(int F, int J, int C, int nheads);
 
+/* Deferred finishes (round 4).  gast_attn_bwd and gast_semch_agg_bwd end with a small reduction of per-wave / per-block partial
+ * rows (dbias, dC_k += column sums; dA = column sums): six launches per training step that nothing in the backward pass waits for
+ * except the adjacency-softmax backward at its very end.  The *_deferred forms skip that launch and describe it in *finish (ws ==
+ * null when the call needed none); the caller keeps the workspace alive and runs all of them as ONE gast_rowsum_multi launch.
+ *   job: out0[c] (+)= sum_r ws[r][c] for c < nb,  out1[c - nb] (+)= sum_r ws[r][c] for nb <= c < ncol   (a null output is skipped) */
+typedef struct { const float* ws; int nrow; long ncol; long nb; float* out0; float* out1; int accumulate; } gast_rowsum_job;
+#define GAST_ROWSUM_MAX_BATCH 8
+int gast_rowsum_multi(const gast_rowsum_job* jobs, int n, gast_stream_t stream);
+int gast_attn_bwd_deferred(int dtype, const void* dY, int ldy, const void* G, int ldg, const void* AC, int ldac,
+                           const float* C_k, int F, int J, int C, int nheads, void* dG, int lddg, void* dAC, int lddac,
+                           float* dC_k, float* dbias, float* ws, gast_rowsum_job* finish, gast_stream_t stream);
+int gast_semch_agg_bwd_deferred(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
+                                const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                                const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                                gast_rowsum_job* finish, gast_stream_t stream);
+
 /* ---- BatchNorm2d (momentum 0.1, eps 1e-5; gast_net.py:20,58-59,147,149 etc.) as a two-phase scheme ---------
  * Producers emit per-row-block partial sums; `gast_bn_finalize` turns them into the per-channel scale/shift that
  * consumers apply on load, and updates the running statistics exactly as nn.BatchNorm2d does in train mode. */

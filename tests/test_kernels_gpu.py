@@ -707,6 +707,43 @@ def test_attention(ops, J, C, F, generic, dt):
     close(host(dCk), dCkh, dt, 'attn bwd dC_k', fp32=1e-4, bf16=3e-2)
 
 
+@pytest.mark.parametrize('J,C,F', [(17, 128, 300), (19, 256, 41), (15, 512, 7)])
+def test_deferred_finishes_equal_the_immediate_ones(ops, J, C, F):
+    """gast_attn_bwd_deferred / gast_semch_agg_bwd_deferred + ONE gast_rowsum_multi == gast_attn_bwd / gast_semch_agg_bwd (whose last
+    launch is that reduction): dbias, dC_k (accumulated) and dA (overwritten), bit for bit; dH untouched by the deferral."""
+    gen = torch.Generator().manual_seed(J * C + F)
+    nh, P = 4, F * J
+    ps, pc = patterns(J)
+    ns, nc = int(ps[1]), int(pc[1])
+    o_s, o_c = 2 + 2 * (J + 1) + 3 * ns, 2 + 2 * (J + 1) + 3 * nc
+    cdeg = (int(ps[o_s + 1]), int(pc[o_c + 1]))
+    ldh = 5 * C + 8
+    H = rand(gen, P, ldh).cuda()
+    Ck = rand(gen, nh, J, J, scale=0.1).cuda()
+    dYa, dY = rand(gen, P, C).cuda(), rand(gen, P, 2 * C).cuda()
+    As, Ac = torch.rand(ns + 1, C, generator=gen), torch.rand(nc + 1, C, generator=gen)
+    As[-1] = 0
+    Ac[-1] = 0
+    As, Ac = As.cuda(), Ac.cuda()
+    out = {}
+    for tag in ('now', 'later'):
+        q = [] if tag == 'later' else None
+        dH = torch.full((P, ldh), 2.0).cuda()
+        dCk, dbias = torch.full((nh, J, J), 0.5).cuda(), torch.full((C + 2 * nh,), -0.25).cuda()
+        dA = torch.full((ns + nc, C), 9.0).cuda()
+        ws = torch.empty(ops.semch_agg_bwd_ws(F, C, ns, nc)).cuda()
+        kw = {} if q is None else {'defer': q}
+        ops.attn_bwd(dYa, H[:, 4 * C:5 * C], H[:, 5 * C:], Ck, F, J, C, nh, dH[:, 4 * C:5 * C], dH[:, 5 * C:], dCk, dbias=dbias, **kw)
+        ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg, **kw)
+        if q is not None:
+            assert len(q) == 2, 'both kernels defer their finish at these head widths'
+            ops.rowsum_multi(q)
+        torch.cuda.synchronize()
+        out[tag] = (dH, dCk, dbias, dA)
+    for a, b, name in zip(out['now'], out['later'], ('dH', 'dC_k', 'dbias', 'dA')):
+        assert torch.equal(a, b), name
+
+
 # ------------------------------------------------------------------------------------------------ BN / elementwise
 def test_bn_finalize_and_backward(ops):
     gen = torch.Generator().manual_seed(3)
