@@ -158,8 +158,15 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
     };
 
-    u32x4 ra0[2], ra1[2];
-    bool rz0[2], rz1[2];
+    // NA register sets of activation tiles in flight (GAST_BIG_NA, default 2; 3 = experiment: one more K step of latency tolerance for
+    // the activation stream -- the only operand that comes from HBM -- at 8 more registers; see the pipeline comment below)
+#ifndef GAST_BIG_NA
+#define GAST_BIG_NA 2
+#endif
+    constexpr int NA = GAST_BIG_NA;
+    static_assert(NA == 2 || NA == 3, "two or three activation register sets");
+    u32x4 ra[NA][2];
+    bool rz[NA][2];
 #ifdef GAST_GEMM_BIG_ABLATION
     const int abl = pl.ablate;          // profiling build only (build.sh ABLATION=1): runtime switches split the K loop's basic blocks
 #else
@@ -231,15 +238,19 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     // ---- pipeline.  Tile j's activations travel in register set j & 1 and LDS stage j & 1, its weights in stage j % 3.
     // Invariant at the top of iteration t (after the counted wait + barrier): LDS holds tile t; set (t+1)&1 holds tile t+1's
     // activations; in flight: the weights of tile t+1 and the activations of tile t+2.
-    Tile d1, d2, d3;                   // tiles t+1, t+2, t+3
+    // dq[i] = tile t+1+i at the top of step t: dq[0] is written to LDS, dq[1]'s weights are requested, dq[NA]'s activations are loaded
+    Tile dq[NA + 1];
     {
         Tile d0;
         next_tile(d0);
         dma_w(d0, 0);
-        load_a(d0, ra0, rz0);
-        next_tile(d1);
-        dma_w(d1, 1);
-        load_a(d1, ra1, rz1);
+        load_a(d0, ra[0], rz[0]);
+#pragma unroll
+        for (int i = 1; i < NA; ++i) {             // tiles 1 .. NA-1 into sets 1 .. NA-1
+            next_tile(dq[i - 1]);
+            if (i == 1) dma_w(dq[0], 1);
+            load_a(dq[i - 1], ra[i], rz[i]);
+        }
         for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
             if (pl.taboff[s] >= 0) {
                 const float* sc = a.seg[s].scale;
@@ -250,11 +261,11 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         gload_wait_n<0>();
         __syncthreads();                                   // tables complete
         fetch_tab(d0);
-        write_a(d0, 0, ra0, rz0);
-        next_tile(d2);
-        load_a(d2, ra0, rz0);
-        next_tile(d3);
-        fetch_tab(d1);
+        write_a(d0, 0, ra[0], rz[0]);
+        next_tile(dq[NA - 1]);                     // tile NA into the freed set 0
+        load_a(dq[NA - 1], ra[0], rz[0]);
+        next_tile(dq[NA]);
+        fetch_tab(dq[0]);
     }
     // One K step.  Order after the barrier: the fragment reads of tile t go out first (their LDS latency is covered by the VALU
     // work of write_a), then tile t+1's activations are written, the transfers of tiles t+2 / t+3 requested, and the MFMAs of
@@ -281,7 +292,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_pair<PAIR>(ah[mi].u, bh[q].u, acc[mi][nh * 2 + q]);
     };
     auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
-        gload_wait_n<WPIECES + 2>();                           // (the newest step's DMA pieces + 2 activation loads stay in flight)
+        // (the newest step's DMA pieces + 2 activation loads stay in flight -- and, with a third register set, the two activation
+        //  loads of the step before: they are younger than the weights this step needs, which the in-order counter therefore allows)
+        gload_wait_n<WPIECES + 2 + 2 * (NA - 2)>();
         __syncthreads();
         const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
         const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * (TN / 2) * ROWB;
@@ -298,7 +311,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
                 bl[q].u = *(const uint4*)(sW + q * 32 * ROWB + olo);
             }
         }
-        if (wr_next) write_a(d1, (t + 1) & 1, ra, rz);          // tile t+1: registers -> LDS (its set is then free for tile t+3)
+        if (wr_next) write_a(dq[0], (t + 1) & 1, ra, rz);       // tile t+1: registers -> LDS (its set is then free for tile t+1+NA)
         if (!(abl & 2)) {
             if (do_mma) mma3(0, ah, al, bh, bl);
             if (NI == 4) {
@@ -312,16 +325,19 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
         // the transfers of tiles t+2 / t+3 are requested AFTER the step's MFMAs have been issued: when the memory system pushes
         // back, a wave stalls at the ISSUE of a VMEM instruction, and everything behind it in program order waits with it
-        dma_w(d2, (t + 2) % 3);
-        load_a(d3, ra, rz);
-        d1 = d2; d2 = d3; next_tile(d3);
-        fetch_tab(d1);                                          // (for the next step's write_a)
+        dma_w(dq[1], (t + 2) % 3);
+        load_a(dq[NA], ra, rz);
+#pragma unroll
+        for (int i = 0; i < NA; ++i) dq[i] = dq[i + 1];
+        next_tile(dq[NA]);
+        fetch_tab(dq[0]);                                       // (for the next step's write_a)
     };
-    for (int t = 0; t < ntile; t += 2) {
-        // even step: tile t+1 lives in set 1; odd step: tile t+2 in set 0.  Past the last tile the odd step still runs its
+    for (int t = 0; t < ntile; t += NA) {
+        // step t + u: tile t+u+1 lives in set (u + 1) % NA.  Past the last tile the remaining steps of the trip still run their
         // (re-requested, unused) transfers so that the loop has ONE exit and the counted waits stay exact.
-        step(t, t + 1 < ntile, true, ra1, rz1);
-        step(t + 1, t + 2 < ntile, t + 1 < ntile, ra0, rz0);
+        step(t, t + 1 < ntile, true, ra[1 % NA], rz[1 % NA]);
+        step(t + 1, t + 2 < ntile, t + 1 < ntile, ra[2 % NA], rz[2 % NA]);
+        if constexpr (NA == 3) step(t + 2, t + 3 < ntile, t + 2 < ntile, ra[0], rz[0]);
     }
     gload_wait_n<0>();                 // (the re-requested tiles past the end: nothing may land in LDS after this point)
     __syncthreads();

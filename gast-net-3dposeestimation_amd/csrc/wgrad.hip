@@ -387,6 +387,9 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
 //     fma + max against a lower clamp that is -inf for a prologue-free segment);
 //   * the step count is padded to an even number and the loads / row tables run two tiles past the end (all out of range).
 // 72 KB of LDS: two blocks per CU.
+#ifndef WG_ABLATE
+#define WG_ABLATE 0
+#endif
 constexpr int wgrad_x3_pipe_lds_bytes() { return 2 * 2 * BT * LSTR; }
 constexpr uint32_t WG_OOB = 0xFFFF0000u;      // buffer size == first out-of-range byte offset (wgrad_check bounds the operands)
 typedef int wg_i32x4 __attribute__((ext_vector_type(4)));
@@ -412,7 +415,12 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
 
     const int op = __builtin_amdgcn_readfirstlane(w >> 1);               // 0: dC (P) staging waves, 1: activation (Q) staging waves
     const int task = tid & (BT - 1);
-    const int mb = task & 3, rc = task >> 2;
+    // lane -> (8-row block mb, column quad rc): the four lanes of a QUAD read 64 contiguous bytes of ONE row.  The texture addresser
+    // coalesces a 16-byte-per-lane load over adjacent lanes only: with the row block as the fastest index (lanes 0..3 = four different
+    // rows) every lane was its own request and the launches took 11 % longer (round 4: 166 / 555 / 142 -> 144 / 491 / 128 us on the
+    // three stages, scripts/r4_wg_map.sh; 8 or 16 lanes per row piece are no better than 4).  The LDS side does not care: a group
+    // of 8 lanes still writes 8 different 4-bank groups.
+    const int mb = (task >> 2) & 3, rc = ((task >> 4) << 2) | (task & 3);
     const float* base = op == 0 ? (const float*)a.P : (const float*)sg.Q;
     const int ld = op == 0 ? a.ldp : sg.ldq;
     const int col = (op == 0 ? tc.rt : tc.st) * BT + rc * 4;
@@ -465,12 +473,26 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
         const uint4 r0 = rp[0], r1 = rp[1];
         S.off[0] = r0.x + colbytes; S.off[1] = r0.y + colbytes; S.off[2] = r0.z + colbytes; S.off[3] = r0.w + colbytes;
         S.off[4] = r1.x + colbytes; S.off[5] = r1.y + colbytes; S.off[6] = r1.z + colbytes; S.off[7] = r1.w + colbytes;
+#if WG_ABLATE == 1        // profiling build: no operand loads at all
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" : "=v"(S.rl[i]));
+#elif WG_ABLATE == 2      // profiling build: every load inside one 64 KB window (cache-resident operands)
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            S.rl[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(S.off[i] & 0xFFF0u), 0, 0));
+#else
 #pragma unroll
         for (int i = 0; i < 8; ++i)
             S.rl[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)S.off[i], 0, 0));
+#endif
     };
     auto store_tile = [&](const Set& S, unsigned char* stage, auto opc) {
         constexpr int OP = decltype(opc)::value;
+#if WG_ABLATE == 4        // profiling build: no conversion, no LDS write (the loads are still waited for)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) asm volatile("" :: "v"(S.rl[i]));
+        return;
+#endif
         float x[8][4];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
@@ -507,6 +529,9 @@ __device__ __forceinline__ void wgrad_x3_pipe_body(unsigned char* smem, const ga
         }
     };
     auto mfma_tile = [&](const unsigned char* stage) {
+#if WG_ABLATE == 3        // profiling build: no fragment reads, no MFMAs
+        return;
+#endif
         const unsigned char* const sP = stage;
         const unsigned char* const sQ = stage + BT * LSTR;
 #pragma unroll
@@ -645,7 +670,11 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
 
     // staging role: the first TILE threads stage P, the others Q; each thread owns an 8(m) x 8(col) block
     const int op = tid / TILE, task = tid - op * TILE;
-    const int mb = task & 7, rc = task >> 3;
+    // lane -> (8-row block mb, 8-column group rc): a quad of lanes reads 64 contiguous bytes of one row (see wgrad_x3_pipe_body);
+    // column groups 2, 3 (mod 4) store their 16-byte slots with slot bit 1 flipped so that a group of 8 lanes -- four column groups x
+    // two row blocks -- writes 8 different 4-bank groups (LSTR = 36 banks: column groups g and g + 2 would share one)
+    const int mb = (task >> 2) & 7, rc = ((task >> 5) << 2) | (task & 3);
+    const int wslot = mb ^ (((rc >> 1) & 1) << 1);
     const bf16_t* base = op == 0 ? (const bf16_t*)a.P : (const bf16_t*)sg.Q;
     const int ld = op == 0 ? a.ldp : sg.ldq;
     const int col = (op == 0 ? tc.rt : tc.st) * TILE + rc * 8;
@@ -730,19 +759,20 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
         uint4 tr[8];
         transpose8x8_bf16(rl, tr);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + mb * 16) = tr[q];
+        for (int q = 0; q < 8; ++q) *(uint4*)(sdst + (rc * 8 + q) * LSTR + wslot * 16) = tr[q];
     };
 
+    const int rswz = ((li >> 4) & 1) << 1;      // (the slot swizzle of the staging writes: row = 32 * n + li, column group = row >> 3)
     auto mfma_tile = [&]() {
 #pragma unroll
         for (int kc = 0; kc < 4; ++kc) {
             union { uint4 u; s16x8 s; } fa[MI], fb[2];
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-                fa[mi].u = *(const uint4*)(sP + (wr * WROWS + mi * 32 + li) * LSTR + (kc * 2 + lh) * 16);
+                fa[mi].u = *(const uint4*)(sP + (wr * WROWS + mi * 32 + li) * LSTR + ((kc * 2 + lh) ^ rswz) * 16);
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni)
-                fb[ni].u = *(const uint4*)(sQ + (wc * 64 + ni * 32 + li) * LSTR + (kc * 2 + lh) * 16);
+                fb[ni].u = *(const uint4*)(sQ + (wc * 64 + ni * 32 + li) * LSTR + ((kc * 2 + lh) ^ rswz) * 16);
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll

@@ -155,6 +155,8 @@ def load_library(h16=torch.bfloat16):
     if lib is not None:
         return lib
     path = LIB_PATH_F16 if h16 == torch.float16 else LIB_PATH
+    if h16 != torch.float16 and os.environ.get('GAST_HIP_LIB_EXPERIMENT'):      # kernel A/B builds (scripts/): a sibling library by suffix
+        path = os.path.join(_HERE, 'libgast_hip_%s.so' % os.environ['GAST_HIP_LIB_EXPERIMENT'])
     if not os.path.exists(path):
         raise RuntimeError('gast_hip: %s not found -- build it with `python -c "import __graft_entry__ as g; g.build()"` '
                            '(hipcc --offload-arch=gfx950). There is no CPU/PyTorch fallback.' % path)
