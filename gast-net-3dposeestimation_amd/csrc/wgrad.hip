@@ -14,6 +14,7 @@
 // M is split over blockIdx (split-M) and partial 128x128 tiles are combined with fp32 atomics into the zero-filled
 // gradient buffer.
 #include "common.h"
+#include "wgrad_common.h"
 #include <type_traits>
 
 namespace {
@@ -21,41 +22,6 @@ namespace {
 constexpr int BT = 128;      // output tile (rows of dW x cols of dW)
 constexpr int LSTR = 144;    // bf16: LDS row stride in bytes
 constexpr int FSTR = 132;    // fp32: LDS row stride in floats
-
-struct TileCoord { int rt, seg, st; };
-
-__device__ __forceinline__ TileCoord decode_tile(const gast_wgrad_args& a, int tile, int tilesS_total, int bt = BT) {
-    TileCoord c;
-    c.rt = tile / tilesS_total;
-    int rem = tile - c.rt * tilesS_total;
-    c.seg = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        int ts = (a.seg[s].S + bt - 1) / bt;
-        if (rem < ts) { c.seg = s; break; }
-        rem -= ts;
-    }
-    c.st = rem;
-    return c;
-}
-
-__device__ __forceinline__ bool is_ident(const gast_rowmap& mp, int Tn) { return mp.t_stride == 1 && mp.t_off == 0 && mp.T_total == Tn; }
-
-__device__ __forceinline__ void rows_for(const gast_wgrad_args& a, const gast_wgrad_seg& sg, int m, int M,
-                                         int& prow, int& qrow) {
-    prow = -1; qrow = -1;
-    if (is_ident(a.pmap, a.Tn) && is_ident(sg.map, a.Tn)) {     // (most jobs: no integer divisions on the per-step path)
-        if (m < M) { prow = m; qrow = m; }
-        return;
-    }
-    if (m < M) {
-        int TJ = a.Tn * a.J;
-        int b = m / TJ, rem = m - b * TJ;
-        int t = rem / a.J, j = rem - t * a.J;
-        prow = (int)map_row(a.pmap, b, t, j, a.J);
-        qrow = (int)map_row(sg.map, b, t, j, a.J);
-        if (prow < 0 || qrow < 0) { prow = -1; qrow = -1; }
-    }
-}
 
 // ------------------------------------------------------------------------------------------------ fp32
 __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
@@ -67,7 +33,7 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const TileCoord tc = decode_tile(a, tile, tilesS_total);
+    const TileCoord tc = decode_tile(a, tile, tilesS_total, BT);
     const gast_wgrad_seg& sg = a.seg[tc.seg];
     const int m_begin = sp * mchunk;
     const int m_end = min(M, m_begin + mchunk);
@@ -193,7 +159,7 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
 // registers -- gets the m-major -> col-major transposition for free: LDS rows are [col][hi: 32 m = 64 B | lo: 64 B] (+16 B pad) and
 // the MFMA loop is gast_gemm's split loop: hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulation.
 // TILE = edge of the square dW tile: 128 (4 waves as 2x2 of 64x64, three blocks per CU) or 256 (8 waves as 2x4 of 128x64, one block
-// per CU, GAST_WGRAD_X3_TILE=256: every staged operand value -- prologue, hi/lo split, transposing pack -- then feeds twice the MFMAs).
+// per CU: the round-2 form of the wide tile, no longer launched -- wgrad_wide.hip is its pipelined successor).
 // DROP: some segment re-derives a dropout mask in its prologue (compile-time: without it the staging pass needs neither the per-row
 // element offsets -- eight serialised LDS reads per step -- nor the hash)
 template <int TILE, bool DROP>
@@ -847,40 +813,6 @@ __global__ void __launch_bounds__(256, 3) wgrad_bf16_kernel(const gast_wgrad_arg
     wgrad_bf16_body<128>(smem, a, M, tilesS_total, mchunk, tile, blockIdx.x - tile * splitM);
 }
 
-// Several weight gradients in ONE launch (gast_wgrad_multi): the split-M atomics cost 30-60 % of a stand-alone weight-gradient
-// launch because every launch needs >= 768 blocks by itself, i.e. 768 partial 128x128 tiles (50 MB of fp32 atomics) whatever
-// its size.  Sharing the block budget among all the weight gradients of a stage divides that volume by their number and
-// leaves one tail instead of one per launch.
-struct WgBatch {
-    gast_wgrad_args a[GAST_WGRAD_MAX_BATCH];
-    int first[GAST_WGRAD_MAX_BATCH + 1];     // first block of each job
-    int M[GAST_WGRAD_MAX_BATCH], tilesS[GAST_WGRAD_MAX_BATCH], splitM[GAST_WGRAD_MAX_BATCH], mchunk[GAST_WGRAD_MAX_BATCH];
-    int tfirst[GAST_WGRAD_MAX_BATCH + 1];    // chunk-major order: first output tile of each job among all tiles of the batch
-    int n, chunk_major;
-};
-// block -> (job, output tile, M chunk).  chunk_major: logical blocks are ordered (M chunk, job, tile) and an XCD owns a contiguous
-// logical range (xcd_remap), so the blocks that run together on one L2 reduce over the SAME rows: the P / Q panels that the
-// tiles of a job -- and the jobs of a stage -- share are read from HBM once.  (PMC: 684 MB per launch for 244 MB of operands in
-// tile-major order.)  Measured: the step is 3 % SLOWER with it (3.29 vs 3.20 ms) -- opt-in via GAST_WGRAD_ORDER=1.
-__device__ __forceinline__ bool wg_decode(const WgBatch& b, int& d, int& tile, int& sp) {
-    if (b.chunk_major) {
-        const int lb = xcd_remap(blockIdx.x, gridDim.x);
-        const int total = b.tfirst[b.n];
-        sp = lb / total;
-        const int r = lb - sp * total;
-        d = 0;
-        while (d + 1 < b.n && r >= b.tfirst[d + 1]) ++d;
-        tile = r - b.tfirst[d];
-        return sp < b.splitM[d];
-    }
-    d = 0;
-    while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    const int lb = blockIdx.x - b.first[d];
-    tile = lb / b.splitM[d];
-    sp = lb - tile * b.splitM[d];
-    return true;
-}
-static_assert(sizeof(WgBatch) <= 8192, "WgBatch travels by value in the HSA kernarg segment (4.4 KB; no 4 KB CUDA-style limit on gfx950)");
 __global__ void __launch_bounds__(256, 3) wgrad_f32_multi_kernel(const WgBatch b) {
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
@@ -893,19 +825,12 @@ __global__ void __launch_bounds__(256, 3) wgrad_x3_multi_kernel(const WgBatch b)
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_x3_body<BT, DROP>(smem, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
-// 256x256 tiles (GAST_WGRAD_X3_TILE=256): 512 threads, 72 KB of dynamic LDS, one block per CU
 template <bool DROP, int NP>
 __global__ void __launch_bounds__(256, 2) wgrad_x3_pipe_multi_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3p[];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
     wgrad_x3_pipe_body<DROP, NP>(dsmem_x3p, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
-}
-__global__ void __launch_bounds__(512, 2) wgrad_x3_multi256_kernel(const WgBatch b) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_x3[];
-    int d, tile, sp;
-    if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_body<256, true>(dsmem_x3, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 __global__ void __launch_bounds__(256, 3) wgrad_bf16_multi_kernel(const WgBatch b) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[wgrad_bf16_lds_bytes(128)];
@@ -1005,8 +930,21 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     // on the C=256 stage (19 vs 74 tiles), 111 vs 86 us on the C=512 stage, 124 vs 105 us on the C=128 stage.  Kept for the
     // next step (a second LDS stage / loader waves), not selected by default.
     static const int tile_env = getenv("GAST_WGRAD_TILE") ? atoi(getenv("GAST_WGRAD_TILE")) : 128;
-    static const int x3_tile_env = getenv("GAST_WGRAD_X3_TILE") ? atoi(getenv("GAST_WGRAD_X3_TILE")) : 128;
-    const int bt = ((args[0].dtype == GAST_BF16 && tile_env == 256) || (args[0].dtype == GAST_F32X3 && x3_tile_env == 256)) ? 256 : BT;
+    // bf16x3: 256 x 256 tiles (wgrad_wide.hip) when the job set fills them -- at least 3/4 of the tile area carries outputs (the
+    // C = 256 and M = B*J stages: 0.93 - 0.95; the C = 128 stage's 128-wide matrices: 0.5, slower there) -- GAST_WGRAD_X3_TILE=128 / 256 forces
+    static const int x3_tile_env = getenv("GAST_WGRAD_X3_TILE") ? atoi(getenv("GAST_WGRAD_X3_TILE")) : 0;
+    bool x3_wide = x3_tile_env == 256;
+    if (args[0].dtype == GAST_F32X3 && x3_tile_env == 0) {
+        double used = 0, area = 0;
+        for (int d = 0; d < n; ++d) {
+            long ts = 0, ssum = 0;
+            for (int q = 0; q < args[d].nseg && q < GAST_MAX_SEG; ++q) { ts += (args[d].seg[q].S + 255) / 256; ssum += args[d].seg[q].S; }
+            used += (double)args[d].R * ssum;
+            area += (double)((args[d].R + 255) / 256) * ts * 65536.0;
+        }
+        x3_wide = area > 0 && used >= 0.75 * area;
+    }
+    const int bt = ((args[0].dtype == GAST_BF16 && tile_env == 256) || (args[0].dtype == GAST_F32X3 && x3_wide)) ? 256 : BT;
     long tile_rows = 0;
     int total_tiles = 0;
     for (int d = 0; d < n; ++d) {
@@ -1020,11 +958,27 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     static const int tgt128 = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
     static const int tgt256 = getenv("GAST_WGRAD_BLOCKS256") ? atoi(getenv("GAST_WGRAD_BLOCKS256")) : 512;   // one resident block per CU
     static const int ring = getenv("GAST_WGRAD_RING") ? atoi(getenv("GAST_WGRAD_RING")) : 1;
-    const int tgt = bt == 256 ? tgt256 : tgt128;
+    const bool wide = args[0].dtype == GAST_F32X3 && bt == 256;      // wgrad_wide.hip: one 4-wave block per CU
+    static const int tgt_wide = getenv("GAST_WGRAD_BLOCKS_WIDE") ? atoi(getenv("GAST_WGRAD_BLOCKS_WIDE")) : 256;
+    const int tgt = wide ? tgt_wide : bt == 256 ? tgt256 : tgt128;
     // one common chunk length (rows of the reduction axis per block) so that every block does the same number of steps
     long chunk = (tile_rows + tgt - 1) / tgt;
     chunk = (chunk + bkm - 1) / bkm * bkm;
     if (chunk < 4 * bkm) chunk = 4 * bkm;
+    if (wide) {
+        // one resident block per CU: the block count is quantised against the 256 slots (266 blocks take twice as long as 256), so
+        // the chunk is the shortest multiple of the kernel's 96-row trip whose launch fits a whole number of rounds
+        auto blocks_for = [&](long c) {
+            long nb = 0;
+            for (int d = 0; d < n; ++d) nb += (long)tilesR[d] * b.tilesS[d] * ((b.M[d] + c - 1) / c);
+            return nb;
+        };
+        long maxM = 0;
+        for (int d = 0; d < n; ++d) if (b.M[d] > maxM) maxM = b.M[d];
+        const long slots = (long)tgt * ((total_tiles + tgt - 1) / tgt);
+        chunk = 96;
+        while (chunk < maxM && blocks_for(chunk) > slots) chunk += 96;
+    }
     const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS");
     if (ring2) {
         // two blocks per CU: the block count is quantised against 512 slots (518 blocks run 1.33x slower than 444), so pick
@@ -1058,7 +1012,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     // bf16x3 kernel: chunk-major (PMC: 2.38 -> 1.07 GB fetched from HBM per launch on the C=256 stage, 535 -> 506 us)
     static const int order = getenv("GAST_WGRAD_ORDER") ? atoi(getenv("GAST_WGRAD_ORDER")) : -1;
     static const int x3_pipe = getenv("GAST_WGRAD_X3_PIPE") ? atoi(getenv("GAST_WGRAD_X3_PIPE")) : 1;
-    b.chunk_major = order >= 0 ? order : (args[0].dtype == GAST_F32X3 && bt == BT && x3_pipe) ? 1 : 0;
+    b.chunk_major = order >= 0 ? order : (args[0].dtype == GAST_F32X3 && ((bt == BT && x3_pipe) || wide)) ? 1 : 0;
     for (int d = 0; d < n; ++d) {
         b.mchunk[d] = (int)(chunk < b.M[d] ? chunk : (b.M[d] + bkm - 1) / bkm * bkm);
         b.splitM[d] = (b.M[d] + b.mchunk[d] - 1) / b.mchunk[d];
@@ -1073,16 +1027,14 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     dim3 grid(b.chunk_major ? max_split * b.tfirst[n] : b.first[n]);
     if (args[0].dtype == GAST_F32)
         hipLaunchKernelGGL(wgrad_f32_multi_kernel, grid, dim3(256), 0, st, b);
-    else if (args[0].dtype == GAST_F32X3 && bt == 256) {
-        constexpr int lds = 2 * 256 * LSTR;
-        const hipError_t attr = wgrad_dyn_lds((const void*)wgrad_x3_multi256_kernel, lds);
-        if (attr != hipSuccess) return (int)attr;
-        hipLaunchKernelGGL(wgrad_x3_multi256_kernel, grid, dim3(512), lds, st, b);
-    } else if (args[0].dtype == GAST_F32X3) {
+    else if (args[0].dtype == GAST_F32X3) {
         bool any_drop = false;
         for (int d = 0; d < n; ++d)
             for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
-        if (x3_pipe) {
+        if (wide) {
+            const int rcw = gast_wgrad_x3_wide_launch(b, grid.x, any_drop, st);
+            if (rcw) return rcw;
+        } else if (x3_pipe) {
             constexpr int lds = wgrad_x3_pipe_lds_bytes();
             static const int np_env = getenv("GAST_WGRAD_X3_PRODUCTS") ? atoi(getenv("GAST_WGRAD_X3_PRODUCTS")) : 3;
             typedef void (*kern_t)(const WgBatch);

@@ -556,7 +556,32 @@ def test_wgrad_multi(ops, mode):
         close(host(jd['dW']), jh['dW'], dt, 'multi ' + WGRAD_CASES[i][0], fp32=1e-4 if mode == 'x3' else 3e-5, bf16=2e-2)
 
 
+WGRAD_WIDE_CASES = [      # job sets that fill 256 x 256 tiles (the library then picks wgrad_wide.hip): edge tiles, taps, prologue, dropout, ragged chunk
+    ('wide_taps_drop', (6, 9, 17), 512, [(256, 11, 1, 0, 1, 0), (256, 11, 1, 2, 2, 256)]),
+    ('wide_edge', (6, 9, 17), 488, [(256, 9, 1, 0, 0, 0)]),
+    ('wide_concat', (6, 9, 17), 256, [(512, 9, 1, 0, 1, 0), (256, 9, 1, 0, 2, 512)]),
+]
+
+
+def test_wgrad_multi_wide_tiles(ops):
+    """bf16x3 weight gradients of matrices that fill 256 x 256 tiles: one launch of wgrad_wide.hip (8 waves, three tiles of operand
+    rows in flight) -- several output tiles per job, an edge tile (R = 488), dilated taps, the BN+ReLU and dropout prologues, and 918
+    reduction rows in chunks of 96 (a ragged last chunk).  GAST_WGRAD_X3_TILE=128 (test_optin_kernel_variants) runs the same jobs on
+    the 128 x 128 kernel."""
+    jobs = [_wgrad_case(c, torch.float32) for c in WGRAD_WIDE_CASES]
+    for i, (jd, jh) in enumerate(jobs):
+        jd['zero_first'] = i % 2 == 0
+    with x3_mode(ops, 'x3'):
+        ops.wgrad_multi([jd for jd, _ in jobs])
+    torch.cuda.synchronize()
+    for i, (jd, jh) in enumerate(jobs):
+        kc.wgrad(jh['dom'], jh['P'], jh['R'], jh['pmap'], jh['segs'], jh['dW'], jh['drop'], i % 2 == 0)
+        close(host(jd['dW']), jh['dW'], torch.float32, 'wide ' + WGRAD_WIDE_CASES[i][0], fp32=1e-4)
+
+
 @pytest.mark.parametrize('knob,select,npass', [('GAST_WGRAD_TILE=256', 'test_wgrad_multi and bf16', 1),
+                                               ('GAST_WGRAD_X3_TILE=256', 'test_wgrad_multi and x3', 1),
+                                               ('GAST_WGRAD_X3_TILE=128', 'test_wgrad_multi_wide_tiles', 1),
                                                ('GAST_WGRAD_RING=2', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_ORDER=1', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_X3_PIPE=0', 'test_wgrad_multi and x3', 1),
@@ -565,7 +590,8 @@ def test_wgrad_multi(ops, mode):
                                                ('GAST_GEMM_BIG_MW=4', 'test_gemm_big_x3', None),
                                                ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
 def test_optin_kernel_variants(knob, select, npass):
-    """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles, two
+    """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles (forced on
+    the small cases / forced off on the wide ones for the bf16x3 kernels), two
     register sets in flight, chunk-major block order, the un-pipelined bf16x3 weight-gradient kernel, both tile widths of the large-M GEMM on every case, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
     in a child process."""
     import os
