@@ -390,6 +390,7 @@ def main():
                          'backward pass of the shallower stages runs (default: one all-reduce between the two graphs of the step)')
     ap.add_argument('--no-parity', action='store_true', help='skip the parity object (timed arithmetic vs fp32 HIP path vs CPU restatement)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-parity', action='store_true', help='with --no-cpu-baseline: still run the CPU restatement FORWARD for the parity object (not its timing)')
     ap.add_argument('--stock-baseline', action='store_true',
                     help='the stock PyTorch-ROCm comparator (SURVEY 8d; fp32, 3 steps by default) also in autocast-bf16 and with a longer sample')
     ap.add_argument('--no-stock-baseline', action='store_true', help='skip the stock PyTorch-ROCm comparator')
@@ -506,7 +507,7 @@ def main():
                                     'mpjpe_mm': 0.1,
                                     'source': 'BASELINE.json north_star: 1e-4 fp32 / 1e-2 bf16, MPJPE within 0.1 mm; bf16x3 '
                                               '(fp32 storage, hi/lo split products) is held to the fp32 bound'}}
-            if world == 1 and not args.no_cpu_baseline:
+            if world == 1 and (not args.no_cpu_baseline or args.cpu_parity):
                 yc, lc = cpu_reference_forward(sd, adj, arc, C, x, y3d)
                 dc = float((outs[args.dtype][0].cpu() - yc).abs().max())
                 parity['vs_cpu_reference_restatement'] = {'max_abs': dc, 'mpjpe_shift_mm': abs(outs[args.dtype][1] - lc) * 1e3,

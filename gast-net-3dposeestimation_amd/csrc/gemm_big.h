@@ -6,6 +6,7 @@ struct BigPlan {
     int M, tilesM, tilesN;
     int ni;                       // 32-column MFMA tiles per wave: 4 = 256-column block tile, 2 = 128
     int mw;                       // 64-row wave rows per block: 2 = 128-row block tile (256 threads), 4 = 256 rows (512 threads)
+    int depth;                    // prefetch distance in K steps: 2, or 4 (NI = 2, MW = 2 only: the M = B*J stage, GAST_GEMM_BIG_DEEP)
     int pair;                     // operand pairs: 1 = bf16 hi/lo (GAST_F32X3), 2 = fp16 hi/lo (GAST_F32X3H, forward epilogues only)
     int ntab;                     // floats in the scale table (= in the shift table) a block keeps in LDS
     int taboff[GAST_MAX_SEG];     // offset of the segment's scale/shift in the tables (-1: no prologue)

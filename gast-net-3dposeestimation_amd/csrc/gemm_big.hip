@@ -44,8 +44,8 @@ constexpr int off_w(int mw) { return off_a(mw) + 2 * a_bytes(mw); }    // three 
 constexpr int lds_block(int mw) { return mw == 2 ? 80 * 1024 : 160 * 1024; }
 constexpr int tn_of(int ni) { return 64 * ni; }
 constexpr int w_bytes(int ni) { return tn_of(ni) * ROWB; }             // 16 KB / 8 KB
-constexpr int off_tab(int ni, int mw) { return off_w(mw) + 3 * w_bytes(ni); }      // scale | shift tables
-constexpr int max_tab(int ni, int mw) { return (lds_block(mw) - off_tab(ni, mw) - 6 * nt_of(mw) * 4) / 8; }
+constexpr int off_tab(int ni, int mw, int d = 2) { return off_w(mw) + (d + 1) * w_bytes(ni); }      // scale | shift tables behind the d + 1 weight stages
+constexpr int max_tab(int ni, int mw, int d = 2) { return (lds_block(mw) - off_tab(ni, mw, d) - 6 * nt_of(mw) * 4) / 8; }
 
 // 16 bytes per lane global -> LDS (DMA): address = sbase + voff + OFF; lands at lds_wave_base + 16 * lane
 template <int OFF>
@@ -60,10 +60,14 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived (compile-time: the
 // epilogue is straight-line code per element); ADD: an addend tensor is present
 // PAIR: 1 = bf16 hi/lo pairs (GAST_F32X3), 2 = fp16 pairs (GAST_F32X3H: the forward GEMMs; weight images of the f16 kind)
-template <int EPI, bool ADD, int NI, int MW, int PAIR>
+// D = prefetch distance in K steps (both operands): 2 (the large-M launches: two or three resident blocks per CU cover each other) or 4
+// (NI = 2 only, the M = B*J stage: at most a block or two per CU, so a block has to cover the memory latency by itself -- five weight
+// stages, four activation register sets, 57 KB of LDS)
+template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
     constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
-    constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW);
+    constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW, D);
+    constexpr int WS = D + 1;                       // weight stages in the ring
     constexpr int WROWS = TN / (2 * MW);            // weight rows a wave's DMA fills per K step
     constexpr int WPIECES = WROWS / 16;             // ... in 16-row (1 KB) pieces: 4, 2 or 1
     static_assert(WPIECES >= 1, "tile too narrow for the wave count");
@@ -158,13 +162,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
     };
 
-    // NA register sets of activation tiles in flight (GAST_BIG_NA, default 2; 3 = experiment: one more K step of latency tolerance for
-    // the activation stream -- the only operand that comes from HBM -- at 8 more registers; see the pipeline comment below)
-#ifndef GAST_BIG_NA
-#define GAST_BIG_NA 2
-#endif
-    constexpr int NA = GAST_BIG_NA;
-    static_assert(NA == 2 || NA == 3, "two or three activation register sets");
+    // NA = D register sets of activation tiles.  (Round 4, large-M launches: a THIRD set with the weights still at distance 2 changed
+    // nothing -- 3.759 / 3.784 vs 3.750 / 3.774 ms -- the activation stream's latency is not what those launches wait for.)
+    constexpr int NA = D;
+    static_assert(D == 2 || D == 4, "prefetch distance 2 or 4");
     u32x4 ra[NA][2];
     bool rz[NA][2];
 #ifdef GAST_GEMM_BIG_ABLATION
@@ -235,10 +236,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const int fkey = (li >> 2) & 3;
     const int ohi = li * ROWB + ((lh ^ fkey) << 4), olo = li * ROWB + (((2 + lh) ^ fkey) << 4);
 
-    // ---- pipeline.  Tile j's activations travel in register set j & 1 and LDS stage j & 1, its weights in stage j % 3.
-    // Invariant at the top of iteration t (after the counted wait + barrier): LDS holds tile t; set (t+1)&1 holds tile t+1's
-    // activations; in flight: the weights of tile t+1 and the activations of tile t+2.
-    // dq[i] = tile t+1+i at the top of step t: dq[0] is written to LDS, dq[1]'s weights are requested, dq[NA]'s activations are loaded
+    // ---- pipeline.  Tile j's activations travel in register set j % D and LDS stage j & 1, its weights in stage j % (D + 1).
+    // Invariant at the top of iteration t (after the counted wait + barrier): LDS holds tile t; set (t+1) % D holds tile t+1's
+    // activations; in flight: the weights of tiles t+1 .. t+D-1 and the activations of tiles t+2 .. t+D.
+    // dq[i] = tile t+1+i at the top of step t: dq[0] is written to LDS, dq[D-1]'s weights are requested, dq[D]'s activations are loaded
     Tile dq[NA + 1];
     {
         Tile d0;
@@ -248,7 +249,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
 #pragma unroll
         for (int i = 1; i < NA; ++i) {             // tiles 1 .. NA-1 into sets 1 .. NA-1
             next_tile(dq[i - 1]);
-            if (i == 1) dma_w(dq[0], 1);
+            dma_w(dq[i - 1], i);
             load_a(dq[i - 1], ra[i], rz[i]);
         }
         for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
@@ -291,13 +292,14 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
 #pragma unroll
             for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_pair<PAIR>(ah[mi].u, bh[q].u, acc[mi][nh * 2 + q]);
     };
+    int wstage = 0;                    // t % (D + 1): the weight stage of the tile the step multiplies
     auto step = [&](int t, bool wr_next, bool do_mma, u32x4 (&ra)[2], bool (&rz)[2]) {
-        // (the newest step's DMA pieces + 2 activation loads stay in flight -- and, with a third register set, the two activation
-        //  loads of the step before: they are younger than the weights this step needs, which the in-order counter therefore allows)
-        gload_wait_n<WPIECES + 2 + 2 * (NA - 2)>();
+        // (the DMA pieces + 2 activation loads of the newest D - 1 steps stay in flight: everything step t - D requested -- the weights
+        //  of tile t, the activations of tile t + 1 -- is older and therefore complete)
+        gload_wait_n<(D - 1) * (WPIECES + 2)>();
         __syncthreads();
         const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
-        const unsigned char* sW = smem + OFF_W + (t % 3) * W_BYTES + wc * (TN / 2) * ROWB;
+        const unsigned char* sW = smem + OFF_W + wstage * W_BYTES + wc * (TN / 2) * ROWB;
         Frag ah[2], al[2], bh[2], bl[2];
         if (!(abl & 2)) {
 #pragma unroll
@@ -325,8 +327,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
         // the transfers of tiles t+2 / t+3 are requested AFTER the step's MFMAs have been issued: when the memory system pushes
         // back, a wave stalls at the ISSUE of a VMEM instruction, and everything behind it in program order waits with it
-        dma_w(dq[1], (t + 2) % 3);
+        dma_w(dq[D - 1], wstage == 0 ? WS - 1 : wstage - 1);     // tile t + D -> stage (t + D) % (D + 1) = the stage before tile t's
         load_a(dq[NA], ra, rz);
+        wstage = wstage == WS - 1 ? 0 : wstage + 1;
 #pragma unroll
         for (int i = 0; i < NA; ++i) dq[i] = dq[i + 1];
         next_tile(dq[NA]);
@@ -337,9 +340,21 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         // (re-requested, unused) transfers so that the loop has ONE exit and the counted waits stay exact.
         step(t, t + 1 < ntile, true, ra[1 % NA], rz[1 % NA]);
         step(t + 1, t + 2 < ntile, t + 1 < ntile, ra[2 % NA], rz[2 % NA]);
-        if constexpr (NA == 3) step(t + 2, t + 3 < ntile, t + 2 < ntile, ra[0], rz[0]);
+        if constexpr (NA == 4) {
+            step(t + 2, t + 3 < ntile, t + 2 < ntile, ra[3], rz[3]);
+            step(t + 3, t + 4 < ntile, t + 3 < ntile, ra[0], rz[0]);
+        }
     }
     gload_wait_n<0>();                 // (the re-requested tiles past the end: nothing may land in LDS after this point)
+    // ... nor in REGISTERS: the activation loads of the tiles past the end are never consumed, so the compiler considers their
+    // destination registers dead from the moment the load is issued and may park an epilogue value there -- computed ABOVE the
+    // wait (only memory operations keep their place relative to an asm statement) and overwritten when the load lands.  Seen
+    // with four sets in flight (round 4: a column's scale pointer, i.e. a memory fault).  An empty asm that reads every set
+    // after the wait keeps them allocated until here.
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        asm volatile("" ::"v"(ra[i][0]), "v"(ra[i][1]));
+    }
     __syncthreads();
 
     if (abl & 32) { if (acc[0][0][0] == 12345.678f) ((float*)a.C)[0] = acc[1][NI - 1][5] + acc[0][1][2] + acc[1][0][1] + acc[1][1][1]; return; }
@@ -476,10 +491,10 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
     return e * 2 + (a.addend ? 1 : 0);
 }
 
-template <int EPI, bool ADD, int NI, int MW, int PAIR>
+template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
 __global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD, NI, MW, PAIR>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -490,12 +505,12 @@ struct BigBatch {
 };
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
-template <int EPI, bool ADD, int NI, int MW, int PAIR>
+template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
 __global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD, NI, MW, PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -541,14 +556,23 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     // Round 3: the short-K GEMMs of the M = B*J stage may take this kernel WITHOUT split-K (GAST_GEMM_BIG_SMALL_MIN_M rows and up, sum K
     // <= GAST_GEMM_BIG_SMALL_MAX_K): a lone block needs ~0.6 us per 16-deep K step, so 32 steps cost what gemm.hip's split-K kernel +
     // finish pair costs, without the partial-tile round trip
+    // Round 4: with prefetch distance FOUR (GAST_GEMM_BIG_DEEP, five weight stages and four activation register sets at the 128 x 128 tile)
+    // a lone block covers the memory latency by itself
     static const int small_min_m = getenv("GAST_GEMM_BIG_SMALL_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_SMALL_MIN_M")) : 0;
     static const int small_max_k = getenv("GAST_GEMM_BIG_SMALL_MAX_K") ? atoi(getenv("GAST_GEMM_BIG_SMALL_MAX_K")) : 512;
+    static const int deep = getenv("GAST_GEMM_BIG_DEEP") ? atoi(getenv("GAST_GEMM_BIG_DEEP")) : 0;
     if (Ml > 0x7fffff00L || a.N < 32) return 0;
-    if (Ml < min_rows) {
+    static const int deep_min_m = getenv("GAST_GEMM_BIG_DEEP_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_DEEP_MIN_M")) : 1024;
+    static const int deep_max_k = getenv("GAST_GEMM_BIG_DEEP_MAX_K") ? atoi(getenv("GAST_GEMM_BIG_DEEP_MAX_K")) : 1 << 30;
+    const bool small = Ml < min_rows;
+    bool want_deep = false;
+    if (small) {
         int ks = 0;
         for (int s = 0; s < a.nseg; ++s) ks += a.seg[s].K;
-        if (!(small_min_m > 0 && Ml >= small_min_m && ks <= small_max_k)) return 0;
+        want_deep = deep && Ml >= deep_min_m && ks <= deep_max_k;
+        if (!want_deep && !(small_min_m > 0 && Ml >= small_min_m && ks <= small_max_k)) return 0;
     }
+    pl.depth = 2;
     // tile width, measured on MI355X (scripts/gemm_table.py bf16x3, B = 128): 128 x 128 (NI = 2, 143-167 VGPRs, three blocks per
     // CU) for N <= 192 -- half of the wide tile would be empty -- and for every BNRELU_BWD epilogue (its X / addend values are
     // gathered per lane from the accumulator layout: at NI = 4 that epilogue spills 27-60 registers; at NI = 2 the short-K input
@@ -567,6 +591,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int mw_env = getenv("GAST_GEMM_BIG_MW") ? atoi(getenv("GAST_GEMM_BIG_MW")) : 2;
     static const int mw_min_k = getenv("GAST_GEMM_BIG_MW_MIN_K") ? atoi(getenv("GAST_GEMM_BIG_MW_MIN_K")) : 0;
     pl.mw = (mw_env == 4 && pl.ni == 4 && ksum >= mw_min_k) ? 4 : 2;
+    if (want_deep) { pl.ni = 2; pl.mw = 2; pl.depth = 4; }
     if (!all_shapes) {
         if (a.N <= 192 && !narrow) return 0;
         if (bwd_epi && bwd_ni != 2 && ksum < 768) return 0;
@@ -586,7 +611,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
-    if (ntab > max_tab(pl.ni, pl.mw)) return 0;
+    if (ntab > max_tab(pl.ni, pl.mw, pl.depth)) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
@@ -603,60 +628,62 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     return 1;
 }
 
-static int big_lds_bytes(int ntab, int ni, int mw) { return off_tab(ni, mw) + 2 * ntab * 4 + 6 * nt_of(mw) * 4; }
+static int big_lds_bytes(int ntab, int ni, int mw, int depth) { return off_tab(ni, mw, depth) + 2 * ntab * 4 + 6 * nt_of(mw) * 4; }
 
 typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
-template <int NI, int MW>
+template <int NI, int MW, int D = 2>
 static big_kernel_t big_kernel_ni(int v, int pair) {
     if (pair == 2) {                // (variants 0..3: gast_gemm_big_plan keeps the BNRELU_BWD epilogues on bf16 pairs)
         switch (v) {
-            case 0: return gemm_big_kernel<0, false, NI, MW, 2>;
-            case 1: return gemm_big_kernel<0, true, NI, MW, 2>;
-            case 2: return gemm_big_kernel<1, false, NI, MW, 2>;
-            case 3: return gemm_big_kernel<1, true, NI, MW, 2>;
+            case 0: return gemm_big_kernel<0, false, NI, MW, 2, D>;
+            case 1: return gemm_big_kernel<0, true, NI, MW, 2, D>;
+            case 2: return gemm_big_kernel<1, false, NI, MW, 2, D>;
+            case 3: return gemm_big_kernel<1, true, NI, MW, 2, D>;
             default: return nullptr;
         }
     }
     switch (v) {
-        case 0: return gemm_big_kernel<0, false, NI, MW, 1>;
-        case 1: return gemm_big_kernel<0, true, NI, MW, 1>;
-        case 2: return gemm_big_kernel<1, false, NI, MW, 1>;
-        case 3: return gemm_big_kernel<1, true, NI, MW, 1>;
-        case 4: return gemm_big_kernel<2, false, NI, MW, 1>;
-        case 5: return gemm_big_kernel<2, true, NI, MW, 1>;
-        case 6: return gemm_big_kernel<3, false, NI, MW, 1>;
-        default: return gemm_big_kernel<3, true, NI, MW, 1>;
+        case 0: return gemm_big_kernel<0, false, NI, MW, 1, D>;
+        case 1: return gemm_big_kernel<0, true, NI, MW, 1, D>;
+        case 2: return gemm_big_kernel<1, false, NI, MW, 1, D>;
+        case 3: return gemm_big_kernel<1, true, NI, MW, 1, D>;
+        case 4: return gemm_big_kernel<2, false, NI, MW, 1, D>;
+        case 5: return gemm_big_kernel<2, true, NI, MW, 1, D>;
+        case 6: return gemm_big_kernel<3, false, NI, MW, 1, D>;
+        default: return gemm_big_kernel<3, true, NI, MW, 1, D>;
     }
 }
 // (the 256-row block tile exists at the wide tile only)
-static big_kernel_t big_kernel(int v, int ni, int mw, int pair) {
+static big_kernel_t big_kernel(int v, int ni, int mw, int pair, int depth) {
+    if (depth == 4) return big_kernel_ni<2, 2, 4>(v, pair);      // (gast_gemm_big_plan: depth 4 comes with NI = 2, MW = 2)
     return mw == 4 ? big_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_kernel_ni<2, 2>(v, pair) : big_kernel_ni<4, 2>(v, pair);
 }
 
 typedef void (*big_multi_kernel_t)(const BigBatch);
-template <int NI, int MW>
+template <int NI, int MW, int D = 2>
 static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
     if (pair == 2) {
         switch (v) {
-            case 0: return gemm_big_multi_kernel<0, false, NI, MW, 2>;
-            case 1: return gemm_big_multi_kernel<0, true, NI, MW, 2>;
-            case 2: return gemm_big_multi_kernel<1, false, NI, MW, 2>;
-            case 3: return gemm_big_multi_kernel<1, true, NI, MW, 2>;
+            case 0: return gemm_big_multi_kernel<0, false, NI, MW, 2, D>;
+            case 1: return gemm_big_multi_kernel<0, true, NI, MW, 2, D>;
+            case 2: return gemm_big_multi_kernel<1, false, NI, MW, 2, D>;
+            case 3: return gemm_big_multi_kernel<1, true, NI, MW, 2, D>;
             default: return nullptr;
         }
     }
     switch (v) {
-        case 0: return gemm_big_multi_kernel<0, false, NI, MW, 1>;
-        case 1: return gemm_big_multi_kernel<0, true, NI, MW, 1>;
-        case 2: return gemm_big_multi_kernel<1, false, NI, MW, 1>;
-        case 3: return gemm_big_multi_kernel<1, true, NI, MW, 1>;
-        case 4: return gemm_big_multi_kernel<2, false, NI, MW, 1>;
-        case 5: return gemm_big_multi_kernel<2, true, NI, MW, 1>;
-        case 6: return gemm_big_multi_kernel<3, false, NI, MW, 1>;
-        default: return gemm_big_multi_kernel<3, true, NI, MW, 1>;
+        case 0: return gemm_big_multi_kernel<0, false, NI, MW, 1, D>;
+        case 1: return gemm_big_multi_kernel<0, true, NI, MW, 1, D>;
+        case 2: return gemm_big_multi_kernel<1, false, NI, MW, 1, D>;
+        case 3: return gemm_big_multi_kernel<1, true, NI, MW, 1, D>;
+        case 4: return gemm_big_multi_kernel<2, false, NI, MW, 1, D>;
+        case 5: return gemm_big_multi_kernel<2, true, NI, MW, 1, D>;
+        case 6: return gemm_big_multi_kernel<3, false, NI, MW, 1, D>;
+        default: return gemm_big_multi_kernel<3, true, NI, MW, 1, D>;
     }
 }
-static big_multi_kernel_t big_multi_kernel(int v, int ni, int mw, int pair) {
+static big_multi_kernel_t big_multi_kernel(int v, int ni, int mw, int pair, int depth) {
+    if (depth == 4) return big_multi_kernel_ni<2, 2, 4>(v, pair);
     return mw == 4 ? big_multi_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_multi_kernel_ni<2, 2>(v, pair) : big_multi_kernel_ni<4, 2>(v, pair);
 }
 
@@ -665,25 +692,25 @@ static void big_setup() {
     hipGetDevice(&dev);               // function attributes are per device (nn.DataParallel replicas launch on several)
     dev &= 63;
     if (big_setup_done[dev].load(std::memory_order_acquire)) return;      // (idempotent set-up: a racing first call repeats it)
-    for (int c = 0; c < 3; ++c) {          // (NI, MW) = (2, 2), (4, 2), (4, 4)
-        const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
+    for (int c = 0; c < 4; ++c) {          // (NI, MW, D) = (2, 2, 2), (4, 2, 2), (4, 4, 2), (2, 2, 4)
+        const int ni = (c == 0 || c == 3) ? 2 : 4, mw = c == 2 ? 4 : 2, depth = c == 3 ? 4 : 2;
         for (int pair = 1; pair <= 2; ++pair)
             for (int v = 0; v < (pair == 2 ? 4 : 8); ++v) {
-                hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
-                hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
             }
     }
     big_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BIG_DEBUG")) {
-        for (int c = 0; c < 3; ++c) {
-            const int ni = c == 0 ? 2 : 4, mw = c == 2 ? 4 : 2;
+        for (int c = 0; c < 4; ++c) {
+            const int ni = (c == 0 || c == 3) ? 2 : 4, mw = c == 2 ? 4 : 2, depth = c == 3 ? 4 : 2;
             for (int pv = 0; pv < 12; pv += 2) {
                 const int pair = pv < 8 ? 1 : 2, v = pv < 8 ? pv : pv - 8;
                 int nb = -1;
-                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni, mw, pair), nt_of(mw), big_lds_bytes(0, ni, mw));
+                (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)big_kernel(v, ni, mw, pair, depth), nt_of(mw), big_lds_bytes(0, ni, mw, depth));
                 hipFuncAttributes fa;
-                (void)hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni, mw, pair));
-                fprintf(stderr, "gemm_big variant %d NI %d MW %d pair %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, mw, pair, nb, big_lds_bytes(0, ni, mw), fa.numRegs, (size_t)fa.localSizeBytes);
+                (void)hipFuncGetAttributes(&fa, (const void*)big_kernel(v, ni, mw, pair, depth));
+                fprintf(stderr, "gemm_big variant %d NI %d MW %d pair %d depth %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", v, ni, mw, pair, depth, nb, big_lds_bytes(0, ni, mw, depth), fa.numRegs, (size_t)fa.localSizeBytes);
             }
         }
     }
@@ -691,7 +718,7 @@ static void big_setup() {
 
 int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair, pl.depth), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw, pl.depth), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -701,13 +728,13 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
     bool done[GAST_GEMM_MAX_BATCH] = {};
     for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
-        const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw, pair = pls[d0].pair;
+        const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw, pair = pls[d0].pair, depth = pls[d0].depth;
         BigBatch b;
         b.n = 0;
         b.first[0] = 0;
         int ntab = 0;
         for (int d = d0; d < n; ++d) {
-            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni || pls[d].mw != mw || pls[d].pair != pair) continue;
+            if (done[d] || epi_variant(args[d]) != v || pls[d].ni != ni || pls[d].mw != mw || pls[d].pair != pair || pls[d].depth != depth) continue;
             done[d] = true;
             const int k = b.n++;
             b.a[k] = args[d];
@@ -715,8 +742,8 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b.a[0], b.pl[0]);
-        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw), st, b);
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair, depth), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair, depth), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b);
         GAST_CHECK_LAUNCH();
     }
     return 0;
