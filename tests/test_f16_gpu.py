@@ -10,7 +10,7 @@ three extra significand bits put the same plan inside it.  Checked here:
   * the reference goldens: eval / train outputs and the direction + scale of every parameter gradient;
   * BASELINE.json configs[1..3] at their own sizes: train-mode outputs within 1e-2 and MPJPE within 0.1 mm of the fp32 HIP path (which
     is pinned to the reference at 1e-4), gradients by relative L2, no non-finite value anywhere;
-  * a short Adam trajectory next to the fp32 path's; the loss scale is needed (scale 1: small gradients are lost).
+  * a short Adam trajectory next to the fp32 path's; the loss scale keeps the gradient when the loss (hence every activation gradient) is 1e-4 times smaller.
 """
 import os
 import subprocess
@@ -144,7 +144,7 @@ def test_f16_at_baseline_sizes(tag, J, arc, ch, B, variant, monkeypatch):
 def test_f16_training_trajectory(monkeypatch):
     """Eight Adam(amsgrad) steps on the configs[1] shape (B = 32): the 16-bit mode's losses stay within 5 % of the fp32 path's (measured
     2.9 %: Adam's first steps move every parameter by lr * sign(g), which amplifies any gradient noise near zero), and the
-    loss scale matters -- with GAST_F16_LOSS_SCALE=1 the small activation gradients are lost and the gradient direction degrades."""
+    loss scale matters once the gradients are small -- see the second half."""
     from gast_hip.optim import FlatAdam
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3, 3], channels=64, causal=False, variant='dilated')
     g = torch.Generator().manual_seed(7)
@@ -168,7 +168,10 @@ def test_f16_training_trajectory(monkeypatch):
     rel = max(abs(a - b) / b for a, b in zip(losses['f16'], losses['fp32']))
     _log(test='f16_training_trajectory', losses_f16=losses['f16'], losses_fp32=losses['fp32'], max_rel=rel)
     assert losses['f16'][-1] < losses['f16'][0] and rel < 0.05, (rel, losses)
-    # the loss scale: gradients of one step with scale 1 vs the default, against the fp32 gradient
+    # the loss scale.  At this batch the activation gradients (1e-7 .. 1e-3) mostly survive binary16 even unscaled (measured: 7.28 % vs
+    # 7.25 % relative L2 to the fp32 gradient -- indistinguishable), so the scale is exercised where it matters: the same step with the
+    # loss multiplied by 1e-4 (the per-position gradients of a 10^4 times larger batch, or of a nearly converged model).  Unscaled, the
+    # chain underflows binary16 and most of the gradient is lost; scaled by 4096 it is as accurate as at full size.
     grads = {}
     for tag, dt, scale in (('fp32', 'fp32', None), ('scaled', 'f16', '4096'), ('unscaled', 'f16', '1')):
         monkeypatch.setenv('GAST_HIP_DTYPE', dt)
@@ -177,9 +180,9 @@ def test_f16_training_trajectory(monkeypatch):
         torch.manual_seed(0)
         m = build(cfg).cuda().train()
         m._runner.graph_mode = False
-        torch.mean(torch.norm(m(x) - y3d, dim=-1)).backward()
+        (1e-4 * torch.mean(torch.norm(m(x) - y3d, dim=-1))).backward()
         grads[tag] = torch.cat([p.grad.reshape(-1) for p in m.parameters()])
     r_s = float((grads['scaled'] - grads['fp32']).norm() / grads['fp32'].norm())
     r_u = float((grads['unscaled'] - grads['fp32']).norm() / grads['fp32'].norm())
-    _log(test='f16_loss_scale', rel_l2_scaled=r_s, rel_l2_unscaled=r_u)
-    assert r_s < r_u, (r_s, r_u)
+    _log(test='f16_loss_scale', loss_factor=1e-4, rel_l2_scaled=r_s, rel_l2_unscaled=r_u)
+    assert r_s < 0.15 and r_u > 2 * r_s, (r_s, r_u)
