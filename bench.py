@@ -956,7 +956,7 @@ def main():
                                    'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
             out['kernels_note'] = ('per-op durations from an EAGER pass with a HIP-event pair around every launch (events cannot be recorded inside a '
                                    'replayed graph): the GPU clocks down between eager launches, so the column sums to more than ms_per_step; '
-                                   'the replayed step itself is broken down in profiles/r03_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
+                                   'the replayed step itself is broken down in profiles/r04_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
             out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
                                   'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)

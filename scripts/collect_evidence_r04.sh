@@ -5,12 +5,12 @@
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; cd "$R"
 O=$R/gpurun_out/r04_evidence; mkdir -p $O
-if [ "$ONLY" != trace ]; then
+if [ "$ONLY" != trace ] && [ "$ONLY" != prof ]; then
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json; echo
 for i in 1 2; do timeout 300 python bench.py --no-cpu-baseline --no-kernel-timer --no-eager --no-twin > $O/bench_repeat_$i.json 2>/dev/null; done
 fi
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --steps 8 --warmup 2 > $O/trace.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 8 --warmup 2 > $O/trace.log 2>&1
 cp $(find /tmp/prof -name "*kernel_stats.csv" | head -1) $O/kernel_stats.csv
 T=$(find /tmp/prof -name "*kernel_trace.csv" | head -1)
 python scripts/trace_step.py $T 3 > $O/step_summary.txt
@@ -42,11 +42,12 @@ PY
 head -4 $O/forward_step_summary.txt
 if [ "$ONLY" = trace ]; then head -12 $O/step_summary.txt; exit 0; fi
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-timer --no-graph --no-twin > $O/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d /tmp/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-timer --no-graph --no-twin --no-f16 --no-stock-baseline > $O/pmc_$c.log 2>&1
 done
 python scripts/pmc_summary.py $(find /tmp/pmc_FETCH_SIZE -name "*counter_collection.csv") $(find /tmp/pmc_WRITE_SIZE -name "*counter_collection.csv") $O/pmc_hbm_bytes_bf16x3.json 3 > $O/pmc_summary.log 2>&1
-timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-timer --no-graph --no-twin > $O/pmc_mfma.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-parity --no-kernel-timer --no-graph --no-twin --no-f16 --no-stock-baseline > $O/pmc_mfma.log 2>&1
 cp $(find /tmp/pmc_mfma -name "*counter_collection.csv") $O/pmc_mfma_counters.csv
+if [ "$ONLY" = prof ]; then ls $O; exit 0; fi
 for cfg in cfg2 cfg3 cfg4 cfg243; do
   # (with the per-kernel timer -> roofline_by_kernel, and the CPU restatement's forward in the parity object; no CPU timing)
   timeout 900 python bench.py --config $cfg --no-cpu-baseline --cpu-parity --no-eager --no-stock-baseline > $O/bench_$cfg.json 2> $O/bench_$cfg.err
