@@ -4,6 +4,7 @@
 // accesses, the J x J tiles live in LDS, no MFMA.
 #include "common.h"
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -355,6 +356,148 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
         }
         float4 r = add4(add4(acc0, acc1), add4(acc2, acc3));
         *(float4*)(part + ((long)fb * nnz_t + k) * C + cg) = r;
+    }
+}
+
+// Round 4: the same backward with the frame tiles staged in LDS.  The kernel above reads every dY row once per neighbour in phase A and
+// once per edge in phase B (and every H row once per edge) -- from L2 / HBM, since a block's frames do not stay in the cache between its
+// phases: 311 MB fetched + written per launch against 249 algorithmic, each as its own 16-byte load.  Here a block stages U frames of its
+// 32-channel chunk (dY: [U][J][2][CC], H: [U][J][4][CC] fp32) with one coalesced load per element, and both phases read LDS:
+//   phase A  thread = (frame u, column j, 4 channels): dh0 / dh1 over the D padded (row, edge) slots of the column;
+//   phase B  thread = up to NPB fixed (edge k, 4 channels) pairs whose dA accumulators live in registers across ALL frames of the block
+//            (one owner per pair: no atomics; the block writes one partial row at the end);
+// the next group's elements are requested into registers before the current group is processed (without that prefetch the kernel
+// was 5 % SLOWER than the one above: two barriers per group with nothing in flight).
+#ifndef GAST_AGG_LDS_U
+#define GAST_AGG_LDS_U 2
+#endif
+constexpr int AGG_LDS_U = GAST_AGG_LDS_U, AGG_LDS_CC = 32, AGG_LDS_NPB = 5;
+template <typename T, int DS, int DC>
+__global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
+                                                                int F, int J, int C,
+                                                                const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
+                                                                const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
+                                                                T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb, int nchunk) {
+    constexpr int U = AGG_LDS_U, CC = AGG_LDS_CC, CC4 = CC / 4, NPB = AGG_LDS_NPB;
+    __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
+    extern __shared__ __attribute__((aligned(16))) float sAggL[];
+    const int tid = threadIdx.x;
+    const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
+    const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
+    const int nnz_s = ps.nnz, nnz_c = pc.nnz, nnz_t = nnz_s + nnz_c;
+    float* const sAs = sAggL;
+    float* const sAc = sAs + (nnz_s + 1) * CC;
+    float* const sDY = sAc + (nnz_c + 1) * CC;
+    float* const sH = sDY + U * J * 2 * CC;
+    const int c0 = ch * CC;
+    for (int t = tid; t < (nnz_s + 1) * CC4; t += 256) {
+        const int k = t / CC4, q = t - k * CC4;
+        *(float4*)(sAs + k * CC + q * 4) = c0 + q * 4 < C ? *(const float4*)(A_sym + (long)k * C + c0 + q * 4) : make_float4(0, 0, 0, 0);
+    }
+    for (int t = tid; t < (nnz_c + 1) * CC4; t += 256) {
+        const int k = t / CC4, q = t - k * CC4;
+        *(float4*)(sAc + k * CC + q * 4) = c0 + q * 4 < C ? *(const float4*)(A_con + (long)k * C + c0 + q * 4) : make_float4(0, 0, 0, 0);
+    }
+    for (int t = tid; t < 2 * J; t += 256) {
+        const Pat& p = t < J ? ps : pc;
+        const int i = t < J ? t : t - J, base = t < J ? 0 : nnz_s;
+        for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) { s_ei[base + k] = i; s_ej[base + k] = p.col[k]; }
+    }
+    __syncthreads();
+    // phase-B ownership: pairs tid + 256 q
+    int pdy[NPB], ph[NPB];        // float offsets of the pair's dY / H values inside frame 0 of the tiles (-1: no pair)
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        const int p = tid + 256 * q;
+        pdy[q] = -1; ph[q] = 0;
+        if (p < nnz_t * CC4) {
+            const int k = p / CC4, c4 = p - k * CC4;
+            const int g = k < nnz_s ? 0 : 1, i = s_ei[k], j = s_ej[k];
+            pdy[q] = (i * 2 + g) * CC + c4 * 4;
+            ph[q] = (j * 4 + g * 2 + (i == j ? 0 : 1)) * CC + c4 * 4;
+        }
+    }
+    float4 acc[NPB];
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) acc[q] = make_float4(0, 0, 0, 0);
+
+    // element t of a tile group: (frame row rj = u * J + j, tensor slice w: 0, 1 = dY sym / con; 2 .. 5 = H h0 / h1 sym, h0 / h1 con, 4 channels);
+    // the NEXT group's elements are requested into registers before the current group is processed
+    constexpr int NPRE = (U * JMAX * 6 * CC4 + 255) / 256;
+    float4 pre[NPRE];
+    auto request = [&](int f0) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int t = tid + 256 * q;
+            pre[q] = make_float4(0, 0, 0, 0);
+            if (t < U * J * 6 * CC4) {
+                const int c4 = t % CC4, r = t / CC4;
+                const int w = r % 6, rj = r / 6;
+                const int u = rj / J, j = rj - u * J;
+                const long f = f0 + u;
+                const int c = c0 + c4 * 4;
+                if (f < F && c < C) pre[q] = w < 2 ? ld4(dY + (f * J + j) * ldy + w * C + c) : ld4(H + (f * J + j) * ldh + (w - 2) * C + c);
+            }
+        }
+    };
+    request(fb * U);
+    for (int f0 = fb * U; f0 < F; f0 += nfb * U) {
+#pragma unroll
+        for (int q = 0; q < NPRE; ++q) {
+            const int t = tid + 256 * q;
+            if (t < U * J * 6 * CC4) {
+                const int c4 = t % CC4, r = t / CC4;
+                const int w = r % 6, rj = r / 6;
+                if (w < 2) *(float4*)(sDY + (rj * 2 + w) * CC + c4 * 4) = pre[q];
+                else *(float4*)(sH + (rj * 4 + (w - 2)) * CC + c4 * 4) = pre[q];
+            }
+        }
+        __syncthreads();
+        request(f0 + nfb * U);          // (past the last frame: zeros, no traffic)
+        // phase A
+        auto cols = [&](auto dtag, const Pat& p, const float* sA, int g) {
+            constexpr int D = decltype(dtag)::value;
+            for (int t = tid; t < U * J * CC4; t += 256) {
+                const int c4 = t % CC4, rj = t / CC4;
+                const int u = rj / J, j = rj - u * J;
+                const long f = f0 + u;
+                const int c = c0 + c4 * 4;
+                if (f >= F || c >= C) continue;
+                float4 d0 = make_float4(0, 0, 0, 0), d1 = make_float4(0, 0, 0, 0);
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    const int ii = p.ell_ci[j * D + d], kk = p.ell_ck[j * D + d];
+                    const float4 av = *(const float4*)(sA + kk * CC + c4 * 4);
+                    const float4 dv = *(const float4*)(sDY + ((u * J + ii) * 2 + g) * CC + c4 * 4);
+                    if (ii == j) d0 = fma4(av, dv, d0); else d1 = fma4(av, dv, d1);
+                }
+                T* o = dH + (f * J + j) * lddh + g * 2 * C + c;
+                st4(o, d0);
+                st4(o + C, d1);
+            }
+        };
+        cols(std::integral_constant<int, DS>(), ps, sAs, 0);
+        cols(std::integral_constant<int, DC>(), pc, sAc, 1);
+        // phase B (frames past F were staged as zeros)
+#pragma unroll
+        for (int q = 0; q < NPB; ++q) {
+            if (pdy[q] < 0) continue;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float4 dv = *(const float4*)(sDY + u * J * 2 * CC + pdy[q]);
+                const float4 hv = *(const float4*)(sH + u * J * 4 * CC + ph[q]);
+                acc[q] = fma4(dv, hv, acc[q]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < NPB; ++q) {
+        const int p = tid + 256 * q;
+        if (p >= nnz_t * CC4) continue;
+        const int k = p / CC4, c4 = p - k * CC4;
+        const int cg = c0 + c4 * 4;
+        if (cg < C) *(float4*)(part + ((long)fb * nnz_t + k) * C + cg) = acc[q];
     }
 }
 
@@ -1497,9 +1640,27 @@ extern "C" int gast_semch_agg_fwd(int dtype, const void* H, int ldh, int F, int 
     return 0;
 }
 
-struct AggBwdCfg { int CC, nchunk, TPF, FB, nfb; };
-static AggBwdCfg agg_bwd_cfg(int F, int C) {
+struct AggBwdCfg { int CC, nchunk, TPF, FB, nfb, lds; };
+// lds_variant: the LDS-staged kernel (fp32 storage only: with 16-bit storage a 32-channel row piece is 64 bytes and the staging pass
+// costs more than the re-reads it saves -- the f16 step was 2.80 vs 2.66 ms with it)
+static AggBwdCfg agg_bwd_cfg(int F, int C, bool lds_variant) {
     AggBwdCfg c;
+    // (measured in the B = 128 step, per launch of the three stages: 19.3 / 104.0 / 70.7 us against the ELL kernel's 34.6 / 127.4 / 76.3;
+    //  block budget 512 = two blocks per CU: 384 / 768 / 1024 are slower; 3 frames per group the same, 4 spill)
+    static const int lds_env = getenv("GAST_AGG_BWD_LDS") ? atoi(getenv("GAST_AGG_BWD_LDS")) : 1;
+    c.lds = lds_env && lds_variant;
+    if (c.lds) {          // semch_agg_bwd_lds_kernel: 32-channel chunks, U frames per iteration
+        c.CC = AGG_LDS_CC;
+        c.nchunk = (C + c.CC - 1) / c.CC;
+        c.TPF = c.CC / 4;
+        c.FB = AGG_LDS_U;
+        static const int want_lds = getenv("GAST_AGG_BWD_BLOCKS") ? atoi(getenv("GAST_AGG_BWD_BLOCKS")) : 512;
+        int want = want_lds / c.nchunk;
+        if (want < 1) want = 1;
+        const int maxfb = (F + c.FB - 1) / c.FB;
+        c.nfb = want < maxfb ? want : maxfb;
+        return c;
+    }
     c.CC = C < 64 ? C : 64;           // channel chunk of a block (its coefficient slices live in LDS)
     c.nchunk = (C + c.CC - 1) / c.CC;
     c.TPF = c.CC / 4;
@@ -1513,8 +1674,8 @@ static AggBwdCfg agg_bwd_cfg(int F, int C) {
 }
 
 extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_con) {
-    AggBwdCfg c = agg_bwd_cfg(F, C);
-    return (long)c.nfb * (nnz_sym + nnz_con) * C;
+    const AggBwdCfg a = agg_bwd_cfg(F, C, false), b = agg_bwd_cfg(F, C, true);      // (the caller does not say which storage type: the larger of the two)
+    return (long)(a.nfb > b.nfb ? a.nfb : b.nfb) * (nnz_sym + nnz_con) * C;
 }
 
 static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
@@ -1524,7 +1685,7 @@ static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H,
     if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA || !ws) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
-    AggBwdCfg c = agg_bwd_cfg(F, C);
+    AggBwdCfg c = agg_bwd_cfg(F, C, dtype == GAST_F32 && (cdeg_sym == 2 && (cdeg_con == 5 || cdeg_con == 6)));
     const int nnz_t = nnz_sym + nnz_con;
     // fixed-degree kernel: LDS for the coefficient slices, at most J * deg + 1 rows per pattern
     size_t smem = (size_t)(J * cdeg_sym + 1 + J * cdeg_con + 1) * c.CC * sizeof(float);
@@ -1548,11 +1709,28 @@ static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H,
                                c.nchunk, c.CC, c.TPF, c.FB);                                                                  \
         }                                                                                                                     \
     } while (0)
+#define AGG_BWD_LDS(DS, DC)                                                                                                   \
+    do {                                                                                                                      \
+        const size_t sm = ((size_t)(J * cdeg_sym + 1 + J * cdeg_con + 1) * AGG_LDS_CC + (size_t)AGG_LDS_U * J * 6 * AGG_LDS_CC) * sizeof(float); \
+        if (dtype == GAST_F32) {                                                                                              \
+            if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<float, DS, DC>,                    \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
+            hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<float, DS, DC>), grid, dim3(256), sm, st, (const float*)dY, ldy,     \
+                               (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk); \
+        } else {                                                                                                              \
+            if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<bf16_t, DS, DC>,                   \
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
+            hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<bf16_t, DS, DC>), grid, dim3(256), sm, st, (const bf16_t*)dY, ldy,   \
+                               (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk); \
+        }                                                                                                                     \
+    } while (0)
     bool fast = true;
-    if (cdeg_sym == 2 && cdeg_con == 5) AGG_BWD_ELL(2, 5);
-    else if (cdeg_sym == 2 && cdeg_con == 6) AGG_BWD_ELL(2, 6);
+    const bool lds_ok = c.lds && (long)nnz_t * (AGG_LDS_CC / 4) <= 256L * AGG_LDS_NPB;
+    if (cdeg_sym == 2 && cdeg_con == 5) { if (lds_ok) AGG_BWD_LDS(2, 5); else AGG_BWD_ELL(2, 5); }
+    else if (cdeg_sym == 2 && cdeg_con == 6) { if (lds_ok) AGG_BWD_LDS(2, 6); else AGG_BWD_ELL(2, 6); }
     else fast = false;
 #undef AGG_BWD_ELL
+#undef AGG_BWD_LDS
     if (fast) {
         GAST_CHECK_LAUNCH();
         long ncol_f = (long)nnz_t * C;

@@ -585,6 +585,7 @@ def test_wgrad_multi_wide_tiles(ops):
                                                ('GAST_WGRAD_RING=2', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_ORDER=1', 'test_wgrad_multi and bf16', 1),
                                                ('GAST_WGRAD_X3_PIPE=0', 'test_wgrad_multi and x3', 1),
+                                               ('GAST_AGG_BWD_LDS=0', 'semch_agg', None),
                                                ('GAST_GEMM_BIG_NI=2', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_NI=4', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_MW=4', 'test_gemm_big_x3', None),
@@ -592,7 +593,7 @@ def test_wgrad_multi_wide_tiles(ops):
 def test_optin_kernel_variants(knob, select, npass):
     """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles (forced on
     the small cases / forced off on the wide ones for the bf16x3 kernels), two
-    register sets in flight, chunk-major block order, the un-pipelined bf16x3 weight-gradient kernel, both tile widths of the large-M GEMM on every case, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
+    register sets in flight, chunk-major block order, the un-pipelined bf16x3 weight-gradient kernel, the aggregation backward without LDS staging, both tile widths of the large-M GEMM on every case, and the VALU (non-MFMA) bf16 attention kernels -- the same parity cases
     in a child process."""
     import os
     import subprocess
