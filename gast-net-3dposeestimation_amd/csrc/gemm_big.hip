@@ -569,7 +569,10 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     if (small) {
         int ks = 0;
         for (int s = 0; s < a.nseg; ++s) ks += a.seg[s].K;
-        want_deep = deep && Ml >= deep_min_m && ks <= deep_max_k;
+        // (GAST_GEMM_BIG_DEEP_MIN_TILES: only GEMMs whose 128 x 128 tiles fill the chip without split-K)
+        static const int deep_min_tiles = getenv("GAST_GEMM_BIG_DEEP_MIN_TILES") ? atoi(getenv("GAST_GEMM_BIG_DEEP_MIN_TILES")) : 0;
+        const long tiles128 = ((Ml + 127) / 128) * ((a.N + 127) / 128);
+        want_deep = deep && Ml >= deep_min_m && ks <= deep_max_k && tiles128 >= deep_min_tiles;
         if (!want_deep && !(small_min_m > 0 && Ml >= small_min_m && ks <= small_max_k)) return 0;
     }
     pl.depth = 2;

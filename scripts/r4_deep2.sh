@@ -1,0 +1,14 @@
+#!/bin/bash
+cd /tmp && export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"; cd "$R"
+O="$R/gpurun_out/r4o"; mkdir -p "$O"
+run() {
+  name="$1"; shift
+  env "$@" timeout 300 python bench.py --no-cpu-baseline --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 30 --warmup 5 > "$O/bench_$name.json" 2> "$O/bench_$name.err"
+  python -c "import json;d=json.loads(open('$O/bench_$name.json').read().strip().splitlines()[-1]);print('$name', d['ms_per_step'], '%.2e' % d['parity']['vs_fp32_hip']['max_abs'], d.get('forward_only',{}).get('ms'))" 2>/dev/null || { echo "$name FAILED"; tail -3 "$O/bench_$name.err"; }
+}
+run base A=1
+run deep_t256 GAST_GEMM_BIG_DEEP=1 GAST_GEMM_BIG_DEEP_MIN_TILES=256
+run deep_t128 GAST_GEMM_BIG_DEEP=1 GAST_GEMM_BIG_DEEP_MIN_TILES=128
+run deep_t340 GAST_GEMM_BIG_DEEP=1 GAST_GEMM_BIG_DEEP_MIN_TILES=340
+run base2 A=1
