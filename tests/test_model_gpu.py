@@ -631,7 +631,9 @@ def test_flat_gradient_buffer_accumulates_like_autograd(mode2):
     for k, p in m.named_parameters():
         assert p.grad.data_ptr() >= sync.flat.data_ptr()
         scale = float(ref[k].abs().max()) + 1e-6
-        assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 2e-5, k
+        # (absolute floor: a BatchNorm bias in front of another BatchNorm has a true gradient of ~0 -- what the buffer holds is the
+        #  round-off of a sum over all positions, whose order the split reductions do not fix: measured up to 2.1e-5)
+        assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 5e-5, k
 
 
 def test_dropout_gradients_by_finite_differences(monkeypatch):
