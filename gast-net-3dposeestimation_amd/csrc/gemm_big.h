@@ -14,7 +14,8 @@ struct BigPlan {
                                   // 4 no weight DMA, 8 no activation loads, 16 no activation LDS writes, 32 no epilogue
 };
 
+// (internal to the library: hidden, so that the dynamic symbol table holds the C ABI of include/gast_hip.h and nothing else)
 // 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip
-int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
-int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
-int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);
+__attribute__((visibility("hidden"))) int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);
