@@ -560,6 +560,7 @@ WGRAD_WIDE_CASES = [      # job sets that fill 256 x 256 tiles (the library then
     ('wide_taps_drop', (6, 9, 17), 512, [(256, 11, 1, 0, 1, 0), (256, 11, 1, 2, 2, 256)]),
     ('wide_edge', (6, 9, 17), 488, [(256, 9, 1, 0, 0, 0)]),
     ('wide_concat', (6, 9, 17), 256, [(512, 9, 1, 0, 1, 0), (256, 9, 1, 0, 2, 512)]),
+    ('wide_strided_taps', (4, 3, 19), 256, [(256, 9, 3, 0, 1, 0), (256, 9, 3, 1, 0, 256), (256, 9, 3, 2, 1, 512)]),
 ]
 
 
