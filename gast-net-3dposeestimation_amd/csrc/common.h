@@ -167,4 +167,17 @@ template <int N> __device__ __forceinline__ void gload_wait_n() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// ---------------------------------------------------------------- GAST_DETERMINISTIC=1 (host side, read once per process)
+// Run-to-run bit-reproducible results: every reduction whose summation order depends on block scheduling is replaced by one with a
+// fixed order -- no split-K (gemm.hip: the finish pass adds its column statistics with atomics), no split-M in the weight gradients
+// (wgrad*.hip: partial tiles meet in dW through atomics), the expand-conv backward's parameter epilogue in one block per input
+// feature (norm_ops.hip).  Slower (the M = B*J stage and the weight gradients lose their parallel slack): a test / debugging mode,
+// see DESIGN.md section 5.  Covers the fp32-storage plans (fp32, bf16x3); the 16-bit flavours keep LDS float atomics in the ELL
+// aggregation backward.
+#include <stdlib.h>
+static inline bool gast_deterministic() {
+    static const int v = getenv("GAST_DETERMINISTIC") ? atoi(getenv("GAST_DETERMINISTIC")) : 0;
+    return v != 0;
+}
+
 #define GAST_CHECK_LAUNCH() do { hipError_t e__ = hipGetLastError(); if (e__ != hipSuccess) return (int)e__; } while (0)

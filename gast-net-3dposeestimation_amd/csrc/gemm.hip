@@ -774,7 +774,7 @@ int gemm_plan(const gast_gemm_args& a, void* ws, long ws_bytes, int& M, int& gri
     splitk = 1;
     static const int allow_splitk = getenv("GAST_GEMM_SPLITK") ? atoi(getenv("GAST_GEMM_SPLITK")) : 1;   // 0: bisecting aid
     static const int splitk_blocks = getenv("GAST_GEMM_SPLITK_BLOCKS") ? atoi(getenv("GAST_GEMM_SPLITK_BLOCKS")) : 512;
-    if (ws && gridM * gridN <= 160 && ntiles >= 4 && allow_splitk) {
+    if (ws && gridM * gridN <= 160 && ntiles >= 4 && allow_splitk && !gast_deterministic()) {
         splitk = splitk_blocks / (gridM * gridN);
         if (splitk > 8) splitk = 8;
         if (splitk > ntiles / 2) splitk = ntiles / 2;

@@ -812,12 +812,17 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(const T* __restrict__ dY,
     if (tid < J * J) atomicAdd(dCk + (long)h * J * J + tid, ck_acc0);
     if (tid + 256 < J * J) atomicAdd(dCk + (long)h * J * J + tid + 256, ck_acc1);
     if (dbias_ac) {
-        // only threads < ub*J hold non-zero sums; one wave-level reduction each, then one atomic per wave
+        // only threads < ub*J hold non-zero sums; wave-level reductions, the block's waves combined in a fixed order, ONE atomic per
+        // block and address (with one block per head -- GAST_DETERMINISTIC -- the result does not depend on scheduling)
+        __shared__ float swave[8][2];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { da_sum += __shfl_xor(da_sum, off); dc_sum += __shfl_xor(dc_sum, off); }
-        if ((tid & 63) == 0 && tid < ((ub * J + 63) & ~63)) {
-            atomicAdd(dbias_ac + h, da_sum);
-            atomicAdd(dbias_ac + nheads + h, dc_sum);
+        if ((tid & 63) == 0) { swave[tid >> 6][0] = da_sum; swave[tid >> 6][1] = dc_sum; }
+        __syncthreads();
+        if (tid < 2) {
+            float v = 0.f;
+            for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) v += swave[wv][tid];
+            atomicAdd(dbias_ac + (tid ? nheads : 0) + h, v);
         }
     }
 }
@@ -2019,7 +2024,7 @@ static int attn_bwd_impl(int dtype, const void* dY, int ldy, const void* G, int 
     }
     if (smem > 160 * 1024) return GAST_ERANGE;
     hipStream_t st = (hipStream_t)stream;
-    int grid = attn_grid(F, nheads, ub);
+    int grid = gast_deterministic() ? nheads : attn_grid(F, nheads, ub);      // (deterministic: one block per head adds dC_k / the bias sums once)
     if (smem > 48 * 1024) {
         hipError_t e = dtype == GAST_F32
             ? hipFuncSetAttribute((const void*)attn_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)

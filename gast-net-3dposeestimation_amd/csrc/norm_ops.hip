@@ -584,49 +584,62 @@ constexpr int EF_CH = 8, EF_LANES = 32;
 __global__ void __launch_bounds__(256) expand_bwd_finish_kernel(const float* __restrict__ ws, int nb, int C, int F_in, int k0,
                                                                 const float* __restrict__ W, const float* __restrict__ gamma0,
                                                                 const float* __restrict__ beta0, float* __restrict__ dW,
-                                                                float* __restrict__ dgamma0, float* __restrict__ dbeta0, int accumulate) {
+                                                                float* __restrict__ dgamma0, float* __restrict__ dbeta0, int accumulate, int det) {
     __shared__ float sred[EF_LANES][EF_CH][2];
     __shared__ float sgb[EF_CH][2];
     const int cx = threadIdx.x % EF_CH, ry = threadIdx.x / EF_CH;
-    const int c = blockIdx.x * EF_CH + cx;
-    const int kk = blockIdx.y;
     const int K0 = F_in * k0, K1 = K0 + 1;
-    const int f = kk / k0, tap = kk - f * k0;
-    float g = 0.f, sv = 0.f;
-    if (c < C) {
+    // default grid: (channel groups of EF_CH, F_in * k0) -- one (group, kk) per block, dgamma0 / dbeta0 by atomics.
+    // GAST_DETERMINISTIC grid: (1, F_in) -- the block walks the taps and channel groups of its input feature in order and adds ONCE.
+    const int ngroups = (C + EF_CH - 1) / EF_CH;
+    const int kk_lo = det ? blockIdx.y * k0 : blockIdx.y, kk_hi = det ? kk_lo + k0 : kk_lo + 1;
+    const int g_lo = det ? 0 : blockIdx.x, g_hi = det ? ngroups : g_lo + 1;
+    float tot = 0.f;               // (threads 0 / 1: the running dgamma0 / dbeta0 contribution of this block)
+    int f = 0;
+    for (int kk = kk_lo; kk < kk_hi; ++kk) {
+        f = kk / k0;
+        const int tap = kk - f * k0;
+        for (int grp = g_lo; grp < g_hi; ++grp) {
+            const int c = grp * EF_CH + cx;
+            float g = 0.f, sv = 0.f;
+            if (c < C) {
 #pragma unroll 4
-        for (int blk = ry; blk < nb; blk += EF_LANES) {
-            const float* p = ws + (long)blk * K1 * C + c;
-            g += p[(long)kk * C];
-            sv += p[(long)K0 * C];
-        }
-    }
-    sred[ry][cx][0] = g;
-    sred[ry][cx][1] = sv;
-    __syncthreads();
-    if (threadIdx.x < EF_CH) {
-        const int ch = threadIdx.x, cc = blockIdx.x * EF_CH + ch;
-        float Gv = 0.f, Sc = 0.f;
+                for (int blk = ry; blk < nb; blk += EF_LANES) {
+                    const float* p = ws + (long)blk * K1 * C + c;
+                    g += p[(long)kk * C];
+                    sv += p[(long)K0 * C];
+                }
+            }
+            __syncthreads();       // (the previous round's readers are done with sred / sgb)
+            sred[ry][cx][0] = g;
+            sred[ry][cx][1] = sv;
+            __syncthreads();
+            if (threadIdx.x < EF_CH) {
+                const int ch = threadIdx.x, cc = grp * EF_CH + ch;
+                float Gv = 0.f, Sc = 0.f;
 #pragma unroll 8
-        for (int r = 0; r < EF_LANES; ++r) { Gv += sred[r][ch][0]; Sc += sred[r][ch][1]; }
-        float dg = 0.f, db = 0.f;
-        if (cc < C) {
-            const long o = ((long)cc * F_in + f) * k0 + tap;
-            const float w = W[o];
-            const float v = gamma0[f] * Gv + beta0[f] * Sc;
-            if (accumulate) dW[o] += v; else dW[o] = v;
-            dg = w * Gv;
-            db = w * Sc;
+                for (int r = 0; r < EF_LANES; ++r) { Gv += sred[r][ch][0]; Sc += sred[r][ch][1]; }
+                float dg = 0.f, db = 0.f;
+                if (cc < C) {
+                    const long o = ((long)cc * F_in + f) * k0 + tap;
+                    const float w = W[o];
+                    const float v = gamma0[f] * Gv + beta0[f] * Sc;
+                    if (accumulate) dW[o] += v; else dW[o] = v;
+                    dg = w * Gv;
+                    db = w * Sc;
+                }
+                sgb[ch][0] = dg;
+                sgb[ch][1] = db;
+            }
+            __syncthreads();
+            if (threadIdx.x < 2) {
+                float v = 0.f;
+                for (int i = 0; i < EF_CH; ++i) v += sgb[i][threadIdx.x];
+                tot += v;
+            }
         }
-        sgb[ch][0] = dg;
-        sgb[ch][1] = db;
     }
-    __syncthreads();
-    if (threadIdx.x < 2) {
-        float v = 0.f;
-        for (int i = 0; i < EF_CH; ++i) v += sgb[i][threadIdx.x];
-        atomicAdd(threadIdx.x ? dbeta0 + f : dgamma0 + f, v);
-    }
+    if (threadIdx.x < 2) atomicAdd(threadIdx.x ? dbeta0 + f : dgamma0 + f, tot);
 }
 
 }  // namespace
@@ -812,6 +825,7 @@ extern "C" int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, 
     RowCfg c = row_cfg(N);
     int nb = row_blocks(rows, N);
     if (nb > 1024) nb = 1024;
+    if (gast_deterministic()) nb = 1;      // one block: one add per column into the zeroed / running destination
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((colsum_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)X, ldx, rows, N, out, c.TPR, c.RB);
     else
@@ -892,8 +906,10 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
                            t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
-    hipLaunchKernelGGL(expand_bwd_finish_kernel, dim3((C + EF_CH - 1) / EF_CH, F_in * k0), dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
-                       dgamma0, dbeta0, accumulate);
+    // (GAST_DETERMINISTIC: one block per input feature walks its taps and channel groups in order -- one add per address)
+    const dim3 fgrid = gast_deterministic() ? dim3(1, F_in) : dim3((C + EF_CH - 1) / EF_CH, F_in * k0);
+    hipLaunchKernelGGL(expand_bwd_finish_kernel, fgrid, dim3(256), 0, st, ws, nb, C, F_in, k0, W, gamma0, beta0, dW,
+                       dgamma0, dbeta0, accumulate, gast_deterministic() ? 1 : 0);
     GAST_CHECK_LAUNCH();
     return 0;
 }

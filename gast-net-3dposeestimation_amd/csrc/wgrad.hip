@@ -892,7 +892,7 @@ extern "C" int gast_wgrad(const gast_wgrad_args* args, gast_stream_t stream) {
     const int bkm = a.dtype == GAST_BF16 ? 64 : 32;
     const int tiles = tilesR * tilesS;
     static const int tgt = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 768;   // 3 resident blocks per CU
-    int splitM = tgt / tiles;
+    int splitM = gast_deterministic() ? 1 : tgt / tiles;      // (deterministic: one block per output tile, one add per element)
     int maxsplit = (M + bkm * 4 - 1) / (bkm * 4);
     if (splitM > maxsplit) splitM = maxsplit;
     if (splitM < 1) splitM = 1;
@@ -979,7 +979,8 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         chunk = 96;
         while (chunk < maxM && blocks_for(chunk) > slots) chunk += 96;
     }
-    const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS");
+    if (gast_deterministic()) chunk = 1L << 40;      // no split-M: every output tile is reduced by ONE block in row order
+    const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS") && !gast_deterministic();
     if (ring2) {
         // two blocks per CU: the block count is quantised against 512 slots (518 blocks run 1.33x slower than 444), so pick
         // the shortest chunk whose launch fits ONE round; if that leaves a quarter of the slots idle (the B*J-row stage: 300 or

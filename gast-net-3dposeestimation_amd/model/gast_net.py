@@ -345,19 +345,6 @@ class _GraphedFunction(torch.autograd.Function):
         return (None, None) + tuple(e.packer.grad_views(e.G.clone()))      # (a copy: the next replay rewrites G in place)
 
 
-_SEAM = [None]      # the resolved `gast_test_seam` module, False when there is none (the product), None before the first look-up
-
-
-def _test_seam():
-    if _SEAM[0] is None:
-        try:
-            import gast_test_seam as seam        # exists only under tests/
-        except ImportError:
-            seam = False
-        _SEAM[0] = seam
-    return _SEAM[0]
-
-
 class _Runner:
     """Per-model glue: op set, activation dtype, dropout stream."""
 
@@ -372,6 +359,7 @@ class _Runner:
         self.grad_sync = None     # optional gast_hip.dist.FlatGradAllReduce in bucketed mode: told when a bucket of grad_sink is complete
         self.pending_zero = []    # buffers whose zero fill rides in the next forward's pass prologue (FlatGradAllReduce.zero_(defer=True))
         self._seeds = {}
+        self._ops_factory = None  # see set_ops(): None in the product
         # Forward / backward of every (shape, mode, arithmetic, BatchNorm momentum, dropout p) are replayed from hipGraphs captured on
         # the third call, so an unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140
         # Python launches (3.9 vs 4.9 ms per step at B = 128).  ON by default since round 3 (GAST_HIP_GRAPH=0 turns it off): the
@@ -387,20 +375,25 @@ class _Runner:
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, 'pending_zero': [], '_seeds': {}, 'graph_mode': self.graph_mode,
+                'grad_sync': None, 'pending_zero': [], '_seeds': {}, '_ops_factory': self._ops_factory, 'graph_mode': self.graph_mode,
                 '_graphs': collections.OrderedDict(), 'graph_cache_max': self.graph_cache_max}
 
     def __setstate__(self, state):
         self.__dict__.update(state)
         self._lock = threading.Lock()
 
+    def set_ops(self, factory):
+        """TEST SEAM, explicit.  The product has ONE op set, gast_hip.binding.HipOps (device tensors, HIP kernels, no fallback), and
+        nothing in the product calls this method.  The test-suite checks the host plan on CPU by handing a model's runner a numpy
+        mirror of that op set (tests/fake_backend.py: use_oracle_ops(model)); `bench.py --dry-run-cpu` does the same for the launcher
+        dry run.  No import look-up, no environment switch: a runner nobody called set_ops() on cannot leave the HIP path."""
+        self._ops_factory = factory
+        self._engine = None
+        self._engines = {}
+
     @property
     def ops_factory(self):
-        """TEST SEAM.  The product has ONE op set, gast_hip.binding.HipOps (device tensors, HIP kernels, no fallback).  The test-suite
-        checks the host plan on CPU through a numpy mirror of that op set; it registers a model for the mirror in `gast_test_seam`, a
-        module that exists only under tests/ -- outside the test tree the import fails and this is always None."""
-        seam = _test_seam()
-        return seam.factory_for(self) if seam else None
+        return self._ops_factory
 
     @property
     def act_dtype(self):

@@ -1,0 +1,91 @@
+#!/usr/bin/env python3
+"""Static screen of hipcc's gfx950 assembly for the inline-asm asynchronous-load hazard.
+
+csrc/common.h issues 16-byte global loads from inline asm (gload16 / gload16s) and waits for them with a separate asm statement
+(gload_wait_n).  The compiler does not know the destination registers are still in flight between the two, so it may legally
+COPY or otherwise touch them there (a phi copy at a loop back edge, a spill, a re-materialisation): the copy then reads whatever
+the register held before the load landed -- a rare, timing-dependent wrong value.  This script walks every function of a `.s`
+file in program order, keeps the FIFO of outstanding VMEM operations (gfx9: loads and stores share vmcnt), and reports every
+instruction that names a register of a still-outstanding inline-asm load before an s_waitcnt vmcnt(N) has retired it.
+
+  hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only csrc/gemm.hip -o /tmp/gemm.s && python scripts/asm_load_hazard.py /tmp/gemm.s
+Linear scan (blocks are walked in layout order; in-flight loads are forgotten at a loop's exit block), so a report is a lead to read, not a proof; no report on a loop whose
+layout order is its execution order is strong evidence.  Exit code 1 when anything was reported.
+"""
+import re
+import sys
+
+VMEM = re.compile(r'^\s*(global_load|global_store|global_atomic|buffer_load|buffer_store|buffer_atomic|scratch_load|scratch_store|flat_load|flat_store|flat_atomic)')
+REG = re.compile(r'\bv(\d+)\b|\bv\[(\d+):(\d+)\]')
+
+
+def regs(tok):
+    out = set()
+    for m in REG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def scan(path):
+    fn, in_asm, fifo, reports, in_loop = None, False, [], [], False
+    for ln, line in enumerate(open(path, errors='replace'), 1):
+        s = line.split(';')[0].rstrip() if not line.lstrip().startswith(';;#') else line.strip()
+        if re.match(r'^[_A-Za-z][\w$.]*:\s*(;.*)?$', line) and not line.startswith('.L'):
+            fn, fifo, in_loop = line.split(':')[0], [], False
+            continue
+        if s.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if s.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        s = s.strip()
+        if line.startswith('.LBB'):
+            # leaving every loop (a block LLVM does not annotate as part of one): the loop's exit edge follows its last counted wait at
+            # run time, although the block is laid out behind the loop's trailing loads -- forget them
+            now_in_loop = 'Loop' in line
+            if in_loop and not now_in_loop:
+                fifo = []
+            in_loop = now_in_loop
+            continue
+        if not s or s.startswith('.') or s.endswith(':'):
+            continue
+        m = re.match(r's_waitcnt\b(.*)', s)
+        if m:
+            v = re.search(r'vmcnt\((\d+)\)', m.group(1))
+            if v:
+                n = int(v.group(1))
+                fifo = fifo[len(fifo) - n:] if n else []
+            continue
+        if s.startswith('s_endpgm'):
+            fifo = []
+            continue
+        if VMEM.match(s):
+            ops = s.split(None, 1)[1] if ' ' in s else ''
+            dst = regs(ops.split(',')[0]) if in_asm and s.startswith('global_load') and 'lds' not in s.split()[0] else set()
+            used = regs(ops) - dst
+            pending = set().union(*[d for d, _ in fifo]) if fifo else set()
+            if used & pending:
+                reports.append((fn, ln, s, sorted(used & pending)))
+            fifo.append((dst, ln))
+            continue
+        pending = set().union(*[d for d, _ in fifo]) if fifo else set()
+        if pending:
+            hit = regs(s) & pending
+            if hit:
+                reports.append((fn, ln, s, sorted(hit)))
+    return reports
+
+
+if __name__ == '__main__':
+    bad = 0
+    for p in sys.argv[1:]:
+        rep = scan(p)
+        for fn, ln, s, hit in rep[:400]:
+            print('%s:%d  %s\n    in %s   touches in-flight v%s' % (p, ln, s, fn, hit))
+        print('%s: %d suspicious instruction(s)' % (p, len(rep)))
+        bad += len(rep)
+    sys.exit(1 if bad else 0)

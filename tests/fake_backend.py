@@ -2,8 +2,8 @@
 
 It lets the product's host-side plan (gast_hip/engine.py) run on CPU so that its *composition* of ops can be pinned
 against the reference-generated golden fixtures without a GPU (tests/test_plan_cpu.py).  Every op forwards to
-oracle/kernel_contract.py.  It lives under tests/ and is injected through the model's documented test seam
-(tests/gast_test_seam.py, looked up by `model._runner.ops_factory`); nothing in the product imports it.
+oracle/kernel_contract.py.  It lives under tests/ and is handed to a model explicitly (`model._runner.set_ops(OracleOps)`, see
+use_oracle_ops below); nothing in the product imports it or looks it up.
 """
 import numpy as np
 import torch
@@ -229,7 +229,5 @@ OracleOps.run_unpack = _run_unpack
 
 def use_oracle_ops(model):
     """Route a model instance through the numpy mirror (CPU tensors allowed)."""
-    import gast_test_seam
-    gast_test_seam.register(model._runner, OracleOps)
-    model._runner._engine = None
+    model._runner.set_ops(OracleOps)
     return model

@@ -42,7 +42,9 @@ class x3_mode:
 def ops():
     import os
     os.environ.setdefault('GAST_GEMM_BIG_ALL', '1')     # kernel tests: every eligible shape on the large-M kernel (read once by the library)
+    from conftest import poison_allocations
     from gast_hip.binding import HipOps, set_h16
+    poison_allocations()           # (GAST_TEST_POISON=1 only)
     set_h16(H16)
     return HipOps()
 
@@ -319,6 +321,24 @@ def test_gemm_big_x3_multi(ops, first, nodrop, pair):
 BWD_CASES = [c for c in GEMM_CASES + GEMM_BIG_CASES if c[4] == 2]
 
 
+def _assert_bit_equal(got, ref, what):
+    """torch.equal with a post-mortem: which elements differ, by how much, and whether a NaN (equal to nothing) is involved -- a bit
+    miss on these outputs is a race or an uninitialised read (no atomics feed them), so the failure has to say WHERE."""
+    g, r = got.detach().cpu(), ref.detach().cpu()
+    same = (g.view(torch.int16 if g.element_size() == 2 else torch.int32) == r.view(torch.int16 if r.element_size() == 2 else torch.int32))
+    if bool(same.all()):
+        return
+    bad = (~same).nonzero()
+    rows, cols = bad[:, 0], bad[:, 1]
+    gf, rf = g.float(), r.float()
+    first = [(int(i), int(j), float(gf[i, j]), float(rf[i, j])) for i, j in bad[:12].tolist()]
+    raise AssertionError('%s: %d of %d elements differ bitwise; rows %d..%d (%d distinct, 128-row tiles %s), columns %d..%d; NaN in got: %d, '
+                         'in ref: %d; max |diff| %.3e; first (row, col, got, ref): %s'
+                         % (what, bad.shape[0], g.numel(), int(rows.min()), int(rows.max()), int(rows.unique().numel()),
+                            sorted(set((rows // 128).tolist()))[:16], int(cols.min()), int(cols.max()), int(torch.isnan(gf).sum()),
+                            int(torch.isnan(rf).sum()), float(torch.nan_to_num(gf - rf).abs().max()), first))
+
+
 @pytest.mark.parametrize('mode', ['f32', 'bf16', 'x3'])
 @pytest.mark.parametrize('case', BWD_CASES, ids=[c[0] for c in BWD_CASES])
 def test_gemm_bwd_second_output(ops, case, mode):
@@ -347,8 +367,8 @@ def test_gemm_bwd_second_output(ops, case, mode):
         close(host(bufs[0]), host(C_ref), dt, 'masked output', fp32=1e-4)
         close(host(C2), host(plain), dt, 'C2', fp32=1e-4)
     else:
-        assert torch.equal(bufs[0], C_ref), 'the masked output changed'
-        assert torch.equal(C2, plain), 'C2 differs from the PLAIN epilogue of the same GEMM'
+        _assert_bit_equal(bufs[0], C_ref, 'the masked output (C) of the call WITH a second output vs the call without')
+        _assert_bit_equal(C2, plain, 'C2 vs the PLAIN epilogue of the same GEMM')
     close(host(bufs[2]).sum(axis=0), host(part_ref).sum(axis=0), dt, 'sums', fp32=1e-5, bf16=1e-5)
 
 

@@ -62,6 +62,9 @@ def _log(**kw):
         pass
 
 
+STRICT = os.environ.get('GAST_TEST_STRICT', '0') not in ('0', '')      # the bounds that only a fixed reduction order can hold
+
+
 def build(cfg, dropout=0.0):
     from model.gast_net import SpatioTemporalModel, SpatioTemporalModelOptimized1f
     from oracle.gast_oracle import adj_from_parents
@@ -633,7 +636,10 @@ def test_flat_gradient_buffer_accumulates_like_autograd(mode2):
         scale = float(ref[k].abs().max()) + 1e-6
         # (absolute floor: a BatchNorm bias in front of another BatchNorm has a true gradient of ~0 -- what the buffer holds is the
         #  round-off of a sum over all positions, whose order the split reductions do not fix: measured up to 2.1e-5)
-        assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + 5e-5, k
+        # GAST_DETERMINISTIC=1 (tests/test_deterministic_gpu.py re-runs this test in a child process with GAST_TEST_STRICT=1): the
+        # reductions have a fixed order, and the tighter floor of round 3 holds again.
+        floor = 2e-5 if STRICT else 5e-5
+        assert float((p.grad - 2 * ref[k]).abs().max()) < 2e-4 * scale + floor, k
 
 
 def test_dropout_gradients_by_finite_differences(monkeypatch):

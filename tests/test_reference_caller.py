@@ -22,6 +22,7 @@ sys.path.insert(0, os.path.join(HERE, 'caller'))
 import scenario as sc  # noqa: E402
 
 REF = '/root/reference'
+STRICT = os.environ.get('GAST_TEST_STRICT', '0') not in ('0', '')      # the pre-round-4 bounds, held under GAST_DETERMINISTIC=1
 # after 2 optimizer steps the two implementations agree to fp32 round-off; over 7 steps Adam amplifies it (see scenario.py).
 # bf16x3 (fp32 storage; forward GEMMs on fp16 hi/lo pairs, gradients on bf16 pairs -- the arithmetic bench.py times) behaves like fp32
 # here since the forward moved to fp16 pairs (measured, round 3: short 6.3e-7 / 0.002 mm / 1.3e-4 / 2.7e-5; epoch 7.8e-5 / 0.014 mm /
@@ -63,7 +64,7 @@ def compare(got, ref, size, arith='fp32', log=None):
     # north star: MPJPE within 0.1 mm of the reference
     assert m['mpjpe_mm'] <= tol['mm'], 'MPJPE %.4f vs %.4f mm' % (got['e1'], ref['e1'])
     # (Procrustes-aligned MPJPE is not part of the north star; it amplifies the same differences through an SVD per frame: twice the bound)
-    assert m['p_mpjpe_mm'] <= 2 * tol['mm'], 'P-MPJPE %.4f vs %.4f mm' % (got['e2'], ref['e2'])
+    assert m['p_mpjpe_mm'] <= (1 if STRICT else 2) * tol['mm'], 'P-MPJPE %.4f vs %.4f mm' % (got['e2'], ref['e2'])
     assert got['pred'].shape == ref['pred'].shape
     assert m['pred_max_abs'] <= tol['pred'], m
     assert sorted(k for k in got if k.startswith('state/')) == sorted(keys)
@@ -73,6 +74,8 @@ def compare(got, ref, size, arith='fp32', log=None):
         # 1e-4 fraction of the entries within the bound, and no entry further than two such flips (4 * lr).
         assert m['param_frac_beyond_tol'] <= 1e-4, '%.2e of the parameter entries differ by more than %.0e' % (m['param_frac_beyond_tol'], tol['param'])
         assert worst[1] <= 4 * sc.LR, '%s differs by %.3e after the training steps' % worst
+        if STRICT:      # GAST_DETERMINISTIC=1 child run (tests/test_deterministic_gpu.py): every entry inside the bound, as before round 4
+            assert worst[1] <= tol['param'], '%s differs by %.3e after the training steps (strict)' % worst
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason='needs the reference checkout (build container only)')
