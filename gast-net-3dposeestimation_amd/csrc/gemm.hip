@@ -19,6 +19,7 @@
 // one M-panel run on the same XCD (shared L2).
 #include "common.h"
 #include "gemm_big.h"
+#include "bn_lazy.h"
 #include <stdlib.h>
 
 namespace {
@@ -615,7 +616,9 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
 template <typename T, typename TO, int X3 = 0, bool F8 = false>
-__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws,
+                                                      const gast_bn_lazy lz) {
+    gastbn::bn_lazy_sync(lz);      // (lazy BatchNorm finalize: the scale / shift of a prologue segment are written by this launch's first blocks)
     gemm_body<T, TO, X3, F8>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
 
@@ -636,7 +639,8 @@ struct GemmBatch {
 };
 static_assert(sizeof(GemmBatch) <= 3712, "GemmBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO, int X3 = 0, bool F8 = false>
-__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
+__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b, const gast_bn_lazy lz) {
+    gastbn::bn_lazy_sync(lz);
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
     gemm_body<T, TO, X3, F8>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], b.splitk[d], b.splitk[d] > 1 ? b.ws + b.ws_off[d] : nullptr,
@@ -801,21 +805,23 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int rc = gemm_plan(a, ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (gastbn::lazy_check(a.lazy)) return GAST_EINVAL;
+    const gast_bn_lazy lz = gastbn::lazy_arg(a.lazy);
     BigPlan bp;
-    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
+    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, lz, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     else if (a.dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_kernel<float, float, 1>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<float, float, 1>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     else if (a.dtype == GAST_F32X3H)
-        hipLaunchKernelGGL((gemm_kernel<float, float, 2>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<float, float, 2>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     else if (a.f8_scale && !a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     else if (a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     else
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
     GAST_CHECK_LAUNCH();
     if (splitk > 1) {
         // the finish kernel accumulates the column statistics with atomics: `partials` arrives zero-filled (gast_hip.h)
@@ -884,24 +890,46 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     }
     (void)deferred_after_own;
     hipStream_t st = (hipStream_t)stream;
+    // a lazy finalize rides in ONE launch of the call: the grid that holds the job carrying it (the plan gives it to the first job; a
+    // call whose jobs split into a large-M and a 128x128-tile grid must not carry one unless every prologue job sits in the same grid)
+    const gast_bn_lazy* lzp = nullptr;
+    int lz_job = -1;
+    for (int d = 0; d < n; ++d) if (args[d].lazy) { if (lzp) return GAST_EINVAL; lzp = args[d].lazy; lz_job = d; }
+    if (gastbn::lazy_check(lzp)) return GAST_EINVAL;
+    if (lzp && deferred_after_own) return GAST_EINVAL;
+    bool lz_big = false;
+    if (lzp) {
+        for (int k = 0; k < nbig; ++k) if (big_a[k].lazy) lz_big = true;
+        // every job with a BatchNorm prologue must run in the grid that waits for the finalize
+        for (int d = 0; d < n; ++d) {
+            bool has_pro = false;
+            for (int q = 0; q < args[d].nseg; ++q) has_pro |= args[d].seg[q].pro != GAST_PRO_NONE;
+            if (!has_pro || d == lz_job) continue;
+            bool in_big = false;
+            for (int k = 0; k < nbig; ++k) in_big |= big_a[k].C == args[d].C;
+            if (in_big != lz_big) return GAST_EINVAL;
+        }
+    }
+    const gast_bn_lazy lz_none = gastbn::lazy_arg(nullptr);
     if (nbig) {
-        int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, st);
+        int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, lz_big ? gastbn::lazy_arg(lzp) : lz_none, st);
         if (rc) return rc;
     }
     if (b.n == 0) return 0;
+    const gast_bn_lazy lz = (lzp && !lz_big) ? gastbn::lazy_arg(lzp) : lz_none;
     dim3 grid(b.first[b.n]), block(256);
     if (args[0].dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b, lz);
     else if (args[0].dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 1>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 1>), grid, block, 0, st, b, lz);
     else if (args[0].dtype == GAST_F32X3H)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 2>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 2>), grid, block, 0, st, b, lz);
     else if (args[0].f8_scale && !args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, b, lz);
     else if (args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b, lz);
     else
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b, lz);
     GAST_CHECK_LAUNCH();
     if (fb.n) {
         dim3 fgrid(fb.first[fb.n]);

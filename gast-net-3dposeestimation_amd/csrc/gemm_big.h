@@ -17,5 +17,6 @@ struct BigPlan {
 // (internal to the library: hidden, so that the dynamic symbol table holds the C ABI of include/gast_hip.h and nothing else)
 // 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip
 __attribute__((visibility("hidden"))) int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
-__attribute__((visibility("hidden"))) int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
-__attribute__((visibility("hidden"))) int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);
+// lz: a lazy BatchNorm finalize that rides in front of the launch (kind 0: none; bn_lazy.h)
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, const gast_bn_lazy& lz, hipStream_t st);
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, const gast_bn_lazy& lz, hipStream_t st);

@@ -22,6 +22,7 @@
 //     are exactly one statistics block (partials[ceil(M/128)][N][2], the layout gemm.hip and the BatchNorm finalizes share).
 #include "common.h"
 #include "gemm_big.h"
+#include "bn_lazy.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <atomic>
@@ -64,7 +65,7 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 // (NI = 2 only, the M = B*J stage: at most a block or two per CU, so a block has to cover the memory latency by itself -- five weight
 // stages, four activation register sets, 57 KB of LDS)
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
+__device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem, const gast_bn_lazy& lz) {
     constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
     constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW, D);
     constexpr int WS = D + 1;                       // weight stages in the ring
@@ -252,6 +253,10 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             dma_w(dq[i - 1], i);
             load_a(dq[i - 1], ra[i], rz[i]);
         }
+        // a lazy BatchNorm finalize (gast_bn_lazy): the first blocks of the launch compute the scale / shift the tables below are read
+        // from, every block waits for them here -- with its first tiles already in flight
+        // (LDS scratch: the first activation stage -- nothing is written there before write_a(d0, 0, ..) below)
+        gastbn::bn_lazy_sync_with(lz, (gastbn::fin_red_t)(smem + OFF_A));
         for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
             if (pl.taboff[s] >= 0) {
                 const float* sc = a.seg[s].scale;
@@ -492,9 +497,9 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
 }
 
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl, const gast_bn_lazy lz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD, NI, MW, PAIR, D>(a, pl, blockIdx.x, smem);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(a, pl, blockIdx.x, smem, lz);
 }
 
 struct BigBatch {
@@ -506,11 +511,11 @@ struct BigBatch {
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b, const gast_bn_lazy lz) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD, NI, MW, PAIR, D>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem, lz);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -633,7 +638,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
 
 static int big_lds_bytes(int ntab, int ni, int mw, int depth) { return off_tab(ni, mw, depth) + 2 * ntab * 4 + 6 * nt_of(mw) * 4; }
 
-typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
+typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan, const gast_bn_lazy);
 template <int NI, int MW, int D = 2>
 static big_kernel_t big_kernel_ni(int v, int pair) {
     if (pair == 2) {                // (variants 0..3: gast_gemm_big_plan keeps the BNRELU_BWD epilogues on bf16 pairs)
@@ -662,7 +667,7 @@ static big_kernel_t big_kernel(int v, int ni, int mw, int pair, int depth) {
     return mw == 4 ? big_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_kernel_ni<2, 2>(v, pair) : big_kernel_ni<4, 2>(v, pair);
 }
 
-typedef void (*big_multi_kernel_t)(const BigBatch);
+typedef void (*big_multi_kernel_t)(const BigBatch, const gast_bn_lazy);
 template <int NI, int MW, int D = 2>
 static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
     if (pair == 2) {
@@ -699,8 +704,13 @@ static void big_setup() {
         const int ni = (c == 0 || c == 3) ? 2 : 4, mw = c == 2 ? 4 : 2, depth = c == 3 ? 4 : 2;
         for (int pair = 1; pair <= 2; ++pair)
             for (int v = 0; v < (pair == 2 ? 4 : 8); ++v) {
-                hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
-                hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                const hipError_t e1 = hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                const hipError_t e2 = hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
+                if (e1 != hipSuccess || e2 != hipSuccess) {      // (e.g. static + dynamic LDS beyond the 160 KB of a CU: say so here, not at some later launch)
+                    fprintf(stderr, "gast_hip: gemm_big set-up failed for variant %d NI %d MW %d pair %d depth %d: %s\n", v, ni, mw, pair, depth,
+                            hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                    (void)hipGetLastError();
+                }
             }
     }
     big_setup_done[dev].store(true, std::memory_order_release);
@@ -719,16 +729,17 @@ static void big_setup() {
     }
 }
 
-int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
+int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, const gast_bn_lazy& lz, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair, pl.depth), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw, pl.depth), st, a, pl);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair, pl.depth), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw, pl.depth), st, a, pl, lz);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
-int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st) {
+int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, const gast_bn_lazy& lz_in, hipStream_t st) {
     big_setup();
     bool done[GAST_GEMM_MAX_BATCH] = {};
+    bool lz_used = false;
     for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
         const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw, pair = pls[d0].pair, depth = pls[d0].depth;
@@ -745,8 +756,11 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair, depth), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b.a[0], b.pl[0]);
-        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair, depth), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b);
+        // (the lazy finalize runs in the FIRST grid of the call; a later grid of the same call starts after it on the stream)
+        const gast_bn_lazy lz = lz_used ? gastbn::lazy_arg(nullptr) : lz_in;
+        lz_used = true;
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair, depth), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b.a[0], b.pl[0], lz);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair, depth), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b, lz);
         GAST_CHECK_LAUNCH();
     }
     return 0;

@@ -3,6 +3,7 @@
 // (reference model/global_attention.py:52-82).  All of them are HBM/latency bound (AI < 5 F/B): coalesced channel-major
 // accesses, the J x J tiles live in LDS, no MFMA.
 #include "common.h"
+#include "bn_lazy.h"
 #include <atomic>
 #include <type_traits>
 
@@ -372,15 +373,23 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
 #define GAST_AGG_LDS_U 2
 #endif
 constexpr int AGG_LDS_U = GAST_AGG_LDS_U, AGG_LDS_CC = 32, AGG_LDS_NPB = 5;
-template <typename T, int DS, int DC>
+// BN (round 5): dY arrives BEFORE the BatchNorm backward of bn_1 | bn_2 (the masked gradient the preceding GEMM epilogue wrote) and the
+// kernel applies dy = ka*dY + kb*Y + kc (Y = the pre-BatchNorm aggregation output of the forward) while staging -- the stand-alone
+// gast_bn_bwd_apply pass over dY (a read-modify-write of P x 2C, at the HBM roofline) disappears; the finalize that makes ka / kb / kc
+// runs lazily in front (gast_bn_lazy).  Same fma nesting as bn_bwd_apply_kernel: the values are bit-equal to the two-launch form.
+template <typename T, int DS, int DC, bool BN = false>
 __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
                                                                 int F, int J, int C,
                                                                 const float* __restrict__ A_sym, const int32_t* __restrict__ pat_sym,
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
-                                                                T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb, int nchunk) {
+                                                                T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb, int nchunk,
+                                                                const T* __restrict__ Yp, int ldyp, const float* ka, const float* kb,
+                                                                const float* kc, const gast_bn_lazy lz) {
     constexpr int U = AGG_LDS_U, CC = AGG_LDS_CC, CC4 = CC / 4, NPB = AGG_LDS_NPB;
     __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
+    __shared__ __attribute__((aligned(16))) float sK[BN ? 3 : 1][2][CC];      // BN: [ka | kb | kc][sym | con half of dY][channel of the chunk]
     extern __shared__ __attribute__((aligned(16))) float sAggL[];
+    if (BN) gastbn::bn_lazy_sync(lz);
     const int tid = threadIdx.x;
     const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
     const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
@@ -402,6 +411,13 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restr
         const Pat& p = t < J ? ps : pc;
         const int i = t < J ? t : t - J, base = t < J ? 0 : nnz_s;
         for (int k = p.row_ptr[i]; k < p.row_ptr[i + 1]; ++k) { s_ei[base + k] = i; s_ej[base + k] = p.col[k]; }
+    }
+    if (BN) {
+        for (int t = tid; t < 3 * 2 * CC; t += 256) {
+            const int which = t / (2 * CC), g = (t / CC) & 1, cl = t % CC;
+            const float* src = which == 0 ? ka : which == 1 ? kb : kc;
+            sK[which][g][cl] = c0 + cl < C ? src[g * C + c0 + cl] : 0.f;
+        }
     }
     __syncthreads();
     // phase-B ownership: pairs tid + 256 q
@@ -425,18 +441,25 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restr
     // the NEXT group's elements are requested into registers before the current group is processed
     constexpr int NPRE = (U * JMAX * 6 * CC4 + 255) / 256;
     float4 pre[NPRE];
+    float4 prey[BN ? NPRE : 1];        // BN: the Y values next to the dY slots
+    unsigned bnmask = 0;               // BN: slots that hold a real dY element (a frame past F stays zero: kc must not leak in)
     auto request = [&](int f0) {
+        bnmask = 0;
 #pragma unroll
         for (int q = 0; q < NPRE; ++q) {
             const int t = tid + 256 * q;
             pre[q] = make_float4(0, 0, 0, 0);
+            if (BN) prey[q] = make_float4(0, 0, 0, 0);
             if (t < U * J * 6 * CC4) {
                 const int c4 = t % CC4, r = t / CC4;
                 const int w = r % 6, rj = r / 6;
                 const int u = rj / J, j = rj - u * J;
                 const long f = f0 + u;
                 const int c = c0 + c4 * 4;
-                if (f < F && c < C) pre[q] = w < 2 ? ld4(dY + (f * J + j) * ldy + w * C + c) : ld4(H + (f * J + j) * ldh + (w - 2) * C + c);
+                if (f < F && c < C) {
+                    pre[q] = w < 2 ? ld4(dY + (f * J + j) * ldy + w * C + c) : ld4(H + (f * J + j) * ldh + (w - 2) * C + c);
+                    if (BN && w < 2) { prey[q] = ld4(Yp + (f * J + j) * ldyp + w * C + c); bnmask |= 1u << q; }
+                }
             }
         }
     };
@@ -448,7 +471,19 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restr
             if (t < U * J * 6 * CC4) {
                 const int c4 = t % CC4, r = t / CC4;
                 const int w = r % 6, rj = r / 6;
-                if (w < 2) *(float4*)(sDY + (rj * 2 + w) * CC + c4 * 4) = pre[q];
+                if (w < 2) {
+                    float4 d = pre[q];
+                    if (BN && (bnmask >> q & 1u)) {
+                        const float4 a = *(const float4*)&sK[0][w][c4 * 4], b = *(const float4*)&sK[BN ? 1 : 0][w][c4 * 4],
+                                     k = *(const float4*)&sK[BN ? 2 : 0][w][c4 * 4], x = prey[q];
+                        d.x = fmaf(a.x, d.x, fmaf(b.x, x.x, k.x));
+                        d.y = fmaf(a.y, d.y, fmaf(b.y, x.y, k.y));
+                        d.z = fmaf(a.z, d.z, fmaf(b.z, x.z, k.z));
+                        d.w = fmaf(a.w, d.w, fmaf(b.w, x.w, k.w));
+                        d = rnd4(d, (const T*)nullptr);          // (16-bit storage: the stand-alone pass rounds what it stores)
+                    }
+                    *(float4*)(sDY + (rj * 2 + w) * CC + c4 * 4) = d;
+                }
                 else *(float4*)(sH + (rj * 4 + (w - 2)) * CC + c4 * 4) = pre[q];
             }
         }
@@ -1683,15 +1718,28 @@ extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_
     return (long)(a.nfb > b.nfb ? a.nfb : b.nfb) * (nnz_sym + nnz_con) * C;
 }
 
+// the BatchNorm-backward apply of dY fused into the staging pass (semch_agg_bwd_lds_kernel<.., BN = true>): Yp != null
+struct AggBwdBn { const void* Yp; int ldyp; const float* ka; const float* kb; const float* kc; const gast_bn_lazy* lazy; };
+
+static bool agg_bwd_takes_lds(int dtype, int F, int C, int nnz_sym, int cdeg_sym, int nnz_con, int cdeg_con) {
+    const AggBwdCfg c = agg_bwd_cfg(F, C, dtype == GAST_F32 && (cdeg_sym == 2 && (cdeg_con == 5 || cdeg_con == 6)));
+    return c.lds && (long)(nnz_sym + nnz_con) * (AGG_LDS_CC / 4) <= 256L * AGG_LDS_NPB;
+}
+
 static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H, int ldh, int F, int J, int C,
                               const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
                               const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
-                              gast_rowsum_job* finish, gast_stream_t stream) {
+                              gast_rowsum_job* finish, gast_stream_t stream, const AggBwdBn* bn = nullptr) {
     if (!dY || !H || !A_sym || !A_con || !pat_sym || !pat_con || !dH || !dA || !ws) return GAST_EINVAL;
     if (dtype != GAST_F32 && dtype != GAST_BF16) return GAST_EINVAL;
     if (C % 4 || ldh % 4 || ldy % 4 || lddh % 4 || J < 1 || J > JMAX || F < 1 || nnz_sym < 1 || nnz_con < 1) return GAST_EALIGN;
     AggBwdCfg c = agg_bwd_cfg(F, C, dtype == GAST_F32 && (cdeg_sym == 2 && (cdeg_con == 5 || cdeg_con == 6)));
     const int nnz_t = nnz_sym + nnz_con;
+    if (bn) {
+        if (!bn->Yp || !bn->ka || !bn->kb || !bn->kc || bn->ldyp % 4 || gastbn::lazy_check(bn->lazy)) return GAST_EINVAL;
+        if (!agg_bwd_takes_lds(dtype, F, C, nnz_sym, cdeg_sym, nnz_con, cdeg_con)) return GAST_EINVAL;      // (ask gast_semch_agg_bwd_fuses_bn first)
+    }
+    const gast_bn_lazy lzv = gastbn::lazy_arg(bn ? bn->lazy : nullptr);
     // fixed-degree kernel: LDS for the coefficient slices, at most J * deg + 1 rows per pattern
     size_t smem = (size_t)(J * cdeg_sym + 1 + J * cdeg_con + 1) * c.CC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
@@ -1720,13 +1768,22 @@ static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H,
         if (dtype == GAST_F32) {                                                                                              \
             if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<float, DS, DC>,                    \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
+            if (bn) {                                                                                                        \
+                if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<float, DS, DC, true>,              \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
+                hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<float, DS, DC, true>), grid, dim3(256), sm, st, (const float*)dY, ldy, \
+                                   (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, \
+                                   (const float*)bn->Yp, bn->ldyp, bn->ka, bn->kb, bn->kc, lzv);                              \
+            } else                                                                                                            \
             hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<float, DS, DC>), grid, dim3(256), sm, st, (const float*)dY, ldy,     \
-                               (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk); \
+                               (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, \
+                               (const float*)nullptr, 0, nullptr, nullptr, nullptr, lzv);                                     \
         } else {                                                                                                              \
             if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<bf16_t, DS, DC>,                   \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
             hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<bf16_t, DS, DC>), grid, dim3(256), sm, st, (const bf16_t*)dY, ldy,   \
-                               (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk); \
+                               (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk, \
+                               (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr, lzv);                                    \
         }                                                                                                                     \
     } while (0)
     bool fast = true;
@@ -1785,6 +1842,21 @@ extern "C" int gast_semch_agg_bwd_deferred(int dtype, const void* dY, int ldy, c
     finish->ws = nullptr;
     return semch_agg_bwd_impl(dtype, dY, ldy, H, ldh, F, J, C, A_sym, pat_sym, nnz_sym, cdeg_sym, A_con, pat_con, nnz_con, cdeg_con, dH, lddh,
                               dA, ws, finish, stream);
+}
+
+extern "C" int gast_semch_agg_bwd_fuses_bn(int dtype, int F, int J, int C, int nnz_sym, int cdeg_sym, int nnz_con, int cdeg_con) {
+    if (J < 1 || J > JMAX || F < 1 || C % 4) return 0;
+    return agg_bwd_takes_lds(dtype, F, C, nnz_sym, cdeg_sym, nnz_con, cdeg_con) ? 1 : 0;
+}
+extern "C" int gast_semch_agg_bwd_bn(int dtype, const void* dY, int ldy, const void* Ypre, int ldyp, const float* ka, const float* kb,
+                                     const float* kc, const gast_bn_lazy* lazy, const void* H, int ldh, int F, int J, int C,
+                                     const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
+                                     const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
+                                     gast_rowsum_job* finish, gast_stream_t stream) {
+    const AggBwdBn bn = {Ypre, ldyp, ka, kb, kc, lazy};
+    if (finish) finish->ws = nullptr;
+    return semch_agg_bwd_impl(dtype, dY, ldy, H, ldh, F, J, C, A_sym, pat_sym, nnz_sym, cdeg_sym, A_con, pat_con, nnz_con, cdeg_con, dH, lddh,
+                              dA, ws, finish, stream, &bn);
 }
 
 static int attn_grid(int F, int nheads, int ub) {

@@ -5,8 +5,10 @@
 // coalescing, column statistics reduced per block in LDS and written as partial rows that `gast_bn_finalize`
 // combines in double precision (deterministic, no atomics on the statistics).
 #include "common.h"
+#include "bn_lazy.h"
 
 namespace {
+using namespace gastbn;
 
 __device__ __forceinline__ float4 f4(float v) { return make_float4(v, v, v, v); }
 
@@ -52,34 +54,8 @@ __device__ __forceinline__ void slot_reduce(float4 (&v)[NV], float (*sred)[4 * N
 // then the 8 lanes are combined in LDS in double precision.  (One thread per column walking all row blocks serially
 // exposed one L2 latency per row block: 80 us for 425 blocks.)
 constexpr int FIN_COLS = 32, FIN_LANES = 8;          // the fused short-tensor kernel (its apply half wants 32 columns)
-// The stand-alone finalizes run on 4..16 blocks, so their time is the serial chain of partial-row loads of one lane:
-// 16 columns x 16 lanes (a 128-byte row segment per load wave) and 8 loads in flight halve that chain again
-// (425 row blocks: 15 us -> 8 us).
-// Round 3: 4 columns x 64 lanes (N / 4 blocks instead of N / 16: 64 .. 256 blocks on 256 CUs), every lane's <= 7 partial-row loads
-// (425 row blocks) all in flight at once, the 16 lanes of a column inside a wave combined with shuffles and the four waves through
-// LDS: the chain is ONE memory latency (5.7 us -> ~3 us per launch; 24 launches per step).
-constexpr int FINS_COLS = 4, FINS_LANES = 64;
-
-// thread = (column cx = tid & 3, lane ry = tid >> 2); sred: [4 waves][FINS_COLS][2]
-__device__ __forceinline__ void finalize_sums_wide(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
-                                                   double (*sred)[FINS_COLS][2], int cx, int ry, double& s1, double& s2) {
-    double a1 = 0.0, a2 = 0.0;
-    if (valid) {
-#pragma unroll 8
-        for (int b = ry; b < nblk; b += FINS_LANES) {
-            const float2 p = *(const float2*)(partials + ((long)b * ncol_total + col) * 2);
-            a1 += (double)p.x;
-            a2 += (double)p.y;
-        }
-    }
-#pragma unroll
-    for (int o = FINS_COLS; o < 64; o <<= 1) { a1 += __shfl_xor(a1, o); a2 += __shfl_xor(a2, o); }      // lanes of equal cx inside the wave
-    const int w = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) < FINS_COLS) { sred[w][cx][0] = a1; sred[w][cx][1] = a2; }
-    __syncthreads();
-    s1 = (sred[0][cx][0] + sred[1][cx][0]) + (sred[2][cx][0] + sred[3][cx][0]);
-    s2 = (sred[0][cx][1] + sred[1][cx][1]) + (sred[2][cx][1] + sred[3][cx][1]);
-}
+// (the stand-alone finalizes' geometry -- 4 columns x 64 lanes per block -- and their bodies live in bn_lazy.h: the lazy finalize that
+// runs in front of a consumer launch shares them)
 
 template <int COLS, int LANES>
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
@@ -103,37 +79,8 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials
 
 __device__ __forceinline__ void bn_finalize_body(const gast_bn_fin_job& j) {
     __shared__ double sred[4][FINS_COLS][2];
-    const float* __restrict__ partials = j.partials;
-    const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N, centered = j.centered;
-    const double count = j.count;
-    const float* __restrict__ gamma = j.gamma;
-    const float* __restrict__ beta = j.beta;
-    float* running_mean = j.running_mean; float* running_var = j.running_var; int64_t* nbt = j.num_batches_tracked;
-    const float momentum = j.momentum, eps = j.eps;
-    float* scale = j.scale; float* shift = j.shift; float* mean_out = j.mean; float* rstd_out = j.rstd;
-    const int cx = threadIdx.x & (FINS_COLS - 1), ry = threadIdx.x / FINS_COLS;
-    const int n = blockIdx.x * FINS_COLS + cx;
-    if ((int)blockIdx.x * FINS_COLS >= N) return;
-    double s1, s2;
-    finalize_sums_wide(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
-    if (ry != 0 || n >= N) return;
-    double mean = s1 / count;
-    double var = s2 / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    float rstd = (float)(1.0 / sqrt(var + (double)eps));
-    float sc = gamma[n] * rstd;
-    scale[n] = sc;
-    shift[n] = beta[n] - (float)mean * sc;
-    mean_out[n] = (float)mean;
-    rstd_out[n] = rstd;
-    if (running_mean) {
-        double unb = count > 1.0 ? var * (count / (count - 1.0)) : var;
-        // centred storage: the statistics are those of x - running_mean, so the true batch mean is running_mean + mean
-        running_mean[n] = centered ? running_mean[n] + momentum * (float)mean
-                                   : (1.f - momentum) * running_mean[n] + momentum * (float)mean;
-        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)unb;
-    }
-    if (n == 0 && nbt) *nbt += 1;
+    if ((int)blockIdx.x * FINS_COLS >= j.N) return;
+    bn_finalize_unit(j, blockIdx.x, sred);
 }
 
 // up to GAST_BN_MAX_BATCH independent finalizes in one launch: blockIdx.y = job
@@ -162,30 +109,8 @@ __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __r
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const gast_bn_bwd_fin_job& j) {
     __shared__ double sred[4][FINS_COLS][2];
-    const float* __restrict__ partials = j.partials;
-    const int nblk = j.nblk, ncol_total = j.ncol_total, col0 = j.col0, N = j.N;
-    const double count = j.count;
-    const float* __restrict__ gamma = j.gamma;
-    const float* __restrict__ mean = j.mean;
-    const float* __restrict__ rstd = j.rstd;
-    float* dgamma = j.dgamma; float* dbeta = j.dbeta; float* ka = j.ka; float* kb = j.kb; float* kc = j.kc;
-    const int accumulate = j.accumulate;
-    const int cx = threadIdx.x & (FINS_COLS - 1), ry = threadIdx.x / FINS_COLS;
-    const int n = blockIdx.x * FINS_COLS + cx;
-    if ((int)blockIdx.x * FINS_COLS >= N) return;
-    double s1, s2;
-    finalize_sums_wide(partials, nblk, ncol_total, col0 + n, n < N, sred, cx, ry, s1, s2);
-    if (ry != 0 || n >= N) return;
-    double mu = mean[n], r = rstd[n], g = gamma[n];
-    double dg = r * (s2 - mu * s1);   // sum dz * xhat
-    double db = s1;
-    if (accumulate) { dgamma[n] += (float)dg; dbeta[n] += (float)db; }      // gradient destinations: plain read-modify-write, one owner per element
-    else { dgamma[n] = (float)dg; dbeta[n] = (float)db; }
-    double a = g * r;
-    double b = -g * r * r * dg / count;
-    ka[n] = (float)a;
-    kb[n] = (float)b;
-    kc[n] = (float)(-b * mu - a * db / count);
+    if ((int)blockIdx.x * FINS_COLS >= j.N) return;
+    bn_bwd_finalize_unit(j, blockIdx.x, sred);
 }
 
 struct BnBwdFinBatch { gast_bn_bwd_fin_job j[GAST_BN_MAX_BATCH]; };
@@ -194,8 +119,9 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_multi_kernel(const BnBwdF
 // ------------------------------------------------------------------------------------------------ elementwise
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, int lddz, const T* __restrict__ X, int ldx, long rows, int N,
-                                                           const float* __restrict__ ka, const float* __restrict__ kb,
-                                                           const float* __restrict__ kc, int TPR, int RB) {
+                                                           const float* ka, const float* kb,
+                                                           const float* kc, int TPR, int RB, const gast_bn_lazy lz) {
+    bn_lazy_sync(lz);          // (lazy BatchNorm-backward finalize: ka / kb / kc are written by this launch's first blocks)
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -266,9 +192,10 @@ __global__ void __launch_bounds__(256) bn_bwd_fused_kernel(const BnBwdFusedBatch
 
 template <typename T>
 __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
-                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* scale, const float* shift,
                                                            T* __restrict__ Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop,
-                                                           int TPR, int RB) {
+                                                           int TPR, int RB, const gast_bn_lazy lz) {
+    bn_lazy_sync(lz);          // (lazy BatchNorm finalize: scale / shift are written by this launch's first blocks)
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -345,10 +272,11 @@ __global__ void __launch_bounds__(256) bnrelu_bwd_mask_kernel(const T* dY, int l
 template <typename T>
 __global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__ O, int ldo, gast_rowmap omap,
                                                            const float* __restrict__ scO, const float* __restrict__ shO,
-                                                           const T* __restrict__ T2, int ldt, const float* __restrict__ sc2,
-                                                           const float* __restrict__ sh2, int use_drop, uint32_t salt,
+                                                           const T* __restrict__ T2, int ldt, const float* sc2,
+                                                           const float* sh2, int use_drop, uint32_t salt,
                                                            gast_dropout drop, int Tn, int J, long rows, int N,
-                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB) {
+                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB, const gast_bn_lazy lz) {
+    bn_lazy_sync(lz);          // (lazy BatchNorm finalize of T2's statistics: sc2 / sh2 are written by this launch's first blocks)
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -444,13 +372,21 @@ constexpr int KMAX = 16;  // F_in * k0 (2 features x up to 7 taps, or 3 x 5)
 template <typename T>
 __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict__ x, int B, int T_in, int J, int F_in, int k0,
                                                          int t_stride, int T_out, const float* __restrict__ W,
-                                                         const float* __restrict__ sc0, const float* __restrict__ sh0, int C,
+                                                         const float* sc0, const float* sh0, int C,
                                                          T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB,
-                                                         const float* __restrict__ center) {
+                                                         const float* __restrict__ center, const gast_bn_lazy lz) {
     extern __shared__ __attribute__((aligned(16))) float sW[];  // [K0][C] then sred
     __shared__ float sred[256][8];
+    __shared__ float sBN0[2][KMAX];
+    bn_lazy_sync(lz);          // (lazy init_bn finalize: sc0 / sh0 are written by this launch's first blocks)
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
+    // scale / shift of the input features through LDS, fetched with device-scope loads: a uniform global read could be served by the
+    // scalar cache, which the acquire of the lazy finalize does not invalidate
+    if (tid < F_in) {
+        sBN0[0][tid] = __hip_atomic_load(sc0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sBN0[1][tid] = __hip_atomic_load(sh0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     for (int t = tid; t < K0 * C; t += 256) {
         int c = t / K0, kk = t - c * K0;     // W is [c][f][tap] = [c][kk]
         sW[kk * C + c] = W[t];
@@ -471,7 +407,7 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
                 int t = rem / J, j = rem - t * J;
                 float4 e = make_float4(0, 0, 0, 0);
                 for (int f = 0; f < F_in; ++f) {
-                    float s = sc0[f], h = sh0[f];
+                    float s = sBN0[0][f], h = sBN0[1][f];
                     for (int tap = 0; tap < k0; ++tap) {
                         long xr = ((long)b * T_in + t * t_stride + tap) * J + j;
                         float xv = fmaf(x[xr * F_in + f], s, h);
@@ -503,12 +439,18 @@ constexpr int XF = 2, XT = 8;
 // atomics, two rows in flight per thread.  Stage 2 (expand_bwd_finish_kernel) sums the block rows and applies the
 // parameter-sized epilogue.  (One pass with <=128 long-running blocks ending in (F_in*k0+1)*C atomics took 115 us for
 // 14 MB of dE: 8 bytes in flight per thread.)
-template <typename T>
+// BN (round 5): dE arrives BEFORE the backward of expand_bn (the masked gradient of the first block's input GEMM) and the kernel applies
+// dz = ka*dE + kb*E + kc while loading -- the stand-alone gast_bn_bwd_apply pass over dE disappears; the finalize that makes ka / kb / kc
+// runs lazily in front (gast_bn_lazy).  Same fma nesting and rounding as bn_bwd_apply_kernel.
+template <typename T, bool BN = false>
 __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ dE, int ldde, const float* __restrict__ x, int B, int T_in,
                                                          int J, int F_in, int k0, int t_stride, int T_out,
                                                          const float* __restrict__ mean0, const float* __restrict__ rstd0, int C,
-                                                         float* __restrict__ ws, int TPR, int RB) {
+                                                         float* __restrict__ ws, int TPR, int RB,
+                                                         const T* __restrict__ Epre, int lde, const float* ka, const float* kb, const float* kc,
+                                                         const gast_bn_lazy lz) {
     __shared__ float sred[256][4];
+    if (BN) bn_lazy_sync(lz);
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
     const int C4 = C >> 2;
@@ -528,11 +470,23 @@ __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ d
 #pragma unroll
             for (int tap = 0; tap < XT; ++tap) g[f][tap] = make_float4(0, 0, 0, 0);
         if (slot < RB && cg < C4) {
+            float4 ca = f4(1.f), cb = f4(0.f), ck = f4(0.f);
+            if (BN) { ca = *(const float4*)(ka + c); cb = *(const float4*)(kb + c); ck = *(const float4*)(kc + c); }
             for (long r0 = (long)blockIdx.x * RB + slot; r0 < rows; r0 += 2 * step) {
                 const long r1 = r0 + step;
                 const bool two = r1 < rows;
-                const float4 d0 = ld4(dE + r0 * ldde + c);
-                const float4 d1 = two ? ld4(dE + r1 * ldde + c) : make_float4(0, 0, 0, 0);
+                float4 d0 = ld4(dE + r0 * ldde + c);
+                float4 d1 = two ? ld4(dE + r1 * ldde + c) : make_float4(0, 0, 0, 0);
+                if (BN) {
+                    const float4 e0 = ld4(Epre + r0 * lde + c);
+                    const float4 e1 = two ? ld4(Epre + r1 * lde + c) : make_float4(0, 0, 0, 0);
+                    d0.x = fmaf(ca.x, d0.x, fmaf(cb.x, e0.x, ck.x)); d0.y = fmaf(ca.y, d0.y, fmaf(cb.y, e0.y, ck.y));
+                    d0.z = fmaf(ca.z, d0.z, fmaf(cb.z, e0.z, ck.z)); d0.w = fmaf(ca.w, d0.w, fmaf(cb.w, e0.w, ck.w));
+                    d1.x = fmaf(ca.x, d1.x, fmaf(cb.x, e1.x, ck.x)); d1.y = fmaf(ca.y, d1.y, fmaf(cb.y, e1.y, ck.y));
+                    d1.z = fmaf(ca.z, d1.z, fmaf(cb.z, e1.z, ck.z)); d1.w = fmaf(ca.w, d1.w, fmaf(cb.w, e1.w, ck.w));
+                    d0 = rnd4(d0, (const T*)nullptr);
+                    d1 = rnd4(d1, (const T*)nullptr);
+                }
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u == 1 && !two) break;
@@ -746,36 +700,47 @@ extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_to
 
 static inline bool bad_dtype(int d) { return d != GAST_F32 && d != GAST_BF16; }
 
-extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
-                                 const float* ka, const float* kb, const float* kc, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1) return GAST_EINVAL;
+extern "C" int gast_bn_bwd_apply_lazy(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
+                                      const float* ka, const float* kb, const float* kc, const gast_bn_lazy* lazy, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1 || lazy_check(lazy)) return GAST_EINVAL;
     if (N % 4 || lddz % 4 || ldx % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
+    const gast_bn_lazy lz = lazy_arg(lazy);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (float*)dz, lddz, (const float*)X, ldx,
-                           rows, N, ka, kb, kc, c.TPR, c.RB);
+                           rows, N, ka, kb, kc, c.TPR, c.RB, lz);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz, (const bf16_t*)X,
-                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB);
+                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB, lz);
     GAST_CHECK_LAUNCH();
     return 0;
 }
+extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
+                                 const float* ka, const float* kb, const float* kc, gast_stream_t stream) {
+    return gast_bn_bwd_apply_lazy(dtype, dz, lddz, X, ldx, rows, N, ka, kb, kc, nullptr, stream);
+}
 
-extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1) return GAST_EINVAL;
+extern "C" int gast_bnrelu_apply_lazy(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                                      void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, const gast_bn_lazy* lazy,
+                                      gast_stream_t stream) {
+    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1 || lazy_check(lazy)) return GAST_EINVAL;
     if (N % 4 || ldx % 4 || ldy % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
+    const gast_bn_lazy lz = lazy_arg(lazy);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bnrelu_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)X, ldx, rows, N, scale,
-                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
+                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
     else
         hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
-                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
+                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
     GAST_CHECK_LAUNCH();
     return 0;
+}
+extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
+    return gast_bnrelu_apply_lazy(dtype, X, ldx, rows, N, scale, shift, Y, ldy, use_drop, salt, drop, nullptr, stream);
 }
 
 extern "C" int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
@@ -799,17 +764,24 @@ extern "C" int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap 
                                  const void* T2, int ldt, const float* sc2, const float* sh2,
                                  int use_drop, uint32_t salt, gast_dropout drop,
                                  int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1) return GAST_EINVAL;
+    return gast_residual_fwd_lazy(dtype, O, ldo, omap, scO, shO, T2, ldt, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, ldxn, nullptr, stream);
+}
+extern "C" int gast_residual_fwd_lazy(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
+                                      const void* T2, int ldt, const float* sc2, const float* sh2,
+                                      int use_drop, uint32_t salt, gast_dropout drop,
+                                      int B, int Tn, int J, int N, void* Xn, int ldxn, const gast_bn_lazy* lazy, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1 || lazy_check(lazy)) return GAST_EINVAL;
+    const gast_bn_lazy lz = lazy_arg(lazy);
     if (N % 4 || ldo % 4 || ldt % 4 || ldxn % 4) return GAST_EALIGN;
     long rows = (long)B * Tn * J;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((residual_fwd_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)O, ldo, omap, scO, shO,
-                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB);
+                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB, lz);
     else
         hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)O, ldo, omap, scO, shO,
-                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB);
+                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB, lz);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -850,7 +822,13 @@ static inline int conv_t_out(int T_in, int k0, int t_stride) { return (T_in - k0
 extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                                const float* W, const float* sc0, const float* sh0, int C,
                                void* E, int lde, float* partials, const float* center, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials) return GAST_EINVAL;
+    return gast_expand_fwd_lazy(dtype, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, lde, partials, center, nullptr, stream);
+}
+extern "C" int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
+                                    const float* W, const float* sc0, const float* sh0, int C,
+                                    void* E, int lde, float* partials, const float* center, const gast_bn_lazy* lazy, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials || lazy_check(lazy)) return GAST_EINVAL;
+    const gast_bn_lazy lz = lazy_arg(lazy);
     if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || lde % 4) return GAST_EALIGN;
     size_t smem = (size_t)F_in * k0 * C * sizeof(float);
@@ -868,10 +846,10 @@ extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J
     }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
-                           C, (float*)E, lde, partials, c.TPR, c.RB, center);
+                           C, (float*)E, lde, partials, c.TPR, c.RB, center, lz);
     else
         hipLaunchKernelGGL((expand_fwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0,
-                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center);
+                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center, lz);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -890,6 +868,18 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
                                int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
                                const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate,
                                gast_stream_t stream) {
+    return gast_expand_bwd_bn(dtype, dE, ldde, nullptr, 0, nullptr, nullptr, nullptr, nullptr, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W,
+                              gamma0, beta0, dW, dgamma0, dbeta0, ws, accumulate, stream);
+}
+extern "C" int gast_expand_bwd_bn(int dtype, const void* dE, int ldde, const void* Epre, int lde, const float* ka, const float* kb,
+                                  const float* kc, const gast_bn_lazy* lazy, const float* x, int B, int T_in, int J, int F_in, int k0,
+                                  int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
+                                  const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate,
+                                  gast_stream_t stream) {
+    const bool bn = Epre != nullptr;
+    if (bn && (!ka || !kb || !kc || lde % 4 || lazy_check(lazy))) return GAST_EINVAL;
+    if (!bn && lazy) return GAST_EINVAL;
+    const gast_bn_lazy lz = lazy_arg(lazy);
     if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !W || !gamma0 || !beta0 || !dW || !dgamma0 || !dbeta0 || !ws)
         return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in > XF || k0 > XT || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
@@ -900,11 +890,18 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
     hipStream_t st = (hipStream_t)stream;
     const int nb = expand_bwd_blocks(rows, C);
     if (dtype == GAST_F32)
-        hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
-                           T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
+        if (bn)
+            hipLaunchKernelGGL((expand_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
+                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)Epre, lde, ka, kb, kc, lz);
+        else
+            hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
+                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)nullptr, 0, nullptr, nullptr, nullptr, lz);
+    else if (bn)
+        hipLaunchKernelGGL((expand_bwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
+                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)Epre, lde, ka, kb, kc, lz);
     else
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
-                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB);
+                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr, lz);
     GAST_CHECK_LAUNCH();
     // (GAST_DETERMINISTIC: one block per input feature walks its taps and channel groups in order -- one add per address)
     const dim3 fgrid = gast_deterministic() ? dim3(1, F_in) : dim3((C + EF_CH - 1) / EF_CH, F_in * k0);

@@ -96,8 +96,16 @@ class FlatGradAllReduce:
     def _active(self):
         return self.world > 1 or self.force
 
+    def _no_pending_zero(self, where):
+        """a zero fill parked by zero_(defer=True) must have been consumed (by the model's forward, or flushed by its backward) before
+        the buffer is exchanged: reducing -- or later wiping -- gradients around an unexecuted fill would be silently wrong"""
+        if self._runner is not None and any(t is self.flat for t in self._runner.pending_zero):
+            raise RuntimeError('FlatGradAllReduce.%s: a deferred zero_() of this buffer is still pending -- zero_(defer=True) is for loops '
+                               'that run zero_() -> model forward -> backward -> sync(); use zero_() (immediate) otherwise' % where)
+
     def bucket_ready(self, i):
         """Called by the model's backward (bucketed mode) when `ranges[i]` holds its final local gradients."""
+        self._no_pending_zero('bucket_ready')
         if i != self._issued:
             # a second backward() before sync() (gradient accumulation) would all-reduce ranges that already hold reduced sums
             raise RuntimeError('bucketed all-reduce: bucket %d reported complete, bucket %d expected -- the bucketed exchange runs ONE '
@@ -117,6 +125,7 @@ class FlatGradAllReduce:
 
     def sync(self):
         """sum over ranks / world size, in place; no-op for a single process."""
+        self._no_pending_zero('sync')
         if not self._active():
             self._issued = 0
             return

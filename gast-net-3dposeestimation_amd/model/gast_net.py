@@ -155,7 +155,8 @@ class _GastFunction(torch.autograd.Function):
             raise RuntimeError('gast_net (MI355X build): the gradient with respect to the input batch is not implemented (the '
                                'reference never asks for it); pass x with requires_grad=False')
         ops = engine.ops
-        if not packer.unchanged(st, frozen=not training and not need_grad):      # (an evaluation loop over frozen weights packs once)
+        # (opt-in: an evaluation loop over weights the caller declared frozen -- model.freeze_packed() -- packs once)
+        if not packer.unchanged(st, frozen=runner.pack_reuse and not training and not need_grad):
             ops.run_pack(packer, st)
         inp = st.get('inp')
         if inp is None:
@@ -166,7 +167,7 @@ class _GastFunction(torch.autograd.Function):
         drop, seed_job = runner.dropout_state(training, x.device)
         # the pass prologue (ONE launch): zero arena, seed bump, and whatever a FlatGradAllReduce.zero_(defer=True) left pending
         pred, sv = engine.forward(x, inp, bufs, training, runner.act_dtype, drop, need_grad=need_grad,
-                                  prep={'seed': seed_job, 'zero': runner.take_pending_zero()})
+                                  prep={'seed': seed_job, 'zero': runner.take_pending_zero(x.device)})
         ctx.engine, ctx.packer, ctx.st, ctx.inp, ctx.sv, ctx.sink, ctx.runner = engine, packer, st, inp, sv, sink, runner
         ctx.graph_entry = runner.__dict__.pop('_eager_entry', None)      # (the graph-cache entry this eager call warms up, if any)
         return pred
@@ -181,6 +182,8 @@ class _GastFunction(torch.autograd.Function):
                                'activations are released by the first backward, retain_graph has no effect); run forward again')
         dev = dpred.device
         sink = ctx.sink
+        if sink is not None:
+            ctx.runner.flush_pending_zero(sink)
         # Every gradient kernel ACCUMULATES into its destination (split-M atomics, += for the directly written BatchNorm / e /
         # expand gradients, accumulate-mode unpack): G is either a fresh zero buffer or the caller's flat gradient buffer
         # (FlatGradAllReduce / FlatAdam), which then sums over backward calls like autograd's .grad does.  With such a sink the
@@ -262,7 +265,7 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     ops = engine.ops
     entry.x = x.clone()
     entry.packer, entry.sink, entry.runner = packer, sink, runner
-    entry.frozen = not training and not need_grad
+    entry.frozen = runner.pack_reuse and not training and not need_grad
     pool = torch.cuda.graph_pool_handle()
     engine.centered = runner.centered
     ops.x3 = runner.x3
@@ -338,6 +341,8 @@ class _GraphedFunction(torch.autograd.Function):
                                'backward belongs to; the captured graphs keep ONE set of activations (call backward before the next '
                                'forward, or unset GAST_HIP_GRAPH)')
         e.dpred.copy_(dpred)
+        if e.sink is not None:
+            e.runner.flush_pending_zero(e.sink)
         e.bwd.replay()
         e.token_ref = None          # the activations may be overwritten by the next forward of this shape
         if e.sink is not None:
@@ -360,6 +365,10 @@ class _Runner:
         self.pending_zero = []    # buffers whose zero fill rides in the next forward's pass prologue (FlatGradAllReduce.zero_(defer=True))
         self._seeds = {}
         self._ops_factory = None  # see set_ops(): None in the product
+        # Reuse of the packed GEMM operands across inference calls is OPT-IN (model.freeze_packed() / GAST_PACK_REUSE=1):
+        # the host cannot see every parameter write (`.data`, a torch optimizer replayed inside the user's own CUDA graph, an EMA swap), and
+        # a stale operand silently corrupts validation numbers, while repacking costs 30-95 us per forward.
+        self.pack_reuse = os.environ.get('GAST_PACK_REUSE', '0') not in ('0', '')
         # Forward / backward of every (shape, mode, arithmetic, BatchNorm momentum, dropout p) are replayed from hipGraphs captured on
         # the third call, so an unchanged training loop (model(x); loss.backward()) runs at the replay speed instead of paying ~140
         # Python launches (3.9 vs 4.9 ms per step at B = 128).  ON by default since round 3 (GAST_HIP_GRAPH=0 turns it off): the
@@ -375,7 +384,7 @@ class _Runner:
 
     def __getstate__(self):
         return {'spec': self.spec, 'p_dropout': self.p_dropout, '_engine': None, '_engines': {}, '_packer': None, 'grad_sink': None,
-                'grad_sync': None, 'pending_zero': [], '_seeds': {}, '_ops_factory': self._ops_factory, 'graph_mode': self.graph_mode,
+                'grad_sync': None, 'pending_zero': [], '_seeds': {}, '_ops_factory': self._ops_factory, 'pack_reuse': self.pack_reuse, 'graph_mode': self.graph_mode,
                 '_graphs': collections.OrderedDict(), 'graph_cache_max': self.graph_cache_max}
 
     def __setstate__(self, state):
@@ -453,9 +462,24 @@ class _Runner:
                 eng = self._engines[key] = self._new_engine()
         return eng
 
-    def take_pending_zero(self):
+    def take_pending_zero(self, dev=None):
+        """the buffers whose deferred zero fill rides in this forward's pass prologue; a buffer on ANOTHER device than the pass (dev) is
+        zeroed right away instead (the prologue launch runs on the pass's device and stream)"""
         z, self.pending_zero = self.pending_zero, []
+        if dev is not None:
+            for t in z:
+                if t.device != dev:
+                    t.zero_()
+            z = [t for t in z if t.device == dev]
         return z
+
+    def flush_pending_zero(self, t):
+        """A backward pass is about to ACCUMULATE into `t`: a zero fill that zero_(defer=True) parked for "the next forward" and that no
+        forward has consumed (a retained graph, an exception between zero_() and the forward, a sink shared with another model) happens
+        now -- otherwise the buffer would not be zeroed before the accumulation and a LATER forward would wipe the accumulated sum."""
+        if any(p is t for p in self.pending_zero):
+            self.pending_zero = [p for p in self.pending_zero if p is not t]
+            t.zero_()
 
     def dropout_state(self, training, dev):
         """A fresh dropout stream per training forward: the seed lives on the device (graph-capture friendly).  Returns (Dropout
@@ -527,12 +551,20 @@ class SpatioTemporalModelBase(nn.Module):
         # kept out of nn.Module's registries (no parameters / buffers of its own -> state_dict is untouched)
         object.__setattr__(self, '_runner', _Runner(spec, dropout))
 
+    def freeze_packed(self, on=True):
+        """Opt in (or out) to reusing the GEMM-ready operands across INFERENCE calls (eval mode under torch.no_grad()): they are then
+        rebuilt only when the host sees the parameters change (optimizer steps, load_state_dict, tracked in-place edits, this library's
+        FlatAdam).  Off by default: every forward repacks (30-95 us), which is always correct.  What the host cannot see once you opted
+        in -- writes through `.data`, a torch optimizer replayed inside your own CUDA graph, `dist.broadcast(p.data)`, an EMA swap --
+        needs `invalidate_packed()` after the write.  Training-mode and gradient-enabled forwards always repack."""
+        self._runner.pack_reuse = bool(on)
+        if not on:
+            self.invalidate_packed()
+        return self
+
     def invalidate_packed(self):
-        """Force the next forward to rebuild the GEMM-ready operands from the parameters.  Needed only in an INFERENCE loop (eval mode
-        under torch.no_grad(), where the operands are packed once and reused) after the parameters were written through `.data`
-        in place (`p.data.mul_()`, `dist.broadcast(p.data)`, an EMA swap by `p.data.copy_()`): such writes leave no trace the host
-        could see.  Optimizer steps, load_state_dict and tracked in-place edits are noticed by themselves; training-mode and
-        gradient-enabled forwards always repack."""
+        """Force the next forward to rebuild the GEMM-ready operands from the parameters.  Only needed after `freeze_packed()`, when the
+        parameters were written in a way that leaves no trace the host could see (see there)."""
         if self._runner._packer is not None:
             self._runner._packer.invalidate()
 

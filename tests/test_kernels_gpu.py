@@ -1092,3 +1092,305 @@ def test_stream_shift_multi(ops):
     torch.cuda.synchronize()
     for (b, _), hb in zip(jobs, hosts):
         assert np.array_equal(b.cpu().numpy(), hb)
+
+
+# ------------------------------------------------------------------------------------------------ lazy BatchNorm finalize (round 5)
+def _bn_jobs(gen, specs, nblk=37):
+    """forward finalize jobs over random partial sums; specs = [(col0, N)] slices of ONE partial buffer (like bn_1 | bn_2)"""
+    ncol = max(c0 + n for c0, n in specs) + 4
+    rows = 4321
+    x = rand(gen, rows, ncol) * 1.5 + 0.3
+    pt = torch.zeros(nblk, ncol, 2)
+    for b, ch in enumerate(torch.chunk(x, nblk)):
+        pt[b, :, 0] = ch.sum(0)
+        pt[b, :, 1] = (ch * ch).sum(0)
+    ptd = pt.cuda()
+    tot = sum(n for _, n in specs)
+    jobs = []
+    for c0, n in specs:
+        jobs.append(dict(partials=ptd, nblk=nblk, col0=c0, N=n, count=float(rows), gamma=(torch.rand(n, generator=gen) + 0.5).cuda(),
+                         beta=rand(gen, n).cuda(), running_mean=rand(gen, n).cuda(), running_var=(torch.rand(n, generator=gen) + 0.5).cuda(),
+                         nbt=torch.tensor(5, dtype=torch.int64).cuda(), momentum=0.1, eps=1e-5))
+    return jobs, tot
+
+
+def _bn_state(jobs, tot):
+    """fresh outputs (one concatenated scale / shift / mean / rstd like engine.BNState) + private copies of the running statistics"""
+    st = {k: torch.full((tot,), float('nan')).cuda() for k in ('scale', 'shift', 'mean', 'rstd')}
+    out, o = [], 0
+    for j in jobs:
+        n = j['N']
+        d = dict(j, running_mean=j['running_mean'].clone(), running_var=j['running_var'].clone(), nbt=j['nbt'].clone(),
+                 **{k: st[k][o:o + n] for k in st})
+        out.append(d)
+        o += n
+    return out, st
+
+
+def _same_bn(a_jobs, a_st, b_jobs, b_st):
+    for k in a_st:
+        _assert_bit_equal(b_st[k].view(1, -1), a_st[k].view(1, -1), 'lazy finalize: ' + k)
+    for a, b in zip(a_jobs, b_jobs):
+        assert torch.equal(a['running_mean'], b['running_mean']) and torch.equal(a['running_var'], b['running_var'])
+        assert int(b['nbt'].item()) == int(a['nbt'].item()) == 6
+
+
+def _flag():
+    return torch.zeros(1, dtype=torch.int32).cuda()
+
+
+@pytest.mark.parametrize('rows', [8, 5000])
+@pytest.mark.parametrize('consumer', ['bnrelu_apply', 'residual_fwd'])
+def test_lazy_finalize_in_a_streaming_consumer(ops, consumer, rows):
+    """gast_bn_lazy: the finalize jobs run inside the consumer launch -- coefficients, running statistics and the consumer's output are
+    BIT-equal to finalize launch + consumer launch.  rows = 8: one block runs all 136 column units itself."""
+    gen = torch.Generator().manual_seed(21)
+    specs = [(0, 416), (416, 128)] if consumer == 'bnrelu_apply' else [(0, 544)]
+    jobs, N = _bn_jobs(gen, specs)
+    B, Tn, J = (1, 1, rows) if rows < 100 else (rows // (17 * 4), 4, 17)
+    P = B * Tn * J
+    X = rand(gen, P, N).cuda()
+    O = rand(gen, B * (Tn + 2) * J, N).cuda()
+    scO, shO = (torch.rand(N, generator=gen) + 0.5).cuda(), rand(gen, N).cuda()
+    outs = []
+    for lazy in (False, True):
+        js, st = _bn_state(jobs, N)
+        tok = None
+        if lazy:
+            tok = ops.bn_lazy_fwd(js, _flag())
+        else:
+            ops.bn_finalize_multi(js)
+        Y = torch.full((P, N), float('nan')).cuda()
+        kw = {'lazy': tok} if lazy else {}
+        if consumer == 'bnrelu_apply':
+            ops.bnrelu_apply(X, P, N, st['scale'], st['shift'], Y, **kw)
+        else:
+            ops.residual_fwd(O, kc.RowMap(Tn + 2, 1, 1), scO, shO, X, st['scale'], st['shift'], False, 0, None, B, Tn, J, N, Y, **kw)
+        torch.cuda.synchronize()
+        outs.append((js, st, Y))
+    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
+    _assert_bit_equal(outs[1][2], outs[0][2], consumer + ' output with the lazy finalize')
+    assert torch.isfinite(outs[1][2]).all()
+
+
+def test_lazy_finalize_in_expand_fwd(ops):
+    gen = torch.Generator().manual_seed(22)
+    B, T_in, J, F_in, k0, C = 6, 9, 17, 2, 3, 64
+    x = rand(gen, B, T_in, J, F_in).cuda()
+    rows_in = B * T_in * J
+    nb = ops.input_stats_blocks(rows_in)
+    W = rand(gen, C, F_in, k0).cuda()
+    outs = []
+    for lazy in (False, True):
+        part = torch.empty(nb, F_in, 2).cuda()
+        ops.input_stats(x, rows_in, F_in, part)
+        jobs = [dict(partials=part, nblk=nb, col0=0, N=F_in, count=float(rows_in), gamma=torch.tensor([1.5, 0.7]).cuda(),
+                     beta=torch.tensor([0.1, -0.2]).cuda(), running_mean=torch.zeros(F_in).cuda(), running_var=torch.ones(F_in).cuda(),
+                     nbt=torch.tensor(5, dtype=torch.int64).cuda(), momentum=0.1, eps=1e-5)]
+        js, st = _bn_state(jobs, F_in)
+        P0 = B * (T_in - k0 + 1) * J
+        E = torch.full((P0, C), float('nan')).cuda()
+        pe = torch.full((ops.rowwise_blocks(P0, C), C, 2), float('nan')).cuda()
+        if lazy:
+            ops.expand_fwd(x, B, T_in, J, F_in, k0, 1, W, st['scale'], st['shift'], C, E, pe, lazy=ops.bn_lazy_fwd(js, _flag()))
+        else:
+            ops.bn_finalize_multi(js)
+            ops.expand_fwd(x, B, T_in, J, F_in, k0, 1, W, st['scale'], st['shift'], C, E, pe)
+        torch.cuda.synchronize()
+        outs.append((js, st, E, pe))
+    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
+    _assert_bit_equal(outs[1][2], outs[0][2], 'expand_fwd output with the lazy finalize')
+    _assert_bit_equal(outs[1][3].view(-1, 2 * C), outs[0][3].view(-1, 2 * C), 'expand_fwd partial sums with the lazy finalize')
+
+
+@pytest.mark.parametrize('rows', [40, 9000])
+def test_lazy_backward_finalize_in_bn_bwd_apply(ops, rows):
+    gen = torch.Generator().manual_seed(23)
+    specs = [(0, 256), (256, 64)]
+    fj, N = _bn_jobs(gen, specs)
+    outs = []
+    dz0, X = rand(gen, rows, N).cuda(), rand(gen, rows, N).cuda()
+    mean, rstd = rand(gen, N).cuda(), (torch.rand(N, generator=gen) + 0.5).cuda()
+    for lazy in (False, True):
+        o, jobs = 0, []
+        ka, kb, kcf = (torch.full((N,), float('nan')).cuda() for _ in range(3))
+        for j in fj:
+            n = j['N']
+            jobs.append(dict(partials=j['partials'], nblk=j['nblk'], col0=j['col0'], N=n, count=j['count'], gamma=j['gamma'], mean=mean[o:o + n],
+                             rstd=rstd[o:o + n], dgamma=torch.full((n,), 0.25).cuda(), dbeta=torch.full((n,), -0.5).cuda(),
+                             ka=ka[o:o + n], kb=kb[o:o + n], kc=kcf[o:o + n], accumulate=True))
+            o += n
+        dz = dz0.clone()
+        if lazy:
+            ops.bn_bwd_apply(dz, X, rows, N, ka, kb, kcf, lazy=ops.bn_lazy_bwd(jobs, _flag()))
+        else:
+            ops.bn_bwd_finalize_multi(jobs)
+            ops.bn_bwd_apply(dz, X, rows, N, ka, kb, kcf)
+        torch.cuda.synchronize()
+        outs.append((jobs, ka, kb, kcf, dz))
+    for i, name in ((1, 'ka'), (2, 'kb'), (3, 'kc')):
+        _assert_bit_equal(outs[1][i].view(1, -1), outs[0][i].view(1, -1), 'lazy backward finalize: ' + name)
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a['dgamma'], b['dgamma']) and torch.equal(a['dbeta'], b['dbeta'])
+    _assert_bit_equal(outs[1][4], outs[0][4], 'bn_bwd_apply output with the lazy finalize')
+
+
+LAZY_GEMM = [('dilated_taps', 'f32'), ('splitk_stats', 'f32'), ('big_taps_pro_stats', 'x3'), ('big_taps_pro_stats', 'x3h'),
+             ('big_taps_pro_stats', 'bf16'), ('small_stats_k1536', 'x3')]
+
+
+@pytest.mark.parametrize('name,mode', LAZY_GEMM, ids=['%s-%s' % c for c in LAZY_GEMM])
+def test_lazy_finalize_in_a_gemm(ops, name, mode):
+    """a GEMM whose prologue segments read the scale / shift of a BatchNorm finalized INSIDE the launch: the 128x128-tile kernel (with
+    and without split-K) and the large-M kernel (bf16 and fp16 pairs), bit-equal to finalize launch + GEMM launch"""
+    case = {c[0]: c for c in GEMM_CASES + GEMM_BIG_CASES + GEMM_SMALL_X3_CASES}[name]
+    dt = MM_DT[mode]
+    gen = torch.Generator().manual_seed(24)
+    pro_K = sorted({sd[0] for sd in case[3] if sd[4] == 1})
+    assert len(pro_K) == 1, 'the case needs prologue segments of one width'
+    K = pro_K[0]
+    jobs, N = _bn_jobs(gen, [(0, K)])
+    outs = []
+    for lazy in (False, True):
+        jd, _, bufs = _gemm_case(case, dt)
+        js, st = _bn_state(jobs, K)
+        for sg in jd['segs']:
+            if sg['pro'] == 1:
+                sg['scale'], sg['shift'] = st['scale'], st['shift']
+        with x3_mode(ops, mode):
+            if mode in ('x3', 'x3h'):
+                _with_images(ops, jd, mode == 'x3h')
+            if lazy:
+                ops.gemm(**dict(jd, lazy=ops.bn_lazy_fwd(js, _flag())))
+            else:
+                ops.bn_finalize_multi(js)
+                ops.gemm(**jd)
+        torch.cuda.synchronize()
+        outs.append((js, st, bufs[0], bufs[2]))
+    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
+    _assert_bit_equal(outs[1][2], outs[0][2], 'GEMM output with the lazy finalize')
+    if name.startswith('big_'):      # (few output tiles -> split-K: its finish pass adds the column statistics with atomics)
+        _assert_bit_equal(outs[1][3].view(outs[1][3].shape[0], -1), outs[0][3].view(outs[0][3].shape[0], -1), 'GEMM column statistics with the lazy finalize')
+    else:
+        close(host(outs[1][3]).sum(axis=0), host(outs[0][3]).sum(axis=0), dt, 'GEMM column statistics with the lazy finalize', fp32=1e-5, bf16=1e-5)
+    assert torch.isfinite(outs[1][2]).all()
+
+
+def test_lazy_finalize_in_a_multi_job_gemm(ops):
+    """G2 | G3 of a block: the first job's prologue reads bn_1 | bn_2 (two finalize jobs), the second has none -- one grid, one wait"""
+    gen = torch.Generator().manual_seed(25)
+    cases = {c[0]: c for c in GEMM_CASES + GEMM_BIG_CASES}
+    c0 = [c for c in GEMM_CASES if any(sd[4] == 1 for sd in c[3]) and len({sd[0] for sd in c[3] if sd[4] == 1}) == 1][0]
+    c1 = [c for c in GEMM_CASES if all(sd[4] == 0 for sd in c[3]) and c[4] != 2][0]
+    K = [sd[0] for sd in c0[3] if sd[4] == 1][0]
+    half = K // 2 // 4 * 4
+    jobs, N = _bn_jobs(gen, [(0, half), (half, K - half)])
+    outs = []
+    for lazy in (False, True):
+        a, _, ba = _gemm_case(c0, torch.float32)
+        b, _, bb = _gemm_case(c1, torch.float32)
+        js, st = _bn_state(jobs, K)
+        for sg in a['segs']:
+            if sg['pro'] == 1:
+                sg['scale'], sg['shift'] = st['scale'], st['shift']
+        if lazy:
+            ops.gemm_multi([dict(a, lazy=ops.bn_lazy_fwd(js, _flag())), b])
+        else:
+            ops.bn_finalize_multi(js)
+            ops.gemm_multi([a, b])
+        torch.cuda.synchronize()
+        outs.append((js, st, ba[0], bb[0]))
+    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
+    _assert_bit_equal(outs[1][2], outs[0][2], 'job 0 output with the lazy finalize')
+    _assert_bit_equal(outs[1][3], outs[0][3], 'job 1 output with the lazy finalize')
+
+
+@pytest.mark.parametrize('J,C,F', [(17, 256, 700), (19, 128, 50), (17, 64, 3), (15, 32, 41)])
+def test_agg_bwd_with_the_batchnorm_backward_fused(ops, J, C, F):
+    """gast_semch_agg_bwd_bn: the aggregation backward applies ka*dY + kb*Y + kc while it stages dY (coefficients from a lazy finalize in
+    front): dH, dA and the BatchNorm parameter gradients are bit-equal to finalize launch + apply launch + aggregation launch"""
+    gen = torch.Generator().manual_seed(J * C + F)
+    ps, pc = patterns(J)
+    P = F * J
+    ldh = 5 * C + 8
+    H = rand(gen, P, ldh).cuda()
+    As, Ac = torch.rand(int(ps[1]) + 1, C, generator=gen), torch.rand(int(pc[1]) + 1, C, generator=gen)
+    As[-1] = 0
+    Ac[-1] = 0
+    As, Ac = As.cuda(), Ac.cuda()
+    o_s, o_c = 2 + 2 * (J + 1) + 3 * int(ps[1]), 2 + 2 * (J + 1) + 3 * int(pc[1])
+    cdeg = (int(ps[o_s + 1]), int(pc[o_c + 1]))
+    if not ops.semch_agg_bwd_fuses_bn(H, F, J, C, As, Ac, cdeg):
+        pytest.skip('this shape takes the kernel without LDS staging')
+    fj, N = _bn_jobs(gen, [(0, C), (C, C)])
+    dY0, Yp = rand(gen, P, 2 * C).cuda(), rand(gen, P, 2 * C).cuda()
+    mean, rstd = rand(gen, N).cuda(), (torch.rand(N, generator=gen) + 0.5).cuda()
+    ns, nc = int(ps[1]), int(pc[1])
+    outs = []
+    for fused in (False, True):
+        o, jobs = 0, []
+        kabc = torch.full((3, N), float('nan')).cuda()
+        for j in fj:
+            n = j['N']
+            jobs.append(dict(partials=j['partials'], nblk=j['nblk'], col0=j['col0'], N=n, count=j['count'], gamma=j['gamma'], mean=mean[o:o + n],
+                             rstd=rstd[o:o + n], dgamma=torch.full((n,), 0.25).cuda(), dbeta=torch.full((n,), -0.5).cuda(),
+                             ka=kabc[0, o:o + n], kb=kabc[1, o:o + n], kc=kabc[2, o:o + n], accumulate=True))
+            o += n
+        dY = dY0.clone()
+        dH = torch.full((P, ldh), 5.0).cuda()
+        dA = torch.full((ns + nc, C), 9.0).cuda()
+        ws = torch.empty(ops.semch_agg_bwd_ws(F, C, ns, nc)).cuda()
+        if fused:
+            ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg, bn=(Yp, kabc[0], kabc[1], kabc[2]),
+                              lazy=ops.bn_lazy_bwd(jobs, _flag()))
+            assert torch.equal(dY, dY0), 'the fused form must not rewrite dY'
+        else:
+            ops.bn_bwd_finalize_multi(jobs)
+            ops.bn_bwd_apply(dY, Yp, P, N, kabc[0], kabc[1], kabc[2])
+            ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg)
+        torch.cuda.synchronize()
+        outs.append((jobs, kabc, dH, dA))
+    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc of the lazy finalize')
+    for a, b in zip(outs[0][0], outs[1][0]):
+        assert torch.equal(a['dgamma'], b['dgamma']) and torch.equal(a['dbeta'], b['dbeta'])
+    _assert_bit_equal(outs[1][2], outs[0][2], 'dH of the aggregation backward with the BatchNorm backward fused')
+    _assert_bit_equal(outs[1][3], outs[0][3], 'dA of the aggregation backward with the BatchNorm backward fused')
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+def test_expand_bwd_with_the_batchnorm_backward_fused(ops, dt):
+    """gast_expand_bwd_bn: dz = ka*dE + kb*E + kc applied while dE is loaded (coefficients from a lazy finalize in front) -- parameter
+    gradients bit-equal to finalize launch + apply launch + expand_bwd launch"""
+    gen = torch.Generator().manual_seed(31)
+    B, T_in, J, F_in, k0, C = 7, 9, 17, 2, 3, 64
+    T_out = T_in - k0 + 1
+    P0 = B * T_out * J
+    x = rand(gen, B, T_in, J, F_in).cuda()
+    dE0, E = rand(gen, P0, C).to(dt).cuda(), rand(gen, P0, C).to(dt).cuda()
+    fj, N = _bn_jobs(gen, [(0, C)])
+    mean, rstd = rand(gen, C).cuda(), (torch.rand(C, generator=gen) + 0.5).cuda()
+    mean0, rstd0 = rand(gen, F_in).cuda(), (torch.rand(F_in, generator=gen) + 0.5).cuda()
+    W, g0, b0 = rand(gen, C, F_in, k0).cuda(), rand(gen, F_in).cuda(), rand(gen, F_in).cuda()
+    outs = []
+    for fused in (False, True):
+        kabc = torch.full((3, C), float('nan')).cuda()
+        j = fj[0]
+        job = dict(partials=j['partials'], nblk=j['nblk'], col0=0, N=C, count=j['count'], gamma=j['gamma'], mean=mean, rstd=rstd,
+                   dgamma=torch.full((C,), 0.25).cuda(), dbeta=torch.full((C,), -0.5).cuda(), ka=kabc[0], kb=kabc[1], kc=kabc[2], accumulate=True)
+        dE = dE0.clone()
+        dW, dg0, db0 = torch.zeros(C, F_in, k0).cuda(), torch.zeros(F_in).cuda(), torch.zeros(F_in).cuda()
+        if fused:
+            ops.expand_bwd(dE, x, B, T_in, J, F_in, k0, 1, mean0, rstd0, C, W, g0, b0, dW, dg0, db0, bn=(E, kabc[0], kabc[1], kabc[2]),
+                           lazy=ops.bn_lazy_bwd([job], _flag()))
+        else:
+            ops.bn_bwd_finalize_multi([job])
+            ops.bn_bwd_apply(dE, E, P0, C, kabc[0], kabc[1], kabc[2])
+            ops.expand_bwd(dE, x, B, T_in, J, F_in, k0, 1, mean0, rstd0, C, W, g0, b0, dW, dg0, db0)
+        torch.cuda.synchronize()
+        outs.append((job, kabc, dW, dg0, db0))
+    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc of the lazy finalize')
+    assert torch.equal(outs[0][0]['dgamma'], outs[1][0]['dgamma']) and torch.equal(outs[0][0]['dbeta'], outs[1][0]['dbeta'])
+    _assert_bit_equal(outs[1][2].view(C, -1), outs[0][2].view(C, -1), 'dW of the expand conv with the BatchNorm backward fused')
+    # (dgamma0 / dbeta0: the finish pass adds 16 x 3 block sums per address with atomics)
+    close(host(outs[1][3]), host(outs[0][3]), torch.float32, 'dgamma0', fp32=1e-5)
+    close(host(outs[1][4]), host(outs[0][4]), torch.float32, 'dbeta0', fp32=1e-5)

@@ -893,6 +893,14 @@ def test_packed_operands_follow_parameter_changes(graph, monkeypatch):
     m = build(cfg).cuda().eval()
     m._runner.graph_mode = graph
     x = (torch.rand(3, 9, 17, 2, generator=torch.Generator().manual_seed(1)) * 2 - 1).cuda()
+    # default: NO reuse -- even a write the host cannot see is picked up by the next inference call
+    with torch.no_grad():
+        ya = [m(x).clone() for _ in range(4)][-1]
+        m.shrink.weight.data.mul_(2.0)
+        yb = [m(x).clone() for _ in range(2)][-1]
+        m.shrink.weight.data.mul_(0.5)
+    assert torch.allclose(yb, 2 * ya, rtol=1e-5, atol=1e-6)
+    m.freeze_packed()     # opt in: from here on the operands are rebuilt only when the host sees a change
 
     def fresh():          # the same weights through a model that has never packed anything
         m2 = build(cfg).cuda().eval()
@@ -962,6 +970,7 @@ def test_training_forward_always_repacks(monkeypatch):
         y1 = m(x).clone()
     assert torch.allclose(y1, 2 * y0, rtol=1e-5, atol=1e-6)
     m.eval()
+    m.freeze_packed()
     monkeypatch.setattr(pk, 'CAPTURED_WRITER', [True])
     with torch.no_grad():
         y2 = m(x).clone()
