@@ -95,14 +95,18 @@ __device__ __forceinline__ void bn_bwd_finalize_unit(const gast_bn_bwd_fin_job& 
 
 // ---- lazy finalize (gast_bn_lazy): called by EVERY thread of EVERY block of a 1-D grid before the first read of a coefficient.
 // The first nfin blocks run the finalize units (4 columns each; more than one per block when the grid is smaller than the unit
-// count), publish (device-scope release) and count themselves on lz.flag; everybody waits for the full count (acquire).
+// count) and publish: results written back at device scope, then ONE word per block, flag[block] = 1.  Every block waits until all
+// nfin words are set.  NO shared counter: same-address atomics serialise at 50 - 170 ns apiece on this chip, so counting 128 blocks on
+// one address took longer than the finalize launch it replaces (measured: +12 us per lazy launch); nfin independent stores do not queue.
 // lazy_red: 256 bytes of LDS scratch ([4][FINS_COLS][2] doubles) nobody else touches during the call.
+constexpr int LAZY_MAX_FIN = 256;       // finalizing blocks (= words of lz.flag that must arrive zeroed: GAST_BN_LAZY_FLAG_WORDS)
 __device__ __forceinline__ void bn_lazy_sync_with(const gast_bn_lazy& lz, fin_red_t lazy_red) {
     if (lz.kind == 0) return;
     const int N0 = lz.kind == GAST_BN_LAZY_FWD ? lz.fwd[0].N : lz.bwd[0].N;
     const int N1 = lz.n > 1 ? (lz.kind == GAST_BN_LAZY_FWD ? lz.fwd[1].N : lz.bwd[1].N) : 0;
     const int u0 = (N0 + FINS_COLS - 1) / FINS_COLS, U = u0 + (N1 + FINS_COLS - 1) / FINS_COLS;
-    const int nfin = U < (int)gridDim.x ? U : (int)gridDim.x;
+    int nfin = U < (int)gridDim.x ? U : (int)gridDim.x;
+    if (nfin > LAZY_MAX_FIN) nfin = LAZY_MAX_FIN;
     if ((int)blockIdx.x < nfin) {
         // (one loop per job, each with a compile-time job index: a run-time index into the by-value argument -- also the one the
         //  compiler re-creates by merging two branches of ONE loop -- parks the jobs' `count` fields in scratch memory, and a kernel
@@ -117,15 +121,33 @@ __device__ __forceinline__ void bn_lazy_sync_with(const gast_bn_lazy& lz, fin_re
             if (lz.kind == GAST_BN_LAZY_FWD) bn_finalize_unit(lz.fwd[1], u - u0, lazy_red);
             else bn_bwd_finalize_unit(lz.bwd[1], u - u0, lazy_red);
         }
-        __threadfence();                      // every writer: its results are visible device-wide before ...
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(lz.flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);      // ... the block is counted
+        // publish: the coefficient writers are threads 0..3 (ry == 0), i.e. wave 0 -- its device-scope release writes the results back
+        // from this XCD's L2 before the block's word is set (a device-scope store: it goes through to memory)
+        if (threadIdx.x < 64) {
+            __threadfence();
+            if (threadIdx.x == 0) __hip_atomic_store(lz.flag + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    if (threadIdx.x == 0) {
-        while (__hip_atomic_load(lz.flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)nfin) __builtin_amdgcn_s_sleep(4);
+    // wait: wave 0 reads the nfin words with device-scope loads (they bypass this XCD's L2, which may cache earlier polls), one word per
+    // lane, with a growing pause between polls.  No cache invalidation afterwards: the launch started with clean caches (the kernel
+    // boundary invalidates them) and nobody reads a coefficient before every word is set, so no stale copy of those lines can exist on
+    // this XCD -- the first read after the barrier misses and fetches what the finalizing blocks wrote back.  (A device-scope ACQUIRE
+    // here -- buffer_inv sc1 by every wave of every block, also of the blocks that start long after the finalize is over -- kept emptying
+    // the L2 under the running kernel: measured +2 ms per training step.)
+    if (threadIdx.x < 64) {
+        int pause = 0;
+        while (true) {
+            bool ok = true;
+            for (int i = threadIdx.x; i < nfin; i += 64)
+                ok = ok && __hip_atomic_load(lz.flag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+            if (__all(ok)) break;
+            if (pause == 0) __builtin_amdgcn_s_sleep(8);
+            else if (pause == 1) __builtin_amdgcn_s_sleep(24);
+            else __builtin_amdgcn_s_sleep(64);
+            ++pause;
+        }
     }
     __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // every wave: the loads that follow see the published coefficients
 }
 
 // the same with a static scratch array of its own (NOT for kernels whose dynamic LDS request sits at the per-block limit or whose

@@ -126,6 +126,7 @@ class _BnBwdFinJob(C.Structure):
 
 
 BN_LAZY_MAX = 2
+BN_LAZY_FLAG_WORDS = 256
 BN_LAZY_FWD, BN_LAZY_BWD = 1, 2
 
 
@@ -633,10 +634,12 @@ class HipOps:
     lazy_bn = True       # this op set can run a finalize inside its consumer (the engine asks before it defers one)
 
     def bn_lazy_fwd(self, jobs, flag):
-        """jobs: <= BN_LAZY_MAX dicts with the arguments of bn_finalize(); flag: one zero uint32 / int32 device element.  Nothing is
+        """jobs: <= BN_LAZY_MAX dicts with the arguments of bn_finalize(); flag: BN_LAZY_FLAG_WORDS zero int32 device elements.  Nothing is
         launched: the returned LazyBN goes to the `lazy=` argument of the first consumer of the jobs' scale / shift."""
         if not 1 <= len(jobs) <= BN_LAZY_MAX:
             raise RuntimeError('gast_hip: a lazy finalize carries 1..%d jobs' % BN_LAZY_MAX)
+        if flag.numel() < BN_LAZY_FLAG_WORDS or flag.element_size() != 4:
+            raise RuntimeError('gast_hip: a lazy finalize needs %d zeroed 32-bit words' % BN_LAZY_FLAG_WORDS)
         c = _BnLazy()
         c.kind, c.n, c.flag = BN_LAZY_FWD, len(jobs), _p(flag)
         for i, j in enumerate(jobs):
@@ -647,6 +650,8 @@ class HipOps:
         """the same for bn_bwd_finalize() jobs: the consumer is the bn_bwd_apply that reads ka / kb / kc"""
         if not 1 <= len(jobs) <= BN_LAZY_MAX:
             raise RuntimeError('gast_hip: a lazy finalize carries 1..%d jobs' % BN_LAZY_MAX)
+        if flag.numel() < BN_LAZY_FLAG_WORDS or flag.element_size() != 4:
+            raise RuntimeError('gast_hip: a lazy finalize needs %d zeroed 32-bit words' % BN_LAZY_FLAG_WORDS)
         c = _BnLazy()
         c.kind, c.n, c.flag = BN_LAZY_BWD, len(jobs), _p(flag)
         for i, j in enumerate(jobs):

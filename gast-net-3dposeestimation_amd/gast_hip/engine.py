@@ -38,6 +38,7 @@ NHEADS = 4
 
 
 FUSED_BN_BWD_ROWS = 8192      # BatchNorm backward: finalize + apply in one launch up to this many rows
+LAZY_FLAG_WORDS = 256         # zeroed words a lazy finalize needs (GAST_BN_LAZY_FLAG_WORDS, include/gast_hip.h: one per finalizing block)
 
 
 def ident(T):
@@ -115,10 +116,13 @@ class Engine:
         # bf16 rounding error scales with the spread of the channel, not with |mean|
         self.centered = bool(centered)
         self.za = ZeroArena()
-        # Lazy BatchNorm finalize (round 5, GAST_LAZY_BN=0 turns it off): a finalize launch is ~1 us of work on a ~5 us launch floor, 24 times
-        # per training step.  Where the op set can (HipOps.lazy_bn), the finalize jobs ride in the launch that first READS their result --
-        # its first blocks run them, every block waits for the published coefficients (gast_bn_lazy, include/gast_hip.h; csrc/bn_lazy.h).
-        self.lazy_bn = bool(getattr(ops, 'lazy_bn', False)) and os.environ.get('GAST_LAZY_BN', '1') not in ('0', '')
+        # Lazy BatchNorm finalize (round 5; OPT-IN, GAST_LAZY_BN=1): the finalize jobs ride in the launch that first READS their result -- its
+        # first blocks run them, every block waits for the published coefficients (gast_bn_lazy, include/gast_hip.h; csrc/bn_lazy.h).  It
+        # removes 24 launches per training step and is bit-equal to the stand-alone finalizes, but it is SLOWER on MI355X: 3.64 vs 3.52 ms
+        # per step on one box, +6.7 us per lazy forward launch -- publishing across the eight XCDs (write-back,
+        # flag store, device-scope polls: four memory-side round trips of 1 - 2 us) costs more than the ~5 us kernel boundary it replaces.
+        self.can_lazy = bool(getattr(ops, 'lazy_bn', False))       # (the HIP op set; the numpy mirror of the tests has neither form)
+        self.lazy_bn = self.can_lazy and os.environ.get('GAST_LAZY_BN', '0') not in ('0', '')
         self._pre = {}           # eval mode: pre-filled (scale, shift) views per BNState name
         self._side = {}          # device -> side stream for independent branches of the plan
         self._keep = []          # operands of side-stream launches, kept alive until the join
@@ -227,7 +231,7 @@ class Engine:
                              momentum=bn.get('momentum', BN_MOMENTUM), eps=bn.get('eps', BN_EPS), scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl],
                              rstd=st.rstd[sl], centered=centered))
         if lazy and self.lazy_bn and len(jobs) <= 2:
-            return ops.bn_lazy_fwd(jobs, self.za.take((1,), torch.int32))
+            return ops.bn_lazy_fwd(jobs, self.za.take((LAZY_FLAG_WORDS,), torch.int32))
         ops.bn_finalize_multi(jobs)
         return None
 
@@ -539,7 +543,7 @@ class Engine:
             o += n
         if self.lazy_bn and len(jobs) <= 2 and (one_apply is not None or len(items) == 1):
             # the finalize jobs ride in the ONE apply launch that reads ka / kb / kc (its first blocks run them)
-            tok = ops.bn_lazy_bwd(jobs, self.za.take((1,), torch.int32))
+            tok = ops.bn_lazy_bwd(jobs, self.za.take((LAZY_FLAG_WORDS,), torch.int32))
             dz, X, rows = one_apply if one_apply is not None else (items[0]['dz'], items[0]['X'], items[0]['rows'])
             ops.bn_bwd_apply(dz, X, rows, ntot, ka, kb, kc, lazy=tok)
             return
@@ -723,12 +727,16 @@ class Engine:
         # dE has ONE reader, the expand-conv backward: it applies the backward of expand_bn while it loads dE (finalize lazily in front)
         # instead of a stand-alone apply pass (GAST_FUSE_EXPAND_BN=0: off)
         bn_exp = {}
-        if P0 > FUSED_BN_BWD_ROWS and self.lazy_bn and os.environ.get('GAST_FUSE_EXPAND_BN', '1') not in ('0', ''):
+        if P0 > FUSED_BN_BWD_ROWS and self.can_lazy and os.environ.get('GAST_FUSE_EXPAND_BN', '1') not in ('0', ''):
             kabc = torch.empty(3, C0, dtype=f32, device=dev)
             bnE = sv['bnE']
             job = dict(partials=partE, nblk=nbr, col0=0, N=C0, count=bnE.count, gamma=inp['expand_bn.weight'], mean=bnE.mean, rstd=bnE.rstd,
                        dgamma=grads['expand_bn.weight'], dbeta=grads['expand_bn.bias'], ka=kabc[0], kb=kabc[1], kc=kabc[2], accumulate=True)
-            bn_exp = dict(bn=(sv['E'], kabc[0], kabc[1], kabc[2]), lazy=ops.bn_lazy_bwd([job], za.take((1,), torch.int32)))
+            bn_exp = dict(bn=(sv['E'], kabc[0], kabc[1], kabc[2]))
+            if self.lazy_bn:
+                bn_exp['lazy'] = ops.bn_lazy_bwd([job], za.take((LAZY_FLAG_WORDS,), torch.int32))
+            else:
+                ops.bn_bwd_finalize_multi([job])
         else:
             self._bn_backward(partE, nbr, 0, C0, sv['bnE'], inp['expand_bn.weight'], grads, 'expand_bn', dE, sv['E'], P0)
         x = sv['x']
@@ -796,7 +804,7 @@ class Engine:
                   dict(partials=partY, nblk=nb, col0=C, n=C, st=st['bnY'], off=C, gamma=inp[g + 'bn_2.weight'], key=g + 'bn_2')]
         # dY has ONE reader, the aggregation backward: where its kernel can, it applies the BatchNorm backward of bn_1 | bn_2 while it
         # stages dY (and runs the finalize lazily in front) -- the stand-alone apply pass over P x 2C disappears (GAST_FUSE_AGG_BN=0: off)
-        fuse_bn = (P > FUSED_BN_BWD_ROWS and self.lazy_bn and hasattr(ops, 'semch_agg_bwd_fuses_bn')
+        fuse_bn = (P > FUSED_BN_BWD_ROWS and self.can_lazy and hasattr(ops, 'semch_agg_bwd_fuses_bn')
                    and os.environ.get('GAST_FUSE_AGG_BN', '1') not in ('0', '')
                    and ops.semch_agg_bwd_fuses_bn(st['H'], F, J, C, st['A_s'], st['A_c'], (sp.deg_sym[1], sp.deg_con[1])))
         bn_agg = None
@@ -809,7 +817,11 @@ class Engine:
                                  rstd=st['bnY'].rstd[sl], dgamma=grads[it['key'] + '.weight'], dbeta=grads[it['key'] + '.bias'],
                                  ka=kabc[0, o:o + C], kb=kabc[1, o:o + C], kc=kabc[2, o:o + C], accumulate=True))
                 o += C
-            bn_agg = dict(bn=(st['Y'], kabc[0], kabc[1], kabc[2]), lazy=ops.bn_lazy_bwd(jobs, za.take((1,), torch.int32)))
+            bn_agg = dict(bn=(st['Y'], kabc[0], kabc[1], kabc[2]))
+            if self.lazy_bn:
+                bn_agg['lazy'] = ops.bn_lazy_bwd(jobs, za.take((LAZY_FLAG_WORDS,), torch.int32))
+            else:
+                ops.bn_bwd_finalize_multi(jobs)
         else:
             self._bn_backward_group(itemsY, grads, one_apply=(dY, st['Y'], P))
         # attention core + aggregation backward fill the column blocks of dH

@@ -332,14 +332,16 @@ int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stre
  * partial sums were written by an EARLIER launch, so no producer pays a fence; blocks are dispatched in index order, so the
  * finalizing blocks are resident before any waiter can occupy their slots.  Same arithmetic, same order of summation, same
  * outputs (scale / shift / mean / rstd / running statistics, or dgamma / dbeta / ka / kb / kc) as the stand-alone finalize.
- * `flag` points at one uint32 that is ZERO when the launch starts (the plan takes it from its zero arena). */
+ * `flag` points at GAST_BN_LAZY_FLAG_WORDS uint32 that are ZERO when the launch starts (the plan takes them from its zero arena): one
+ * word per finalizing block -- a shared counter would serialise (same-address atomics cost 50 - 170 ns apiece on this chip). */
+#define GAST_BN_LAZY_FLAG_WORDS 256
 #define GAST_BN_LAZY_MAX 2
 #define GAST_BN_LAZY_FWD 1
 #define GAST_BN_LAZY_BWD 2
 typedef struct gast_bn_lazy {
     int kind;               /* GAST_BN_LAZY_FWD: fwd[i] (gast_bn_finalize) | GAST_BN_LAZY_BWD: bwd[i] (gast_bn_bwd_finalize) */
     int n;                  /* 1 .. GAST_BN_LAZY_MAX jobs */
-    unsigned int* flag;     /* device counter, zero at launch */
+    unsigned int* flag;     /* GAST_BN_LAZY_FLAG_WORDS device words, zero at launch */
     gast_bn_fin_job fwd[GAST_BN_LAZY_MAX];      /* (two plain arrays, not a union: a float of one job type aliasing a pointer of the other */
     gast_bn_bwd_fin_job bwd[GAST_BN_LAZY_MAX];  /*  costs the kernels a scratch slot)                                                    */
 } gast_bn_lazy;

@@ -1136,7 +1136,7 @@ def _same_bn(a_jobs, a_st, b_jobs, b_st):
 
 
 def _flag():
-    return torch.zeros(1, dtype=torch.int32).cuda()
+    return torch.zeros(256, dtype=torch.int32).cuda()      # GAST_BN_LAZY_FLAG_WORDS
 
 
 @pytest.mark.parametrize('rows', [8, 5000])
