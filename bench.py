@@ -481,6 +481,7 @@ def main():
     # ---- parity, measured in this run before anything is timed: the same weights and batch, train mode (batch statistics), dropout
     # off, through (a) the timed arithmetic, (b) the fp32 HIP path, (c) the CPU restatement of the reference on stock ATen operators
     parity = None
+    cpu_ref = None
     if rank == 0 and not args.no_parity:
         try:
             pm = cls(adj, J, 2, J, filter_widths=arc, causal=False, dropout=0.0, channels=C)
@@ -509,6 +510,7 @@ def main():
                                               '(fp32 storage, hi/lo split products) is held to the fp32 bound'}}
             if world == 1 and (not args.no_cpu_baseline or args.cpu_parity):
                 yc, lc = cpu_reference_forward(sd, adj, arc, C, x, y3d)
+                cpu_ref = (yc, lc)             # (the 16-bit variant's parity block below compares with the same restatement)
                 dc = float((outs[args.dtype][0].cpu() - yc).abs().max())
                 parity['vs_cpu_reference_restatement'] = {'max_abs': dc, 'mpjpe_shift_mm': abs(outs[args.dtype][1] - lc) * 1e3,
                                                           'fp32_hip_max_abs': float((outs['fp32'][0].cpu() - yc).abs().max()),
@@ -772,6 +774,13 @@ def main():
                                  'tolerance': {'max_abs': 1e-2, 'mpjpe_mm': 0.1, 'source': 'BASELINE.json north_star: 1e-2 for 16-bit arithmetic, '
                                                                                          'MPJPE within 0.1 mm'},
                                  'pass': bool(d16 < 1e-2 and sh16 < 0.1)}
+                if cpu_ref is not None:        # oracle side: the CPU restatement of the reference (same weights and batch: same seeds)
+                    dc16 = float((outs['f16'][0].cpu() - cpu_ref[0]).abs().max())
+                    f16['parity']['vs_cpu_reference_restatement'] = {'max_abs': dc16, 'mpjpe_shift_mm': abs(outs['f16'][1] - cpu_ref[1]) * 1e3,
+                                                                     'what': 'oracle/torch_ops.py on stock PyTorch CPU operators, fp32'}
+                    f16['parity']['pass'] = bool(f16['parity']['pass'] and dc16 < 1e-2 and abs(outs['f16'][1] - cpu_ref[1]) * 1e3 < 0.1)
+                f16['parity']['scope'] = ('specified for BASELINE configs[1] and [3]; at configs[2] (C0 = 64, four temporal levels, B = 256) the mode '
+                                          'sits AT the 1e-2 bound (9.7e-3 .. 9.8e-3 measured): tests/test_f16_gpu.py')
                 del pm, outs
             os.environ['GAST_HIP_DTYPE'] = 'f16'
             fm.train()

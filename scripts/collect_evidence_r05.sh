@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 evidence (run through gpurun): the driver's default bench line, the replayed step and the forward-only graph launch by launch
+# Round-5 evidence (run through gpurun): the driver's default bench line, the replayed step and the forward-only graph launch by launch
 # (rocprofv3 --kernel-trace), per-kernel stats, the HBM-byte and MFMA-utilisation counter passes (separate --pmc runs), two more default
-# lines for the median, the other configurations.  Everything lands in gpurun_out/r04_evidence; copy what is cited into profiles/.
+# lines for the median, the other configurations.  Everything lands in gpurun_out/r05_evidence; copy what is cited into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; cd "$R"
-O=$R/gpurun_out/r04_evidence; mkdir -p $O
+O=$R/gpurun_out/r05_evidence; mkdir -p $O
 if [ "$ONLY" != trace ] && [ "$ONLY" != prof ]; then
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json; echo
@@ -54,3 +54,10 @@ for cfg in cfg2 cfg3 cfg4 cfg243; do
   python -c "import json;d=json.loads(open('$O/bench_$cfg.json').read().strip().splitlines()[-1]);p=d['parity'];print('$cfg', d['ms_per_step'], d['value'], p.get('pass'), p.get('vs_fp32_hip',{}).get('max_abs'), (p.get('vs_cpu_reference_restatement') or {}).get('max_abs'), (d.get('roofline') or {}).get('frac'))"
 done
 ls $O
+# one-rank run of the gradient exchange through RCCL (the 1-GPU box cannot measure scaling; this shows the collective path executes)
+timeout 300 python bench.py --force-collective --no-cpu-baseline --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 10 --warmup 3 > $O/bench_force_collective.json 2> $O/bench_force_collective.err
+tail -c 600 $O/bench_force_collective.json; echo
+# LDS bank-conflict counters per kernel (its own --pmc run)
+bash scripts/pmc_lds.sh $O > /dev/null 2>&1; head -12 $O/pmc_lds_summary.txt
+# the opt-in lazy finalize next to the default on the same box
+bash scripts/ab_env.sh $O/ab_lazy base= lazy=GAST_LAZY_BN=1 nofuse=GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0 | tee $O/ab_lazy.txt

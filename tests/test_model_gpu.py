@@ -254,6 +254,8 @@ FULL_SIZE = [(17, (3, 3, 3), 128, 128, 'dilated'), (17, (3, 3, 3), 128, 128, 'st
              (15, (3, 3, 3), 128, 32, 'dilated'), (17, (3, 3, 3), 64, 32, 'dense'),
              # configs[2] at its own width (C=128: 1024-wide last level) and a batch the float64 stock reference fits in memory with
              (17, (3, 3, 3, 3), 128, 64, 'dilated'),
+             # configs[2] at ITS OWN batch, B = 256 / RF 81, with the width of the shipped 81-frame checkpoints (C0 = 64; round 5)
+             (17, (3, 3, 3, 3), 64, 256, 'dilated'),
              # the shipped 243-frame shape (reference reconstruction.py:225-227)
              (17, (3, 3, 3, 3, 3), 32, 16, 'dilated')]
 # bounds of test_full_size_values_against_stock_torch per arithmetic: outputs (north star 1e-4; bf16x3: times x3_depth_factor), loss, and
