@@ -911,7 +911,7 @@ def main():
                     peak, unit = peak_tf, 'TFLOP/s'
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-                    pmc_name = next(n for n in ('r04_pmc_hbm_bytes_%s.json' % args.dtype, 'r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
+                    pmc_name = next(n for n in ('r05_pmc_hbm_bytes_%s.json' % args.dtype, 'r04_pmc_hbm_bytes_%s.json' % args.dtype, 'r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
                                     if os.path.exists(os.path.join(ROOT, 'profiles', n)))      # counters of the committed kernels, newest round first
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
                     GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<',
@@ -965,7 +965,7 @@ def main():
                                    'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
             out['kernels_note'] = ('per-op durations from an EAGER pass with a HIP-event pair around every launch (events cannot be recorded inside a '
                                    'replayed graph): the GPU clocks down between eager launches, so the column sums to more than ms_per_step; '
-                                   'the replayed step itself is broken down in profiles/r04_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
+                                   'the replayed step itself is broken down in profiles/r05_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
             out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
                                   'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)

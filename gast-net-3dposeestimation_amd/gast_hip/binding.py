@@ -6,6 +6,7 @@ never synchronises.
 """
 import ctypes as C
 import os
+import threading
 from collections import namedtuple
 
 import torch
@@ -160,10 +161,31 @@ class _BnBwdJob(C.Structure):
 
 # The library exists in two 16-bit STORAGE flavours built from the same sources (csrc/build.sh, csrc/common.h): libgast_hip.so keeps
 # GAST_BF16 tensors as bfloat16, libgast_hip_f16.so as IEEE binary16 (GAST_HIP_DTYPE=f16).  Same ABI; the process-wide flavour
-# (`set_h16`) decides which one the op set calls and which 16-bit torch dtype `_dt` accepts -- a tensor of the other kind raises.
+# (`set_h16`, per thread) decides which one the op set calls and which 16-bit torch dtype `_dt` accepts -- a tensor of the other kind raises.
 LIB_PATH_F16 = os.path.join(_HERE, 'libgast_hip_f16.so')
 _libs = {}
-_H16 = {'dtype': torch.bfloat16}
+
+
+class _Flavour(threading.local):
+    """The 16-bit storage flavour is per THREAD: every entry point of the plan (forward, backward -- which autograd runs
+    on its own thread --, the causal stream, DataParallel replica threads) selects it for its own launches, so two models of different
+    16-bit dtypes driven from different threads cannot flip it under each other."""
+    dtype = torch.bfloat16
+
+
+_H16F = _Flavour()
+
+
+class _H16View:
+    """(dict-style access kept for the call sites below)"""
+    def __getitem__(self, k):
+        return _H16F.dtype
+
+    def __setitem__(self, k, v):
+        _H16F.dtype = v
+
+
+_H16 = _H16View()
 
 
 def set_h16(dtype):
