@@ -1010,3 +1010,37 @@ def test_fused_parameter_packing_equals_the_three_launch_path(ch, arc, variant, 
     assert torch.equal(got['0']['Xb'].view(torch.int16), got['1']['Xb'].view(torch.int16)), 'weight images differ'
     assert got['1']['Xb'].view(torch.int16).ne(0).any()
 
+
+
+@pytest.mark.parametrize('switch', ['GAST_LAZY_BN=1', 'GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0'], ids=['lazy_finalize', 'round4_plan'])
+def test_round5_plan_switches_agree_with_the_default(switch, mode2, monkeypatch):
+    """The opt-in lazy BatchNorm finalize (gast_bn_lazy: finalize jobs inside the first consumer launch) and the bisecting switches that
+    restore the round-4 plan (stand-alone bn_bwd_apply over dY / dE, materialised first-block input) compute the same training step as the
+    default plan: same arithmetic, same order inside every kernel -- the only run-to-run freedom is the order of the split reductions, so
+    the comparison is at round-off level, not bitwise."""
+    cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3, 3], channels=64, causal=False, variant='dilated')
+    gen = torch.Generator().manual_seed(41)
+    x = (torch.rand(96, 27, 17, 2, generator=gen) * 2 - 1).cuda()          # (96 x 27 x 17 rows: the large-M kernels and the fused consumers run)
+    y3d = (torch.randn(96, 1, 17, 3, generator=gen) * 0.3).cuda()
+    res = {}
+    for name, envs in (('default', ''), ('switched', switch)):
+        for kv in switch.split(','):
+            monkeypatch.delenv(kv.split('=')[0], raising=False)
+        for kv in filter(None, envs.split(',')):
+            monkeypatch.setenv(*kv.split('='))
+        torch.manual_seed(0)
+        m = build(cfg, dropout=0.05).cuda().train()
+        m._runner.graph_mode = False
+        y = m(x)
+        loss = torch.mean(torch.norm(y - y3d, dim=-1))
+        loss.backward()
+        res[name] = (y.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters()},
+                     {k: b.clone() for k, b in m.named_buffers()})
+    ya, ga, ba = res['default']
+    yb, gb, bb = res['switched']
+    assert float((ya - yb).abs().max()) < 2e-6 * max(1.0, float(ya.abs().max()))
+    gmax = max(float(v.abs().max()) for v in ga.values())
+    for k in ga:
+        assert float((ga[k] - gb[k]).abs().max()) < 2e-5 * gmax + 2e-4 * float(ga[k].abs().max()), k
+    for k in ba:
+        assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-5, atol=1e-6), k
