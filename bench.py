@@ -61,7 +61,7 @@ CONFIGS = {
     'cfg243': dict(J=17, arc=[3, 3, 3, 3, 3], channels=32, batch=128, what='243-frame model: 17 joints, arc 3,3,3,3,3 (RF 243), channels=32, B=128'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per
+MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per
 # FLOP pair; fp8: the forward GEMMs run at the 5 PF fp8 rate, the gradient GEMMs -- 2/3 of the work -- at the bf16 rate: priced at bf16)
 
 

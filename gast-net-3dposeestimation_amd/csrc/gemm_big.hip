@@ -68,6 +68,15 @@ template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
 __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem, const gast_bn_lazy& lz) {
     constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
     constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW, D);
+    // PAIR = 3: 16-bit STORAGE (GAST_BF16: bfloat16, or binary16 in the -DGAST_H16_F16 build), ONE product.  A K step then covers 32
+    // values: a row image is [32 x 16 bit] = the same 64 bytes, four 16-byte chunks of 8 values; the chunk a lane reads for the first
+    // 16-deep MFMA is the one that holds the hi halves in the split layout (chunk lh), for the second the lo one (chunk 2 + lh) -- the
+    // weight DMA, the fragment reads and the LDS swizzle are the split kernel's, the products per K step drop from 3 x 8 to 2 x 8
+    // per column half, and the activation path converts (prologue only) instead of splitting.
+    constexpr bool H16 = PAIR == 3;
+    constexpr int ESZ = H16 ? 2 : 4;                // bytes per stored element
+    constexpr int CV = 16 / ESZ;                    // values per 16-byte chunk: 4 / 8
+    constexpr int TKV = H16 ? 32 : TK;              // K values per step
     constexpr int WS = D + 1;                       // weight stages in the ring
     constexpr int WROWS = TN / (2 * MW);            // weight rows a wave's DMA fills per K step
     constexpr int WPIECES = WROWS / 16;             // ... in 16-row (1 KB) pieces: 4, 2 or 1
@@ -131,7 +140,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             const bool ok = b >= 0 && ts >= 0 && ts < sg.map.T_total;
             const uint32_t srow = ok ? (uint32_t)((b * sg.map.T_total + ts) * a.J + j) : 0u;
             zrow[i] = !ok;                                   // out-of-range tap (or a row past M): reads as zero
-            offA[i] = (srow * (uint32_t)sg.lda + c * 4) * 4u;
+            offA[i] = (srow * (uint32_t)sg.lda + c * CV) * (uint32_t)ESZ;
         }
     };
     // Weight stream (DMA): wave w fills the 16-row pieces (w*4 + i) of the 256 x 64 B tile, which is ONE contiguous 16 KB block
@@ -140,26 +149,26 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const uint32_t offW = (uint32_t)(n0 + w * WROWS + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
     // A tile descriptor carries everything the K loop needs to know about its segment (K, table offset, operand bases), fetched
     // from the kernel arguments only when the generator enters a new segment: a dependent s_load per use costs ~200 clk.
-    struct Tile { int seg, k0, K, toff; const float* abase; const char* wbase; };
+    struct Tile { int seg, k0, K, toff; const char* abase; const char* wbase; };
     int ntile = 0;
-    for (int s = 0; s < a.nseg; ++s) ntile += (a.seg[s].K + TK - 1) / TK;
+    for (int s = 0; s < a.nseg; ++s) ntile += (a.seg[s].K + TKV - 1) / TKV;
     int seg_l = 0, k_l = 0, gen = 0, K_l = a.seg[0].K, toff_l = pl.taboff[0];
-    const float* A_l = (const float*)a.seg[0].A;
+    const char* A_l = (const char*)a.seg[0].A;
     const char* W_l = (const char*)a.seg[0].Wx;
     long ldg_l = (long)a.seg[0].ldwx * 2;                     // bytes per k-group of the weight image
     Tile last_tile = {0, 0, K_l, toff_l, A_l, W_l};
     auto next_tile = [&](Tile& t) {                          // tiles in order; past the end: the last tile again
         if (gen >= ntile) { t = last_tile; return; }
         t.seg = seg_l; t.k0 = k_l; t.K = K_l; t.toff = toff_l;
-        t.abase = A_l + k_l;
-        t.wbase = W_l + (long)(k_l >> 4) * ldg_l;
+        t.abase = A_l + k_l * ESZ;
+        t.wbase = W_l + (long)(k_l / TKV) * ldg_l;
         last_tile = t;
         ++gen;
-        k_l += TK;
+        k_l += TKV;
         if (k_l >= K_l && seg_l + 1 < a.nseg) {
             k_l = 0; ++seg_l;
             K_l = a.seg[seg_l].K; toff_l = pl.taboff[seg_l];
-            A_l = (const float*)a.seg[seg_l].A; W_l = (const char*)a.seg[seg_l].Wx; ldg_l = (long)a.seg[seg_l].ldwx * 2;
+            A_l = (const char*)a.seg[seg_l].A; W_l = (const char*)a.seg[seg_l].Wx; ldg_l = (long)a.seg[seg_l].ldwx * 2;
         }
     };
 
@@ -177,7 +186,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     auto load_a = [&](const Tile& t, u32x4 (&ra)[2], bool (&rz)[2]) {
         enter_a(t.seg);
         if (abl & 8) return;
-        const bool kin = t.k0 + c * 4 < t.K;
+        const bool kin = t.k0 + c * CV < t.K;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             gload16s(ra[i], kin ? offA[i] : offA[i] - c * 16, t.abase);     // (past the K tail: any valid address, the values are zeroed)
@@ -197,19 +206,43 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     };
     // scale / shift of a tile's prologue (this thread's 4 K values), fetched from the LDS tables one step before write_a uses them
     float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tsc2 = tsc, tsh2 = tsh;                   // (PAIR = 3: values 4 .. 7 of the thread's chunk)
     auto fetch_tab = [&](const Tile& t) {
         if (t.toff >= 0) {
-            const int k = t.toff + min(t.k0 + c * 4, t.K - 4);
+            const int k = t.toff + min(t.k0 + c * CV, t.K - CV);
             tsc = *(const float4*)(sSc + k);
             tsh = *(const float4*)(sSh + k);
+            if constexpr (H16) {
+                tsc2 = *(const float4*)(sSc + k + 4);
+                tsh2 = *(const float4*)(sSh + k + 4);
+            }
         }
     };
     const int wa_key = (rbase >> 2) & 3;             // (rows rbase and rbase + TM/2 share the swizzle key)
     const int wa_hi = rbase * ROWB + (((c >> 1) ^ wa_key) << 4) + (c & 1) * 8, wa_lo = rbase * ROWB + (((2 + (c >> 1)) ^ wa_key) << 4) + (c & 1) * 8;
+    const int wa_h16 = rbase * ROWB + ((c ^ wa_key) << 4);      // PAIR = 3: chunk c of the row, whole
     auto write_a = [&](const Tile& t, int stage, const u32x4 (&ra)[2], const bool (&rz)[2]) {
         if (abl & 16) return;
         unsigned char* sA = smem + OFF_A + stage * A_BYTES;
         const bool pro = t.toff >= 0;
+        if constexpr (H16) {
+            // 8 stored values per row: pass through, or BN + ReLU on the unpacked values and round back to the storage type
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint32_t w4[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                const float sc8[8] = {tsc.x, tsc.y, tsc.z, tsc.w, tsc2.x, tsc2.y, tsc2.z, tsc2.w};
+                const float sh8[8] = {tsh.x, tsh.y, tsh.z, tsh.w, tsh2.x, tsh2.y, tsh2.z, tsh2.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float lo, hi;
+                    h16x2_unpack(w4[p], lo, hi);
+                    const uint32_t pw = pack_h16x2(fmaxf(fmaf(lo, sc8[2 * p], sh8[2 * p]), 0.f), fmaxf(fmaf(hi, sc8[2 * p + 1], sh8[2 * p + 1]), 0.f));
+                    w4[p] = rz[i] ? 0u : (pro ? pw : w4[p]);
+                }
+                *(uint4*)(sA + wa_h16 + i * (TM / 2) * ROWB) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float x0 = __uint_as_float(ra[i].x), x1 = __uint_as_float(ra[i].y), x2 = __uint_as_float(ra[i].z), x3 = __uint_as_float(ra[i].w);
@@ -281,6 +314,17 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         if (abl & 1) {      // keep the fragment reads alive without the matrix cores
 #pragma unroll
             for (int q = 0; q < 2; ++q) acc[0][nh * 2 + q][0] += __uint_as_float(bh[q].u.x ^ bl[q].u.y ^ ah[q].u.z ^ al[q].u.w);
+            return;
+        }
+        if constexpr (H16) {      // two 16-deep products of the 32-value step: k 0..15 (chunks 0 / 1), k 16..31 (chunks 2 / 3)
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_h16(ah[mi].u, bh[q].u, acc[mi][nh * 2 + q]);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[mi][nh * 2 + q] = mfma_h16(al[mi].u, bl[q].u, acc[mi][nh * 2 + q]);
             return;
         }
         // small terms first; consecutive MFMAs on different accumulators
@@ -374,16 +418,27 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
     const float inv_keep = a.drop.inv_keep;
     const uint32_t xkey = xdrop ? drop_key(a.drop, a.xsalt) : 0u;
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * 4), RSRC3);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * 4) : 0, RSRC3);
+    // (PAIR = 3: C / C2 / X / addend are tensors of the 16-bit storage type -- two-byte buffer accesses, values rounded to the storage
+    //  type BEFORE they enter the column sums, as in gemm.hip: the statistics are those of the tensor that is stored)
+    constexpr uint32_t ESO = H16 ? 2u : 4u, NISTEP = 32u * ESO;
+    auto ldv = [&](const __amdgpu_buffer_rsrc_t& r, uint32_t off) -> float {
+        if constexpr (H16) return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+    };
+    auto stv = [&](float v, const __amdgpu_buffer_rsrc_t& r, uint32_t off) {
+        if constexpr (H16) __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), r, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0);
+    };
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * ESO), RSRC3);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * ESO) : 0, RSRC3);
     // second output of the BNRELU_BWD epilogues: the value before the mask (a null C2 gets a zero-sized descriptor: its stores are dropped).
     // Only in the variants WITHOUT an addend (what the plan needs: gast_gemm_big_plan): with one the extra descriptor and store push the
     // narrow-tile kernel from 167 to 173 registers, i.e. from three to two blocks per CU.
     constexpr bool C2OK = bwd && !ADD;
     const bool has2 = C2OK && a.C2 != nullptr;
-    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(has2 ? a.C2 : a.C, 0, has2 ? (int)(((rowsC - 1) * a.ldc2 + N) * 4) : 0, RSRC3);
+    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(has2 ? a.C2 : a.C, 0, has2 ? (int)(((rowsC - 1) * a.ldc2 + N) * ESO) : 0, RSRC3);
     const long rowsAdd = ADD ? (long)a.B * a.addmap.T_total * a.J : 1;
-    const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(ADD ? a.addend : a.C), 0, ADD ? (int)(((rowsAdd - 1) * a.ldadd + N) * 4) : 0, RSRC3);
+    const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(ADD ? a.addend : a.C), 0, ADD ? (int)(((rowsAdd - 1) * a.ldadd + N) * ESO) : 0, RSRC3);
     const int col0 = n0 + wc * (TN / 2) + li;          // the lane's first column; the others are + 32 ni
     bool nin[NI];
     float bias[NI], xs[NI], xh[NI], s1[NI], s2[NI];
@@ -407,10 +462,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         if (bwd) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t off = crow[buf][r] >= 0 ? (uint32_t)(crow[buf][r] * a.ldx + col0) * 4u : OOB;
+                const uint32_t off = crow[buf][r] >= 0 ? (uint32_t)(crow[buf][r] * a.ldx + col0) * ESO : OOB;
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    xv[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rX, off + 128 * ni, 0, 0));
+                for (int ni = 0; ni < NI; ++ni) xv[buf][ni][r] = ldv(rX, off + NISTEP * ni);
             }
         }
         if (ADD) {
@@ -418,10 +472,9 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             const int ar[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const uint32_t off = ar[r] >= 0 ? (uint32_t)(ar[r] * a.ldadd + col0) * 4u : OOB;     // unmapped addend row: reads 0
+                const uint32_t off = ar[r] >= 0 ? (uint32_t)(ar[r] * a.ldadd + col0) * ESO : OOB;     // unmapped addend row: reads 0
 #pragma unroll
-                for (int ni = 0; ni < NI; ++ni)
-                    av[buf][ni][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rAdd, off + 128 * ni, 0, 0));
+                for (int ni = 0; ni < NI; ++ni) av[buf][ni][r] = ldv(rAdd, off + NISTEP * ni);
             }
         }
     };
@@ -433,25 +486,26 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int cr = crow[buf][r];
-            const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * 4u;
+            const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * ESO;
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni) {
                 const bool ok = cr >= 0 && nin[ni];
                 float v = acc[mi][ni][4 * q + r] + bias[ni];
                 if (ADD) v += av[buf][ni][r];
                 if (bwd) {
-                    if constexpr (C2OK)
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rC2, ok ? (uint32_t)(cr * a.ldc2 + col0) * 4u + 128 * ni : OOB, 0, 0);
+                    if constexpr (C2OK) stv(v, rC2, ok ? (uint32_t)(cr * a.ldc2 + col0) * ESO + NISTEP * ni : OOB);
                     const float x = xv[buf][ni][r];
                     v = fmaf(x, xs[ni], xh[ni]) > 0.f ? v : 0.f;
                     if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(cr * a.ldx + col0 + 32 * ni));
+                    if constexpr (H16) v = bf2f(f2bf(v));
                     s1[ni] += ok ? v : 0.f;
                     s2[ni] += ok ? v * x : 0.f;
                 } else if (EPI == 1) {
+                    if constexpr (H16) v = bf2f(f2bf(v));
                     s1[ni] += ok ? v : 0.f;
                     s2[ni] += ok ? v * v : 0.f;
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), rC, ok ? coff + 128 * ni : OOB, 0, 0);
+                stv(v, rC, ok ? coff + NISTEP * ni : OOB);
             }
         }
         __builtin_amdgcn_sched_barrier(0);             // keep the units apart: interleaving them only adds register pressure
@@ -526,6 +580,18 @@ __global__ void __launch_bounds__(256) x3_image_kernel(const ImageBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
     const gast_x3_image_job& j = b.j[d];
+    if (j.f16 == 2) {
+        // 16-bit storage, one product (PAIR = 3): a LAYOUT change only -- img[(k >> 5) * ldimg + r * 32 + (k & 31)] = W[r][k], zero
+        // for K <= k < 32 * ceil(K / 32); one 16-byte chunk (8 values) per thread
+        const int Kp8 = (j.K + 31) / 32 * 4;
+        const long idx = (long)(blockIdx.x - b.first[d]) * 256 + threadIdx.x;
+        if (idx >= (long)j.R * Kp8) return;
+        const int r = (int)(idx / Kp8), k = (int)(idx - (long)r * Kp8) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (k < j.K) v = *(const uint4*)((const bf16_t*)j.W + (long)r * j.ldw + k);
+        *(uint4*)((bf16_t*)j.img + (long)(k >> 5) * j.ldimg + (long)r * 32 + (k & 31)) = v;
+        return;
+    }
     const int Kp4 = (j.K + 15) / 16 * 4;                          // 4-value chunks per padded row
     const long idx = (long)(blockIdx.x - b.first[d]) * 256 + threadIdx.x;
     if (idx >= (long)j.R * Kp4) return;
@@ -550,10 +616,16 @@ std::atomic<bool> big_setup_done[64];      // (zero-initialised: static storage)
 int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     static const int enabled = getenv("GAST_GEMM_BIG") ? atoi(getenv("GAST_GEMM_BIG")) : 1;
     static const int min_rows = getenv("GAST_GEMM_BIG_MIN_M") ? atoi(getenv("GAST_GEMM_BIG_MIN_M")) : 8192;
-    if (!enabled || (a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H)) return 0;
+    // Round 5: 16-bit storage (GAST_BF16 tensors: bfloat16, or binary16 in the f16 build) with ONE product per value (pair = 3),
+    // every epilogue; 16-bit output only, no fp8 operands.  GAST_GEMM_BIG_H16=0: those GEMMs stay on gemm.hip's kernel.
+    static const int h16_enabled = getenv("GAST_GEMM_BIG_H16") ? atoi(getenv("GAST_GEMM_BIG_H16")) : 1;
+    const bool h16 = a.dtype == GAST_BF16;
+    if (!enabled || (a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H && !h16)) return 0;
+    if (h16 && (!h16_enabled || a.out_f32 || a.f8_scale)) return 0;
     // fp16 pairs: forward epilogues only (a gradient operand does not fit fp16's range; gemm.hip has every variant)
     if (a.dtype == GAST_F32X3H && a.epi == GAST_EPI_BNRELU_BWD) return 0;
-    pl.pair = a.dtype == GAST_F32X3H ? 2 : 1;
+    pl.pair = h16 ? 3 : a.dtype == GAST_F32X3H ? 2 : 1;
+    const int esz = h16 ? 2 : 4, cv = 16 / esz;
     const long Ml = (long)a.B * a.Tn * a.J;
     static const int all_shapes = getenv("GAST_GEMM_BIG_ALL") ? atoi(getenv("GAST_GEMM_BIG_ALL")) : 0;
     // (the M = B*J stage stays on gemm.hip's split-K path: a split-K version of this kernel was built and measured slower on every
@@ -608,8 +680,8 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     int ntab = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_gemm_seg& g = a.seg[s];
-        if (!g.Wx || !aligned16(g.Wx) || g.ldwx % 8 || !g.A || !aligned16(g.A) || g.lda % 4 || g.K % 4 || g.K < 4) return 0;
-        if ((long)a.B * g.map.T_total * a.J * g.lda * 4 >= 0xffffffffL) return 0;      // 32-bit byte offsets into the activation tensor
+        if (!g.Wx || !aligned16(g.Wx) || g.ldwx % 8 || !g.A || !aligned16(g.A) || g.lda % cv || g.K % cv || g.K < cv) return 0;
+        if ((long)a.B * g.map.T_total * a.J * g.lda * esz >= 0xffffffffL) return 0;      // 32-bit byte offsets into the activation tensor
         if (g.pro == GAST_PRO_BNRELU_DROP) return 0;
         pl.taboff[s] = -1;
         if (g.pro == GAST_PRO_BNRELU) {
@@ -624,9 +696,9 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     // the epilogue addresses C / X / addend with 32-bit byte offsets inside buffer descriptors
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
-    if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
-    if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || a.addend || rowsC * a.ldc2 * 4 >= 0x7fffffffL)) return 0;
-    if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
+    if (rowsC * a.ldc * esz >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * esz >= 0x7fffffffL)) return 0;
+    if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || a.addend || rowsC * a.ldc2 * esz >= 0x7fffffffL)) return 0;
+    if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * esz >= 0x7fffffffL) return 0;
     static const int ablate = getenv("GAST_GEMM_BIG_ABLATE") ? atoi(getenv("GAST_GEMM_BIG_ABLATE")) : 0;
     pl.ablate = ablate;
     pl.M = (int)Ml;
@@ -648,6 +720,18 @@ static big_kernel_t big_kernel_ni(int v, int pair) {
             case 2: return gemm_big_kernel<1, false, NI, MW, 2, D>;
             case 3: return gemm_big_kernel<1, true, NI, MW, 2, D>;
             default: return nullptr;
+        }
+    }
+    if (pair == 3) {
+        switch (v) {
+            case 0: return gemm_big_kernel<0, false, NI, MW, 3, D>;
+            case 1: return gemm_big_kernel<0, true, NI, MW, 3, D>;
+            case 2: return gemm_big_kernel<1, false, NI, MW, 3, D>;
+            case 3: return gemm_big_kernel<1, true, NI, MW, 3, D>;
+            case 4: return gemm_big_kernel<2, false, NI, MW, 3, D>;
+            case 5: return gemm_big_kernel<2, true, NI, MW, 3, D>;
+            case 6: return gemm_big_kernel<3, false, NI, MW, 3, D>;
+            default: return gemm_big_kernel<3, true, NI, MW, 3, D>;
         }
     }
     switch (v) {
@@ -679,6 +763,18 @@ static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
             default: return nullptr;
         }
     }
+    if (pair == 3) {
+        switch (v) {
+            case 0: return gemm_big_multi_kernel<0, false, NI, MW, 3, D>;
+            case 1: return gemm_big_multi_kernel<0, true, NI, MW, 3, D>;
+            case 2: return gemm_big_multi_kernel<1, false, NI, MW, 3, D>;
+            case 3: return gemm_big_multi_kernel<1, true, NI, MW, 3, D>;
+            case 4: return gemm_big_multi_kernel<2, false, NI, MW, 3, D>;
+            case 5: return gemm_big_multi_kernel<2, true, NI, MW, 3, D>;
+            case 6: return gemm_big_multi_kernel<3, false, NI, MW, 3, D>;
+            default: return gemm_big_multi_kernel<3, true, NI, MW, 3, D>;
+        }
+    }
     switch (v) {
         case 0: return gemm_big_multi_kernel<0, false, NI, MW, 1, D>;
         case 1: return gemm_big_multi_kernel<0, true, NI, MW, 1, D>;
@@ -702,7 +798,7 @@ static void big_setup() {
     if (big_setup_done[dev].load(std::memory_order_acquire)) return;      // (idempotent set-up: a racing first call repeats it)
     for (int c = 0; c < 4; ++c) {          // (NI, MW, D) = (2, 2, 2), (4, 2, 2), (4, 4, 2), (2, 2, 4)
         const int ni = (c == 0 || c == 3) ? 2 : 4, mw = c == 2 ? 4 : 2, depth = c == 3 ? 4 : 2;
-        for (int pair = 1; pair <= 2; ++pair)
+        for (int pair = 1; pair <= 3; ++pair)
             for (int v = 0; v < (pair == 2 ? 4 : 8); ++v) {
                 const hipError_t e1 = hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
                 const hipError_t e2 = hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
@@ -776,10 +872,11 @@ extern "C" int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_st
         b.first[0] = 0;
         for (int d = 0; d < b.n; ++d) {
             const gast_x3_image_job& j = jobs[i0 + d];
-            if (!j.W || !j.img || j.R < 1 || j.K < 4) return GAST_EINVAL;
-            if (j.K % 4 || j.ldw % 4 || !aligned16(j.W) || !aligned16(j.img) || j.ldimg % 8 || j.ldimg < (long)j.R * 32) return GAST_EALIGN;
+            const int cv = j.f16 == 2 ? 8 : 4;          // values per 16-byte chunk of the source operand (f16 == 2: a 16-bit operand)
+            if (!j.W || !j.img || j.R < 1 || j.K < cv || j.f16 < 0 || j.f16 > 2) return GAST_EINVAL;
+            if (j.K % cv || j.ldw % cv || !aligned16(j.W) || !aligned16(j.img) || j.ldimg % 8 || j.ldimg < (long)j.R * 32) return GAST_EALIGN;
             b.j[d] = j;
-            const long chunks = (long)j.R * ((j.K + 15) / 16 * 4);
+            const long chunks = j.f16 == 2 ? (long)j.R * ((j.K + 31) / 32 * 4) : (long)j.R * ((j.K + 15) / 16 * 4);
             b.first[d + 1] = b.first[d] + (int)((chunks + 255) / 256);
         }
         hipLaunchKernelGGL(x3_image_kernel, dim3(b.first[b.n]), dim3(256), 0, (hipStream_t)stream, b);

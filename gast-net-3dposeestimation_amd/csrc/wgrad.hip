@@ -933,8 +933,12 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     // bf16x3: 256 x 256 tiles (wgrad_wide.hip) when the job set fills them -- at least 3/4 of the tile area carries outputs (the
     // C = 256 and M = B*J stages: 0.93 - 0.95; the C = 128 stage's 128-wide matrices: 0.5, slower there) -- GAST_WGRAD_X3_TILE=128 / 256 forces
     static const int x3_tile_env = getenv("GAST_WGRAD_X3_TILE") ? atoi(getenv("GAST_WGRAD_X3_TILE")) : 0;
-    bool x3_wide = x3_tile_env == 256;
-    if (args[0].dtype == GAST_F32X3 && x3_tile_env == 0) {
+    // Round 5: 16-bit storage (GAST_BF16 jobs) takes the same kernel in its one-product form under the same rule (GAST_WGRAD_H16_WIDE=0:
+    // the 128 x 128 kernel as in rounds 1-4)
+    static const int h16_wide_env = getenv("GAST_WGRAD_H16_WIDE") ? atoi(getenv("GAST_WGRAD_H16_WIDE")) : 1;
+    const bool h16_cand = args[0].dtype == GAST_BF16 && h16_wide_env && tile_env != 256;
+    bool x3_wide = x3_tile_env == 256 && !h16_cand;
+    if ((args[0].dtype == GAST_F32X3 && x3_tile_env == 0) || h16_cand) {
         double used = 0, area = 0;
         for (int d = 0; d < n; ++d) {
             long ts = 0, ssum = 0;
@@ -944,7 +948,16 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         }
         x3_wide = area > 0 && used >= 0.75 * area;
     }
-    const int bt = ((args[0].dtype == GAST_BF16 && tile_env == 256) || (args[0].dtype == GAST_F32X3 && x3_wide)) ? 256 : BT;
+    bool h16_range = true;      // (the wide kernel addresses its operands with 32-bit byte offsets inside 4 GB buffer descriptors)
+    for (int d = 0; d < n && h16_cand; ++d) {
+        const gast_wgrad_args& a = args[d];
+        if (a.nseg < 1 || a.nseg > GAST_MAX_SEG) { h16_range = false; break; }
+        if ((long)a.B * a.pmap.T_total * a.J * a.ldp * 2 >= 0xffff0000L || a.R > 16000) h16_range = false;
+        for (int q = 0; q < a.nseg; ++q)
+            if ((long)a.B * a.seg[q].map.T_total * a.J * a.seg[q].ldq * 2 >= 0xffff0000L || a.seg[q].S > 16000) h16_range = false;
+    }
+    const bool h16_wide = h16_cand && x3_wide && h16_range;
+    const int bt = ((args[0].dtype == GAST_BF16 && tile_env == 256) || (args[0].dtype == GAST_F32X3 && x3_wide) || h16_wide) ? 256 : BT;
     long tile_rows = 0;
     int total_tiles = 0;
     for (int d = 0; d < n; ++d) {
@@ -958,7 +971,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     static const int tgt128 = getenv("GAST_WGRAD_BLOCKS") ? atoi(getenv("GAST_WGRAD_BLOCKS")) : 1024;
     static const int tgt256 = getenv("GAST_WGRAD_BLOCKS256") ? atoi(getenv("GAST_WGRAD_BLOCKS256")) : 512;   // one resident block per CU
     static const int ring = getenv("GAST_WGRAD_RING") ? atoi(getenv("GAST_WGRAD_RING")) : 1;
-    const bool wide = args[0].dtype == GAST_F32X3 && bt == 256;      // wgrad_wide.hip: one 4-wave block per CU
+    const bool wide = (args[0].dtype == GAST_F32X3 && bt == 256) || h16_wide;      // wgrad_wide.hip: one 8-wave block per CU
     static const int tgt_wide = getenv("GAST_WGRAD_BLOCKS_WIDE") ? atoi(getenv("GAST_WGRAD_BLOCKS_WIDE")) : 256;
     const int tgt = wide ? tgt_wide : bt == 256 ? tgt256 : tgt128;
     // one common chunk length (rows of the reduction axis per block) so that every block does the same number of steps
@@ -976,8 +989,9 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         long maxM = 0;
         for (int d = 0; d < n; ++d) if (b.M[d] > maxM) maxM = b.M[d];
         const long slots = (long)tgt * ((total_tiles + tgt - 1) / tgt);
-        chunk = 96;
-        while (chunk < maxM && blocks_for(chunk) > slots) chunk += 96;
+        const long trip = h16_wide ? 192 : 96;      // six steps of 16 (16-bit storage: 32) reduction rows
+        chunk = trip;
+        while (chunk < maxM && blocks_for(chunk) > slots) chunk += trip;
     }
     if (gast_deterministic()) chunk = 1L << 40;      // no split-M: every output tile is reduced by ONE block in row order
     const bool ring2 = ring == 2 && bt == 128 && args[0].dtype == GAST_BF16 && !getenv("GAST_WGRAD_BLOCKS") && !gast_deterministic();
@@ -1013,7 +1027,7 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
     // bf16x3 kernel: chunk-major (PMC: 2.38 -> 1.07 GB fetched from HBM per launch on the C=256 stage, 535 -> 506 us)
     static const int order = getenv("GAST_WGRAD_ORDER") ? atoi(getenv("GAST_WGRAD_ORDER")) : -1;
     static const int x3_pipe = getenv("GAST_WGRAD_X3_PIPE") ? atoi(getenv("GAST_WGRAD_X3_PIPE")) : 1;
-    b.chunk_major = order >= 0 ? order : (args[0].dtype == GAST_F32X3 && ((bt == BT && x3_pipe) || wide)) ? 1 : 0;
+    b.chunk_major = order >= 0 ? order : ((args[0].dtype == GAST_F32X3 && ((bt == BT && x3_pipe) || wide)) || h16_wide) ? 1 : 0;
     for (int d = 0; d < n; ++d) {
         b.mchunk[d] = (int)(chunk < b.M[d] ? chunk : (b.M[d] + bkm - 1) / bkm * bkm);
         b.splitM[d] = (b.M[d] + b.mchunk[d] - 1) / b.mchunk[d];
@@ -1048,6 +1062,13 @@ extern "C" int gast_wgrad_multi(const gast_wgrad_args* args, int n, gast_stream_
         }
         else if (any_drop) hipLaunchKernelGGL(wgrad_x3_multi_kernel<true>, grid, dim3(256), 0, st, b);
         else hipLaunchKernelGGL(wgrad_x3_multi_kernel<false>, grid, dim3(256), 0, st, b);
+    }
+    else if (h16_wide) {
+        bool any_drop = false;
+        for (int d = 0; d < n; ++d)
+            for (int q = 0; q < args[d].nseg; ++q) any_drop |= args[d].seg[q].pro == GAST_PRO_BNRELU_DROP && args[d].drop.thresh != 0;
+        const int rcw = gast_wgrad_x3_wide_launch(b, grid.x, any_drop, st, true);
+        if (rcw) return rcw;
     }
     else if (bt == 256) {
         constexpr int lds = wgrad_bf16_lds_bytes(256);

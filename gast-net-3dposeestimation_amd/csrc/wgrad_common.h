@@ -78,4 +78,5 @@ static_assert(sizeof(WgBatch) <= 8192, "WgBatch travels by value in the HSA kern
 using namespace gastwg;
 
 // wgrad_wide.hip: the 256 x 256-tile bf16x3 weight gradient (one 8-wave block per CU).  Returns a hipError_t as int.
-__attribute__((visibility("hidden"))) int gast_wgrad_x3_wide_launch(const WgBatch& b, unsigned grid, bool any_drop, hipStream_t st);
+// h16: the one-product variant on 16-bit storage (GAST_BF16 jobs; 32 reduction rows per step)
+__attribute__((visibility("hidden"))) int gast_wgrad_x3_wide_launch(const WgBatch& b, unsigned grid, bool any_drop, hipStream_t st, bool h16 = false);

@@ -32,17 +32,26 @@ namespace {
 #define WG_ABLATE 0                         // profiling builds (EXTRA_FLAGS): 1 no operand loads, 2 loads inside one 64 KB window, 3 no MFMA, 4 no conversion
 #endif
 constexpr int WT = 256;                     // tile edge
-constexpr int WK = 16;                      // reduction rows per step
+constexpr int WK = 16;                      // reduction rows per step (bf16x3; 16-bit storage: 32, see H16 below)
 constexpr int WSTR = 80;                    // LDS bytes per tile column and step
 constexpr int WSTAGE = 2 * WT * WSTR;       // P columns, then Q columns
 constexpr int WD = 3;                       // register sets (tiles in flight)
 constexpr int WUNROLL = 6;                  // lcm(WD, 2 stages); also the number of row-offset generations
 constexpr uint32_t WW_OOB = 0xFFFF0000u;    // buffer size == first out-of-range byte offset (wgrad_check bounds the operands)
 
-template <bool DROP>
+// H16 (round 5): the same kernel on 16-BIT STORAGE (GAST_BF16 tensors: bfloat16, or binary16 in the -DGAST_H16_F16 build), one product.
+// A step covers 32 reduction rows: the LDS image of a tile column is [32 m x 16 bit] = the 64 bytes that hold [16 hi | 16 lo] in the
+// split kernel, so the fragment addresses do not change -- the first 32 bytes feed the first 16-deep MFMA, the second 32 the second
+// (16 MFMAs per wave and step for twice the rows).  A thread owns 4(m) x 8(col): the same four 16-byte loads per set, the same eight
+// 8-byte LDS writes; without a prologue the m-major -> col-major transposition is eight v_perm pairs, with one the values pass
+// through fp32 (BN + ReLU (+ dropout)) and are packed in PAIRS of reduction rows like the split kernel's hi / lo words.
+template <bool DROP, bool H16>
 __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const gast_wgrad_args& a, int M, int tilesS_total, int mchunk, int tile, int sp) {
-    __shared__ __attribute__((aligned(16))) uint32_t sOffP[WUNROLL][WK];      // byte offsets of the rows of tile j: generation j % 6
-    __shared__ __attribute__((aligned(16))) uint32_t sOffQ[WUNROLL][WK];
+    constexpr int WKS = H16 ? 32 : WK;          // reduction rows per step
+    constexpr int CPT = H16 ? 8 : 4;            // columns per thread (one 16-byte load per row)
+    constexpr uint32_t ESZ = H16 ? 2u : 4u;     // bytes per stored element
+    __shared__ __attribute__((aligned(16))) uint32_t sOffP[WUNROLL][32];      // byte offsets of the rows of tile j: generation j % 6
+    __shared__ __attribute__((aligned(16))) uint32_t sOffQ[WUNROLL][32];
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wr = w >> 2, wc = w & 3;      // 8 waves: 2 x 4 of 128 x 64
     const int li = lane & 31, lh = lane >> 5;
@@ -51,31 +60,32 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
     const int m_begin = sp * mchunk;
     const int m_end = min(M, m_begin + mchunk);
     if (m_begin >= m_end) return;
-    const int ntile = ((m_end - m_begin + WK - 1) / WK + WUNROLL - 1) / WUNROLL * WUNROLL;
+    const int ntile = ((m_end - m_begin + WKS - 1) / WKS + WUNROLL - 1) / WUNROLL * WUNROLL;
 
     const int op = __builtin_amdgcn_readfirstlane(w >> 2);               // 0: dC (P) staging waves, 1: activation (Q) staging waves
     const int task = tid & 255;
-    const int mb = (task >> 2) & 3, rc = ((task >> 4) << 2) | (task & 3);      // 4(m) x 4(col) per thread; a quad of lanes = 64 contiguous bytes of one row
+    // 4(m) x 4(col) per thread (H16: 4 x 8); a quad of lanes = 64 contiguous bytes of one row
+    const int mb = H16 ? (task >> 2) & 7 : (task >> 2) & 3, rc = H16 ? ((task >> 5) << 2) | (task & 3) : ((task >> 4) << 2) | (task & 3);
     const float* base = op == 0 ? (const float*)a.P : (const float*)sg.Q;
-    const int col = (op == 0 ? tc.rt : tc.st) * WT + rc * 4;
+    const int col = (op == 0 ? tc.rt : tc.st) * WT + rc * CPT;
     const bool cin = col < (op == 0 ? a.R : sg.S);
     const bool pro = op == 1 && sg.pro != GAST_PRO_NONE;
     const bool drop = DROP && op == 1 && sg.pro == GAST_PRO_BNRELU_DROP && a.drop.thresh != 0;
     const uint32_t key = drop ? drop_key(a.drop, sg.salt) : 0u;
     // prologue constants of this thread's 4 columns; identity (scale 1, shift 0, clamp -inf) without a prologue; columns past S
     // feed only outputs that are never stored
-    float sc[4], sh[4];
+    float sc[CPT], sh[CPT];
     const float lowclamp = pro ? 0.f : -__builtin_inff();
 #pragma unroll
-    for (int q = 0; q < 4; ++q) { sc[q] = 1.f; sh[q] = 0.f; }
+    for (int q = 0; q < CPT; ++q) { sc[q] = 1.f; sh[q] = 0.f; }
     if (pro && cin) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { sc[q] = sg.scale[col + q]; sh[q] = sg.shift[col + q]; }
+        for (int q = 0; q < CPT; ++q) { sc[q] = sg.scale[col + q]; sh[q] = sg.shift[col + q]; }
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sh[q]));      // (the compiler's wait for these loads lands here, not in the loop)
-    const uint32_t colbytes = (uint32_t)(cin ? col : 0) * 4u;
-    const int sdst_off = (op == 0 ? 0 : WT * WSTR) + rc * 4 * WSTR + mb * 8;
+    for (int q = 0; q < CPT; ++q) asm volatile("" : "+v"(sc[q]), "+v"(sh[q]));      // (the compiler's wait for these loads lands here, not in the loop)
+    const uint32_t colbytes = (uint32_t)(cin ? col : 0) * ESZ;
+    const int sdst_off = (op == 0 ? 0 : WT * WSTR) + rc * CPT * WSTR + mb * 8;
     // buffer resource of this wave's operand: base, stride 0, WW_OOB bytes, raw 32-bit dwords
     const float* const sbase = (const float*)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)((uint64_t)base >> 32)) << 32) |
                                               (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(uint64_t)base));
@@ -89,10 +99,10 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    const uint32_t ldp4 = (uint32_t)a.ldp * 4u, ldq4 = (uint32_t)sg.ldq * 4u;
-    auto compute_rows = [&](int it, int gen) {      // wave 0 only: byte offsets of the 16 rows of tile `it`
-        if (tid < WK) {
-            const int m = m_begin + it * WK + tid;
+    const uint32_t ldp4 = (uint32_t)a.ldp * ESZ, ldq4 = (uint32_t)sg.ldq * ESZ;
+    auto compute_rows = [&](int it, int gen) {      // wave 0 only: byte offsets of the 16 (32) rows of tile `it`
+        if (tid < WKS) {
+            const int m = m_begin + it * WKS + tid;
             int pr, qr;
             rows_for(a, sg, m < m_end ? m : M, M, pr, qr);
             sOffP[gen][tid] = pr < 0 ? WW_OOB : (uint32_t)pr * ldp4;
@@ -122,6 +132,39 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
         for (int i = 0; i < 4; ++i) asm volatile("" :: "v"(s[i]));
         return;
 #endif
+        if constexpr (H16) {
+            unsigned char* const d0 = stage + sdst_off;
+            if (OP == 0 || !pro) {
+                // no prologue: a pure 4 x 8 transposition of 16-bit values -- low halves of word p of rows (0,1) / (2,3) = column 2p, high = 2p+1
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const uint32_t r0 = s[0][p], r1 = s[1][p], r2 = s[2][p], r3 = s[3][p];
+                    *(uint2*)(d0 + (2 * p) * WSTR) = make_uint2(__builtin_amdgcn_perm(r1, r0, 0x05040100u), __builtin_amdgcn_perm(r3, r2, 0x05040100u));
+                    *(uint2*)(d0 + (2 * p + 1) * WSTR) = make_uint2(__builtin_amdgcn_perm(r1, r0, 0x07060302u), __builtin_amdgcn_perm(r3, r2, 0x07060302u));
+                }
+                return;
+            }
+            float x[4][8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int p = 0; p < 4; ++p) h16x2_unpack(s[i][p], x[i][2 * p], x[i][2 * p + 1]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) x[i][q] = fmaxf(fmaf(x[i][q], sc[q], sh[q]), lowclamp);
+            if (DROP && drop) {
+                const uint4 r0 = *(const uint4*)(sOffQ[gen] + mb * 4);
+                const uint32_t e[4] = {(r0.x + colbytes) >> 1, (r0.y + colbytes) >> 1, (r0.z + colbytes) >> 1, (r0.w + colbytes) >> 1};
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) x[i][q] *= drop_mul(key, a.drop.thresh, a.drop.inv_keep, e[i] + q);
+            }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) *(uint2*)(d0 + q * WSTR) = make_uint2(pack_h16x2(x[0][q], x[1][q]), pack_h16x2(x[2][q], x[3][q]));
+            return;
+        } else {
         float x[4][4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -157,6 +200,7 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
             *(uint2*)d = make_uint2(h[0], h[1]);
             *(uint2*)(d + 32) = make_uint2(l[0], l[1]);
         }
+        }
     };
     auto mfma_tile = [&](const unsigned char* stage) {
 #if WG_ABLATE == 3
@@ -176,6 +220,13 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
             F bh, bl;
             bh.u = *(const uint4*)(sQ + ni * 32 * WSTR);
             bl.u = *(const uint4*)(sQ + ni * 32 * WSTR + 32);
+            if constexpr (H16) {      // reduction rows 0..15 (bytes 0..31 of the column image), then 16..31
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_h16(ah[mi].u, bh.u, acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = mfma_h16(al[mi].u, bl.u, acc[mi][ni]);
+                continue;
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mi].s, bh.s, acc[mi][ni], 0, 0, 0);
 #pragma unroll
@@ -232,19 +283,20 @@ __device__ __forceinline__ void wgrad_x3_wide_body(unsigned char* smem, const ga
     }
 }
 
-template <bool DROP>
+template <bool DROP, bool H16 = false>
 __global__ void __launch_bounds__(512, 2) wgrad_x3_wide_multi_kernel(const WgBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char dsmem_wide[];
     int d, tile, sp;
     if (!wg_decode(b, d, tile, sp)) return;
-    wgrad_x3_wide_body<DROP>(dsmem_wide, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
+    wgrad_x3_wide_body<DROP, H16>(dsmem_wide, b.a[d], b.M[d], b.tilesS[d], b.mchunk[d], tile, sp);
 }
 
 }  // namespace
 
-int gast_wgrad_x3_wide_launch(const WgBatch& b, unsigned grid, bool any_drop, hipStream_t st) {
+int gast_wgrad_x3_wide_launch(const WgBatch& b, unsigned grid, bool any_drop, hipStream_t st, bool h16) {
     typedef void (*kern_t)(const WgBatch);
-    const kern_t kern = any_drop ? wgrad_x3_wide_multi_kernel<true> : wgrad_x3_wide_multi_kernel<false>;
+    const kern_t kern = h16 ? (any_drop ? wgrad_x3_wide_multi_kernel<true, true> : wgrad_x3_wide_multi_kernel<false, true>)
+                            : (any_drop ? wgrad_x3_wide_multi_kernel<true> : wgrad_x3_wide_multi_kernel<false>);
     // (hipFuncSetAttribute is per device and nn.DataParallel replicas launch from several threads: set on every launch)
     const hipError_t at = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * WSTAGE);
     if (at != hipSuccess) return (int)at;

@@ -404,7 +404,7 @@ class HipOps:
                 raise RuntimeError('gast_hip: mixed operand dtypes in gemm')
             g.A, g.lda, g.K, g.map = _p(s['A']), _ld(s['A']), int(s['K']), _rm(s['map'])
             g.W, g.ldw = _p(W), _ld(W)
-            if img is not None and self.x3:
+            if img is not None and (self.x3 or st_dtype == GAST_BF16):
                 g.Wx, g.ldwx = _p(img), img.stride(0)
             g.pro = int(s.get('pro', PRO_NONE))
             g.scale, g.shift = _p(s.get('scale')), _p(s.get('shift'))
@@ -462,6 +462,20 @@ class HipOps:
         self.launches += 1
         _check(self.lib.gast_x3_image_multi(job, 1, _stream()), 'gast_x3_image_multi')
         return X3Weight(W, img, f16)
+
+    def h16_weight(self, W):
+        """16-bit [N][K] row-major operand (K % 8 == 0) -> X3Weight(group = 32) carrying its k-group-major layout image
+        (gast_x3_image_multi, kind 2): what Packer.inputs() hands the engine in the 16-bit modes."""
+        if W.dtype == torch.float32:
+            raise RuntimeError('gast_hip: h16_weight needs a 16-bit operand')
+        ld = int(self.lib.gast_x3_image_ld(int(W.shape[0])))
+        img = torch.zeros((W.shape[1] + 31) // 32, ld // 32, 32, dtype=W.dtype, device=W.device)
+        job = (_X3ImageJob * 1)()
+        job[0].W, job[0].R, job[0].K, job[0].ldw, job[0].img, job[0].ldimg = _p(W), W.shape[0], W.shape[1], _ld(W), _p(img), ld
+        job[0].f16 = 2
+        self.launches += 1
+        _check(self.lib.gast_x3_image_multi(job, 1, _stream()), 'gast_x3_image_multi')
+        return X3Weight(W, img, False, 32)
 
     def gemm_multi(self, jobs):
         """jobs: list of dicts with the arguments of gemm() (keys dom, N, segs, C_, cmap + keywords): independent GEMMs of one plan
@@ -1001,7 +1015,7 @@ class HipOps:
         dev = st['Wb'].device
         tb = self._tables(packer, st, dev)
         bases = self._bases(W=st['Wb'], F=st['Fb'])
-        if st.get('Xb') is not None and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
+        if st.get('Xb') is not None and not st.get('h16img') and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
             # GAST_F32X3: operands, folds and their pre-split images in ONE launch (gast_pack_all; GAST_PACK_FUSED=0: the three
             # launches of rounds 2-3)
             px = tb.get('packx')
@@ -1027,14 +1041,14 @@ class HipOps:
                 tb['f8scale'] = arr
             self.launches += 1
             _check(self.lib.gast_f8_scale_multi(arr, len(arr), _stream()), 'gast_f8_scale_multi')
-        if st.get('Xb') is not None:          # GAST_F32X3: the pre-split bf16 images of all packed operands, one launch
+        if st.get('Xb') is not None:          # GAST_F32X3: the pre-split images of all packed operands, one launch (16-bit modes: layout images)
             arr = tb.get('x3img')
             if arr is None:
                 jobs = packer.image_jobs(st)
                 arr = (_X3ImageJob * len(jobs))()
                 for a, (wv, iv, f16) in zip(arr, jobs):
                     a.W, a.R, a.K, a.ldw, a.img, a.ldimg = _p(wv), wv.shape[0], wv.shape[1], _ld(wv), _p(iv), iv.stride(0)
-                    a.f16 = int(f16)
+                    a.f16 = int(f16)         # (image kind: 0 / 1 / 2, packer.image_jobs)
                 tb['x3img'] = arr
             self.launches += 1
             _check(self.lib.gast_x3_image_multi(arr, len(arr), _stream()), 'gast_x3_image_multi')

@@ -83,16 +83,24 @@ def x3_forward_f16():
     return v != 'bf16'
 
 
+def h16_images():
+    """GAST_H16_IMAGES = 1 (default) | 0: the 16-bit modes keep a k-group-major layout image of every packed operand, so that their
+    large-M GEMMs take gemm_big.hip (round 5); 0 = the round-1..4 behaviour (every GEMM on the 128 x 128 kernel)."""
+    return os.environ.get('GAST_H16_IMAGES', '1') not in ('0', '')
+
+
 class X3Weight:
     """An fp32 [N][K] GEMM operand together with its pre-split image (GAST_F32X3 / GAST_F32X3H; `gast_x3_image_multi`,
     include/gast_hip.h): img is the k-group-major 3-D view [ceil(K/16)][rows + zero padding][32].  f16: the GEMMs that read this
     operand run on fp16 pairs (and the image, when present, holds fp16 halves) -- set on the forward operands, never on the
     transposed twins the input gradients read.  Slices like the tensor it wraps (`w[r0:r1]`, `w[:, k0:k1]`); a column slice that is
-    not aligned to the 16-value groups drops the image (the GEMM then splits the fp32 operand itself)."""
-    __slots__ = ('t', 'img', 'f16')
+    not aligned to the 16-value groups drops the image (the GEMM then splits the fp32 operand itself).
+    group = 32 (round 5): a 16-BIT operand with its k-group-major LAYOUT image (32 values per 64-byte row, one product: the large-M
+    kernel in the 16-bit modes, `gast_x3_image_job.f16 == 2`); f16 is False there -- the element type is the build's storage type."""
+    __slots__ = ('t', 'img', 'f16', 'group')
 
-    def __init__(self, t, img, f16=False):
-        self.t, self.img, self.f16 = t, img, bool(f16)
+    def __init__(self, t, img, f16=False, group=16):
+        self.t, self.img, self.f16, self.group = t, img, bool(f16), int(group)
 
     def __getitem__(self, idx):
         rs, cs = idx if isinstance(idx, tuple) else (idx, slice(None))
@@ -101,9 +109,10 @@ class X3Weight:
             R, K = self.t.shape
             a, b, step = cs.indices(K)
             r0, _, rstep = rs.indices(R)
-            if step == 1 and rstep == 1 and a % 16 == 0 and (b % 16 == 0 or b == K):
-                img = self.img[a // 16:(b + 15) // 16, r0:]       # (keeps the rows behind the slice: tiles read 256 rows from r0)
-        return X3Weight(self.t[rs, cs], img, self.f16)
+            g = self.group
+            if step == 1 and rstep == 1 and a % g == 0 and (b % g == 0 or b == K):
+                img = self.img[a // g:(b + g - 1) // g, r0:]       # (keeps the rows behind the slice: tiles read 256 rows from r0)
+        return X3Weight(self.t[rs, cs], img, self.f16, self.group)
 
 
 class F8Weight:
@@ -266,11 +275,12 @@ class Packer:
     def f8_jobs(self, st):
         return [(self.W.view(st['Wb'], n), st['F8s'][i]) for i, n in enumerate(self.f8_regions())]
 
-    def state(self, dev, dt, x3=False, f8=False):
+    def state(self, dev, dt, x3=False, f8=False, h16=True):
         """Per (device, dtype, x3) persistent buffers + device job tables.  x3 (GAST_F32X3): every packed fp32 operand also gets a
         pre-split bf16 image (`Xb`), refreshed by ops.run_pack after the copy / fold launches."""
         f16fwd = bool(x3) and dt == torch.float32 and x3_forward_f16()
-        key = (str(dev), dt, bool(x3), bool(f8), f16fwd)
+        h16 = bool(h16) and dt != torch.float32 and not f8 and h16_images()
+        key = (str(dev), dt, bool(x3), bool(f8), f16fwd, h16)
         st = self._dev.get(key)
         ptrs = tuple(p.data_ptr() for p in self.params)
         if st is None or st['ptrs'] != ptrs:
@@ -285,6 +295,15 @@ class Packer:
                 st['X'] = X
                 st['f16fwd'] = f16fwd
                 st['Xb'] = torch.zeros(X.size, dtype=torch.bfloat16, device=dev)
+            elif h16:
+                # 16-bit modes (round 5): the layout image of every packed operand, 32 values per row -- what the large-M kernel's
+                # weight DMA streams (operands whose K is no multiple of 8 get none: their GEMMs stay on the 128 x 128 kernel)
+                X = Layout()
+                for n, (_, r, c) in self.W.regions.items():
+                    X.add(n, (c + 31) // 32, x3_image_rows(r) * 32)
+                st['X'] = X
+                st['h16img'] = True
+                st['Xb'] = torch.zeros(X.size, dtype=dt, device=dev)
             self._dev[key] = st
         return st
 
@@ -316,8 +335,15 @@ class Packer:
             st['packed_sig'] = None
 
     def image_jobs(self, st):
-        """(fp32 operand view, image view, fp16 pairs?) per packed operand, for ops.run_pack."""
-        return [(self.W.view(st['Wb'], n), self._image(st, n), self._f16(st, n)) for n in self.W.regions]
+        """(operand view, image view, kind) per packed operand, for ops.run_pack; kind = gast_x3_image_job.f16: 0 bf16 pairs, 1 fp16
+        pairs (fp32 operands), 2 the layout image of a 16-bit operand"""
+        if st.get('h16img'):
+            return [(self.W.view(st['Wb'], n), self._image(st, n), 2) for n in self.W.regions if self._h16_ok(n)]
+        return [(self.W.view(st['Wb'], n), self._image(st, n), int(self._f16(st, n))) for n in self.W.regions]
+
+    def _h16_ok(self, n):
+        _, r, c = self.W.regions[n]
+        return c % 8 == 0 and c >= 8
 
     @staticmethod
     def _f16(st, n):
@@ -331,7 +357,9 @@ class Packer:
     def inputs(self, st):
         """engine `inp` dict: operand views (act dtype), fp32 packed views, raw parameters."""
         inp = {n: self.W.view(st['Wb'], n) for n in self.W.regions}
-        if st.get('Xb') is not None:
+        if st.get('h16img'):
+            inp = {n: (X3Weight(w, self._image(st, n), False, 32) if self._h16_ok(n) else w) for n, w in inp.items()}
+        elif st.get('Xb') is not None:
             inp = {n: X3Weight(w, self._image(st, n), self._f16(st, n)) for n, w in inp.items()}
         if st.get('F8s') is not None:
             for i, n in enumerate(self.f8_regions()):

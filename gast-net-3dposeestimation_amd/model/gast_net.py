@@ -624,7 +624,7 @@ class SpatioTemporalModelBase(nn.Module):
             if runner.act_dtype != torch.float32 and hasattr(engine.ops, 'set_h16'):
                 engine.ops.set_h16(runner.act_dtype)        # (which flavour of the library the launches of this call go to)
             st = packer.state(x.device, runner.act_dtype, x3=runner.x3 and runner.ops_factory is None,
-                              f8=runner.f8 and runner.ops_factory is None)
+                              f8=runner.f8 and runner.ops_factory is None, h16=runner.ops_factory is None)
             # (inside an autograd.Function grad mode is off and needs_input_grad ignores torch.no_grad(): decided here)
             need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in packer.params)
             gs = runner.grad_sync

@@ -90,7 +90,8 @@ typedef struct {
     const float* shift;  /* [K] */
     uint32_t salt;       /* dropout stream id of tensor A (pro == BNRELU_DROP) */
     const void* Wx;      /* optional (GAST_F32X3): pre-split bf16 image of W made by gast_x3_image_multi, [N][ldwx]; lets the GEMM
-                          * take the large-M path (gemm_big.hip) whose weight tiles stream global -> LDS without passing registers */
+                          * take the large-M path (gemm_big.hip) whose weight tiles stream global -> LDS without passing registers.
+                          * GAST_BF16 (16-bit storage, round 5): the k-group-major LAYOUT image of the 16-bit operand (image kind 2) */
     int ldwx;
 } gast_gemm_seg;
 
@@ -154,8 +155,9 @@ long gast_gemm_splitk_ws_bytes(long M, int N);
 #define GAST_F8_SCALE_MAX_BATCH 64
 typedef struct { const void* W; int R, K, ldw; float* out; } gast_f8_scale_job;
 int gast_f8_scale_multi(const gast_f8_scale_job* jobs, int n, gast_stream_t stream);
-/* which kernel gast_gemm_ws would launch for these arguments: 0 = the 128x128-tile kernel, 1 = the large-M GAST_F32X3 kernel
- * (needs every segment's Wx image, >= 8192 rows, N >= 32, no dropout prologue) */
+/* which kernel gast_gemm_ws would launch for these arguments: 0 = the 128x128-tile kernel, 1 = the large-M kernel (GAST_F32X3 /
+ * GAST_F32X3H, and GAST_BF16 with 16-bit output and no fp8 scale; needs every segment's Wx image, >= 8192 rows, N >= 32, no
+ * dropout prologue) */
 int gast_gemm_path(const gast_gemm_args* args);
 /* Pre-split weight image for GAST_F32X3, k-group-major: for every group g of 16 K values and every row r of the fp32 operand
  * W[R][ldw] (K columns used), 16 bf16 "hi" = bf16(w) followed by 16 bf16 "lo" = bf16(w - hi):
@@ -165,10 +167,15 @@ int gast_gemm_path(const gast_gemm_args* args);
  * k-group) >= gast_x3_image_ld(R) = 32 * (round_up(R, 16) + 256): the rows past R must exist and be ZERO-FILLED by the caller (a
  * tile may start at any row and always spans 256).  A row slice W[r0:] has the image img + 32 * r0, a column slice W[:, k0:]
  * with k0 % 16 == 0 the image img + (k0 / 16) * ldimg (same ldimg).  gast_gemm_seg.Wx / ldwx carry img / ldimg.
+ * Image kind 2 (round 5): W is a 16-BIT operand [R][ldw] of the build's storage type (K, ldw multiples of 8) and the image is a pure
+ * layout change for the one-product large-M kernel of GAST_BF16 GEMMs: groups of 32 K values,
+ *   img[g * ldimg + r * 32 + (k & 31)] = W[r][k],  g = k >> 5,  zero for K <= k < 32 * ceil(K / 32)
+ * (same 64-byte rows, same ldimg rule, same slicing with 32 in the place of 16).
  * n jobs in one launch (GAST_X3_IMAGE_MAX_BATCH per launch). */
 #define GAST_X3_IMAGE_MAX_BATCH 64
 typedef struct { const float* W; int R, K, ldw; void* img; int ldimg;
-                 int f16;   /* 0: bf16 hi/lo pairs (GAST_F32X3), 1: fp16 hi/lo pairs (GAST_F32X3H); same layout and size */
+                 int f16;   /* image kind -- 0: bf16 hi/lo pairs (GAST_F32X3), 1: fp16 hi/lo pairs (GAST_F32X3H), same layout and size;
+                             * 2: layout image of a 16-bit operand (W points at 16-bit values) */
 } gast_x3_image_job;
 int gast_x3_image_multi(const gast_x3_image_job* jobs, int n, gast_stream_t stream);
 long gast_x3_image_ld(int R);

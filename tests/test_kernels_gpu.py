@@ -318,6 +318,57 @@ def test_gemm_big_x3_multi(ops, first, nodrop, pair):
         _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
+def _with_h16_images(ops, jd):
+    for s in jd['segs']:
+        s['W'] = ops.h16_weight(s['W'])
+    return jd
+
+
+@pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
+@pytest.mark.parametrize('case', GEMM_BIG_CASES, ids=[c[0] for c in GEMM_BIG_CASES])
+def test_gemm_big_bf16_storage(ops, case, nodrop):
+    """Round 5: the large-M kernel on 16-bit STORAGE (GAST_BF16 tensors: bfloat16 here, binary16 when the suite runs in the f16 flavour),
+    one product per value, 32 K values per step, weights from the k-group-major layout image (HipOps.h16_weight) -- every epilogue,
+    row maps, prologue, K tails; same numpy contract as the 128 x 128 kernel's 16-bit cases."""
+    if nodrop and case[4] != 2:
+        pytest.skip('only the BNRELU_BWD epilogue has a dropout variant')
+    jd, jh, bufs = _gemm_case(case, H16)
+    if nodrop:
+        jd['xdrop'] = jh['xdrop'] = False
+    assert ops.gemm_path(**_with_h16_images(ops, jd)) == 1, 'kernel selection (gemm_big.hip = 1)'
+    ops.gemm(**jd)
+    kc.gemm(**jh)
+    torch.cuda.synchronize()
+    _gemm_check(case, H16, bufs, 'bf16')
+
+
+@pytest.mark.parametrize('first', [0, 3, 6])
+def test_gemm_big_bf16_storage_multi(ops, first):
+    cases = (GEMM_BIG_CASES + GEMM_BIG_CASES[:1])[first:first + 3]
+    built = [_gemm_case(c, H16) for c in cases]
+    ops.gemm_multi([_with_h16_images(ops, jd) for jd, _, _ in built])
+    torch.cuda.synchronize()
+    for c, (jd, jh, bufs) in zip(cases, built):
+        kc.gemm(**jh)
+        _gemm_check(c, H16, bufs, 'bf16')
+
+
+def test_gemm_big_bf16_storage_matches_the_small_kernel(ops):
+    """the same 16-bit GEMM with and without the layout image: two kernels, two summation orders, one contract"""
+    case = GEMM_BIG_CASES[1]
+    jd, _, bufs = _gemm_case(case, H16)
+    assert ops.gemm_path(**jd) == 0
+    ops.gemm(**jd)
+    torch.cuda.synchronize()
+    C0, p0 = bufs[0].clone(), bufs[2].clone()
+    bufs[0].fill_(7.0)
+    assert ops.gemm_path(**_with_h16_images(ops, jd)) == 1
+    ops.gemm(**jd)
+    torch.cuda.synchronize()
+    close(host(bufs[0]), host(C0), H16, 'C')
+    close(host(bufs[2]).sum(axis=0), host(p0).sum(axis=0), H16, 'column sums', bf16=3e-2)
+
+
 BWD_CASES = [c for c in GEMM_CASES + GEMM_BIG_CASES if c[4] == 2]
 
 
@@ -350,6 +401,8 @@ def test_gemm_bwd_second_output(ops, case, mode):
     with x3_mode(ops, mode):
         if big and mode == 'x3':
             _with_images(ops, jd)
+        if big and mode == 'bf16':
+            _with_h16_images(ops, jd)
         ops.gemm(**jd)
         torch.cuda.synchronize()
         C_ref, part_ref = bufs[0].clone(), bufs[2].clone()
@@ -361,7 +414,7 @@ def test_gemm_bwd_second_output(ops, case, mode):
         C2 = torch.full_like(bufs[0], 7.0)
         ops.gemm(**dict(jd, C2=C2[:, :case[2]]))
         torch.cuda.synchronize()
-    if big and mode == 'x3' and jd.get('addend') is not None:
+    if big and mode in ('x3', 'bf16') and jd.get('addend') is not None:
         # (the large-M kernel carries the second output in its addend-free variants only: with an addend this call takes the 128x128-tile
         #  kernel -- another summation order than the large-M run it is compared with)
         close(host(bufs[0]), host(C_ref), dt, 'masked output', fp32=1e-4)
@@ -369,7 +422,10 @@ def test_gemm_bwd_second_output(ops, case, mode):
     else:
         _assert_bit_equal(bufs[0], C_ref, 'the masked output (C) of the call WITH a second output vs the call without')
         _assert_bit_equal(C2, plain, 'C2 vs the PLAIN epilogue of the same GEMM')
-    close(host(bufs[2]).sum(axis=0), host(part_ref).sum(axis=0), dt, 'sums', fp32=1e-5, bf16=1e-5)
+    # (16-bit storage, two kernels: a value that rounds the other way in ONE of the two summation orders moves a column sum by an ulp of
+    #  the stored type -- the 128 x 128 kernel's own 16-bit bound applies there, not the same-kernel one)
+    two_kernels = big and mode == 'bf16' and jd.get('addend') is not None
+    close(host(bufs[2]).sum(axis=0), host(part_ref).sum(axis=0), dt, 'sums', fp32=1e-5, bf16=3e-2 if two_kernels else 1e-5)
 
 
 def test_gemm_fp16_pairs_range(ops):
@@ -600,7 +656,22 @@ def test_wgrad_multi_wide_tiles(ops):
         close(host(jd['dW']), jh['dW'], torch.float32, 'wide ' + WGRAD_WIDE_CASES[i][0], fp32=1e-4)
 
 
+def test_wide_wgrad_bf16_storage(ops):
+    """Round 5: the same job sets on 16-bit STORAGE (bfloat16 / binary16 by flavour) -- wgrad_wide.hip in its one-product form, 32
+    reduction rows per step (918 rows in chunks of 192: a ragged last chunk), v_perm transposition on the operand without a prologue.
+    GAST_WGRAD_H16_WIDE=0 (test_optin_kernel_variants) runs them on the 128 x 128 kernel."""
+    jobs = [_wgrad_case(c, H16) for c in WGRAD_WIDE_CASES]
+    for i, (jd, jh) in enumerate(jobs):
+        jd['zero_first'] = i % 2 == 0
+    ops.wgrad_multi([jd for jd, _ in jobs])
+    torch.cuda.synchronize()
+    for i, (jd, jh) in enumerate(jobs):
+        kc.wgrad(jh['dom'], jh['P'], jh['R'], jh['pmap'], jh['segs'], jh['dW'], jh['drop'], i % 2 == 0)
+        close(host(jd['dW']), jh['dW'], H16, 'wide 16-bit ' + WGRAD_WIDE_CASES[i][0], bf16=2e-2)
+
+
 @pytest.mark.parametrize('knob,select,npass', [('GAST_WGRAD_TILE=256', 'test_wgrad_multi and bf16', 1),
+                                               ('GAST_WGRAD_H16_WIDE=0', 'test_wide_wgrad_bf16_storage', 1),
                                                ('GAST_WGRAD_X3_TILE=256', 'test_wgrad_multi and x3', 1),
                                                ('GAST_WGRAD_X3_TILE=128', 'test_wgrad_multi_wide_tiles', 1),
                                                ('GAST_WGRAD_RING=2', 'test_wgrad_multi and bf16', 1),
