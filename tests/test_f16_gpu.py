@@ -136,7 +136,7 @@ def test_f16_at_baseline_sizes(tag, J, arc, ch, B, variant, monkeypatch):
     with go.use_backend(torch_ops):
         om = go.OracleModel(go.adj_from_parents(PARENTS[J]), list(arc), ch, dropout=0.0, variant=variant, dtype=torch.float64)
         loss_ref, y_ref, g_ref, _ = om.loss_and_grads(sd, x, y3d, training=True)
-    d_ref = float((y16.double() - y_ref).abs().max())
+    d_ref = float((y16.detach().double() - y_ref).abs().max())
     g_ref_flat = torch.cat([g_ref[k].reshape(-1) for k, _ in m.named_parameters()])
     rel_ref = float((g16.double() - g_ref_flat).norm() / g_ref_flat.norm())
     _log(test='f16_at_baseline_sizes_vs_oracle', tag=tag, max_abs_vs_float64_oracle=d_ref, mpjpe_shift_mm_vs_oracle=abs(l16 - float(loss_ref)) * 1000,
