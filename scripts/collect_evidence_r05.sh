@@ -61,3 +61,7 @@ tail -c 600 $O/bench_force_collective.json; echo
 bash scripts/pmc_lds.sh $O > /dev/null 2>&1; head -12 $O/pmc_lds_summary.txt
 # the opt-in lazy finalize next to the default on the same box
 bash scripts/ab_env.sh $O/ab_lazy base= lazy=GAST_LAZY_BN=1 nofuse=GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0 | tee $O/ab_lazy.txt
+# the 16-bit mode: the replayed f16 step per kernel, and its round-5 kernels (16-bit gemm_big / wgrad_wide) switched off on the same box
+GAST_HIP_DTYPE=f16 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_f16 -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 8 --warmup 2 > $O/trace_f16.log 2>&1
+python scripts/trace_step.py $(find /tmp/prof_f16 -name "*kernel_trace.csv" | head -1) 3 > $O/f16_step_summary.txt
+bash scripts/ab_env.sh $O/ab_f16 "r4kernels=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=0,GAST_WGRAD_H16_WIDE=0" "wgrad_wide=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=0" "default=GAST_HIP_DTYPE=f16" | tee $O/ab_f16.txt
