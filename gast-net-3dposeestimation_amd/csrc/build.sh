@@ -35,7 +35,13 @@ build_flavour() {   # $1 = object directory, $2 = output library, $3 = extra fla
   $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$LIB" $OBJS
   echo "built $LIB (${#pids[@]} of $(echo $SRCS | wc -w) translation units recompiled)"
 }
-build_flavour "$HERE/build" "$OUT" ""
+# (the two flavours compile side by side: a from-scratch build is bounded by ONE gemm_big.hip compile, ~2 min)
+build_flavour "$HERE/build" "$OUT" "" &
+P1=$!
+P2=""
 if [ -z "$GAST_SKIP_F16" ]; then      # (GAST_SKIP_F16=1: kernel-development builds that only need the bfloat16 flavour)
-  build_flavour "$HERE/build/f16" "$HERE/../gast_hip/libgast_hip_f16.so" "-DGAST_H16_F16"
+  build_flavour "$HERE/build/f16" "$HERE/../gast_hip/libgast_hip_f16.so" "-DGAST_H16_F16" &
+  P2=$!
 fi
+wait $P1 || exit 1
+if [ -n "$P2" ]; then wait $P2 || exit 1; fi

@@ -649,7 +649,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
         // (GAST_GEMM_BIG_DEEP_MIN_TILES: only GEMMs whose 128 x 128 tiles fill the chip without split-K)
         static const int deep_min_tiles = getenv("GAST_GEMM_BIG_DEEP_MIN_TILES") ? atoi(getenv("GAST_GEMM_BIG_DEEP_MIN_TILES")) : 0;
         const long tiles128 = ((Ml + 127) / 128) * ((a.N + 127) / 128);
-        want_deep = deep && Ml >= deep_min_m && ks <= deep_max_k && tiles128 >= deep_min_tiles;
+        want_deep = deep && !h16 && Ml >= deep_min_m && ks <= deep_max_k && tiles128 >= deep_min_tiles;
         if (!want_deep && !(small_min_m > 0 && Ml >= small_min_m && ks <= small_max_k)) return 0;
     }
     pl.depth = 2;
@@ -670,7 +670,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
     // block rows: 256 (MW = 4, one 8-wave block per CU) at the wide tile with GAST_GEMM_BIG_MW=4, else 128
     static const int mw_env = getenv("GAST_GEMM_BIG_MW") ? atoi(getenv("GAST_GEMM_BIG_MW")) : 2;
     static const int mw_min_k = getenv("GAST_GEMM_BIG_MW_MIN_K") ? atoi(getenv("GAST_GEMM_BIG_MW_MIN_K")) : 0;
-    pl.mw = (mw_env == 4 && pl.ni == 4 && ksum >= mw_min_k) ? 4 : 2;
+    pl.mw = (mw_env == 4 && pl.ni == 4 && ksum >= mw_min_k && !h16) ? 4 : 2;
     if (want_deep) { pl.ni = 2; pl.mw = 2; pl.depth = 4; }
     if (!all_shapes) {
         if (a.N <= 192 && !narrow) return 0;
@@ -723,7 +723,9 @@ static big_kernel_t big_kernel_ni(int v, int pair) {
         }
     }
     if (pair == 3) {
-        switch (v) {
+        // (16-bit storage: the 128-row block tile at prefetch distance 2 only -- gast_gemm_big_plan never asks for the opt-in shapes)
+        if constexpr (MW != 2 || D != 2) return nullptr;
+        else switch (v) {
             case 0: return gemm_big_kernel<0, false, NI, MW, 3, D>;
             case 1: return gemm_big_kernel<0, true, NI, MW, 3, D>;
             case 2: return gemm_big_kernel<1, false, NI, MW, 3, D>;
@@ -764,7 +766,9 @@ static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
         }
     }
     if (pair == 3) {
-        switch (v) {
+        // (16-bit storage: the 128-row block tile at prefetch distance 2 only -- gast_gemm_big_plan never asks for the opt-in shapes)
+        if constexpr (MW != 2 || D != 2) return nullptr;
+        else switch (v) {
             case 0: return gemm_big_multi_kernel<0, false, NI, MW, 3, D>;
             case 1: return gemm_big_multi_kernel<0, true, NI, MW, 3, D>;
             case 2: return gemm_big_multi_kernel<1, false, NI, MW, 3, D>;
@@ -800,6 +804,7 @@ static void big_setup() {
         const int ni = (c == 0 || c == 3) ? 2 : 4, mw = c == 2 ? 4 : 2, depth = c == 3 ? 4 : 2;
         for (int pair = 1; pair <= 3; ++pair)
             for (int v = 0; v < (pair == 2 ? 4 : 8); ++v) {
+                if (pair == 3 && (mw != 2 || depth != 2)) continue;
                 const hipError_t e1 = hipFuncSetAttribute((const void*)big_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
                 const hipError_t e2 = hipFuncSetAttribute((const void*)big_multi_kernel(v, ni, mw, pair, depth), hipFuncAttributeMaxDynamicSharedMemorySize, lds_block(mw));
                 if (e1 != hipSuccess || e2 != hipSuccess) {      // (e.g. static + dynamic LDS beyond the 160 KB of a CU: say so here, not at some later launch)
