@@ -150,3 +150,29 @@ def test_segment_limit_is_the_same_everywhere():
     hdr = open(os.path.join(ROOT, 'include', 'gast_hip.h')).read()
     n = int(re.search(r'#define\s+GAST_MAX_SEG\s+(\d+)', hdr).group(1))
     assert engine.MAX_SEG == binding.MAX_SEG == n
+
+
+def test_operand_images_follow_their_slices():
+    """packer.X3Weight: a GEMM operand travels with its k-group-major image (include/gast_hip.h, gast_x3_image_multi).  A row slice keeps
+    the rows behind it (a tile reads 256 image rows from its first row), a column slice aligned to the K groups -- 16 values for the
+    split images of fp32 operands, 32 for the layout image of a 16-bit operand (round 5) -- moves the group index, any other column
+    slice DROPS the image (the GEMM then takes the 128 x 128 kernel, which needs none).  Host logic only: no device."""
+    from gast_hip.packer import X3Weight, x3_image_rows
+    R, K = 40, 96
+    for group, dt in ((16, torch.float32), (32, torch.float16)):
+        w = torch.arange(R * K, dtype=torch.float32).reshape(R, K).to(dt)
+        img = torch.zeros((K + group - 1) // group, x3_image_rows(R), 32, dtype=torch.bfloat16 if group == 16 else dt)
+        x = X3Weight(w, img, False, group)
+        a = x[8:24]                                            # rows: the operand is the slice, the image starts at row 8 and keeps its tail
+        assert a.t.shape == (16, K) and a.img.shape == (img.shape[0], img.shape[1] - 8, 32) and a.img.data_ptr() == img[:, 8:].data_ptr()
+        b = x[:, 2 * group:]                                   # aligned column slice: group index 2
+        assert b.t.shape == (R, K - 2 * group) and b.img.shape[0] == img.shape[0] - 2 and b.img.data_ptr() == img[2:].data_ptr()
+        c = x[:, group:2 * group][4:]                          # both, chained
+        assert c.t.shape == (R - 4, group) and c.img.shape[0] == 1 and c.img.data_ptr() == img[1:2, 4:].data_ptr() and c.group == group
+        assert x[:, 8:40].img is None and x[:, 8:40].t.shape == (R, 32)          # not on a group boundary: no image
+        assert x[:, :group + 8].img is None                                       # ragged end inside the operand: no image
+        assert x[:, 3 * group:].img is not None                                   # ... but the operand's own K tail is fine
+        assert x[::2].img is None                                                 # strided rows: no image
+    # (a 16-value boundary is NOT a boundary of the 32-value layout image)
+    w16 = torch.zeros(R, K, dtype=torch.float16)
+    assert X3Weight(w16, torch.zeros(3, x3_image_rows(R), 32, dtype=torch.float16), False, 32)[:, 16:48].img is None
