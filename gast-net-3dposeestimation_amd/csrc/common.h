@@ -166,6 +166,11 @@ template <int N> __device__ __forceinline__ void gload_wait_n() {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
+// The wait does not NAME the destination registers, so by itself it does not stop the compiler from moving register-only uses of them
+// above it (round 5: hipcc did exactly that in a gemm_big build whose conversion had no other anchor -- scripts/asm_load_hazard.py
+// --strict finds such code).  gload_pin(r) directly behind the wait makes every later use of r depend on a statement that volatile-asm
+// ordering keeps behind the wait; it emits no instruction.
+__device__ __forceinline__ void gload_pin(u32x4& r) { asm volatile("" : "+v"(r)); }
 
 // ---------------------------------------------------------------- GAST_DETERMINISTIC=1 (host side, read once per process)
 // Run-to-run bit-reproducible results: every reduction whose summation order depends on block scheduling is replaced by one with a

@@ -357,6 +357,10 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
         load_set(R0, S0, k0_0);
         while (true) {
             gload_wait_n<0>();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { gload_pin(R0.a[i]); gload_pin(R0.b[i]); }
+#pragma unroll
+            for (int q = 0; q < NSS; ++q) { gload_pin(R0.sc[q]); gload_pin(R0.sh[q]); }
             __syncthreads();                // everyone finished reading the previous tile
             store_set(R0, S0, k0_0);
             __syncthreads();

@@ -299,6 +299,13 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         }
         gload_wait_n<0>();
         __syncthreads();                                   // tables complete
+        // The loads are inline asm the compiler does not track and the wait above does not name their registers: nothing but this
+        // statement keeps the conversion's VALU instructions -- pure register code -- BEHIND the wait (volatile asm statements keep their
+        // order, and the values write_a reads now come out of this one).  Round 5: a build of this kernel WITHOUT the prologue's fma / max
+        // had nothing else anchoring them -- hipcc hoisted the whole conversion above the wait, and the GEMM multiplied whatever the
+        // registers held (scripts/asm_load_hazard.py --strict reports it).  With the prologue the scale / shift reads happen to anchor the
+        // code; the pin makes that a property of the source.
+        asm volatile("" : "+v"(ra[0][0]), "+v"(ra[0][1]));
         fetch_tab(d0);
         write_a(d0, 0, ra[0], rz[0]);
         next_tile(dq[NA - 1]);                     // tile NA into the freed set 0
@@ -347,6 +354,7 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
         //  of tile t, the activations of tile t + 1 -- is older and therefore complete)
         gload_wait_n<(D - 1) * (WPIECES + 2)>();
         __syncthreads();
+        asm volatile("" : "+v"(ra[0]), "+v"(ra[1]));        // (the set this step converts is complete NOW: see the pipeline fill above)
         const unsigned char* sA = smem + OFF_A + (t & 1) * A_BYTES + wr * 64 * ROWB;
         const unsigned char* sW = smem + OFF_W + wstage * W_BYTES + wc * (TN / 2) * ROWB;
         Frag ah[2], al[2], bh[2], bl[2];

@@ -85,6 +85,8 @@ __device__ __forceinline__ void wgrad_f32_body(const gast_wgrad_args& a, int M, 
     auto store_tile = [&](int buf) {
         gload_wait_n<0>();
 #pragma unroll
+        for (int i = 0; i < 4; ++i) { gload_pin(rp[i]); gload_pin(rq[i]); }
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             int r = rb0 + 8 * i;
             const int pr_ = sRowP[buf][r], qr_ = sRowQ[buf][r];
@@ -318,6 +320,8 @@ __device__ __forceinline__ void wgrad_x3_body(unsigned char* smem, const gast_wg
     for (int it = 0; it < ntile; ++it) {
         __syncthreads();
         gload_wait_n<0>();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) gload_pin(rl[i]);
         store_tile(it & 1);
         __syncthreads();
         if (it + 1 < ntile) load_tile((it + 1) & 1);
@@ -755,6 +759,8 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
         for (int it = 0; it < ntile; ++it) {
             __syncthreads();
             gload_wait_n<0>();
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gload_pin(rl[i]);
             store_tile(rl, it & 1);
             __syncthreads();
             if (it + 1 < ntile) load_tile(rl, (it + 1) & 1);
@@ -766,6 +772,8 @@ __device__ __forceinline__ void wgrad_bf16_body(unsigned char* __restrict__ smem
         auto step = [&](u32x4 (&set)[8], int it) {
             __syncthreads();                                   // every wave is done with the previous LDS tile
             if (it + 1 < ntile) gload_wait_n<8>(); else gload_wait_n<0>();     // the other set's 8 loads stay in flight
+#pragma unroll
+            for (int i = 0; i < 8; ++i) gload_pin(set[i]);
             store_tile(set, it & 3);
             __syncthreads();
             if (it + 2 < ntile) load_tile(set, (it + 2) & 3);
