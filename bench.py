@@ -61,6 +61,16 @@ CONFIGS = {
     'cfg243': dict(J=17, arc=[3, 3, 3, 3, 3], channels=32, batch=128, what='243-frame model: 17 joints, arc 3,3,3,3,3 (RF 243), channels=32, B=128'),
 }
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+def _capture(g, **kw):
+    """torch.cuda.graph(g): with a process group alive, RCCL's watchdog thread polls its work events (hipEventQuery) at any time, and in the
+    default GLOBAL capture mode such a call from ANOTHER thread is an error -- raised in the watchdog, which then terminates the process
+    (seen once in `--force-collective`: 'operation not permitted when stream is capturing').  Thread-local mode only polices the
+    capturing thread."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        kw.setdefault('capture_error_mode', 'thread_local')
+    return torch.cuda.graph(g, **kw)
+
+
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per
 # FLOP pair; fp8: the forward GEMMs run at the 5 PF fp8 rate, the gradient GEMMs -- 2/3 of the work -- at the bf16 rate: priced at bf16)
 
@@ -149,7 +159,7 @@ class KernelTimer:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with _capture(g):
                 for r in calls:
                     r[1](*r[2], **r[3])
             for _ in range(3):
@@ -571,16 +581,15 @@ def main():
             torch.cuda.synchronize()
             if want == 'full':
                 g0 = torch.cuda.CUDAGraph()
-                # (collectives inside the capture: RCCL's watchdog thread queries events meanwhile -- thread-local capture mode)
-                with torch.cuda.graph(g0, **({'capture_error_mode': 'thread_local'} if collective else {})):
+                with _capture(g0):
                     static_loss = step()
                 graphs = [g0]
                 graph_note = 'hipGraph replay of the whole step (captured through torch.cuda.graph)'
             else:
                 ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(ga):
+                with _capture(ga):
                     static_loss = step_compute()
-                with torch.cuda.graph(gb, pool=ga.pool()):
+                with _capture(gb, pool=ga.pool()):
                     opt.step()
                 graphs = [ga, gb]
                 graph_note = ('two hipGraphs per step (zero_grad+fwd+loss+bwd | Adam) around an eagerly launched flat-gradient '
@@ -681,7 +690,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             gf = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gf), torch.no_grad():
+            with _capture(gf), torch.no_grad():
                 model(x)
             for _ in range(3):
                 gf.replay()
@@ -724,7 +733,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             tg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(tg):
+            with _capture(tg):
                 tloss = tstep()
             for _ in range(args.warmup):
                 tg.replay()
@@ -803,7 +812,7 @@ def main():
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             fg = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(fg):
+            with _capture(fg):
                 floss = fstep()
             for _ in range(args.warmup):
                 fg.replay()

@@ -229,6 +229,15 @@ class _GastFunction(torch.autograd.Function):
         return (None,) * 9 + tuple(packer.grad_views(G))
 
 
+def _capture_kwargs():
+    """keyword arguments of torch.cuda.graph() for the module's own captures: with a process group alive, RCCL's watchdog thread polls
+    its work events at any time, which the default GLOBAL capture mode turns into an error in THAT thread (and torch then terminates
+    the process); thread-local mode only polices the capturing thread"""
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return {'capture_error_mode': 'thread_local'}
+    return {}
+
+
 class _GraphEntry:
     """GAST_HIP_GRAPH=1: the captured forward (and backward) hipGraphs of one (shape, mode, arithmetic) of a model, their static
     input / output buffers and the activations the backward graph reads (all in the graphs' private memory pool)."""
@@ -280,7 +289,7 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     # the parameters changed since the operands were last packed (a training loop: every step; an evaluation loop: once)
     entry.st, entry.ops = st, ops
     g = torch.cuda.CUDAGraph()
-    with torch.no_grad(), torch.cuda.graph(g, pool=pool):
+    with torch.no_grad(), torch.cuda.graph(g, pool=pool, **_capture_kwargs()):
         inp = st.get('inp')
         if inp is None:
             inp = st['inp'] = packer.inputs(st)
@@ -291,7 +300,7 @@ def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, 
     if need_grad:
         entry.dpred = torch.zeros_like(pred)
         gb = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(gb, pool=pool):
+        with torch.no_grad(), torch.cuda.graph(gb, pool=pool, **_capture_kwargs()):
             scale = engine.loss_scale(sv['dt'])
             priv = sink is None or scale != 1.0
             G = torch.empty(packer.gsize, dtype=torch.float32, device=dev) if priv else sink
