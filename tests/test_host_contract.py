@@ -176,3 +176,41 @@ def test_operand_images_follow_their_slices():
     # (a 16-value boundary is NOT a boundary of the 32-value layout image)
     w16 = torch.zeros(R, K, dtype=torch.float16)
     assert X3Weight(w16, torch.zeros(3, x3_image_rows(R), 32, dtype=torch.float16), False, 32)[:, 16:48].img is None
+
+
+def test_asm_load_hazard_scanner_modes(tmp_path):
+    """scripts/asm_load_hazard.py on two synthetic listings.  (1) A register of an inline-asm load is read between the load and the wait
+    the source wrote, behind a compiler-inserted wait that sits on a conditionally executed path: the default walk lets that wait retire the
+    load (no report), --strict does not (one report) -- the shape of the round-5 miss.  (2) A load issued BEFORE a short loop stays pending
+    when the walk leaves the loop; loads issued inside it are forgotten at its exit (their wait is the loop's own)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('asm_load_hazard', os.path.join(ROOT, 'scripts', 'asm_load_hazard.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    one = tmp_path / 'one.s'
+    one.write_text('\n'.join([
+        'kern_a:', '\t;;#ASMSTART', '\tglobal_load_dwordx4 v[6:9], v3, s[4:5]', '\t;;#ASMEND',
+        '\ts_cbranch_execz .LBB0_2',
+        '\tglobal_load_dword v20, v[12:13], off', '\ts_waitcnt vmcnt(0)',          # the compiler's own load and wait, conditional
+        '.LBB0_2:',
+        '\tv_cndmask_b32_e64 v6, v6, 0, s[2:3]',                                     # <- reads v6 before the source's wait
+        '\t;;#ASMSTART', '\ts_waitcnt vmcnt(0)', '\t;;#ASMEND',
+        '\tv_add_f32_e32 v1, v6, v7', '\ts_endpgm', '']))
+    mod.STRICT = False
+    assert mod.scan(str(one)) == []
+    mod.STRICT = True
+    rep = mod.scan(str(one))
+    assert len(rep) == 1 and rep[0][3] == [6] and 'v_cndmask' in rep[0][2]
+    two = tmp_path / 'two.s'
+    two.write_text('\n'.join([
+        'kern_b:', '\t;;#ASMSTART', '\tglobal_load_dwordx4 v[6:9], v3, s[4:5]', '\t;;#ASMEND',
+        '.LBB1_1:                                ; =>This Loop Header: Depth=1',
+        '\t;;#ASMSTART', '\tglobal_load_dwordx4 v[30:33], v4, s[4:5]', '\t;;#ASMEND',
+        '\ts_cbranch_scc1 .LBB1_1',
+        '.LBB1_2:',
+        '\tv_mov_b32_e32 v40, v30',                                                  # issued inside the loop: forgotten at its exit
+        '\tv_mov_b32_e32 v41, v8',                                                   # <- issued before the loop: still pending
+        '\t;;#ASMSTART', '\ts_waitcnt vmcnt(0)', '\t;;#ASMEND', '\ts_endpgm', '']))
+    rep = mod.scan(str(two))
+    assert len(rep) == 1 and rep[0][3] == [8]
+    mod.STRICT = False
