@@ -214,3 +214,27 @@ def test_asm_load_hazard_scanner_modes(tmp_path):
     rep = mod.scan(str(two))
     assert len(rep) == 1 and rep[0][3] == [8]
     mod.STRICT = False
+
+
+def test_compiled_kernels_pass_the_strict_load_hazard_screen(tmp_path):
+    """hipcc's gfx950 code for the kernels that issue asynchronous loads from inline asm (csrc/common.h: gload16 / gload_wait_n), screened
+    with scripts/asm_load_hazard.py --strict: no instruction may name a register of an in-flight load before a wait the SOURCE wrote.
+    gemm.hip and wgrad.hip compile in about a minute side by side; gemm_big.hip (two minutes by itself) joins with GAST_TEST_ASM_SCAN_ALL=1
+    (it is screened by hand whenever it changes: DESIGN.md section 4, round 5)."""
+    import shutil
+    hipcc = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        pytest.skip('no hipcc')
+    csrc = os.path.join(PKG, 'csrc')
+    files = ['gemm', 'wgrad'] + (['gemm_big'] if os.environ.get('GAST_TEST_ASM_SCAN_ALL') else [])
+    procs = []
+    for f in files:
+        out = str(tmp_path / (f + '.s'))
+        procs.append((f, out, subprocess.Popen([hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-comment', '-S', '--cuda-device-only',
+                                                os.path.join(csrc, f + '.hip'), '-o', out], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)))
+    for f, out, p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0 and os.path.exists(out), '%s.hip did not compile: %s' % (f, err.decode()[-800:])
+    for f, out, _ in procs:
+        r = subprocess.run(['python', os.path.join(ROOT, 'scripts', 'asm_load_hazard.py'), '--strict', out], capture_output=True, text=True)
+        assert r.returncode == 0 and '0 suspicious instruction(s)' in r.stdout, '%s.hip: %s' % (f, r.stdout[-1500:])
