@@ -29,6 +29,7 @@ Extra objects in that line:
 """
 import argparse
 import json
+import contextlib
 import os
 import sys
 import time
@@ -68,7 +69,22 @@ def _capture(g, **kw):
     capturing thread."""
     if torch.distributed.is_available() and torch.distributed.is_initialized():
         kw.setdefault('capture_error_mode', 'thread_local')
-    return torch.cuda.graph(g, **kw)
+    return _no_gc_capture(g, kw)
+
+
+@contextlib.contextmanager
+def _no_gc_capture(g, kw):
+    """(no cyclic garbage collection inside the capture: a collection may finalize objects of earlier captures whose destructors free
+    device memory, which a capturing stream does not allow -- model/gast_net.py: _no_gc)"""
+    import gc
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, **kw):
+            yield
+    finally:
+        if was:
+            gc.enable()
 
 
 MFMA_PEAK_TFLOPS = {'bf16': 2500.0, 'f16': 2500.0, 'fp32': 157.3, 'bf16x3': 2500.0 / 3, 'fp8': 2500.0}   # dense peaks (bf16x3: three bf16 products per

@@ -11,8 +11,8 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-comment"
 if [ -n "$ABLATION" ]; then FLAGS="$FLAGS -DGAST_GEMM_BIG_ABLATION"; fi
 # EXTRA_FLAGS="-DGAST_..." : experiment switches of single kernels (scripts/ab_variants.sh builds and times several variants on the GPU box)
 if [ -n "$EXTRA_FLAGS" ]; then FLAGS="$FLAGS $EXTRA_FLAGS"; fi
-HDRS="$HERE/common.h $HERE/gemm_big.h $HERE/bn_lazy.h $HERE/wgrad_common.h $HERE/../../include/gast_hip.h"
-SRCS="gemm gemm_big wgrad wgrad_wide graph_ops norm_ops pack_ops optim_ops data_ops"
+HDRS="$HERE/common.h $HERE/gemm_big.h $HERE/bn_finalize.h $HERE/wgrad_common.h $HERE/../../include/gast_hip.h"
+SRCS="gemm gemm_big gemm_bj wgrad wgrad_wide graph_ops norm_ops pack_ops optim_ops data_ops"
 # Two storage flavours of the SAME sources (common.h): libgast_hip.so keeps GAST_BF16 tensors as bfloat16, libgast_hip_f16.so
 # (-DGAST_H16_F16) as IEEE binary16 -- GAST_HIP_DTYPE=f16, the 16-bit mode that meets the north star's 1e-2 bound.  Same ABI.
 build_flavour() {   # $1 = object directory, $2 = output library, $3 = extra flags

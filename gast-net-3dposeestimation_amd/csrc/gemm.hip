@@ -19,7 +19,6 @@
 // one M-panel run on the same XCD (shared L2).
 #include "common.h"
 #include "gemm_big.h"
-#include "bn_lazy.h"
 #include <stdlib.h>
 
 namespace {
@@ -620,9 +619,7 @@ __device__ __forceinline__ void gemm_body(const gast_gemm_args& a, int M, int gr
 // grid = (N tiles of 128 columns) x (groups of 8 rows); thread = (row, 4 consecutive columns); the column statistics of the 8 rows
 // are combined in LDS and added atomically to the row tile's (pre-zeroed) partial row.
 template <typename T, typename TO, int X3 = 0, bool F8 = false>
-__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws,
-                                                      const gast_bn_lazy lz) {
-    gastbn::bn_lazy_sync(lz);      // (lazy BatchNorm finalize: the scale / shift of a prologue segment are written by this launch's first blocks)
+__global__ void __launch_bounds__(256, 3) gemm_kernel(const gast_gemm_args a, int M, int gridM, int gridN, int vec_epi, int splitk, float* __restrict__ ws) {
     gemm_body<T, TO, X3, F8>(a, M, gridM, gridN, vec_epi, splitk, ws, blockIdx.x);
 }
 
@@ -643,8 +640,7 @@ struct GemmBatch {
 };
 static_assert(sizeof(GemmBatch) <= 3712, "GemmBatch travels as a kernel argument (4 KB limit)");
 template <typename T, typename TO, int X3 = 0, bool F8 = false>
-__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b, const gast_bn_lazy lz) {
-    gastbn::bn_lazy_sync(lz);
+__global__ void __launch_bounds__(256, 3) gemm_multi_kernel(const GemmBatch b) {
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
     gemm_body<T, TO, X3, F8>(b.a[d], b.M[d], b.gridM[d], b.gridN[d], b.vec_epi[d], b.splitk[d], b.splitk[d] > 1 ? b.ws + b.ws_off[d] : nullptr,
@@ -809,23 +805,23 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
     int rc = gemm_plan(a, ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
     if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
-    if (gastbn::lazy_check(a.lazy)) return GAST_EINVAL;
-    const gast_bn_lazy lz = gastbn::lazy_arg(a.lazy);
     BigPlan bp;
-    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, lz, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
+    if (gast_gemm_big_plan(a, bp)) return gast_gemm_big_launch(a, bp, st);
+    BjPlan jp;      // the M = B*J stage (gemm_bj.hip): needs zero-filled `partials`, which only the workspace entry points promise
+    if (ws && gast_gemm_bj_plan(a, jp)) return gast_gemm_bj_launch_multi(&a, &jp, 1, st);      // large-M GAST_F32X3 GEMMs: gemm_big.hip
     dim3 grid(gridM * gridN * splitk), block(256);
     if (a.dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<float, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_kernel<float, float, 1>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<float, float, 1>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.dtype == GAST_F32X3H)
-        hipLaunchKernelGGL((gemm_kernel<float, float, 2>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<float, float, 2>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.f8_scale && !a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else if (a.out_f32)
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, float>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     else
-        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws, lz);
+        hipLaunchKernelGGL((gemm_kernel<bf16_t, bf16_t>), grid, block, 0, st, a, M, gridM, gridN, vec_epi, splitk, (float*)ws);
     GAST_CHECK_LAUNCH();
     if (splitk > 1) {
         // the finish kernel accumulates the column statistics with atomics: `partials` arrives zero-filled (gast_hip.h)
@@ -844,7 +840,9 @@ extern "C" int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes,
 extern "C" int gast_gemm_path(const gast_gemm_args* args) {
     if (!args) return GAST_EINVAL;
     BigPlan bp;
-    return gast_gemm_big_plan(*args, bp) ? 1 : 0;
+    if (gast_gemm_big_plan(*args, bp)) return 1;
+    BjPlan jp;
+    return gast_gemm_bj_plan(*args, jp) ? 2 : 0;
 }
 
 extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long ws_bytes, gast_stream_t stream) {
@@ -858,16 +856,17 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
     fb.first[0] = 0;
     fb.ws = (const float*)ws;
     long ws_used = 0;
-    bool deferred_after_own = false;
-    gast_gemm_args big_a[GAST_GEMM_MAX_BATCH];
+    gast_gemm_args big_a[GAST_GEMM_MAX_BATCH], bj_a[GAST_GEMM_MAX_BATCH];
     BigPlan big_p[GAST_GEMM_MAX_BATCH];
-    int nbig = 0;
+    BjPlan bj_p[GAST_GEMM_MAX_BATCH];
+    int nbig = 0, nbj = 0;
     for (int d = 0; d < n; ++d) {
         if (args[d].dtype != args[0].dtype || args[d].out_f32 != args[0].out_f32 || !args[d].f8_scale != !args[0].f8_scale) return GAST_EINVAL;
         int M, gridM, gridN, vec_epi, splitk;
         int rc = gemm_plan(args[d], ws, ws_bytes, M, gridM, gridN, vec_epi, splitk);
         if (rc) return rc;
         if (gast_gemm_big_plan(args[d], big_p[nbig])) { big_a[nbig++] = args[d]; continue; }
+        if (ws && gast_gemm_bj_plan(args[d], bj_p[nbj])) { bj_a[nbj++] = args[d]; continue; }
         long off = 0;
         if (splitk > 1) {                       // small-M job: its K ranges join the grid, its slice of the workspace follows the others'
             off = ws_used;
@@ -876,7 +875,6 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
             if (!multi_splitk || (off + need) * (long)sizeof(float) > ws_bytes) {      // (0: bisecting aid) own split-K launch pair
                 rc = gast_gemm_ws(&args[d], ws, ws_bytes, stream);
                 if (rc) return rc;
-                deferred_after_own = true;
                 continue;
             }
             ws_used += (need + 63) / 64 * 64;
@@ -892,48 +890,29 @@ extern "C" int gast_gemm_multi(const gast_gemm_args* args, int n, void* ws, long
             fb.first[f + 1] = fb.first[f] + gridN * ((M + 7) / 8);
         }
     }
-    (void)deferred_after_own;
     hipStream_t st = (hipStream_t)stream;
-    // a lazy finalize rides in ONE launch of the call: the grid that holds the job carrying it (the plan gives it to the first job; a
-    // call whose jobs split into a large-M and a 128x128-tile grid must not carry one unless every prologue job sits in the same grid)
-    const gast_bn_lazy* lzp = nullptr;
-    int lz_job = -1;
-    for (int d = 0; d < n; ++d) if (args[d].lazy) { if (lzp) return GAST_EINVAL; lzp = args[d].lazy; lz_job = d; }
-    if (gastbn::lazy_check(lzp)) return GAST_EINVAL;
-    if (lzp && deferred_after_own) return GAST_EINVAL;
-    bool lz_big = false;
-    if (lzp) {
-        for (int k = 0; k < nbig; ++k) if (big_a[k].lazy) lz_big = true;
-        // every job with a BatchNorm prologue must run in the grid that waits for the finalize
-        for (int d = 0; d < n; ++d) {
-            bool has_pro = false;
-            for (int q = 0; q < args[d].nseg; ++q) has_pro |= args[d].seg[q].pro != GAST_PRO_NONE;
-            if (!has_pro || d == lz_job) continue;
-            bool in_big = false;
-            for (int k = 0; k < nbig; ++k) in_big |= big_a[k].C == args[d].C;
-            if (in_big != lz_big) return GAST_EINVAL;
-        }
-    }
-    const gast_bn_lazy lz_none = gastbn::lazy_arg(nullptr);
     if (nbig) {
-        int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, lz_big ? gastbn::lazy_arg(lzp) : lz_none, st);
+        int rc = gast_gemm_big_launch_multi(big_a, big_p, nbig, st);
+        if (rc) return rc;
+    }
+    if (nbj) {
+        int rc = gast_gemm_bj_launch_multi(bj_a, bj_p, nbj, st);
         if (rc) return rc;
     }
     if (b.n == 0) return 0;
-    const gast_bn_lazy lz = (lzp && !lz_big) ? gastbn::lazy_arg(lzp) : lz_none;
     dim3 grid(b.first[b.n]), block(256);
     if (args[0].dtype == GAST_F32)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float>), grid, block, 0, st, b);
     else if (args[0].dtype == GAST_F32X3)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 1>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 1>), grid, block, 0, st, b);
     else if (args[0].dtype == GAST_F32X3H)
-        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 2>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<float, float, 2>), grid, block, 0, st, b);
     else if (args[0].f8_scale && !args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t, 0, true>), grid, block, 0, st, b);
     else if (args[0].out_f32)
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, float>), grid, block, 0, st, b);
     else
-        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b, lz);
+        hipLaunchKernelGGL((gemm_multi_kernel<bf16_t, bf16_t>), grid, block, 0, st, b);
     GAST_CHECK_LAUNCH();
     if (fb.n) {
         dim3 fgrid(fb.first[fb.n]);

@@ -1,4 +1,5 @@
-// Internal interface between gemm.hip (argument validation, dispatch) and gemm_big.hip (the 128x256 / 128x128-tile pipelined GAST_F32X3 kernel).
+// Internal interface between gemm.hip (argument validation, dispatch), gemm_big.hip (the 128x256 / 128x128-tile pipelined GAST_F32X3 kernel)
+// and gemm_bj.hip (the 64-row-tile kernel of the M = B*J stage).
 #pragma once
 #include "common.h"
 
@@ -17,6 +18,18 @@ struct BigPlan {
 // (internal to the library: hidden, so that the dynamic symbol table holds the C ABI of include/gast_hip.h and nothing else)
 // 1 when the GEMM can run on the big-tile kernel (fills the plan), else 0: the caller uses the 128x128 kernel of gemm.hip
 __attribute__((visibility("hidden"))) int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl);
-// lz: a lazy BatchNorm finalize that rides in front of the launch (kind 0: none; bn_lazy.h)
-__attribute__((visibility("hidden"))) int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, const gast_bn_lazy& lz, hipStream_t st);
-__attribute__((visibility("hidden"))) int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, const gast_bn_lazy& lz, hipStream_t st);
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st);
+__attribute__((visibility("hidden"))) int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st);
+
+// gemm_bj.hip: the M = B*J stage (rows < GAST_GEMM_BIG_MIN_M) in GAST_F32X3 / GAST_F32X3H -- 64-row tiles, the K loop split over two
+// k-groups of waves INSIDE the block, no workspace and no finish launch.  `partials` must arrive zero-filled (as on gemm.hip's
+// split-K path, which it replaces): the caller only takes this path when it was given a workspace, i.e. through gast_gemm_ws / _multi.
+struct BjPlan {
+    int M, tilesM, tilesN;
+    int nj;                       // 32-column MFMA tiles per wave: 1 = 64-column block tile, 2 = 128 (picked per launch)
+    int pair;                     // 1 = bf16 hi/lo, 2 = fp16 hi/lo
+    int ntab;
+    int taboff[GAST_MAX_SEG];
+};
+__attribute__((visibility("hidden"))) int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl);
+__attribute__((visibility("hidden"))) int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hipStream_t st);

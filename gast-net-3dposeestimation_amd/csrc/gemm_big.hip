@@ -22,7 +22,6 @@
 //     are exactly one statistics block (partials[ceil(M/128)][N][2], the layout gemm.hip and the BatchNorm finalizes share).
 #include "common.h"
 #include "gemm_big.h"
-#include "bn_lazy.h"
 #include <stdlib.h>
 #include <stdio.h>
 #include <atomic>
@@ -65,7 +64,7 @@ __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* 
 // (NI = 2 only, the M = B*J stage: at most a block or two per CU, so a block has to cover the memory latency by itself -- five weight
 // stages, four activation register sets, 57 KB of LDS)
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem, const gast_bn_lazy& lz) {
+__device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan& pl, int blk, unsigned char* smem) {
     constexpr int TM = tm_of(MW), NT = nt_of(MW), A_BYTES = a_bytes(MW), OFF_A = off_a(MW), OFF_W = off_w(MW);
     constexpr int TN = tn_of(NI), W_BYTES = w_bytes(NI), OFF_TAB = off_tab(NI, MW, D);
     // PAIR = 3: 16-bit STORAGE (GAST_BF16: bfloat16, or binary16 in the -DGAST_H16_F16 build), ONE product.  A K step then covers 32
@@ -286,10 +285,6 @@ __device__ __forceinline__ void big_body(const gast_gemm_args& a, const BigPlan&
             dma_w(dq[i - 1], i);
             load_a(dq[i - 1], ra[i], rz[i]);
         }
-        // a lazy BatchNorm finalize (gast_bn_lazy): the first blocks of the launch compute the scale / shift the tables below are read
-        // from, every block waits for them here -- with its first tiles already in flight
-        // (LDS scratch: the first activation stage -- nothing is written there before write_a(d0, 0, ..) below)
-        gastbn::bn_lazy_sync_with(lz, (gastbn::fin_red_t)(smem + OFF_A));
         for (int s = 0; s < a.nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
             if (pl.taboff[s] >= 0) {
                 const float* sc = a.seg[s].scale;
@@ -559,9 +554,9 @@ __host__ __device__ __forceinline__ int epi_variant(const gast_gemm_args& a) {  
 }
 
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl, const gast_bn_lazy lz) {
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_kernel(const gast_gemm_args a, const BigPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    big_body<EPI, ADD, NI, MW, PAIR, D>(a, pl, blockIdx.x, smem, lz);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(a, pl, blockIdx.x, smem);
 }
 
 struct BigBatch {
@@ -573,11 +568,11 @@ struct BigBatch {
 static_assert(sizeof(BigBatch) <= 3840, "BigBatch travels as a kernel argument (4 KB limit)");
 // several jobs with the SAME epilogue variant in one grid (one launch, one tail): G2 | G3 of a block, ...
 template <int EPI, bool ADD, int NI, int MW, int PAIR, int D = 2>
-__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b, const gast_bn_lazy lz) {
+__global__ void __launch_bounds__(128 * MW, MW == 2 ? 2 : 1) gemm_big_multi_kernel(const BigBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    big_body<EPI, ADD, NI, MW, PAIR, D>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem, lz);
+    big_body<EPI, ADD, NI, MW, PAIR, D>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 // ---- pre-split weight image, k-group-major: img[(k>>4) * ldimg + r * 32 + (k&15)] = bf16 hi(W[r][k]),  + 16: bf16 lo;
@@ -718,7 +713,7 @@ int gast_gemm_big_plan(const gast_gemm_args& a, BigPlan& pl) {
 
 static int big_lds_bytes(int ntab, int ni, int mw, int depth) { return off_tab(ni, mw, depth) + 2 * ntab * 4 + 6 * nt_of(mw) * 4; }
 
-typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan, const gast_bn_lazy);
+typedef void (*big_kernel_t)(const gast_gemm_args, const BigPlan);
 template <int NI, int MW, int D = 2>
 static big_kernel_t big_kernel_ni(int v, int pair) {
     if (pair == 2) {                // (variants 0..3: gast_gemm_big_plan keeps the BNRELU_BWD epilogues on bf16 pairs)
@@ -761,7 +756,7 @@ static big_kernel_t big_kernel(int v, int ni, int mw, int pair, int depth) {
     return mw == 4 ? big_kernel_ni<4, 4>(v, pair) : ni == 2 ? big_kernel_ni<2, 2>(v, pair) : big_kernel_ni<4, 2>(v, pair);
 }
 
-typedef void (*big_multi_kernel_t)(const BigBatch, const gast_bn_lazy);
+typedef void (*big_multi_kernel_t)(const BigBatch);
 template <int NI, int MW, int D = 2>
 static big_multi_kernel_t big_multi_kernel_ni(int v, int pair) {
     if (pair == 2) {
@@ -838,17 +833,16 @@ static void big_setup() {
     }
 }
 
-int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, const gast_bn_lazy& lz, hipStream_t st) {
+int gast_gemm_big_launch(const gast_gemm_args& a, const BigPlan& pl, hipStream_t st) {
     big_setup();
-    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair, pl.depth), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw, pl.depth), st, a, pl, lz);
+    hipLaunchKernelGGL(big_kernel(epi_variant(a), pl.ni, pl.mw, pl.pair, pl.depth), dim3(pl.tilesM * pl.tilesN), dim3(nt_of(pl.mw)), big_lds_bytes(pl.ntab, pl.ni, pl.mw, pl.depth), st, a, pl);
     GAST_CHECK_LAUNCH();
     return 0;
 }
 
-int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, const gast_bn_lazy& lz_in, hipStream_t st) {
+int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, int n, hipStream_t st) {
     big_setup();
     bool done[GAST_GEMM_MAX_BATCH] = {};
-    bool lz_used = false;
     for (int d0 = 0; d0 < n; ++d0) {          // one grid per (epilogue variant, tile width) present in the batch
         if (done[d0]) continue;
         const int v = epi_variant(args[d0]), ni = pls[d0].ni, mw = pls[d0].mw, pair = pls[d0].pair, depth = pls[d0].depth;
@@ -865,11 +859,8 @@ int gast_gemm_big_launch_multi(const gast_gemm_args* args, const BigPlan* pls, i
             b.first[k + 1] = b.first[k] + pls[d].tilesM * pls[d].tilesN;
             if (pls[d].ntab > ntab) ntab = pls[d].ntab;
         }
-        // (the lazy finalize runs in the FIRST grid of the call; a later grid of the same call starts after it on the stream)
-        const gast_bn_lazy lz = lz_used ? gastbn::lazy_arg(nullptr) : lz_in;
-        lz_used = true;
-        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair, depth), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b.a[0], b.pl[0], lz);
-        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair, depth), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b, lz);
+        if (b.n == 1) hipLaunchKernelGGL(big_kernel(v, ni, mw, pair, depth), dim3(b.first[1]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b.a[0], b.pl[0]);
+        else hipLaunchKernelGGL(big_multi_kernel(v, ni, mw, pair, depth), dim3(b.first[b.n]), dim3(nt_of(mw)), big_lds_bytes(ntab, ni, mw, depth), st, b);
         GAST_CHECK_LAUNCH();
     }
     return 0;

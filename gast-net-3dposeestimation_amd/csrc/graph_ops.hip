@@ -3,7 +3,6 @@
 // (reference model/global_attention.py:52-82).  All of them are HBM/latency bound (AI < 5 F/B): coalesced channel-major
 // accesses, the J x J tiles live in LDS, no MFMA.
 #include "common.h"
-#include "bn_lazy.h"
 #include <atomic>
 #include <type_traits>
 
@@ -375,8 +374,8 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_ell_kernel(const T* __restr
 constexpr int AGG_LDS_U = GAST_AGG_LDS_U, AGG_LDS_CC = 32, AGG_LDS_NPB = 5;
 // BN (round 5): dY arrives BEFORE the BatchNorm backward of bn_1 | bn_2 (the masked gradient the preceding GEMM epilogue wrote) and the
 // kernel applies dy = ka*dY + kb*Y + kc (Y = the pre-BatchNorm aggregation output of the forward) while staging -- the stand-alone
-// gast_bn_bwd_apply pass over dY (a read-modify-write of P x 2C, at the HBM roofline) disappears; the finalize that makes ka / kb / kc
-// runs lazily in front (gast_bn_lazy).  Same fma nesting as bn_bwd_apply_kernel: the values are bit-equal to the two-launch form.
+// gast_bn_bwd_apply pass over dY (a read-modify-write of P x 2C, at the HBM roofline) disappears.  Same fma nesting as
+// bn_bwd_apply_kernel: the values are bit-equal to the two-launch form.
 template <typename T, int DS, int DC, bool BN = false>
 __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restrict__ dY, int ldy, const T* __restrict__ H, int ldh,
                                                                 int F, int J, int C,
@@ -384,12 +383,11 @@ __global__ void __launch_bounds__(256) semch_agg_bwd_lds_kernel(const T* __restr
                                                                 const float* __restrict__ A_con, const int32_t* __restrict__ pat_con,
                                                                 T* __restrict__ dH, int lddh, float* __restrict__ part, int nfb, int nchunk,
                                                                 const T* __restrict__ Yp, int ldyp, const float* ka, const float* kb,
-                                                                const float* kc, const gast_bn_lazy lz) {
+                                                                const float* kc) {
     constexpr int U = AGG_LDS_U, CC = AGG_LDS_CC, CC4 = CC / 4, NPB = AGG_LDS_NPB;
     __shared__ int s_ei[2 * JMAX * JMAX], s_ej[2 * JMAX * JMAX];     // (i, j) of every edge, sym edges first
     __shared__ __attribute__((aligned(16))) float sK[BN ? 3 : 1][2][CC];      // BN: [ka | kb | kc][sym | con half of dY][channel of the chunk]
     extern __shared__ __attribute__((aligned(16))) float sAggL[];
-    if (BN) gastbn::bn_lazy_sync(lz);
     const int tid = threadIdx.x;
     const int fb = blockIdx.x / nchunk, ch = blockIdx.x - fb * nchunk;
     const Pat ps = make_pat(pat_sym, J, pat_sym[1]), pc = make_pat(pat_con, J, pat_con[1]);
@@ -1719,7 +1717,7 @@ extern "C" long gast_semch_agg_bwd_ws_floats(int F, int C, int nnz_sym, int nnz_
 }
 
 // the BatchNorm-backward apply of dY fused into the staging pass (semch_agg_bwd_lds_kernel<.., BN = true>): Yp != null
-struct AggBwdBn { const void* Yp; int ldyp; const float* ka; const float* kb; const float* kc; const gast_bn_lazy* lazy; };
+struct AggBwdBn { const void* Yp; int ldyp; const float* ka; const float* kb; const float* kc; };
 
 static bool agg_bwd_takes_lds(int dtype, int F, int C, int nnz_sym, int cdeg_sym, int nnz_con, int cdeg_con) {
     const AggBwdCfg c = agg_bwd_cfg(F, C, dtype == GAST_F32 && (cdeg_sym == 2 && (cdeg_con == 5 || cdeg_con == 6)));
@@ -1736,10 +1734,9 @@ static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H,
     AggBwdCfg c = agg_bwd_cfg(F, C, dtype == GAST_F32 && (cdeg_sym == 2 && (cdeg_con == 5 || cdeg_con == 6)));
     const int nnz_t = nnz_sym + nnz_con;
     if (bn) {
-        if (!bn->Yp || !bn->ka || !bn->kb || !bn->kc || bn->ldyp % 4 || gastbn::lazy_check(bn->lazy)) return GAST_EINVAL;
+        if (!bn->Yp || !bn->ka || !bn->kb || !bn->kc || bn->ldyp % 4) return GAST_EINVAL;
         if (!agg_bwd_takes_lds(dtype, F, C, nnz_sym, cdeg_sym, nnz_con, cdeg_con)) return GAST_EINVAL;      // (ask gast_semch_agg_bwd_fuses_bn first)
     }
-    const gast_bn_lazy lzv = gastbn::lazy_arg(bn ? bn->lazy : nullptr);
     // fixed-degree kernel: LDS for the coefficient slices, at most J * deg + 1 rows per pattern
     size_t smem = (size_t)(J * cdeg_sym + 1 + J * cdeg_con + 1) * c.CC * sizeof(float);
     hipStream_t st = (hipStream_t)stream;
@@ -1773,17 +1770,17 @@ static int semch_agg_bwd_impl(int dtype, const void* dY, int ldy, const void* H,
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
                 hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<float, DS, DC, true>), grid, dim3(256), sm, st, (const float*)dY, ldy, \
                                    (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, \
-                                   (const float*)bn->Yp, bn->ldyp, bn->ka, bn->kb, bn->kc, lzv);                              \
+                                   (const float*)bn->Yp, bn->ldyp, bn->ka, bn->kb, bn->kc);                                   \
             } else                                                                                                            \
             hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<float, DS, DC>), grid, dim3(256), sm, st, (const float*)dY, ldy,     \
                                (const float*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (float*)dH, lddh, ws, c.nfb, c.nchunk, \
-                               (const float*)nullptr, 0, nullptr, nullptr, nullptr, lzv);                                     \
+                               (const float*)nullptr, 0, nullptr, nullptr, nullptr);                                          \
         } else {                                                                                                              \
             if (sm > 48 * 1024) hipFuncSetAttribute((const void*)semch_agg_bwd_lds_kernel<bf16_t, DS, DC>,                   \
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);                     \
             hipLaunchKernelGGL((semch_agg_bwd_lds_kernel<bf16_t, DS, DC>), grid, dim3(256), sm, st, (const bf16_t*)dY, ldy,   \
                                (const bf16_t*)H, ldh, F, J, C, A_sym, pat_sym, A_con, pat_con, (bf16_t*)dH, lddh, ws, c.nfb, c.nchunk, \
-                               (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr, lzv);                                    \
+                               (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr);                                         \
         }                                                                                                                     \
     } while (0)
     bool fast = true;
@@ -1849,11 +1846,11 @@ extern "C" int gast_semch_agg_bwd_fuses_bn(int dtype, int F, int J, int C, int n
     return agg_bwd_takes_lds(dtype, F, C, nnz_sym, cdeg_sym, nnz_con, cdeg_con) ? 1 : 0;
 }
 extern "C" int gast_semch_agg_bwd_bn(int dtype, const void* dY, int ldy, const void* Ypre, int ldyp, const float* ka, const float* kb,
-                                     const float* kc, const gast_bn_lazy* lazy, const void* H, int ldh, int F, int J, int C,
+                                     const float* kc, const void* H, int ldh, int F, int J, int C,
                                      const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
                                      const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
                                      gast_rowsum_job* finish, gast_stream_t stream) {
-    const AggBwdBn bn = {Ypre, ldyp, ka, kb, kc, lazy};
+    const AggBwdBn bn = {Ypre, ldyp, ka, kb, kc};
     if (finish) finish->ws = nullptr;
     return semch_agg_bwd_impl(dtype, dY, ldy, H, ldh, F, J, C, A_sym, pat_sym, nnz_sym, cdeg_sym, A_con, pat_con, nnz_con, cdeg_con, dH, lddh,
                               dA, ws, finish, stream, &bn);

@@ -5,7 +5,7 @@
 // coalescing, column statistics reduced per block in LDS and written as partial rows that `gast_bn_finalize`
 // combines in double precision (deterministic, no atomics on the statistics).
 #include "common.h"
-#include "bn_lazy.h"
+#include "bn_finalize.h"
 
 namespace {
 using namespace gastbn;
@@ -54,8 +54,7 @@ __device__ __forceinline__ void slot_reduce(float4 (&v)[NV], float (*sred)[4 * N
 // then the 8 lanes are combined in LDS in double precision.  (One thread per column walking all row blocks serially
 // exposed one L2 latency per row block: 80 us for 425 blocks.)
 constexpr int FIN_COLS = 32, FIN_LANES = 8;          // the fused short-tensor kernel (its apply half wants 32 columns)
-// (the stand-alone finalizes' geometry -- 4 columns x 64 lanes per block -- and their bodies live in bn_lazy.h: the lazy finalize that
-// runs in front of a consumer launch shares them)
+// (the stand-alone finalizes' geometry -- 4 columns x 64 lanes per block -- and their bodies live in bn_finalize.h)
 
 template <int COLS, int LANES>
 __device__ __forceinline__ void finalize_sums(const float* __restrict__ partials, int nblk, int ncol_total, int col, bool valid,
@@ -120,8 +119,7 @@ __global__ void __launch_bounds__(256) bn_bwd_finalize_multi_kernel(const BnBwdF
 template <typename T>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, int lddz, const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* ka, const float* kb,
-                                                           const float* kc, int TPR, int RB, const gast_bn_lazy lz) {
-    bn_lazy_sync(lz);          // (lazy BatchNorm-backward finalize: ka / kb / kc are written by this launch's first blocks)
+                                                           const float* kc, int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -194,8 +192,7 @@ template <typename T>
 __global__ void __launch_bounds__(256) bnrelu_apply_kernel(const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* scale, const float* shift,
                                                            T* __restrict__ Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop,
-                                                           int TPR, int RB, const gast_bn_lazy lz) {
-    bn_lazy_sync(lz);          // (lazy BatchNorm finalize: scale / shift are written by this launch's first blocks)
+                                                           int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -275,8 +272,7 @@ __global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__
                                                            const T* __restrict__ T2, int ldt, const float* sc2,
                                                            const float* sh2, int use_drop, uint32_t salt,
                                                            gast_dropout drop, int Tn, int J, long rows, int N,
-                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB, const gast_bn_lazy lz) {
-    bn_lazy_sync(lz);          // (lazy BatchNorm finalize of T2's statistics: sc2 / sh2 are written by this launch's first blocks)
+                                                           T* __restrict__ Xn, int ldxn, int TPR, int RB) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -374,18 +370,16 @@ __global__ void __launch_bounds__(256) expand_fwd_kernel(const float* __restrict
                                                          int t_stride, int T_out, const float* __restrict__ W,
                                                          const float* sc0, const float* sh0, int C,
                                                          T* __restrict__ E, int lde, float* __restrict__ partials, int TPR, int RB,
-                                                         const float* __restrict__ center, const gast_bn_lazy lz) {
+                                                         const float* __restrict__ center) {
     extern __shared__ __attribute__((aligned(16))) float sW[];  // [K0][C] then sred
     __shared__ float sred[256][8];
     __shared__ float sBN0[2][KMAX];
-    bn_lazy_sync(lz);          // (lazy init_bn finalize: sc0 / sh0 are written by this launch's first blocks)
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
-    // scale / shift of the input features through LDS, fetched with device-scope loads: a uniform global read could be served by the
-    // scalar cache, which the acquire of the lazy finalize does not invalidate
+    // scale / shift of the input features through LDS
     if (tid < F_in) {
-        sBN0[0][tid] = __hip_atomic_load(sc0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        sBN0[1][tid] = __hip_atomic_load(sh0 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sBN0[0][tid] = sc0[tid];
+        sBN0[1][tid] = sh0[tid];
     }
     for (int t = tid; t < K0 * C; t += 256) {
         int c = t / K0, kk = t - c * K0;     // W is [c][f][tap] = [c][kk]
@@ -440,17 +434,15 @@ constexpr int XF = 2, XT = 8;
 // parameter-sized epilogue.  (One pass with <=128 long-running blocks ending in (F_in*k0+1)*C atomics took 115 us for
 // 14 MB of dE: 8 bytes in flight per thread.)
 // BN (round 5): dE arrives BEFORE the backward of expand_bn (the masked gradient of the first block's input GEMM) and the kernel applies
-// dz = ka*dE + kb*E + kc while loading -- the stand-alone gast_bn_bwd_apply pass over dE disappears; the finalize that makes ka / kb / kc
-// runs lazily in front (gast_bn_lazy).  Same fma nesting and rounding as bn_bwd_apply_kernel.
+// dz = ka*dE + kb*E + kc while loading -- the stand-alone gast_bn_bwd_apply pass over dE disappears.  Same fma nesting and rounding as
+// bn_bwd_apply_kernel.
 template <typename T, bool BN = false>
 __global__ void __launch_bounds__(256) expand_bwd_kernel(const T* __restrict__ dE, int ldde, const float* __restrict__ x, int B, int T_in,
                                                          int J, int F_in, int k0, int t_stride, int T_out,
                                                          const float* __restrict__ mean0, const float* __restrict__ rstd0, int C,
                                                          float* __restrict__ ws, int TPR, int RB,
-                                                         const T* __restrict__ Epre, int lde, const float* ka, const float* kb, const float* kc,
-                                                         const gast_bn_lazy lz) {
+                                                         const T* __restrict__ Epre, int lde, const float* ka, const float* kb, const float* kc) {
     __shared__ float sred[256][4];
-    if (BN) bn_lazy_sync(lz);
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     const int K0 = F_in * k0;
     const int C4 = C >> 2;
@@ -700,47 +692,36 @@ extern "C" int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_to
 
 static inline bool bad_dtype(int d) { return d != GAST_F32 && d != GAST_BF16; }
 
-extern "C" int gast_bn_bwd_apply_lazy(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
-                                      const float* ka, const float* kb, const float* kc, const gast_bn_lazy* lazy, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1 || lazy_check(lazy)) return GAST_EINVAL;
+extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
+                                 const float* ka, const float* kb, const float* kc, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1) return GAST_EINVAL;
     if (N % 4 || lddz % 4 || ldx % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
-    const gast_bn_lazy lz = lazy_arg(lazy);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (float*)dz, lddz, (const float*)X, ldx,
-                           rows, N, ka, kb, kc, c.TPR, c.RB, lz);
+                           rows, N, ka, kb, kc, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz, (const bf16_t*)X,
-                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB, lz);
+                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
 }
-extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
-                                 const float* ka, const float* kb, const float* kc, gast_stream_t stream) {
-    return gast_bn_bwd_apply_lazy(dtype, dz, lddz, X, ldx, rows, N, ka, kb, kc, nullptr, stream);
-}
 
-extern "C" int gast_bnrelu_apply_lazy(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                                      void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, const gast_bn_lazy* lazy,
-                                      gast_stream_t stream) {
-    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1 || lazy_check(lazy)) return GAST_EINVAL;
+extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
+                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !X || !Y || !scale || !shift || rows < 1) return GAST_EINVAL;
     if (N % 4 || ldx % 4 || ldy % 4) return GAST_EALIGN;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
-    const gast_bn_lazy lz = lazy_arg(lazy);
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((bnrelu_apply_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)X, ldx, rows, N, scale,
-                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
+                           shift, (float*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
-                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB, lz);
+                           shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
-}
-extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                                 void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, gast_stream_t stream) {
-    return gast_bnrelu_apply_lazy(dtype, X, ldx, rows, N, scale, shift, Y, ldy, use_drop, salt, drop, nullptr, stream);
 }
 
 extern "C" int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int ldx, long rows, int N,
@@ -764,24 +745,17 @@ extern "C" int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap 
                                  const void* T2, int ldt, const float* sc2, const float* sh2,
                                  int use_drop, uint32_t salt, gast_dropout drop,
                                  int B, int Tn, int J, int N, void* Xn, int ldxn, gast_stream_t stream) {
-    return gast_residual_fwd_lazy(dtype, O, ldo, omap, scO, shO, T2, ldt, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, ldxn, nullptr, stream);
-}
-extern "C" int gast_residual_fwd_lazy(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
-                                      const void* T2, int ldt, const float* sc2, const float* sh2,
-                                      int use_drop, uint32_t salt, gast_dropout drop,
-                                      int B, int Tn, int J, int N, void* Xn, int ldxn, const gast_bn_lazy* lazy, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1 || lazy_check(lazy)) return GAST_EINVAL;
-    const gast_bn_lazy lz = lazy_arg(lazy);
+    if (bad_dtype(dtype) || !O || !scO || !shO || !T2 || !sc2 || !sh2 || !Xn || B < 1 || Tn < 1 || J < 1) return GAST_EINVAL;
     if (N % 4 || ldo % 4 || ldt % 4 || ldxn % 4) return GAST_EALIGN;
     long rows = (long)B * Tn * J;
     RowCfg c = row_cfg(N);
     hipStream_t st = (hipStream_t)stream;
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((residual_fwd_kernel<float>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const float*)O, ldo, omap, scO, shO,
-                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB, lz);
+                           (const float*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (float*)Xn, ldxn, c.TPR, c.RB);
     else
         hipLaunchKernelGGL((residual_fwd_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)O, ldo, omap, scO, shO,
-                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB, lz);
+                           (const bf16_t*)T2, ldt, sc2, sh2, use_drop, salt, drop, Tn, J, rows, N, (bf16_t*)Xn, ldxn, c.TPR, c.RB);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -822,13 +796,7 @@ static inline int conv_t_out(int T_in, int k0, int t_stride) { return (T_in - k0
 extern "C" int gast_expand_fwd(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
                                const float* W, const float* sc0, const float* sh0, int C,
                                void* E, int lde, float* partials, const float* center, gast_stream_t stream) {
-    return gast_expand_fwd_lazy(dtype, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C, E, lde, partials, center, nullptr, stream);
-}
-extern "C" int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                                    const float* W, const float* sc0, const float* sh0, int C,
-                                    void* E, int lde, float* partials, const float* center, const gast_bn_lazy* lazy, gast_stream_t stream) {
-    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials || lazy_check(lazy)) return GAST_EINVAL;
-    const gast_bn_lazy lz = lazy_arg(lazy);
+    if (bad_dtype(dtype) || !x || !W || !sc0 || !sh0 || !E || !partials) return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in * k0 > KMAX || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
     if (C % 4 || lde % 4) return GAST_EALIGN;
     size_t smem = (size_t)F_in * k0 * C * sizeof(float);
@@ -846,10 +814,10 @@ extern "C" int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, 
     }
     if (dtype == GAST_F32)
         hipLaunchKernelGGL((expand_fwd_kernel<float>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0, sh0,
-                           C, (float*)E, lde, partials, c.TPR, c.RB, center, lz);
+                           C, (float*)E, lde, partials, c.TPR, c.RB, center);
     else
         hipLaunchKernelGGL((expand_fwd_kernel<bf16_t>), dim3(nb), dim3(256), smem, st, x, B, T_in, J, F_in, k0, t_stride, T_out, W, sc0,
-                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center, lz);
+                           sh0, C, (bf16_t*)E, lde, partials, c.TPR, c.RB, center);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -868,18 +836,16 @@ extern "C" int gast_expand_bwd(int dtype, const void* dE, int ldde, const float*
                                int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
                                const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate,
                                gast_stream_t stream) {
-    return gast_expand_bwd_bn(dtype, dE, ldde, nullptr, 0, nullptr, nullptr, nullptr, nullptr, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W,
+    return gast_expand_bwd_bn(dtype, dE, ldde, nullptr, 0, nullptr, nullptr, nullptr, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C, W,
                               gamma0, beta0, dW, dgamma0, dbeta0, ws, accumulate, stream);
 }
 extern "C" int gast_expand_bwd_bn(int dtype, const void* dE, int ldde, const void* Epre, int lde, const float* ka, const float* kb,
-                                  const float* kc, const gast_bn_lazy* lazy, const float* x, int B, int T_in, int J, int F_in, int k0,
+                                  const float* kc, const float* x, int B, int T_in, int J, int F_in, int k0,
                                   int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
                                   const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate,
                                   gast_stream_t stream) {
     const bool bn = Epre != nullptr;
-    if (bn && (!ka || !kb || !kc || lde % 4 || lazy_check(lazy))) return GAST_EINVAL;
-    if (!bn && lazy) return GAST_EINVAL;
-    const gast_bn_lazy lz = lazy_arg(lazy);
+    if (bn && (!ka || !kb || !kc || lde % 4)) return GAST_EINVAL;
     if (bad_dtype(dtype) || !dE || !x || !mean0 || !rstd0 || !W || !gamma0 || !beta0 || !dW || !dgamma0 || !dbeta0 || !ws)
         return GAST_EINVAL;
     if (F_in < 1 || k0 < 1 || F_in > XF || k0 > XT || t_stride < 1 || T_in < k0 || B < 1 || J < 1) return GAST_ERANGE;
@@ -892,16 +858,16 @@ extern "C" int gast_expand_bwd_bn(int dtype, const void* dE, int ldde, const voi
     if (dtype == GAST_F32)
         if (bn)
             hipLaunchKernelGGL((expand_bwd_kernel<float, true>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
-                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)Epre, lde, ka, kb, kc, lz);
+                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)Epre, lde, ka, kb, kc);
         else
             hipLaunchKernelGGL((expand_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dE, ldde, x, B, T_in, J, F_in, k0, t_stride,
-                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)nullptr, 0, nullptr, nullptr, nullptr, lz);
+                               T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const float*)nullptr, 0, nullptr, nullptr, nullptr);
     else if (bn)
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t, true>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
-                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)Epre, lde, ka, kb, kc, lz);
+                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)Epre, lde, ka, kb, kc);
     else
         hipLaunchKernelGGL((expand_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dE, ldde, x, B, T_in, J, F_in, k0,
-                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr, lz);
+                           t_stride, T_out, mean0, rstd0, C, ws, c.TPR, c.RB, (const bf16_t*)nullptr, 0, nullptr, nullptr, nullptr);
     GAST_CHECK_LAUNCH();
     // (GAST_DETERMINISTIC: one block per input feature walks its taps and channel groups in order -- one add per address)
     const dim3 fgrid = gast_deterministic() ? dim3(1, F_in) : dim3((C + EF_CH - 1) / EF_CH, F_in * k0);

@@ -63,8 +63,7 @@ class _GemmArgs(C.Structure):
                 ('nseg', C.c_int), ('seg', _GemmSeg * MAX_SEG), ('C', C.c_void_p), ('ldc', C.c_int), ('cmap', _RowMap),
                 ('bias', C.c_void_p), ('bias_neg', C.c_int), ('addend', C.c_void_p), ('ldadd', C.c_int), ('addmap', _RowMap), ('epi', C.c_int),
                 ('partials', C.c_void_p), ('X', C.c_void_p), ('ldx', C.c_int), ('xscale', C.c_void_p), ('xshift', C.c_void_p),
-                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('C2', C.c_void_p), ('ldc2', C.c_int), ('f8_scale', C.c_void_p),
-                ('lazy', C.c_void_p)]
+                ('xdrop', C.c_int), ('xsalt', C.c_uint32), ('drop', _Dropout), ('C2', C.c_void_p), ('ldc2', C.c_int), ('f8_scale', C.c_void_p)]
 
 
 class _F8ScaleJob(C.Structure):
@@ -124,35 +123,6 @@ class _BnBwdFinJob(C.Structure):
     _fields_ = [('partials', C.c_void_p), ('nblk', C.c_int), ('ncol_total', C.c_int), ('col0', C.c_int), ('N', C.c_int),
                 ('count', C.c_double), ('gamma', C.c_void_p), ('mean', C.c_void_p), ('rstd', C.c_void_p), ('dgamma', C.c_void_p),
                 ('dbeta', C.c_void_p), ('ka', C.c_void_p), ('kb', C.c_void_p), ('kc', C.c_void_p), ('accumulate', C.c_int)]
-
-
-BN_LAZY_MAX = 2
-BN_LAZY_FLAG_WORDS = 256
-BN_LAZY_FWD, BN_LAZY_BWD = 1, 2
-
-
-class _BnLazy(C.Structure):
-    _fields_ = [('kind', C.c_int), ('n', C.c_int), ('flag', C.c_void_p), ('fwd', _BnFinJob * BN_LAZY_MAX), ('bwd', _BnBwdFinJob * BN_LAZY_MAX)]
-
-
-class LazyBN:
-    """A BatchNorm finalize (forward: scale / shift / mean / rstd / running statistics; backward: dgamma / dbeta / ka / kb / kc) that the
-    NEXT launch -- the first consumer of its results -- performs itself (gast_bn_lazy, include/gast_hip.h).  Holds the C struct and
-    every tensor it points at; hand it to exactly one launch (`lazy=`)."""
-    __slots__ = ('c', 'keep', 'used')
-
-    def __init__(self, c, keep):
-        self.c, self.keep, self.used = c, keep, False
-
-    def ptr(self):
-        if self.used:
-            raise RuntimeError('gast_hip: a lazy BatchNorm finalize was handed to a second launch')
-        self.used = True
-        return C.addressof(self.c)
-
-
-def _lazy_ptr(lazy):
-    return None if lazy is None else lazy.ptr()
 
 
 class _BnBwdJob(C.Structure):
@@ -234,7 +204,7 @@ def load_library(h16=torch.bfloat16):
         'gast_semch_agg_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp, vp],
         'gast_semch_agg_bwd_ws_floats': [ci, ci, ci, ci],
         'gast_semch_agg_bwd_fuses_bn': [ci, ci, ci, ci, ci, ci, ci, ci],
-        'gast_semch_agg_bwd_bn': [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp,
+        'gast_semch_agg_bwd_bn': [ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, vp, vp, ci, ci, vp, ci, vp, vp,
                                   C.POINTER(_RowsumJob), vp],
         'gast_attn_fwd': [ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp],
         'gast_attn_bwd': [ci, vp, ci, vp, ci, vp, ci, vp, ci, ci, ci, ci, vp, ci, vp, ci, vp, vp, vp, vp],
@@ -250,11 +220,7 @@ def load_library(h16=torch.bfloat16):
         'gast_bn_bwd_fused_multi': [ci, C.POINTER(_BnBwdJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
-        'gast_bn_bwd_apply_lazy': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, cu, _Dropout, vp],
-        'gast_bnrelu_apply_lazy': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, cu, _Dropout, vp, vp],
-        'gast_residual_fwd_lazy': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp, vp],
-        'gast_expand_fwd_lazy': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp, vp],
         'gast_bnrelu_bwd_mask': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
         'gast_rowwise_blocks': [cl, ci],
         'gast_residual_fwd': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp],
@@ -263,7 +229,7 @@ def load_library(h16=torch.bfloat16):
         'gast_expand_fwd': [ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, vp, ci, vp, ci, vp, vp, vp],
         'gast_expand_bwd': [ci, vp, ci, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp],
         'gast_expand_bwd_ws_floats': [cl, ci, ci, ci],
-        'gast_expand_bwd_bn': [ci, vp, ci, vp, ci, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp],
+        'gast_expand_bwd_bn': [ci, vp, ci, vp, ci, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, ci, vp],
         'gast_colsum': [ci, vp, ci, cl, ci, vp, ci, vp],
         'gast_strided_copy': [vp, vp, ci, vp, vp],
         'gast_fold': [vp, ci, ci, vp, vp],
@@ -293,7 +259,6 @@ def load_library(h16=torch.bfloat16):
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_f8_scale_multi', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_semch_agg_bwd_fuses_bn', 'gast_semch_agg_bwd_bn', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats', 'gast_rowsum_multi', 'gast_attn_bwd_deferred', 'gast_semch_agg_bwd_deferred',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
-                    'gast_bn_bwd_apply_lazy', 'gast_bnrelu_apply_lazy', 'gast_residual_fwd_lazy', 'gast_expand_fwd_lazy',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_bn', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
@@ -381,9 +346,8 @@ class HipOps:
         return self.lib.gast_gemm_row_blocks(int(M))
 
     def _gemm_args(self, a, dom, N, segs, C_, cmap, bias=None, addend=None, addmap=None, epi=EPI_PLAIN, partials=None, X=None,
-                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, C2=None, lazy=None):
+                   xscale=None, xshift=None, xdrop=False, xsalt=0, drop=None, bias_neg=False, C2=None):
         a.dtype = _dt(segs[0]['A'])
-        a.lazy = _lazy_ptr(lazy)         # (a lazy BatchNorm finalize this launch runs in front of its own work)
         a.out_f32 = 1 if (C_.dtype == torch.float32 and a.dtype == GAST_BF16) else 0
         st_dtype = a.dtype
         a.B, a.Tn, a.J = (int(v) for v in dom)
@@ -591,16 +555,16 @@ class HipOps:
         return bool(self.lib.gast_semch_agg_bwd_fuses_bn(_dt(H), int(F), int(J), int(C_), A_sym.shape[0] - 1, int(cdeg[0]), A_con.shape[0] - 1,
                                                          int(cdeg[1])))
 
-    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0), defer=None, bn=None, lazy=None):
+    def semch_agg_bwd(self, dY, H, F, J, C_, A_sym, pat_sym, A_con, pat_con, dH, dA, ws, cdeg=(0, 0), defer=None, bn=None):
         """dA: [nnz_sym + nnz_con][C] fp32 (sym rows first), fully written; ws: workspace of semch_agg_bwd_ws() floats;
         cdeg = (Dc_sym, Dc_con).  defer: a list -- the final row reduction into dA is not launched but appended to it (rowsum_multi).
         bn = (Ypre, ka, kb, kc): dY is the gradient BEFORE the BatchNorm backward of bn_1 | bn_2 and the kernel applies
-        ka*dY + kb*Ypre + kc while it stages dY (ask semch_agg_bwd_fuses_bn first); lazy: the finalize that writes ka / kb / kc."""
+        ka*dY + kb*Ypre + kc while it stages dY (ask semch_agg_bwd_fuses_bn first)."""
         if bn is not None:
             Yp, ka, kb, kc = bn
             job = _RowsumJob()
             self.launches += 1 if defer is not None else 2
-            _check(self.lib.gast_semch_agg_bwd_bn(_dt(H), _p(dY), _ld(dY), _p(Yp), _ld(Yp), _p(ka), _p(kb), _p(kc), _lazy_ptr(lazy), _p(H), _ld(H),
+            _check(self.lib.gast_semch_agg_bwd_bn(_dt(H), _p(dY), _ld(dY), _p(Yp), _ld(Yp), _p(ka), _p(kb), _p(kc), _p(H), _ld(H),
                                                   F, J, C_, _p(A_sym), _p(pat_sym), A_sym.shape[0] - 1, int(cdeg[0]), _p(A_con), _p(pat_con),
                                                   A_con.shape[0] - 1, int(cdeg[1]), _p(dH), _ld(dH), _p(dA), _p(ws),
                                                   C.byref(job) if defer is not None else None, _stream()), 'gast_semch_agg_bwd_bn')
@@ -667,32 +631,7 @@ class HipOps:
         a.scale, a.shift, a.mean, a.rstd = _p(j['scale']), _p(j['shift']), _p(j['mean']), _p(j['rstd'])
         a.centered = int(bool(j.get('centered', False)))
 
-    lazy_bn = True       # this op set can run a finalize inside its consumer (the engine asks before it defers one)
-
-    def bn_lazy_fwd(self, jobs, flag):
-        """jobs: <= BN_LAZY_MAX dicts with the arguments of bn_finalize(); flag: BN_LAZY_FLAG_WORDS zero int32 device elements.  Nothing is
-        launched: the returned LazyBN goes to the `lazy=` argument of the first consumer of the jobs' scale / shift."""
-        if not 1 <= len(jobs) <= BN_LAZY_MAX:
-            raise RuntimeError('gast_hip: a lazy finalize carries 1..%d jobs' % BN_LAZY_MAX)
-        if flag.numel() < BN_LAZY_FLAG_WORDS or flag.element_size() != 4:
-            raise RuntimeError('gast_hip: a lazy finalize needs %d zeroed 32-bit words' % BN_LAZY_FLAG_WORDS)
-        c = _BnLazy()
-        c.kind, c.n, c.flag = BN_LAZY_FWD, len(jobs), _p(flag)
-        for i, j in enumerate(jobs):
-            self._fill_fin(c.fwd[i], j)
-        return LazyBN(c, (jobs, flag))
-
-    def bn_lazy_bwd(self, jobs, flag):
-        """the same for bn_bwd_finalize() jobs: the consumer is the bn_bwd_apply that reads ka / kb / kc"""
-        if not 1 <= len(jobs) <= BN_LAZY_MAX:
-            raise RuntimeError('gast_hip: a lazy finalize carries 1..%d jobs' % BN_LAZY_MAX)
-        if flag.numel() < BN_LAZY_FLAG_WORDS or flag.element_size() != 4:
-            raise RuntimeError('gast_hip: a lazy finalize needs %d zeroed 32-bit words' % BN_LAZY_FLAG_WORDS)
-        c = _BnLazy()
-        c.kind, c.n, c.flag = BN_LAZY_BWD, len(jobs), _p(flag)
-        for i, j in enumerate(jobs):
-            self._fill_bwd_fin(c.bwd[i], j)
-        return LazyBN(c, (jobs, flag))
+    fuses_bn_bwd = True  # semch_agg_bwd(bn=...) / expand_bwd(bn=...) apply the BatchNorm backward of their input gradient on load
 
     def bn_finalize_multi(self, jobs):
         """jobs: dicts with the arguments of bn_finalize(); BN_MAX_BATCH per launch."""
@@ -764,16 +703,15 @@ class HipOps:
                                              _p(rstd), _p(dgamma), _p(dbeta), _p(ka), _p(kb), _p(kc), _stream()),
                'gast_bn_bwd_finalize')
 
-    def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc, lazy=None):
+    def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc):
         self.launches += 1
-        _check(self.lib.gast_bn_bwd_apply_lazy(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _lazy_ptr(lazy),
-                                               _stream()), 'gast_bn_bwd_apply')
+        _check(self.lib.gast_bn_bwd_apply(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _stream()), 'gast_bn_bwd_apply')
 
-    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None, lazy=None):
+    def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
         """Y = drop(relu(scale*X + shift)); the dropout stream `salt` is indexed by the element offset in X."""
         self.launches += 1
-        _check(self.lib.gast_bnrelu_apply_lazy(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), int(bool(use_drop)),
-                                               int(salt), _drop(drop), _lazy_ptr(lazy), _stream()), 'gast_bnrelu_apply')
+        _check(self.lib.gast_bnrelu_apply(_dt(X), _p(X), _ld(X), rows, N, _p(scale), _p(shift), _p(Y), _ld(Y), int(bool(use_drop)),
+                                               int(salt), _drop(drop), _stream()), 'gast_bnrelu_apply')
 
     def rowwise_blocks(self, rows, N):
         return self.lib.gast_rowwise_blocks(int(rows), int(N))
@@ -784,11 +722,10 @@ class HipOps:
                                              int(bool(use_drop)), int(salt), _drop(drop), _p(dz), _ld(dz), _p(partials), _stream()),
                'gast_bnrelu_bwd_mask')
 
-    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, lazy=None):
+    def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
         self.launches += 1
-        _check(self.lib.gast_residual_fwd_lazy(_dt(O), _p(O), _ld(O), _rm(omap), _p(scO), _p(shO), _p(T2), _ld(T2), _p(sc2), _p(sh2),
-                                               int(bool(use_drop)), int(salt), _drop(drop), B, Tn, J, N, _p(Xn), _ld(Xn), _lazy_ptr(lazy),
-                                               _stream()), 'gast_residual_fwd')
+        _check(self.lib.gast_residual_fwd(_dt(O), _p(O), _ld(O), _rm(omap), _p(scO), _p(shO), _p(T2), _ld(T2), _p(sc2), _p(sh2),
+                                               int(bool(use_drop)), int(salt), _drop(drop), B, Tn, J, N, _p(Xn), _ld(Xn), _stream()), 'gast_residual_fwd')
 
     def colsum(self, X, rows, N, out, zero_first=True):
         self.launches += 1
@@ -802,23 +739,22 @@ class HipOps:
         self.launches += 1
         _check(self.lib.gast_input_stats(_p(x), rows, F_in, _p(partials), None, _stream()), 'gast_input_stats')
 
-    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None, lazy=None):
+    def expand_fwd(self, x, B, T_in, J, F_in, k0, t_stride, W, sc0, sh0, C_, E, partials, center=None):
         self.launches += 1
-        _check(self.lib.gast_expand_fwd_lazy(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
-                                             _p(partials), _p(center), _lazy_ptr(lazy), _stream()), 'gast_expand_fwd')
+        _check(self.lib.gast_expand_fwd(_dt(E), _p(x), B, T_in, J, F_in, k0, t_stride, _p(W), _p(sc0), _p(sh0), C_, _p(E), _ld(E),
+                                             _p(partials), _p(center), _stream()), 'gast_expand_fwd')
 
     def expand_bwd(self, dE, x, B, T_in, J, F_in, k0, t_stride, mean0, rstd0, C_, W, gamma0, beta0, dW, dgamma0, dbeta0, accumulate=False,
-                   bn=None, lazy=None):
+                   bn=None):
         """dW written (or += with accumulate); dgamma0 / dbeta0 always accumulated (zero-filled by the caller).
-        bn = (Epre, ka, kb, kc): dE is the gradient BEFORE the backward of expand_bn; the kernel applies ka*dE + kb*Epre + kc on load
-        (lazy: the finalize that writes the coefficients, run in front of the launch)."""
+        bn = (Epre, ka, kb, kc): dE is the gradient BEFORE the backward of expand_bn; the kernel applies ka*dE + kb*Epre + kc on load."""
         self.launches += 2
         T_out = (T_in - k0) // t_stride + 1
         n = self.lib.gast_expand_bwd_ws_floats(B * T_out * J, C_, F_in, k0)
         ws = torch.empty(n, dtype=torch.float32, device=dE.device)
         Ep, ka, kb, kc = bn if bn is not None else (None, None, None, None)
         _check(self.lib.gast_expand_bwd_bn(_dt(dE), _p(dE), _ld(dE), _p(Ep), _ld(Ep) if Ep is not None else 0, _p(ka), _p(kb), _p(kc),
-                                           _lazy_ptr(lazy), _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
+                                           _p(x), B, T_in, J, F_in, k0, t_stride, _p(mean0), _p(rstd0), C_,
                                            _p(W), _p(gamma0), _p(beta0), _p(dW), _p(dgamma0), _p(dbeta0), _p(ws), int(bool(accumulate)), _stream()),
                'gast_expand_bwd')
 

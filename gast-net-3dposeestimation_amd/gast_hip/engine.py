@@ -38,7 +38,6 @@ NHEADS = 4
 
 
 FUSED_BN_BWD_ROWS = 8192      # BatchNorm backward: finalize + apply in one launch up to this many rows
-LAZY_FLAG_WORDS = 256         # zeroed words a lazy finalize needs (GAST_BN_LAZY_FLAG_WORDS, include/gast_hip.h: one per finalizing block)
 
 
 def ident(T):
@@ -116,13 +115,8 @@ class Engine:
         # bf16 rounding error scales with the spread of the channel, not with |mean|
         self.centered = bool(centered)
         self.za = ZeroArena()
-        # Lazy BatchNorm finalize (round 5; OPT-IN, GAST_LAZY_BN=1): the finalize jobs ride in the launch that first READS their result -- its
-        # first blocks run them, every block waits for the published coefficients (gast_bn_lazy, include/gast_hip.h; csrc/bn_lazy.h).  It
-        # removes 24 launches per training step and is bit-equal to the stand-alone finalizes, but it is SLOWER on MI355X: 3.64 vs 3.52 ms
-        # per step on one box, +6.7 us per lazy forward launch -- publishing across the eight XCDs (write-back,
-        # flag store, device-scope polls: four memory-side round trips of 1 - 2 us) costs more than the ~5 us kernel boundary it replaces.
-        self.can_lazy = bool(getattr(ops, 'lazy_bn', False))       # (the HIP op set; the numpy mirror of the tests has neither form)
-        self.lazy_bn = self.can_lazy and os.environ.get('GAST_LAZY_BN', '0') not in ('0', '')
+        # (the HIP op set fuses the BatchNorm backward of dY / dE into their one reader; the numpy mirror of the tests has neither form)
+        self.fuse_bn_bwd = bool(getattr(ops, 'fuses_bn_bwd', False))
         self._pre = {}           # eval mode: pre-filled (scale, shift) views per BNState name
         self._side = {}          # device -> side stream for independent branches of the plan
         self._keep = []          # operands of side-stream launches, kept alive until the join
@@ -162,15 +156,9 @@ class Engine:
         per = 128 // torch.empty((), dtype=dt).element_size()
         return torch.empty(rows, (cols + per - 1) // per * per, dtype=dt, device=dev)[:, :cols]
 
-    @staticmethod
-    def _lz(tok):
-        """keyword for the consumer launch of a deferred finalize (nothing when the finalize already ran)"""
-        return {'lazy': tok} if tok is not None else {}
-
-    def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0, centered=False, lazy=False):
-        """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n).
-        lazy: the caller hands the returned token to the launch that first reads st.scale / st.shift (None: already finalized)."""
-        return self._bn_forward_group([(partials, nblk, col0, n, count, bn, st, off)], training, centered=centered, lazy=lazy)
+    def _bn_forward(self, partials, nblk, col0, n, count, bn, st, training, off=0, centered=False):
+        """bn: module-like with weight/bias/running_mean/running_var/num_batches_tracked; st: BNState (slice off..off+n)."""
+        self._bn_forward_group([(partials, nblk, col0, n, count, bn, st, off)], training, centered=centered)
 
     def _eval_table(self, inp, bufs, dev, need_grad=False):
         """Eval mode: scale/shift of EVERY BatchNorm in one launch (they depend on parameters and running statistics only).
@@ -211,10 +199,9 @@ class Engine:
             self.ops.bn_eval_multi(js, eps)
         return out
 
-    def _bn_forward_group(self, items, training, centered=False, lazy=False):
+    def _bn_forward_group(self, items, training, centered=False):
         """items: (partials, nblk, col0, n, count, bn, st, off) -- independent BatchNorms whose statistics are ready at the same
-        point of the plan (bn_1 + bn_2, lcat_bn + gcat_bn): one multi-job finalize launch in training mode -- or, with lazy=True and
-        an op set that can, NO launch: the returned token carries the jobs into the launch that first reads the coefficients."""
+        point of the plan (bn_1 + bn_2, lcat_bn + gcat_bn): one multi-job finalize launch in training mode."""
         ops = self.ops
         if not training:
             if not self._pre:       # (eval states are normally pre-filled by _eval_table)
@@ -222,7 +209,7 @@ class Engine:
                     sl = slice(off, off + n)
                     ops.bn_eval(bn['weight'], bn['bias'], bn['running_mean'], bn['running_var'], bn.get('eps', BN_EPS), n, st.scale[sl],
                                 st.shift[sl], centered=centered)
-            return None
+            return
         jobs = []
         for partials, nblk, col0, n, count, bn, st, off in items:
             sl = slice(off, off + n)
@@ -230,10 +217,7 @@ class Engine:
                              running_mean=bn['running_mean'], running_var=bn['running_var'], nbt=bn['num_batches_tracked'],
                              momentum=bn.get('momentum', BN_MOMENTUM), eps=bn.get('eps', BN_EPS), scale=st.scale[sl], shift=st.shift[sl], mean=st.mean[sl],
                              rstd=st.rstd[sl], centered=centered))
-        if lazy and self.lazy_bn and len(jobs) <= 2:
-            return ops.bn_lazy_fwd(jobs, self.za.take((LAZY_FLAG_WORDS,), torch.int32))
         ops.bn_finalize_multi(jobs)
-        return None
 
     # ------------------------------------------------------------------------------------------ side stream
     # Opt-in (GAST_HIP_SIDE_STREAM=1): independent branches (the attention core of a block in the forward pass, the deferred
@@ -294,9 +278,9 @@ class Engine:
             nb = ops.input_stats_blocks(rows_in)
             part = torch.empty(nb, F_in, 2, dtype=torch.float32, device=dev)
             ops.input_stats(x, rows_in, F_in, part)
-            lz0 = self._bn_forward(part, nb, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, True, lazy=True)
+            self._bn_forward(part, nb, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, True)
         else:
-            lz0 = self._bn_forward(None, 0, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, False)
+            self._bn_forward(None, 0, 0, F_in, rows_in, bufs['init_bn'] | inp_bn(inp, 'init_bn'), bn0, False)
         C0 = sp.channels
         P0 = B * T[0] * J
         E = self._new(P0, C0, dt, dev)
@@ -304,9 +288,9 @@ class Engine:
         partE = torch.empty(nbE, C0, 2, dtype=torch.float32, device=dev)
         cen = self.centered
         ops.expand_fwd(x, B, T_in, J, F_in, k0, s0, inp['expand_w'], bn0.scale, bn0.shift, C0, E, partE,
-                       center=self._ctr(bufs['expand_bn']), **self._lz(lz0))
+                       center=self._ctr(bufs['expand_bn']))
         bnE = BNState(C0, dev, P0, pre('bnE'))
-        lzE = self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen, lazy=True)
+        self._bn_forward(partE, nbE, 0, C0, P0, bufs['expand_bn'] | inp_bn(inp, 'expand_bn'), bnE, training, centered=cen)
         # The first block's input X = relu(expand_bn(E)) is never materialised (round 5): its four readers -- G1, the X segment of G4 and
         # their two weight gradients -- apply BatchNorm + ReLU while loading E, like every other lazily-normalised tensor of the plan (the
         # prologue is a fused multiply-add + max the GEMM kernels execute either way).  One elementwise launch and 2 x P x C x s bytes
@@ -315,8 +299,7 @@ class Engine:
             X, xpro = E, dict(pro=PRO_BNRELU, scale=bnE.scale, shift=bnE.shift)
         else:
             X, xpro = self._new(P0, C0, dt, dev), {}
-            ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X, **self._lz(lzE))
-            lzE = None
+            ops.bnrelu_apply(E, P0, C0, bnE.scale, bnE.shift, X)
         sv.update(x=x, bn0=bn0, E=E, bnE=bnE, T=T)
 
         # ---- masked-softmax adjacencies of every block (parameters only; local_attention.py:40-42): one launch for all of them
@@ -357,23 +340,22 @@ class Engine:
                 part1 = za.take((nb, C, 2))
                 segs = [dict(A=prev['O'], K=C, map=taps[tap], W=Wc[:, tap * C:(tap + 1) * C], pro=PRO_BNRELU,
                              scale=prev['bnO'].scale, shift=prev['bnO'].shift) for tap in range(k)]
-                # (the previous block's cat_bn finalize rides in this launch: its first reader)
                 self._gemm_chunked((B, Tn, J), C, segs, T1, ident(Tn), epi=EPI_STATS, partials=part1,
-                                   bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen, **self._lz(prev.pop('lazyO', None)))
+                                   bias=self._ctr(bufs['l%d.bn0' % s]), bias_neg=cen)
                 bn1 = BNState(C, dev, P, pre('l%d.bn1' % s))
-                lz1 = self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen, lazy=True)
+                self._bn_forward(part1, nb, 0, C, P, bufs['l%d.bn0' % s] | inp_bn(inp, 'l%d.bn0' % s), bn1, training, centered=cen)
                 T2 = self._new(P, C, dt, dev)
                 part2 = za.take((nb, C, 2))
                 ops.gemm((B, Tn, J), C, [dict(A=T1, K=C, map=ident(Tn), W=W1, pro=PRO_BNRELU, scale=bn1.scale, shift=bn1.shift)],
-                         T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen, **self._lz(lz1))
+                         T2, ident(Tn), epi=EPI_STATS, partials=part2, bias=self._ctr(bufs['l%d.bn1' % s]), bias_neg=cen)
                 bn2 = BNState(C, dev, P, pre('l%d.bn2' % s))
-                lz2 = self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen, lazy=True)
+                self._bn_forward(part2, nb, 0, C, P, bufs['l%d.bn1' % s] | inp_bn(inp, 'l%d.bn1' % s), bn2, training, centered=cen)
                 X = self._new(P, C, dt, dev)
                 ops.residual_fwd(prev['O'], resmap, prev['bnO'].scale, prev['bnO'].shift, T2, bn2.scale, bn2.shift,
-                                 use_drop, 3 * s, drop, B, Tn, J, C, X, **self._lz(lz2))
+                                 use_drop, 3 * s, drop, B, Tn, J, C, X)
                 levels.append(dict(T1=T1, T2=T2, bn1=bn1, bn2=bn2, taps=taps, resmap=resmap, k=k))
-                xpro, lzE = {}, None
-            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, adjs[s], xpro=xpro, lazyX=lzE))
+                xpro = {}
+            stages.append(self._gab_forward(s, X, B, T[s], J, C, inp, bufs, training, dt, drop, use_drop, adjs[s], xpro=xpro))
 
         # ---- shrink (gast_net.py:99)
         last = stages[-1]
@@ -382,14 +364,13 @@ class Engine:
         Wsh = inp['shrink']   # [3][CL]
         pred = torch.empty(PL, 3, dtype=torch.float32, device=dev)
         ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
-                                         scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]), **self._lz(last.pop('lazyO', None)))
+                                         scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
         sv.update(stages=stages, levels=levels)
         za.end()
         return pred.view(B, T[-1], J, 3), sv
 
-    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop, adj, xpro=None, lazyX=None):
-        """xpro: load prologue of X (BatchNorm + ReLU keys of a K segment) when X is a pre-BatchNorm tensor read lazily (block 0: E);
-        lazyX: the pending finalize of that BatchNorm, carried by G1 -- the first launch that reads its coefficients."""
+    def _gab_forward(self, s, X, B, Tn, J, C, inp, bufs, training, dt, drop, use_drop, adj, xpro=None):
+        """xpro: load prologue of X (BatchNorm + ReLU keys of a K segment) when X is a pre-BatchNorm tensor read lazily (block 0: E)."""
         xpro = xpro or {}
         sp, ops, za = self.spec, self.ops, self.za
         dev = X.device
@@ -406,7 +387,7 @@ class Engine:
         nb = ops.gemm_row_blocks(P)
         # G1: everything that reads X in one pass (local_attention.py:37-38, global_attention.py:56-72)
         H = self._new_rows128(P, N1, dt, dev)
-        ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1, **xpro)], H, im, bias=inp[g + 'bias1'], **self._lz(lazyX))
+        ops.gemm(dom, N1, [dict(A=X, K=C, map=im, W=Wg1, **xpro)], H, im, bias=inp[g + 'bias1'])
         cen = self.centered
         # ---- everything both branches touch is allocated here, on the main stream, before the fork
         A_s, A_c = adj
@@ -431,47 +412,43 @@ class Engine:
         # ---- local branch: neighbour aggregation + bn_1/bn_2 statistics (one finalize launch for both)
         ops.semch_agg_fwd(H, F, J, C, A_s, sp.pat_sym(dev), A_c, sp.pat_con(dev), Y, partY, deg=(sp.deg_sym[0], sp.deg_con[0]),
                           center=(self._ctr(bufs[g + 'bn_1']), self._ctr(bufs[g + 'bn_2'])))
-        lzY = self._bn_forward_group([(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
-                                      (partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, C)], training, centered=cen, lazy=True)
+        self._bn_forward_group([(partY, nba, 0, C, P, bufs[g + 'bn_1'] | inp_bn(inp, g + 'bn_1'), bnY, 0),
+                                      (partY, nba, C, C, P, bufs[g + 'bn_2'] | inp_bn(inp, g + 'bn_2'), bnY, C)], training, centered=cen)
         self._join(side)
         # ---- G2 (local cat conv) and G3 (global cat conv) are independent: one grid, then one finalize for lcat_bn + gcat_bn
         ops.gemm_multi([dict(dom=dom, N=C, segs=[dict(A=Y, K=2 * C, map=im, W=Wlc, pro=PRO_BNRELU, scale=bnY.scale, shift=bnY.shift)],
-                             C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen, **self._lz(lzY)),
+                             C_=Lp, cmap=im, epi=EPI_STATS, partials=partL, bias=self._ctr(bufs[g + 'lcat_bn']), bias_neg=cen),
                         dict(dom=dom, N=C, segs=[dict(A=Ya, K=C, map=im, W=Wgc)], C_=Gp, cmap=im, epi=EPI_STATS, partials=partG,
                              bias=self._ctr(bufs[g + 'gcat_bn']), bias_neg=cen)])
-        lzLG = self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnLG, 0),
-                                       (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnLG, C)], training, centered=cen,
-                                      lazy=True)
-        ops.bnrelu_apply(LG, P, 2 * C, bnLG.scale, bnLG.shift, ZLG, use_drop=use_drop, salt=3 * s + 1, drop=drop, **self._lz(lzLG))
+        self._bn_forward_group([(partL, nb, 0, C, P, bufs[g + 'lcat_bn'] | inp_bn(inp, g + 'lcat_bn'), bnLG, 0),
+                                       (partG, nb, 0, C, P, bufs[g + 'gcat_bn'] | inp_bn(inp, g + 'gcat_bn'), bnLG, C)], training, centered=cen)
+        ops.bnrelu_apply(LG, P, 2 * C, bnLG.scale, bnLG.shift, ZLG, use_drop=use_drop, salt=3 * s + 1, drop=drop)
         # G4: cat(residual, local, global) . W (gast_net.py:28-32), concat never materialised: two K segments
         O = self._new(P, 2 * C, dt, dev)
         partO = za.take((nb, 2 * C, 2))
         segs = [dict(A=X, K=C, map=im, W=Wbc[:, 0:C], **xpro), dict(A=ZLG, K=2 * C, map=im, W=Wbc[:, C:3 * C])]
         ops.gemm(dom, 2 * C, segs, O, im, epi=EPI_STATS, partials=partO, bias=self._ctr(bufs[g + 'cat_bn']), bias_neg=cen)
         bnO = BNState(2 * C, dev, P, self._pre.get(g + 'bnO'))
-        # (lazyO: the finalize of this block's output statistics, carried by the next launch that reads bnO -- the next temporal
-        #  convolution or the shrink layer; forward() pops it)
-        lzO = self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen, lazy=True)
+        self._bn_forward(partO, nb, 0, 2 * C, P, bufs[g + 'cat_bn'] | inp_bn(inp, g + 'cat_bn'), bnO, training, centered=cen)
         return dict(X=X, H=H, A_s=A_s, A_c=A_c, Y=Y, bnY=bnY, Ya=Ya, LG=LG, ZLG=ZLG, bnLG=bnLG, Lp=Lp, Gp=Gp, O=O, bnO=bnO,
-                    C=C, Tn=Tn, P=P, use_drop=use_drop, lazyO=lzO, xpro=xpro)
+                    C=C, Tn=Tn, P=P, use_drop=use_drop, xpro=xpro)
 
     def _gemm_multi_chunked(self, jobs):
         """ops.gemm_multi for any number of independent jobs (GEMM_MAX_BATCH = 3 per launch)"""
         for i in range(0, len(jobs), 3):
             self.ops.gemm_multi(jobs[i:i + 3])
 
-    def _gemm_chunked(self, dom, N, segs, out, cmap, addend=None, addmap=None, lazy=None, **epilogue):
+    def _gemm_chunked(self, dom, N, segs, out, cmap, addend=None, addmap=None, **epilogue):
         """ops.gemm for any number of K segments (the 7- and 19-tap convolutions of the dense=True ablation exceed the MAX_SEG
         segments of one launch): MAX_SEG segments per launch, each launch adding the previous partial result (`out` itself as
         the addend: every element is read and rewritten by the same thread), the caller's addend in the first and its epilogue
         (bias, statistics, ReLU/BN backward) in the last."""
         if len(segs) <= MAX_SEG:
-            return self.ops.gemm(dom, N, segs, out, cmap, addend=addend, addmap=addmap, **self._lz(lazy), **epilogue)
+            return self.ops.gemm(dom, N, segs, out, cmap, addend=addend, addmap=addmap, **epilogue)
         chunks = [segs[i:i + MAX_SEG] for i in range(0, len(segs), MAX_SEG)]
         for ci, ch in enumerate(chunks):
             a, am = (addend, addmap) if ci == 0 else (out, cmap)
-            self.ops.gemm(dom, N, ch, out, cmap, addend=a, addmap=am, **(self._lz(lazy) if ci == 0 else {}),
-                          **(epilogue if ci == len(chunks) - 1 else {}))
+            self.ops.gemm(dom, N, ch, out, cmap, addend=a, addmap=am, **(epilogue if ci == len(chunks) - 1 else {}))
 
     # ------------------------------------------------------------------------------------------ backward
     def _wgrad(self, dom, P, R, pmap, segs, dW, drop=None, zero_first=False):
@@ -541,12 +518,6 @@ class Engine:
                              mean=st.mean[sl], rstd=st.rstd[sl], dgamma=gout[it['key'] + '.weight'], dbeta=gout[it['key'] + '.bias'],
                              ka=ka[o:o + n], kb=kb[o:o + n], kc=kc[o:o + n], accumulate=True))
             o += n
-        if self.lazy_bn and len(jobs) <= 2 and (one_apply is not None or len(items) == 1):
-            # the finalize jobs ride in the ONE apply launch that reads ka / kb / kc (its first blocks run them)
-            tok = ops.bn_lazy_bwd(jobs, self.za.take((LAZY_FLAG_WORDS,), torch.int32))
-            dz, X, rows = one_apply if one_apply is not None else (items[0]['dz'], items[0]['X'], items[0]['rows'])
-            ops.bn_bwd_apply(dz, X, rows, ntot, ka, kb, kc, lazy=tok)
-            return
         ops.bn_bwd_finalize_multi(jobs)
         if one_apply is not None:
             dz, X, rows = one_apply
@@ -724,19 +695,16 @@ class Engine:
             partE = torch.empty(nbr, C0, 2, dtype=f32, device=dev)
             dE = self._new(P0, C0, dt, dev)
             ops.bnrelu_bwd_mask(dX, sv['E'], P0, C0, sv['bnE'].scale, sv['bnE'].shift, False, 0, None, dE, partE)
-        # dE has ONE reader, the expand-conv backward: it applies the backward of expand_bn while it loads dE (finalize lazily in front)
+        # dE has ONE reader, the expand-conv backward: it applies the backward of expand_bn while it loads dE
         # instead of a stand-alone apply pass (GAST_FUSE_EXPAND_BN=0: off)
         bn_exp = {}
-        if P0 > FUSED_BN_BWD_ROWS and self.can_lazy and os.environ.get('GAST_FUSE_EXPAND_BN', '1') not in ('0', ''):
+        if P0 > FUSED_BN_BWD_ROWS and self.fuse_bn_bwd and os.environ.get('GAST_FUSE_EXPAND_BN', '1') not in ('0', ''):
             kabc = torch.empty(3, C0, dtype=f32, device=dev)
             bnE = sv['bnE']
             job = dict(partials=partE, nblk=nbr, col0=0, N=C0, count=bnE.count, gamma=inp['expand_bn.weight'], mean=bnE.mean, rstd=bnE.rstd,
                        dgamma=grads['expand_bn.weight'], dbeta=grads['expand_bn.bias'], ka=kabc[0], kb=kabc[1], kc=kabc[2], accumulate=True)
             bn_exp = dict(bn=(sv['E'], kabc[0], kabc[1], kabc[2]))
-            if self.lazy_bn:
-                bn_exp['lazy'] = ops.bn_lazy_bwd([job], za.take((LAZY_FLAG_WORDS,), torch.int32))
-            else:
-                ops.bn_bwd_finalize_multi([job])
+            ops.bn_bwd_finalize_multi([job])
         else:
             self._bn_backward(partE, nbr, 0, C0, sv['bnE'], inp['expand_bn.weight'], grads, 'expand_bn', dE, sv['E'], P0)
         x = sv['x']
@@ -803,8 +771,8 @@ class Engine:
         itemsY = [dict(partials=partY, nblk=nb, col0=0, n=C, st=st['bnY'], off=0, gamma=inp[g + 'bn_1.weight'], key=g + 'bn_1'),
                   dict(partials=partY, nblk=nb, col0=C, n=C, st=st['bnY'], off=C, gamma=inp[g + 'bn_2.weight'], key=g + 'bn_2')]
         # dY has ONE reader, the aggregation backward: where its kernel can, it applies the BatchNorm backward of bn_1 | bn_2 while it
-        # stages dY (and runs the finalize lazily in front) -- the stand-alone apply pass over P x 2C disappears (GAST_FUSE_AGG_BN=0: off)
-        fuse_bn = (P > FUSED_BN_BWD_ROWS and self.can_lazy and hasattr(ops, 'semch_agg_bwd_fuses_bn')
+        # stages dY -- the stand-alone apply pass over P x 2C disappears (GAST_FUSE_AGG_BN=0: off)
+        fuse_bn = (P > FUSED_BN_BWD_ROWS and self.fuse_bn_bwd and hasattr(ops, 'semch_agg_bwd_fuses_bn')
                    and os.environ.get('GAST_FUSE_AGG_BN', '1') not in ('0', '')
                    and ops.semch_agg_bwd_fuses_bn(st['H'], F, J, C, st['A_s'], st['A_c'], (sp.deg_sym[1], sp.deg_con[1])))
         bn_agg = None
@@ -818,10 +786,7 @@ class Engine:
                                  ka=kabc[0, o:o + C], kb=kabc[1, o:o + C], kc=kabc[2, o:o + C], accumulate=True))
                 o += C
             bn_agg = dict(bn=(st['Y'], kabc[0], kabc[1], kabc[2]))
-            if self.lazy_bn:
-                bn_agg['lazy'] = ops.bn_lazy_bwd(jobs, za.take((LAZY_FLAG_WORDS,), torch.int32))
-            else:
-                ops.bn_bwd_finalize_multi(jobs)
+            ops.bn_bwd_finalize_multi(jobs)
         else:
             self._bn_backward_group(itemsY, grads, one_apply=(dY, st['Y'], P))
         # attention core + aggregation backward fill the column blocks of dH

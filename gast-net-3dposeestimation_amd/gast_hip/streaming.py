@@ -196,7 +196,8 @@ class CausalStream:
                     self._step()                 # eager warm-up (lazy workspaces) before the capture
                 else:
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, **({'capture_error_mode': 'thread_local'} if (torch.distributed.is_available() and torch.distributed.is_initialized()) else {})):
+                    from model.gast_net import _no_gc          # (no cyclic collection inside a capture)
+                    with _no_gc(), torch.cuda.graph(g, **({'capture_error_mode': 'thread_local'} if (torch.distributed.is_available() and torch.distributed.is_initialized()) else {})):
                         self._step()
                     self._graph = g
                     # (the capture does not execute: run the step it recorded)

@@ -20,6 +20,7 @@ Environment knob (never a constructor argument): `GAST_HIP_DTYPE` = `fp32` (defa
 """
 import collections
 import contextlib
+import gc
 import os
 import threading
 import weakref
@@ -267,9 +268,29 @@ class _Token:
     __slots__ = ('__weakref__',)
 
 
+@contextlib.contextmanager
+def _no_gc():
+    """No cyclic garbage collection while a stream is capturing: a collection that happens to run inside the capture may finalize
+    objects of EARLIER captures (graphs, their private pools) whose destructors free device memory -- prohibited during a capture,
+    and an error inside a destructor terminates the process (seen once in the GPU suite: 'Fatal Python error: Aborted' with the
+    collector on the stack, in the middle of engine.backward under capture).  Reference counting is unaffected."""
+    was = gc.isenabled()
+    gc.disable()
+    try:
+        yield
+    finally:
+        if was:
+            gc.enable()
+
+
 def _capture_graphs(entry, runner, x, training, packer, st, bufs, engine, sink, need_grad):
     """Capture what _GastFunction.forward / .backward launch for this call as two hipGraphs sharing one memory pool: the saved
     activations of the forward capture are the operands of the backward capture.  Nothing runs here; the caller replays."""
+    with _no_gc():
+        _capture_graphs_body(entry, runner, x, training, packer, st, bufs, engine, sink, need_grad)
+
+
+def _capture_graphs_body(entry, runner, x, training, packer, st, bufs, engine, sink, need_grad):
     dev = x.device
     ops = engine.ops
     entry.x = x.clone()

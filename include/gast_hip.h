@@ -76,8 +76,6 @@ typedef struct {
     float inv_keep;
 } gast_dropout;
 
-struct gast_bn_lazy;   /* (below: a BatchNorm finalize that the launch which first consumes its result performs itself) */
-
 typedef struct {
     const void* A;       /* [rows][lda]  activation operand of this K segment */
     int lda;
@@ -134,8 +132,6 @@ typedef struct {
                             * ("mixed fp8", BASELINE.json configs[4]).  Device pointer to {s, 1/s}: every weight is multiplied by s
                             * (a power of two, gast_f8_scale_multi) before the conversion, the accumulators by 1/s; activations are
                             * converted as they are (post-BatchNorm values are O(1)).  All segments share the scale. */
-    const struct gast_bn_lazy* lazy; /* optional HOST pointer (read at launch): the BatchNorm finalize whose scale / shift a prologue segment of this
-                            * GEMM is the first to read runs inside this launch (see gast_bn_lazy).  gast_gemm_multi honours the first job's. */
 } gast_gemm_args;
 
 int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
@@ -282,13 +278,12 @@ int gast_rowsum_multi(const gast_rowsum_job* jobs, int n, gast_stream_t stream);
 /* Aggregation backward with the BatchNorm backward of its input fused in (round 5).  dY is the gradient BEFORE the backward of
  * bn_1 | bn_2 (what the preceding GEMM's BNRELU_BWD epilogue wrote), Ypre the pre-BatchNorm aggregation output of the forward
  * ([F*J][2C]: sym half, con half, like dY), ka / kb / kc the [2C] coefficients of dx = ka*dz + kb*x + kc; the kernel applies them while
- * it stages dY, so the stand-alone gast_bn_bwd_apply pass over dY (local_attention.py:139-141 backward) never runs.  `lazy`
- * (nullable): the finalize that writes ka / kb / kc runs in front of this launch.  finish: nullable, as gast_semch_agg_bwd_deferred.
+ * it stages dY, so the stand-alone gast_bn_bwd_apply pass over dY (local_attention.py:139-141 backward) never runs.
+ * finish: nullable, as gast_semch_agg_bwd_deferred.
  * Only where gast_semch_agg_bwd_fuses_bn(...) returns 1 (the LDS-staged kernel: fp32 storage, column degrees of the shipped skeletons). */
-struct gast_bn_lazy;
 int gast_semch_agg_bwd_fuses_bn(int dtype, int F, int J, int C, int nnz_sym, int cdeg_sym, int nnz_con, int cdeg_con);
 int gast_semch_agg_bwd_bn(int dtype, const void* dY, int ldy, const void* Ypre, int ldyp, const float* ka, const float* kb,
-                          const float* kc, const struct gast_bn_lazy* lazy, const void* H, int ldh, int F, int J, int C,
+                          const float* kc, const void* H, int ldh, int F, int J, int C,
                           const float* A_sym, const int32_t* pat_sym, int nnz_sym, int cdeg_sym, const float* A_con,
                           const int32_t* pat_con, int nnz_con, int cdeg_con, void* dH, int lddh, float* dA, float* ws,
                           gast_rowsum_job* finish, gast_stream_t stream);
@@ -332,37 +327,6 @@ typedef struct { const float* gamma; const float* beta; const float* running_mea
 int gast_bn_eval_multi(const gast_bn_eval_job* jobs, int n, float eps, gast_stream_t stream);
 int gast_bn_finalize_multi(const gast_bn_fin_job* jobs, int n, gast_stream_t stream);
 int gast_bn_bwd_finalize_multi(const gast_bn_bwd_fin_job* jobs, int n, gast_stream_t stream);
-/* Lazy finalize (round 5).  A finalize launch does ~1 us of work on a ~5 us launch floor, 24 times per training step.  Instead, the
- * launch that is the FIRST to read a BatchNorm's scale / shift (or the BatchNorm backward's ka / kb / kc) carries the finalize jobs: its
- * first blocks (4 columns each, the stand-alone kernels' code) run them, publish the results with a device-scope release and count
- * themselves on `flag`; every block of the launch waits (acquire) until the count is complete before it reads a coefficient.  The
- * partial sums were written by an EARLIER launch, so no producer pays a fence; blocks are dispatched in index order, so the
- * finalizing blocks are resident before any waiter can occupy their slots.  Same arithmetic, same order of summation, same
- * outputs (scale / shift / mean / rstd / running statistics, or dgamma / dbeta / ka / kb / kc) as the stand-alone finalize.
- * `flag` points at GAST_BN_LAZY_FLAG_WORDS uint32 that are ZERO when the launch starts (the plan takes them from its zero arena): one
- * word per finalizing block -- a shared counter would serialise (same-address atomics cost 50 - 170 ns apiece on this chip). */
-#define GAST_BN_LAZY_FLAG_WORDS 256
-#define GAST_BN_LAZY_MAX 2
-#define GAST_BN_LAZY_FWD 1
-#define GAST_BN_LAZY_BWD 2
-typedef struct gast_bn_lazy {
-    int kind;               /* GAST_BN_LAZY_FWD: fwd[i] (gast_bn_finalize) | GAST_BN_LAZY_BWD: bwd[i] (gast_bn_bwd_finalize) */
-    int n;                  /* 1 .. GAST_BN_LAZY_MAX jobs */
-    unsigned int* flag;     /* GAST_BN_LAZY_FLAG_WORDS device words, zero at launch */
-    gast_bn_fin_job fwd[GAST_BN_LAZY_MAX];      /* (two plain arrays, not a union: a float of one job type aliasing a pointer of the other */
-    gast_bn_bwd_fin_job bwd[GAST_BN_LAZY_MAX];  /*  costs the kernels a scratch slot)                                                    */
-} gast_bn_lazy;
-/* the streaming consumers with a lazy finalize in front (lazy == NULL: exactly the plain entry points below) */
-int gast_bn_bwd_apply_lazy(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
-                           const float* ka, const float* kb, const float* kc, const gast_bn_lazy* lazy, gast_stream_t stream);
-int gast_bnrelu_apply_lazy(int dtype, const void* X, int ldx, long rows, int N, const float* scale, const float* shift,
-                           void* Y, int ldy, int use_drop, uint32_t salt, gast_dropout drop, const gast_bn_lazy* lazy, gast_stream_t stream);
-int gast_residual_fwd_lazy(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,
-                           const void* T2, int ldt, const float* sc2, const float* sh2, int use_drop, uint32_t salt, gast_dropout drop,
-                           int B, int Tn, int J, int N, void* Xn, int ldxn, const gast_bn_lazy* lazy, gast_stream_t stream);
-int gast_expand_fwd_lazy(int dtype, const float* x, int B, int T_in, int J, int F_in, int k0, int t_stride,
-                         const float* W, const float* sc0, const float* sh0, int C,
-                         void* E, int lde, float* partials, const float* center, const gast_bn_lazy* lazy, gast_stream_t stream);
 int gast_bn_eval(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                  float eps, int N, float* scale, float* shift, int centered, gast_stream_t stream);
 /* partials hold {sum dz, sum dz*x}; writes dgamma, dbeta and the per-channel coefficients of
@@ -408,10 +372,10 @@ int gast_expand_bwd(int dtype, const void* dE, int ldde, const float* x, int B, 
                     const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate, gast_stream_t stream);
 long gast_expand_bwd_ws_floats(long rows, int C, int F_in, int k0);
 /* The same with the backward of expand_bn fused in (round 5): dE is the gradient BEFORE that BatchNorm backward, Epre ([rows][lde]) the
- * pre-BatchNorm output of the expand conv, ka / kb / kc the [C] coefficients of dz = ka*dE + kb*Epre + kc applied on load; `lazy`
- * (nullable): the finalize that writes them runs in front of the launch.  Epre == NULL: exactly gast_expand_bwd. */
+ * pre-BatchNorm output of the expand conv, ka / kb / kc the [C] coefficients of dz = ka*dE + kb*Epre + kc applied on load.
+ * Epre == NULL: exactly gast_expand_bwd. */
 int gast_expand_bwd_bn(int dtype, const void* dE, int ldde, const void* Epre, int lde, const float* ka, const float* kb, const float* kc,
-                       const struct gast_bn_lazy* lazy, const float* x, int B, int T_in, int J, int F_in, int k0,
+                       const float* x, int B, int T_in, int J, int F_in, int k0,
                        int t_stride, const float* mean0, const float* rstd0, int C, const float* W, const float* gamma0,
                        const float* beta0, float* dW, float* dgamma0, float* dbeta0, float* ws, int accumulate, gast_stream_t stream);
 

@@ -493,6 +493,89 @@ def test_gemm_small_x3_images(ops, case, pair):
     _gemm_check(case, torch.float32, bufs, 'x3h' if pair == 'f16' else 'x3')
 
 
+# the M = B*J kernel (csrc/gemm_bj.hip): every small-M case with weight images attached runs on it unless a segment carries the dropout
+# prologue (gemm.hip keeps that variant) -- row maps, K tails (168 = 5*32 + 8: a second k-group past the segment's end; 2568 = 160*16 + 8),
+# one-step K = 8, N = 3 (the shrink layer), both epilogue families, addend, centred bias, N tails
+GEMM_BJ_CASES = GEMM_CASES + GEMM_SMALL_X3_CASES + [
+    ('bj_g1_bwd_k2568', (40, 1, 17), 136, [(2568, 1, 1, 0, 0), (1024, 1, 1, 0, 0)], 2, False, False),
+    ('bj_k8_bwd', (128, 1, 17), 1024, [(8, 1, 1, 0, 0)], 2, False, False),
+    ('bj_shrink_n3', (128, 1, 17), 3, [(1024, 1, 1, 0, 1)], 0, False, False),
+    ('bj_scatter_taps_add', (50, 1, 17), 192, [(256, 1, 1, 0, 0)], 2, True, False),
+    ('bj_wide_n2568', (33, 1, 17), 2568, [(128, 1, 1, 0, 0)], 0, False, True),
+    ('bj_two_pro_tables', (20, 3, 15), 100, [(200, 3, 1, 0, 1), (72, 5, 1, 2, 1), (40, 3, 1, 0, 0)], 1, True, 'neg'),
+]
+
+
+def _bj_expected(case, f16):
+    if any(sd[4] == 2 for sd in case[3]) or (f16 and case[4] == 2):
+        return 0
+    return 2
+
+
+@pytest.mark.parametrize('pair', PAIRS)
+@pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
+@pytest.mark.parametrize('case', GEMM_BJ_CASES, ids=[c[0] for c in GEMM_BJ_CASES])
+def test_gemm_bj_x3(ops, case, nodrop, pair, monkeypatch):
+    if nodrop and case[4] != 2:
+        pytest.skip('only the BNRELU_BWD epilogue has a dropout variant')
+    f16 = pair == 'f16'
+    outs = []
+    for rep in range(2):
+        jd, jh, bufs = _gemm_case(case, torch.float32)
+        if nodrop:
+            jd['xdrop'] = jh['xdrop'] = False
+        with x3_mode(ops, 'x3'):
+            assert ops.gemm_path(**_with_images(ops, jd, f16)) == _bj_expected(case, f16), 'kernel selection (gemm_bj.hip = 2)'
+            ops.gemm(**jd)
+        torch.cuda.synchronize()
+        outs.append(bufs)
+    kc.gemm(**jh)
+    _gemm_check(case, torch.float32, outs[1], 'x3h' if f16 else 'x3')
+    if _bj_expected(case, f16) == 2:      # no cross-block reduction on the output, two commutative adds per statistics element
+        _assert_bit_equal(outs[1][0], outs[0][0], case[0] + ': output of two runs')
+        if case[4]:
+            _assert_bit_equal(outs[1][2].view(outs[1][2].shape[0], -1), outs[0][2].view(outs[0][2].shape[0], -1), case[0] + ': column statistics of two runs')
+
+
+@pytest.mark.parametrize('pair', PAIRS)
+@pytest.mark.parametrize('first', list(range(0, len(GEMM_BJ_CASES), 3)))
+def test_gemm_bj_x3_multi(ops, first, pair):
+    """the same cases as jobs of multi-job launches (3 per call; a call may mix the M = B*J kernel with gemm.hip's for a dropout prologue)"""
+    cases = GEMM_BJ_CASES[first:first + 3]
+    built = [_gemm_case(c, torch.float32) for c in cases]
+    f16 = pair == 'f16'
+    with x3_mode(ops, 'x3'):
+        ops.gemm_multi([_with_images(ops, jd, f16) for jd, _, _ in built])
+    torch.cuda.synchronize()
+    for c, (jd, jh, bufs) in zip(cases, built):
+        kc.gemm(**jh)
+        _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
+
+
+@pytest.mark.parametrize('case', [c for c in GEMM_BJ_CASES if c[4] == 2], ids=lambda c: c[0])
+def test_gemm_bj_second_output(ops, case):
+    """gast_gemm_args.C2 on the M = B*J kernel, with and without an addend: bit-equal to the PLAIN epilogue of the same GEMM; C and
+    the column sums unchanged by it"""
+    jd, jh, bufs = _gemm_case(case, torch.float32)
+    N = case[2]
+    with x3_mode(ops, 'x3'):
+        _with_images(ops, jd)
+        assert ops.gemm_path(**jd) == 2
+        ops.gemm(**jd)
+        torch.cuda.synchronize()
+        C_ref, part_ref = bufs[0].clone(), bufs[2].clone()
+        plain = torch.full_like(bufs[0], 7.0)
+        ops.gemm(**dict(jd, C_=plain[:, :N], epi=0, partials=None, X=None, xscale=None, xshift=None, xdrop=False))
+        bufs[0].fill_(7.0)
+        bufs[2].zero_()
+        C2 = torch.full_like(bufs[0], 7.0)
+        ops.gemm(**dict(jd, C2=C2[:, :N]))
+        torch.cuda.synchronize()
+    _assert_bit_equal(bufs[0], C_ref, 'the masked output (C) of the call WITH a second output vs the call without')
+    _assert_bit_equal(C2, plain, 'C2 vs the PLAIN epilogue of the same GEMM')
+    _assert_bit_equal(bufs[2].view(bufs[2].shape[0], -1), part_ref.view(part_ref.shape[0], -1), 'column sums')
+
+
 def test_x3_image_layout(ops):
     """k-group-major image: img[k>>4][r][k&15] = bf16(w), [...][16 + (k&15)] = bf16(w - hi); zero K padding and zero rows behind"""
     gen = torch.Generator().manual_seed(11)
@@ -1165,7 +1248,7 @@ def test_stream_shift_multi(ops):
         assert np.array_equal(b.cpu().numpy(), hb)
 
 
-# ------------------------------------------------------------------------------------------------ lazy BatchNorm finalize (round 5)
+# ------------------------------------------------------------------------------------------------ BatchNorm backward fused into its one reader (round 5)
 def _bn_jobs(gen, specs, nblk=37):
     """forward finalize jobs over random partial sums; specs = [(col0, N)] slices of ONE partial buffer (like bn_1 | bn_2)"""
     ncol = max(c0 + n for c0, n in specs) + 4
@@ -1185,201 +1268,9 @@ def _bn_jobs(gen, specs, nblk=37):
     return jobs, tot
 
 
-def _bn_state(jobs, tot):
-    """fresh outputs (one concatenated scale / shift / mean / rstd like engine.BNState) + private copies of the running statistics"""
-    st = {k: torch.full((tot,), float('nan')).cuda() for k in ('scale', 'shift', 'mean', 'rstd')}
-    out, o = [], 0
-    for j in jobs:
-        n = j['N']
-        d = dict(j, running_mean=j['running_mean'].clone(), running_var=j['running_var'].clone(), nbt=j['nbt'].clone(),
-                 **{k: st[k][o:o + n] for k in st})
-        out.append(d)
-        o += n
-    return out, st
-
-
-def _same_bn(a_jobs, a_st, b_jobs, b_st):
-    for k in a_st:
-        _assert_bit_equal(b_st[k].view(1, -1), a_st[k].view(1, -1), 'lazy finalize: ' + k)
-    for a, b in zip(a_jobs, b_jobs):
-        assert torch.equal(a['running_mean'], b['running_mean']) and torch.equal(a['running_var'], b['running_var'])
-        assert int(b['nbt'].item()) == int(a['nbt'].item()) == 6
-
-
-def _flag():
-    return torch.zeros(256, dtype=torch.int32).cuda()      # GAST_BN_LAZY_FLAG_WORDS
-
-
-@pytest.mark.parametrize('rows', [8, 5000])
-@pytest.mark.parametrize('consumer', ['bnrelu_apply', 'residual_fwd'])
-def test_lazy_finalize_in_a_streaming_consumer(ops, consumer, rows):
-    """gast_bn_lazy: the finalize jobs run inside the consumer launch -- coefficients, running statistics and the consumer's output are
-    BIT-equal to finalize launch + consumer launch.  rows = 8: one block runs all 136 column units itself."""
-    gen = torch.Generator().manual_seed(21)
-    specs = [(0, 416), (416, 128)] if consumer == 'bnrelu_apply' else [(0, 544)]
-    jobs, N = _bn_jobs(gen, specs)
-    B, Tn, J = (1, 1, rows) if rows < 100 else (rows // (17 * 4), 4, 17)
-    P = B * Tn * J
-    X = rand(gen, P, N).cuda()
-    O = rand(gen, B * (Tn + 2) * J, N).cuda()
-    scO, shO = (torch.rand(N, generator=gen) + 0.5).cuda(), rand(gen, N).cuda()
-    outs = []
-    for lazy in (False, True):
-        js, st = _bn_state(jobs, N)
-        tok = None
-        if lazy:
-            tok = ops.bn_lazy_fwd(js, _flag())
-        else:
-            ops.bn_finalize_multi(js)
-        Y = torch.full((P, N), float('nan')).cuda()
-        kw = {'lazy': tok} if lazy else {}
-        if consumer == 'bnrelu_apply':
-            ops.bnrelu_apply(X, P, N, st['scale'], st['shift'], Y, **kw)
-        else:
-            ops.residual_fwd(O, kc.RowMap(Tn + 2, 1, 1), scO, shO, X, st['scale'], st['shift'], False, 0, None, B, Tn, J, N, Y, **kw)
-        torch.cuda.synchronize()
-        outs.append((js, st, Y))
-    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
-    _assert_bit_equal(outs[1][2], outs[0][2], consumer + ' output with the lazy finalize')
-    assert torch.isfinite(outs[1][2]).all()
-
-
-def test_lazy_finalize_in_expand_fwd(ops):
-    gen = torch.Generator().manual_seed(22)
-    B, T_in, J, F_in, k0, C = 6, 9, 17, 2, 3, 64
-    x = rand(gen, B, T_in, J, F_in).cuda()
-    rows_in = B * T_in * J
-    nb = ops.input_stats_blocks(rows_in)
-    W = rand(gen, C, F_in, k0).cuda()
-    outs = []
-    for lazy in (False, True):
-        part = torch.empty(nb, F_in, 2).cuda()
-        ops.input_stats(x, rows_in, F_in, part)
-        jobs = [dict(partials=part, nblk=nb, col0=0, N=F_in, count=float(rows_in), gamma=torch.tensor([1.5, 0.7]).cuda(),
-                     beta=torch.tensor([0.1, -0.2]).cuda(), running_mean=torch.zeros(F_in).cuda(), running_var=torch.ones(F_in).cuda(),
-                     nbt=torch.tensor(5, dtype=torch.int64).cuda(), momentum=0.1, eps=1e-5)]
-        js, st = _bn_state(jobs, F_in)
-        P0 = B * (T_in - k0 + 1) * J
-        E = torch.full((P0, C), float('nan')).cuda()
-        pe = torch.full((ops.rowwise_blocks(P0, C), C, 2), float('nan')).cuda()
-        if lazy:
-            ops.expand_fwd(x, B, T_in, J, F_in, k0, 1, W, st['scale'], st['shift'], C, E, pe, lazy=ops.bn_lazy_fwd(js, _flag()))
-        else:
-            ops.bn_finalize_multi(js)
-            ops.expand_fwd(x, B, T_in, J, F_in, k0, 1, W, st['scale'], st['shift'], C, E, pe)
-        torch.cuda.synchronize()
-        outs.append((js, st, E, pe))
-    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
-    _assert_bit_equal(outs[1][2], outs[0][2], 'expand_fwd output with the lazy finalize')
-    _assert_bit_equal(outs[1][3].view(-1, 2 * C), outs[0][3].view(-1, 2 * C), 'expand_fwd partial sums with the lazy finalize')
-
-
-@pytest.mark.parametrize('rows', [40, 9000])
-def test_lazy_backward_finalize_in_bn_bwd_apply(ops, rows):
-    gen = torch.Generator().manual_seed(23)
-    specs = [(0, 256), (256, 64)]
-    fj, N = _bn_jobs(gen, specs)
-    outs = []
-    dz0, X = rand(gen, rows, N).cuda(), rand(gen, rows, N).cuda()
-    mean, rstd = rand(gen, N).cuda(), (torch.rand(N, generator=gen) + 0.5).cuda()
-    for lazy in (False, True):
-        o, jobs = 0, []
-        ka, kb, kcf = (torch.full((N,), float('nan')).cuda() for _ in range(3))
-        for j in fj:
-            n = j['N']
-            jobs.append(dict(partials=j['partials'], nblk=j['nblk'], col0=j['col0'], N=n, count=j['count'], gamma=j['gamma'], mean=mean[o:o + n],
-                             rstd=rstd[o:o + n], dgamma=torch.full((n,), 0.25).cuda(), dbeta=torch.full((n,), -0.5).cuda(),
-                             ka=ka[o:o + n], kb=kb[o:o + n], kc=kcf[o:o + n], accumulate=True))
-            o += n
-        dz = dz0.clone()
-        if lazy:
-            ops.bn_bwd_apply(dz, X, rows, N, ka, kb, kcf, lazy=ops.bn_lazy_bwd(jobs, _flag()))
-        else:
-            ops.bn_bwd_finalize_multi(jobs)
-            ops.bn_bwd_apply(dz, X, rows, N, ka, kb, kcf)
-        torch.cuda.synchronize()
-        outs.append((jobs, ka, kb, kcf, dz))
-    for i, name in ((1, 'ka'), (2, 'kb'), (3, 'kc')):
-        _assert_bit_equal(outs[1][i].view(1, -1), outs[0][i].view(1, -1), 'lazy backward finalize: ' + name)
-    for a, b in zip(outs[0][0], outs[1][0]):
-        assert torch.equal(a['dgamma'], b['dgamma']) and torch.equal(a['dbeta'], b['dbeta'])
-    _assert_bit_equal(outs[1][4], outs[0][4], 'bn_bwd_apply output with the lazy finalize')
-
-
-LAZY_GEMM = [('dilated_taps', 'f32'), ('splitk_stats', 'f32'), ('big_taps_pro_stats', 'x3'), ('big_taps_pro_stats', 'x3h'),
-             ('big_taps_pro_stats', 'bf16'), ('small_stats_k1536', 'x3')]
-
-
-@pytest.mark.parametrize('name,mode', LAZY_GEMM, ids=['%s-%s' % c for c in LAZY_GEMM])
-def test_lazy_finalize_in_a_gemm(ops, name, mode):
-    """a GEMM whose prologue segments read the scale / shift of a BatchNorm finalized INSIDE the launch: the 128x128-tile kernel (with
-    and without split-K) and the large-M kernel (bf16 and fp16 pairs), bit-equal to finalize launch + GEMM launch"""
-    case = {c[0]: c for c in GEMM_CASES + GEMM_BIG_CASES + GEMM_SMALL_X3_CASES}[name]
-    dt = MM_DT[mode]
-    gen = torch.Generator().manual_seed(24)
-    pro_K = sorted({sd[0] for sd in case[3] if sd[4] == 1})
-    assert len(pro_K) == 1, 'the case needs prologue segments of one width'
-    K = pro_K[0]
-    jobs, N = _bn_jobs(gen, [(0, K)])
-    outs = []
-    for lazy in (False, True):
-        jd, _, bufs = _gemm_case(case, dt)
-        js, st = _bn_state(jobs, K)
-        for sg in jd['segs']:
-            if sg['pro'] == 1:
-                sg['scale'], sg['shift'] = st['scale'], st['shift']
-        with x3_mode(ops, mode):
-            if mode in ('x3', 'x3h'):
-                _with_images(ops, jd, mode == 'x3h')
-            if lazy:
-                ops.gemm(**dict(jd, lazy=ops.bn_lazy_fwd(js, _flag())))
-            else:
-                ops.bn_finalize_multi(js)
-                ops.gemm(**jd)
-        torch.cuda.synchronize()
-        outs.append((js, st, bufs[0], bufs[2]))
-    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
-    _assert_bit_equal(outs[1][2], outs[0][2], 'GEMM output with the lazy finalize')
-    if name.startswith('big_'):      # (few output tiles -> split-K: its finish pass adds the column statistics with atomics)
-        _assert_bit_equal(outs[1][3].view(outs[1][3].shape[0], -1), outs[0][3].view(outs[0][3].shape[0], -1), 'GEMM column statistics with the lazy finalize')
-    else:
-        close(host(outs[1][3]).sum(axis=0), host(outs[0][3]).sum(axis=0), dt, 'GEMM column statistics with the lazy finalize', fp32=1e-5, bf16=1e-5)
-    assert torch.isfinite(outs[1][2]).all()
-
-
-def test_lazy_finalize_in_a_multi_job_gemm(ops):
-    """G2 | G3 of a block: the first job's prologue reads bn_1 | bn_2 (two finalize jobs), the second has none -- one grid, one wait"""
-    gen = torch.Generator().manual_seed(25)
-    cases = {c[0]: c for c in GEMM_CASES + GEMM_BIG_CASES}
-    c0 = [c for c in GEMM_CASES if any(sd[4] == 1 for sd in c[3]) and len({sd[0] for sd in c[3] if sd[4] == 1}) == 1][0]
-    c1 = [c for c in GEMM_CASES if all(sd[4] == 0 for sd in c[3]) and c[4] != 2][0]
-    K = [sd[0] for sd in c0[3] if sd[4] == 1][0]
-    half = K // 2 // 4 * 4
-    jobs, N = _bn_jobs(gen, [(0, half), (half, K - half)])
-    outs = []
-    for lazy in (False, True):
-        a, _, ba = _gemm_case(c0, torch.float32)
-        b, _, bb = _gemm_case(c1, torch.float32)
-        js, st = _bn_state(jobs, K)
-        for sg in a['segs']:
-            if sg['pro'] == 1:
-                sg['scale'], sg['shift'] = st['scale'], st['shift']
-        if lazy:
-            ops.gemm_multi([dict(a, lazy=ops.bn_lazy_fwd(js, _flag())), b])
-        else:
-            ops.bn_finalize_multi(js)
-            ops.gemm_multi([a, b])
-        torch.cuda.synchronize()
-        outs.append((js, st, ba[0], bb[0]))
-    _same_bn(outs[0][0], outs[0][1], outs[1][0], outs[1][1])
-    _assert_bit_equal(outs[1][2], outs[0][2], 'job 0 output with the lazy finalize')
-    _assert_bit_equal(outs[1][3], outs[0][3], 'job 1 output with the lazy finalize')
-
-
 @pytest.mark.parametrize('J,C,F', [(17, 256, 700), (19, 128, 50), (17, 64, 3), (15, 32, 41)])
 def test_agg_bwd_with_the_batchnorm_backward_fused(ops, J, C, F):
-    """gast_semch_agg_bwd_bn: the aggregation backward applies ka*dY + kb*Y + kc while it stages dY (coefficients from a lazy finalize in
-    front): dH, dA and the BatchNorm parameter gradients are bit-equal to finalize launch + apply launch + aggregation launch"""
+    """gast_semch_agg_bwd_bn: the aggregation backward applies ka*dY + kb*Y + kc while it stages dY: dH, dA and the BatchNorm parameter gradients are bit-equal to finalize launch + apply launch + aggregation launch"""
     gen = torch.Generator().manual_seed(J * C + F)
     ps, pc = patterns(J)
     P = F * J
@@ -1412,8 +1303,8 @@ def test_agg_bwd_with_the_batchnorm_backward_fused(ops, J, C, F):
         dA = torch.full((ns + nc, C), 9.0).cuda()
         ws = torch.empty(ops.semch_agg_bwd_ws(F, C, ns, nc)).cuda()
         if fused:
-            ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg, bn=(Yp, kabc[0], kabc[1], kabc[2]),
-                              lazy=ops.bn_lazy_bwd(jobs, _flag()))
+            ops.bn_bwd_finalize_multi(jobs)
+            ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg, bn=(Yp, kabc[0], kabc[1], kabc[2]))
             assert torch.equal(dY, dY0), 'the fused form must not rewrite dY'
         else:
             ops.bn_bwd_finalize_multi(jobs)
@@ -1421,7 +1312,7 @@ def test_agg_bwd_with_the_batchnorm_backward_fused(ops, J, C, F):
             ops.semch_agg_bwd(dY, H, F, J, C, As, dev(ps), Ac, dev(pc), dH, dA, ws, cdeg=cdeg)
         torch.cuda.synchronize()
         outs.append((jobs, kabc, dH, dA))
-    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc of the lazy finalize')
+    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc')
     for a, b in zip(outs[0][0], outs[1][0]):
         assert torch.equal(a['dgamma'], b['dgamma']) and torch.equal(a['dbeta'], b['dbeta'])
     _assert_bit_equal(outs[1][2], outs[0][2], 'dH of the aggregation backward with the BatchNorm backward fused')
@@ -1430,7 +1321,7 @@ def test_agg_bwd_with_the_batchnorm_backward_fused(ops, J, C, F):
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
 def test_expand_bwd_with_the_batchnorm_backward_fused(ops, dt):
-    """gast_expand_bwd_bn: dz = ka*dE + kb*E + kc applied while dE is loaded (coefficients from a lazy finalize in front) -- parameter
+    """gast_expand_bwd_bn: dz = ka*dE + kb*E + kc applied while dE is loaded -- parameter
     gradients bit-equal to finalize launch + apply launch + expand_bwd launch"""
     gen = torch.Generator().manual_seed(31)
     B, T_in, J, F_in, k0, C = 7, 9, 17, 2, 3, 64
@@ -1451,15 +1342,15 @@ def test_expand_bwd_with_the_batchnorm_backward_fused(ops, dt):
         dE = dE0.clone()
         dW, dg0, db0 = torch.zeros(C, F_in, k0).cuda(), torch.zeros(F_in).cuda(), torch.zeros(F_in).cuda()
         if fused:
-            ops.expand_bwd(dE, x, B, T_in, J, F_in, k0, 1, mean0, rstd0, C, W, g0, b0, dW, dg0, db0, bn=(E, kabc[0], kabc[1], kabc[2]),
-                           lazy=ops.bn_lazy_bwd([job], _flag()))
+            ops.bn_bwd_finalize_multi([job])
+            ops.expand_bwd(dE, x, B, T_in, J, F_in, k0, 1, mean0, rstd0, C, W, g0, b0, dW, dg0, db0, bn=(E, kabc[0], kabc[1], kabc[2]))
         else:
             ops.bn_bwd_finalize_multi([job])
             ops.bn_bwd_apply(dE, E, P0, C, kabc[0], kabc[1], kabc[2])
             ops.expand_bwd(dE, x, B, T_in, J, F_in, k0, 1, mean0, rstd0, C, W, g0, b0, dW, dg0, db0)
         torch.cuda.synchronize()
         outs.append((job, kabc, dW, dg0, db0))
-    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc of the lazy finalize')
+    _assert_bit_equal(outs[1][1], outs[0][1], 'ka / kb / kc')
     assert torch.equal(outs[0][0]['dgamma'], outs[1][0]['dgamma']) and torch.equal(outs[0][0]['dbeta'], outs[1][0]['dbeta'])
     _assert_bit_equal(outs[1][2].view(C, -1), outs[0][2].view(C, -1), 'dW of the expand conv with the BatchNorm backward fused')
     # (dgamma0 / dbeta0: the finish pass adds 16 x 3 block sums per address with atomics)

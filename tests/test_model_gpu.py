@@ -1012,10 +1012,9 @@ def test_fused_parameter_packing_equals_the_three_launch_path(ch, arc, variant, 
 
 
 
-@pytest.mark.parametrize('switch', ['GAST_LAZY_BN=1', 'GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0'], ids=['lazy_finalize', 'round4_plan'])
+@pytest.mark.parametrize('switch', ['GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0'], ids=['round4_plan'])
 def test_round5_plan_switches_agree_with_the_default(switch, mode2, monkeypatch):
-    """The opt-in lazy BatchNorm finalize (gast_bn_lazy: finalize jobs inside the first consumer launch) and the bisecting switches that
-    restore the round-4 plan (stand-alone bn_bwd_apply over dY / dE, materialised first-block input) compute the same training step as the
+    """The bisecting switches that restore the round-4 plan (stand-alone bn_bwd_apply over dY / dE, materialised first-block input) compute the same training step as the
     default plan: same arithmetic, same order inside every kernel -- the only run-to-run freedom is the order of the split reductions, so
     the comparison is at round-off level, not bitwise."""
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3, 3], channels=64, causal=False, variant='dilated')
