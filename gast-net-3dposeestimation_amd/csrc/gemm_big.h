@@ -30,6 +30,7 @@ struct BjPlan {
     int pair;                     // 1 = bf16 hi/lo, 2 = fp16 hi/lo
     int ntab;
     int taboff[GAST_MAX_SEG];
+    int ablate;                   // GAST_GEMM_BJ_ABLATE (profiling aid, results are wrong when set): 1 no statistics atomics, 2 no epilogue, 4 no K loop
 };
 __attribute__((visibility("hidden"))) int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl);
 __attribute__((visibility("hidden"))) int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hipStream_t st);

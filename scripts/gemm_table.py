@@ -46,9 +46,13 @@ def timeit(fn, a, k, reps=20):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 
+MAXM = int(os.environ.get('GEMM_TABLE_MAXM', '0'))      # only the launches with at most this many rows (0: all)
 tot = 0.0
 print('%-12s %-34s %9s %9s %8s %8s %8s' % ('op', 'shape', 'GFLOP', 'MB', 'us', 'TF/s', 'GB/s'))
 for name, fn, a, k in calls:
+    rows_ = (a[0][0] * a[0][1] * a[0][2]) if name == 'gemm' else (a[0][0]['dom'][0] * a[0][0]['dom'][1] * a[0][0]['dom'][2])
+    if MAXM and rows_ > MAXM:
+        continue
     if name == 'gemm':
         fl, by = kt.cost_gemm(*a, **k)
         dom, N, segs = a[0], a[1], a[2]

@@ -6,14 +6,19 @@
 // per block.  Rounds 1-5 ran it on gemm.hip's 128 x 128 kernel with a CROSS-block split-K (fp32 partial tiles out to a workspace and
 // back through a finish launch: 4.3 x the algorithmic bytes, two launches per GEMM, 0.08 of the HBM roof).  Here the split is INSIDE
 // the block:
-//   * block tile 64 x 64 (NJ = 1) or 64 x 128 (NJ = 2), 512 threads = 8 waves = 2 k-groups x (2 x 2) waves of 32 x 32 NJ; a K step
-//     covers 32 values, k-group g multiplies the 16-deep half g of every step -- each wave's dependent MFMA chain is half as long, 34
-//     row tiles x N / 64 blocks fill the chip without a workspace (272 blocks for N = 512), two blocks = 4 waves per SIMD cover each
-//     other's barrier / LDS / VALU phases;
+//   * block tile 64 x 64 (NJ = 1) or 64 x 128 (NJ = 2), 512 threads = 8 waves = 2 k-groups x (2 x 2) waves of 32 x 32 NJ, ONE block
+//     per CU; a K step covers 64 values (four 16-deep sub-tiles), k-group g multiplies sub-tiles 2g, 2g + 1 -- each wave's dependent
+//     chain is half as long, 34 row tiles x N / 64 blocks fill the chip without a workspace (272 blocks for N = 512);
+//   * a wave issues one instruction per four cycles, and a K step is one chain through a barrier: what bounds this loop is the
+//     INSTRUCTION COUNT per step, whatever the unit (measured on the first version of this file: 190 instructions for 3 MFMAs per
+//     32-value step = 0.55 us per step, the same with a third of the VALU work removed).  Hence 64 values per step, operand streams
+//     advanced by pointer increments in scalar registers, every LDS stage / register-set index a compile-time constant (the loop is
+//     unrolled over the stage periods), zero rows / K tails / the prologue as block-uniform branches off the common path:
+//     ~80 instructions for 6 MFMAs (NJ = 1);
 //   * operands as in gemm_big.hip: weights stream global -> LDS by DMA (global_load_lds_dwordx4) from the pre-split k-group-major
-//     image (gast_x3_image_multi) into a ring of three stages, activations pass through registers (BN+ReLU prologue, hi/lo split) into
-//     two LDS stages, prefetch distance two, ONE counted s_waitcnt and one barrier per K step; 64-byte row images [16 hi | 16 lo]
-//     with the same XOR swizzle;
+//     image (gast_x3_image_multi) into a ring of 4 (NJ = 1) / 3 (NJ = 2) stages, activations pass through 4 / 3 register sets
+//     (BN+ReLU prologue, hi/lo split) into two LDS stages, ONE counted s_waitcnt and one barrier per K step; 64-byte row images
+//     [16 hi | 16 lo] with the same XOR swizzle;
 //   * the two k-groups' accumulators meet in LDS after the loop (each group keeps the rows it then finishes: half of the epilogue
 //     per wave), in a fixed order: no atomics on the output, results are run-to-run reproducible;
 //   * branch-free buffer-addressed epilogue straight from the accumulators; the column statistics of a 64-row block are ADDED
@@ -28,17 +33,17 @@
 
 namespace {
 
-constexpr int ROWB = 64;                         // LDS row image of one 16-deep k-group: 16 x 16-bit hi | 16 x 16-bit lo
-constexpr int TM = 64, NT = 512, KG = 2;
-constexpr int OFF_BAD = 2 * TM * 4;              // crow[TM] | addrow[TM] in front, then the per-row zero-row flags
-constexpr int OFF_A = OFF_BAD + TM * 4;
-constexpr int A_BYTES = KG * TM * ROWB;          // 8 KB per stage
+constexpr int ROWB = 64;                         // LDS row image of one 16-deep sub-tile: 16 x 16-bit hi | 16 x 16-bit lo
+constexpr int TM = 64, NT = 512, KG = 2, KS = 64, NSUB = KS / 16;
+constexpr int OFF_A = 2 * TM * 4;                // crow[TM] | addrow[TM] in front
+constexpr int A_BYTES = NSUB * TM * ROWB;        // 16 KB per stage
 constexpr int OFF_W = OFF_A + 2 * A_BYTES;
-constexpr int WS = 4;                            // weight stages
 constexpr int tn_of(int nj) { return 64 * nj; }
-constexpr int w_bytes(int nj) { return KG * tn_of(nj) * ROWB; }          // 8 KB per stage at the 64-column tile
-constexpr int off_tab(int nj) { return OFF_W + WS * w_bytes(nj); }
-constexpr int LDS_BLOCK = 64 * 1024;             // two blocks per CU with room to spare
+constexpr int ws_of(int nj) { return nj == 1 ? 4 : 3; }                  // weight stages
+constexpr int na_of(int nj) { return nj == 1 ? 4 : 3; }                  // activation register sets
+constexpr int w_bytes(int nj) { return NSUB * tn_of(nj) * ROWB; }        // 16 KB / 32 KB per stage
+constexpr int off_tab(int nj) { return OFF_W + ws_of(nj) * w_bytes(nj); }
+constexpr int LDS_BLOCK = 160 * 1024;            // one block per CU
 constexpr int max_tab(int nj) { return (LDS_BLOCK - off_tab(nj)) / 8; }
 
 template <int OFF>
@@ -47,6 +52,13 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
 }
 __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// a wave-uniform pointer the compiler's divergence analysis lost track of (loop-carried through a lambda): back into scalar registers
+__device__ __forceinline__ const char* uni(const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
 struct Frag { uint4 u; };
@@ -143,8 +155,8 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
     if (EPI != 0) {
         // column sums of the block's 64 rows: the two lane halves by shuffle, the four waves (kg, wr) of a column half through LDS
         // (the K loop's stages are free by now), then ONE add per column into the 128-row statistics block
-        float* const sRed = (float*)(smem + OFF_W + 2 * w_bytes(NJ));
-        static_assert(OFF_W + 2 * w_bytes(NJ) >= OFF_A + 2 * NJ * 8 * 256 * 4, "sRed overlaps the exchange buffer");      // [4][TN][2]: the third weight stage (the accumulator exchange uses the space in front)
+        float* const sRed = (float*)(smem + OFF_W);      // [4][TN][2], behind the accumulator exchange (OFF_A .. OFF_A + 16 NJ KB)
+        static_assert(OFF_W >= OFF_A + 2 * NJ * 8 * 256 * 4, "sRed overlaps the exchange buffer");
         (void)M;
 #pragma unroll
         for (int q = 0; q < NJ; ++q) {
@@ -171,25 +183,24 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
 }
 
 // PAIR: 1 = bf16 hi/lo pairs (GAST_F32X3), 2 = fp16 pairs (GAST_F32X3H: forward epilogues, images of the f16 kind)
-//
-// The K loop.  Three operand streams run ahead of the MFMAs, each with its own tile generator in scalar registers (a queue of full
-// tile descriptors cost 140 spilled SGPRs):
-//   * weights: DMA into a ring of WS = 4 stages, DW = 3 steps ahead;
-//   * activations: NA = 4 register sets, loaded 5 steps ahead, converted (prologue + hi/lo split) one step ahead into 2 LDS stages;
-//   * conversion facts (prologue? zero rows / K tail? scale / shift of the thread's 4 values): one step ahead of the conversion.
-// The loop is unrolled by 4 so that every stage / register-set index is a compile-time constant (LDS offsets are immediates); zero
-// rows / K tails and the prologue are block-uniform branches off the common path.
 template <int NJ, int PAIR>
 __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& pl, int blk, unsigned char* smem) {
-    static_assert(NJ == 1, "the stage budget below is the 64-column tile's");
-    constexpr int TN = tn_of(NJ), W_BYTES = w_bytes(NJ), OFF_TAB = off_tab(NJ);
-    constexpr int NW = NJ;                           // 1 KB DMA pieces per wave and K step
+    constexpr int TN = tn_of(NJ), W_BYTES = w_bytes(NJ), OFF_TAB = off_tab(NJ), WS = ws_of(NJ), NA = na_of(NJ);
+    constexpr int NWP = 2 * NJ;                      // 1 KB DMA pieces per wave and K step
+    constexpr int DW = WS - 1;                       // the weights of tile t + DW are requested in step t
+    constexpr int UNROLL = NJ == 1 ? 4 : 6;          // a common multiple of 2 (activation stages), WS and NA
+    static_assert(UNROLL % 2 == 0 && UNROLL % WS == 0 && UNROLL % NA == 0, "unroll period");
+    // transfers that may still be in flight at the top of a step: everything requested after the weights of tile t (the activations
+    // of tile t + 1 are older): the 2 activation loads of that step + (DW - 1) full steps
+    constexpr int INFLIGHT = 2 + (DW - 1) * (NWP + 2);
+    static_assert(INFLIGHT <= (NA - 1) * (NWP + 2), "the activations of tile t + 1 must be older than the weights of tile t");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kg = w >> 2, wr = (w >> 1) & 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int M = pl.M;
+    if (pl.ablate & 256) return;
     // tile order: a contiguous chunk of the logical order runs on one XCD (xcd_remap), i.e. shares one L2.  Every activation row is
-    // read by all N / 64 column tiles and every weight row by all M / 64 row tiles; the operand that is re-fetched per XCD should be the
+    // read by all N / TN column tiles and every weight row by all M / 64 row tiles; the operand that is re-fetched per XCD should be the
     // SMALLER one: M >= N (most GEMMs of the stage: N = 512 / 1024 against 2 176 rows) -> the column tiles of one row tile are
     // consecutive (activations cross the fabric once, the weight panel once per XCD), else (G1: N = 5C + 8) the other way round.
     const int lb = xcd_remap(blk, pl.tilesM * pl.tilesN);
@@ -200,21 +211,18 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
 
     int* const sCrow = (int*)smem;
     int* const sAdd = sCrow + TM;
-    int* const sBad = (int*)(smem + OFF_BAD);        // [TM]: bit s = segment s maps this tile row to a row that must read as zero
-    float* const sSc = (float*)(smem + OFF_TAB);
-    float* const sSh = sSc + pl.ntab;
     const int nseg = a.nseg;
 
-    // ---- staging duties.  Activations: thread = (row ra_row of the tile, 16-byte chunk c8 of the 32-value step: k-group c8 >> 2,
-    // chunk c8 & 3 of its 16 values)
-    const int ra_row = tid >> 3, c8 = tid & 7, kgA = c8 >> 2, cA = c8 & 3;
+    // ---- staging duties.  Activations: thread = (row ra_row of the tile, 16-byte chunk c8 of each 32-value half of the step):
+    // half h, chunk c8 = values 32 h + 4 c8 .. + 3 = sub-tile 2 h + (c8 >> 2), chunk c8 & 3 of its 16 values
+    const int ra_row = tid >> 3, c8 = tid & 7, cA = c8 & 3;
     const int TJ = a.Tn * a.J;
     int pb = -1, pt = 0, pj = 0;
     {
         const int m = m0 + ra_row;
         if (m < M) { pb = m / TJ; const int rem = m - pb * TJ; pt = rem / a.J; pj = rem - pt * a.J; }
     }
-    if (c8 == 0) {          // one thread per tile row: output / addend rows, and which segments read this row as zero
+    if (c8 == 0) {          // one thread per tile row: output / addend rows
         int crow = -1, arow = -1;
         if (pb >= 0) {
             crow = (int)map_row(a.cmap, pb, pt, pj, a.J);
@@ -222,104 +230,142 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
         }
         sCrow[ra_row] = crow;
         sAdd[ra_row] = arow;
-        int bad = 0;
-        for (int s = 0; s < nseg; ++s) {
-            const int ts = pt * a.seg[s].map.t_stride + a.seg[s].map.t_off;
-            if (pb < 0 || ts < 0 || ts >= a.seg[s].map.T_total) bad |= 1 << s;
-        }
-        sBad[ra_row] = bad;
     }
+    // can a tile of segment s contain a row that must read as zero?  (block-uniform, conservative: the host knows which segments map
+    // every position of the domain -- pl.segfull -- and only the last row tile can run past M)
+    const bool tile_partial = m0 + TM > M;
 
-    // ---- the activation-load stream (tile t + 5 at step t)
-    struct Gen { int seg, k0, K; };
-    auto advance = [&](Gen& g) -> bool {             // next tile; past the last tile: stay.  true: entered a new segment
-        g.k0 += 32;
-        if (g.k0 < g.K) return false;
-        if (g.seg + 1 < nseg) { ++g.seg; g.k0 = 0; g.K = a.seg[g.seg].K; return true; }
-        g.k0 -= 32;
-        return false;
-    };
-    Gen ga = {0, 0, a.seg[0].K};
-    const char* A_l = (const char*)a.seg[0].A;
+    // ---- the three operand streams: {segment, values left in the segment from the current tile on, pointer}
+    // activation loads (tile t + 1 + NA at step t)
+    int a_seg = 0, a_rem = a.seg[0].K;
+    const char* a_ptr = (const char*)a.seg[0].A;
     uint32_t offA = 0;
-    bool zrow = true;
-    auto enter_a = [&]() {
-        const gast_gemm_seg& sg = a.seg[ga.seg];
-        A_l = (const char*)sg.A;
+    int zmask = 0;                                   // bit s: this thread's row reads as zero in segment s
+    auto row_of = [&](const gast_gemm_seg& sg, bool& ok) -> uint32_t {
         const int ts = pt * sg.map.t_stride + sg.map.t_off;
-        const bool ok = pb >= 0 && ts >= 0 && ts < sg.map.T_total;
-        const uint32_t srow = ok ? (uint32_t)((pb * sg.map.T_total + ts) * a.J + pj) : 0u;
-        zrow = !ok;                                      // out-of-range tap (or a row past M): reads as zero
-        offA = (srow * (uint32_t)sg.lda + c8 * 4) * 4u;
+        ok = pb >= 0 && ts >= 0 && ts < sg.map.T_total;
+        return ok ? (uint32_t)((pb * sg.map.T_total + ts) * a.J + pj) : 0u;
     };
-    enter_a();
-    u32x4 ra[4];
-    bool rz[4];
-    auto load_a = [&](u32x4& r, bool& z) {
-        // (K tail: chunks past K re-read the step's first chunk and are zeroed by the conversion; branch-free -- three VALU
-        //  instructions -- so that the load is ONE instruction behind the address arithmetic on every path)
-        const bool kin = ga.k0 + c8 * 4 < ga.K;
-        gload16s(r, offA - (kin ? 0u : (uint32_t)c8 * 16u), A_l + ga.k0 * 4);
-        z = zrow || !kin;
-        if (advance(ga)) enter_a();
+    {
+        bool ok;
+        const uint32_t srow = row_of(a.seg[0], ok);
+        offA = (srow * (uint32_t)a.seg[0].lda + c8 * 4) * 4u;
+        if (!ok) zmask |= 1;
+    }
+    const int kofs0 = c8 * 4, kofs1 = 32 + c8 * 4;   // the thread's value offsets inside a step
+    u32x4 ra[NA][2];
+    auto load_a = [&](u32x4 (&r)[2]) {
+        // K tail: a chunk past K re-reads the row's first chunk of the step (its values are zeroed by the conversion); branch-free
+        const uint32_t row0 = offA - (uint32_t)c8 * 16u;
+        const uint32_t v0 = kofs0 < a_rem ? offA : row0;
+        const uint32_t v1 = kofs1 < a_rem ? offA + 128u : row0;
+        const char* const ap = uni(a_ptr);
+        if (!(pl.ablate & 16)) {
+            gload16s(r[0], v0, ap);
+            gload16s(r[1], v1, ap);
+        }
+        a_ptr += KS * 4;
+        a_rem -= KS;
+        if (a_rem <= 0) {
+            if (a_seg + 1 < nseg) {
+                ++a_seg;
+                const gast_gemm_seg& sg = a.seg[a_seg];
+                a_rem = sg.K;
+                a_ptr = (const char*)sg.A;
+                bool ok;
+                const uint32_t srow = row_of(sg, ok);
+                offA = (srow * (uint32_t)sg.lda + c8 * 4) * 4u;
+                if (!ok) zmask |= 1 << a_seg;
+            } else { a_ptr -= KS * 4; a_rem += KS; }          // past the last tile: the last tile again
+        }
     };
-    // ---- the weight stream (tile t + 3 at step t).  DMA: wave w fills the 1 KB pieces (w & 3) * NW + i of k-group w >> 2: 16 rows x
+    // weights (tile t + DW at step t).  DMA: wave w fills sub-tile w >> 1, the NWP 1 KB pieces from row (w & 1) * TN / 2 on: 16 rows x
     // 64 B each, contiguous in the k-group-major image; lane = (row r16, slot s4), slot s4 receives source chunk s4 ^ key(row)
     const int r16 = lane >> 2, s4 = lane & 3;
-    const int kgW = __builtin_amdgcn_readfirstlane(w >> 2), pieceW = __builtin_amdgcn_readfirstlane((w & 3) * NW);
-    const uint32_t offW = (uint32_t)(n0 + pieceW * 16 + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
-    const uint32_t sW0 = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + kgW * (TN * ROWB) + pieceW * 1024);
-    Gen gw = {0, 0, a.seg[0].K};
-    const char* W_l = (const char*)a.seg[0].Wx;
-    long ldg_l = (long)a.seg[0].ldwx * 2;                     // bytes per k-group of the weight image
+    const int subW = __builtin_amdgcn_readfirstlane(w >> 1), rowW = __builtin_amdgcn_readfirstlane((w & 1) * (TN / 2));
+    const uint32_t offW = (uint32_t)(n0 + rowW + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
+    const uint32_t sW0 = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + subW * (TN * ROWB) + rowW * ROWB);
+    int w_seg = 0, w_rem = a.seg[0].K;
+    const char* w_ptr = (const char*)a.seg[0].Wx;
+    long w_ldg = (long)a.seg[0].ldwx * 2;                     // bytes per 16-value group of the weight image
+    long w_sub = w_ldg * subW;                                // this wave's sub-tile inside a step
     auto dma_w = [&](int stage) {
-        // this wave's k-group of the step; a step whose second half lies past the segment's last 16-value group re-reads the first
-        // one (the activations of that half are written as zeros)
-        const int g = (gw.k0 >> 4) + kgW;
-        const char* wbase = W_l + (long)(g * 16 < gw.K ? g : (gw.k0 >> 4)) * ldg_l;
+        // (a sub-tile past the segment's last 16-value group re-reads the step's first one: its activations are written as zeros)
+        const char* wbase = uni(w_ptr + (subW * 16 < w_rem ? w_sub : 0));
         const uint32_t sW = sW0 + stage * W_BYTES;
-        glds16<0>(offW, wbase, sW);
-        if (NW == 2) glds16<1024>(offW, wbase, sW);
-        if (advance(gw)) { W_l = (const char*)a.seg[gw.seg].Wx; ldg_l = (long)a.seg[gw.seg].ldwx * 2; }
-    };
-    // ---- the conversion stream: facts of the tile that the NEXT step converts
-    Gen gc = {0, 0, a.seg[0].K};
-    int toff_l = pl.taboff[0];
-    float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
-    bool c_pro = false, c_fix = false, bad_l = false;
-    int rowmask = 0;                                      // lane l: the zero-row bits of tile row l (loaded behind the first barrier)
-    auto conv_facts = [&]() {                             // facts of the generator's tile, then advance
-        c_pro = toff_l >= 0;
-        c_fix = bad_l || gc.k0 + 32 > gc.K;
-        if (c_pro) {
-            const int k = toff_l + min(gc.k0 + c8 * 4, gc.K - 4);
-            tsc = *(const float4*)(sSc + k);
-            tsh = *(const float4*)(sSh + k);
+        if (!(pl.ablate & 8)) {
+            glds16<0>(offW, wbase, sW);
+            glds16<1024>(offW, wbase, sW);
+            if (NWP == 4) {
+                glds16<2048>(offW, wbase, sW);
+                glds16<3072>(offW, wbase, sW);
+            }
         }
-        if (advance(gc)) { toff_l = pl.taboff[gc.seg]; bad_l = __ballot((rowmask >> gc.seg) & 1) != 0; }
+        w_ptr += NSUB * w_ldg;
+        w_rem -= KS;
+        if (w_rem <= 0) {
+            if (w_seg + 1 < nseg) {
+                ++w_seg;
+                w_rem = a.seg[w_seg].K;
+                w_ptr = (const char*)a.seg[w_seg].Wx;
+                w_ldg = (long)a.seg[w_seg].ldwx * 2;
+                w_sub = w_ldg * subW;
+            } else { w_ptr -= NSUB * w_ldg; w_rem += KS; }
+        }
+    };
+    // conversion facts of the tile the NEXT step converts (prologue? zero rows / K tail? scale / shift of the thread's 8 values)
+    int c_seg = 0, c_rem = a.seg[0].K, c_tab = pl.taboff[0] >= 0 ? OFF_TAB + pl.taboff[0] * 4 : -1;      // LDS byte address of the tile's first scale
+    const int tab_sh = pl.ntab * 4;                           // shift table behind the scale table
+    float4 tsc[2], tsh[2];
+    bool c_pro = false, c_fix = false;
+    int c_seg_now = 0, c_rem_now = 0;
+    auto conv_facts = [&]() {
+        c_pro = c_tab >= 0;
+        c_seg_now = c_seg;
+        c_rem_now = c_rem;
+        c_fix = tile_partial || !((pl.segfull >> c_seg) & 1) || c_rem < KS;
+        if (c_pro) {
+            const int lim = (c_rem - 4) * 4;
+            const unsigned char* t0 = smem + c_tab + min(kofs0 * 4, lim);
+            const unsigned char* t1 = smem + c_tab + min(kofs1 * 4, lim);
+            tsc[0] = *(const float4*)t0; tsh[0] = *(const float4*)(t0 + tab_sh);
+            tsc[1] = *(const float4*)t1; tsh[1] = *(const float4*)(t1 + tab_sh);
+            c_tab += KS * 4;
+        }
+        c_rem -= KS;
+        if (c_rem <= 0) {
+            if (c_seg + 1 < nseg) {
+                ++c_seg;
+                c_rem = a.seg[c_seg].K;
+                c_tab = pl.taboff[c_seg] >= 0 ? OFF_TAB + pl.taboff[c_seg] * 4 : -1;
+            } else { c_rem += KS; if (c_pro) c_tab -= KS * 4; }
+        }
     };
     const int wa_key = (ra_row >> 2) & 3;
-    const int wa_base = OFF_A + kgA * (TM * ROWB) + ra_row * ROWB + (cA & 1) * 8;
+    const int wa_base = OFF_A + (c8 >> 2) * (TM * ROWB) + ra_row * ROWB + (cA & 1) * 8;
     const int wa_hi = wa_base + (((cA >> 1) ^ wa_key) << 4), wa_lo = wa_base + (((2 + (cA >> 1)) ^ wa_key) << 4);
-    auto write_a = [&](int stage, const u32x4& r, bool z) {
-        float x0 = __uint_as_float(r.x), x1 = __uint_as_float(r.y), x2 = __uint_as_float(r.z), x3 = __uint_as_float(r.w);
-        if (c_pro) {         // BN + ReLU prologue
-            x0 = fmaxf(fmaf(x0, tsc.x, tsh.x), 0.f);
-            x1 = fmaxf(fmaf(x1, tsc.y, tsh.y), 0.f);
-            x2 = fmaxf(fmaf(x2, tsc.z, tsh.z), 0.f);
-            x3 = fmaxf(fmaf(x3, tsc.w, tsh.w), 0.f);
+    auto write_a = [&](int stage, const u32x4 (&r)[2]) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float x0 = __uint_as_float(r[h].x), x1 = __uint_as_float(r[h].y), x2 = __uint_as_float(r[h].z), x3 = __uint_as_float(r[h].w);
+            if (c_pro) {         // BN + ReLU prologue
+                x0 = fmaxf(fmaf(x0, tsc[h].x, tsh[h].x), 0.f);
+                x1 = fmaxf(fmaf(x1, tsc[h].y, tsh[h].y), 0.f);
+                x2 = fmaxf(fmaf(x2, tsc[h].z, tsh[h].z), 0.f);
+                x3 = fmaxf(fmaf(x3, tsc[h].w, tsh[h].w), 0.f);
+            }
+            if (c_fix) {         // zero rows / the K tail must read as zero (relu(shift) must not leak in)
+                const bool z = ((zmask >> c_seg_now) & 1) || (h == 0 ? kofs0 : kofs1) >= c_rem_now;
+                x0 = z ? 0.f : x0; x1 = z ? 0.f : x1; x2 = z ? 0.f : x2; x3 = z ? 0.f : x3;
+            }
+            uint2 hh, ll;
+            split_pair4<PAIR>(x0, x1, x2, x3, hh, ll);
+            *(uint2*)(smem + stage * A_BYTES + h * (2 * TM * ROWB) + wa_hi) = hh;
+            *(uint2*)(smem + stage * A_BYTES + h * (2 * TM * ROWB) + wa_lo) = ll;
         }
-        if (c_fix) {         // zero rows / the K tail must read as zero (relu(shift) must not leak in)
-            x0 = z ? 0.f : x0; x1 = z ? 0.f : x1; x2 = z ? 0.f : x2; x3 = z ? 0.f : x3;
-        }
-        uint2 h, l;
-        split_pair4<PAIR>(x0, x1, x2, x3, h, l);
-        *(uint2*)(smem + stage * A_BYTES + wa_hi) = h;
-        *(uint2*)(smem + stage * A_BYTES + wa_lo) = l;
     };
 
-    int ntile = 0;
-    for (int s = 0; s < nseg; ++s) ntile += (a.seg[s].K + 31) / 32;
+    const int ntile = pl.ntile;
 
     // two accumulators per output tile: the large products and the two correction products -- two independent MFMA chains per step
     f32x16 acc[NJ], acl[NJ];
@@ -329,73 +375,91 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
         for (int r = 0; r < 16; ++r) { acc[q][r] = 0.f; acl[q][r] = 0.f; }
     const int fkey = (li >> 2) & 3;
     const int ohi = li * ROWB + ((lh ^ fkey) << 4), olo = li * ROWB + (((2 + lh) ^ fkey) << 4);
-    const unsigned char* const fA = smem + OFF_A + kg * (TM * ROWB) + wr * 32 * ROWB;
-    const unsigned char* const fW = smem + OFF_W + kg * (TN * ROWB) + wc * (TN / 2) * ROWB;
+    const unsigned char* const fA = smem + OFF_A + (2 * kg) * (TM * ROWB) + wr * 32 * ROWB;
+    const unsigned char* const fW = smem + OFF_W + (2 * kg) * (TN * ROWB) + wc * (TN / 2) * ROWB;
 
-    // ---- pipeline fill: W(0), A(0), A(1) first (the wait below needs exactly these), then W(1), A(2), W(2), A(3)
+    // ---- pipeline fill: W(0), A(0), A(1) first (the wait below needs exactly these), then the rest of the look-ahead
     dma_w(0);
-    load_a(ra[0], rz[0]);
-    load_a(ra[1], rz[1]);
-    dma_w(1);
-    load_a(ra[2], rz[2]);
-    dma_w(2);
-    load_a(ra[3], rz[3]);
-    for (int s = 0; s < nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
-        if (pl.taboff[s] >= 0) {
-            const float* sc = a.seg[s].scale;
-            const float* sh = a.seg[s].shift;
-            for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
+    load_a(ra[0]);
+    load_a(ra[1]);
+#pragma unroll
+    for (int j = 1; j < DW; ++j) {
+        dma_w(j);
+        if (j + 1 < NA) load_a(ra[j + 1]);
+    }
+#pragma unroll
+    for (int j = DW + 1; j < NA; ++j) load_a(ra[j]);
+    {
+        float* const sSc = (float*)(smem + OFF_TAB);
+        float* const sSh = sSc + pl.ntab;
+        for (int s = 0; s < nseg; ++s) {                 // scale / shift tables (while the first tiles are in flight)
+            if (pl.taboff[s] >= 0) {
+                const float* sc = a.seg[s].scale;
+                const float* sh = a.seg[s].shift;
+                for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
+            }
         }
     }
-    gload_wait_n<2 + 2 * NW>();
-    __syncthreads();                                   // tables, row maps and zero-row flags complete
-    gload_pin(ra[0]);
-    gload_pin(ra[1]);
-    rowmask = sBad[lane];
-    bad_l = __ballot(rowmask & 1) != 0;
+    gload_wait_n<(DW - 1) * NWP + (NA - 2) * 2>();
+    __syncthreads();                                   // tables and row maps complete
+    if (pl.ablate & 512) { gload_wait_n<0>(); return; }
+    gload_pin(ra[0][0]); gload_pin(ra[0][1]);
+    gload_pin(ra[1][0]); gload_pin(ra[1][1]);
     conv_facts();                                      // tile 0
-    write_a(0, ra[0], rz[0]);
-    load_a(ra[0], rz[0]);                              // tile 4
+    write_a(0, ra[0]);
+    load_a(ra[0]);                                     // tile NA
     conv_facts();                                      // tile 1 (converted by step 0)
 
-    // One K step (U = t % 4).  At the top, after the counted wait + barrier: LDS holds tile t (activations in stage t & 1, weights in
-    // stage t % 4); register set (t + 1) % 4 holds tile t + 1's activations; in flight: the weights of tiles t+1, t+2, the activations
-    // of tiles t+2 .. t+4 -- 3 + 2 NW transfers, everything older is complete.
+    // One K step (U = t % UNROLL).  At the top, after the counted wait + barrier: LDS holds tile t (activations in stage t & 1,
+    // weights in stage t % WS); register set (t + 1) % NA holds tile t + 1's activations; in flight: INFLIGHT transfers at most.
     auto step = [&](auto Uc, int t) {
         constexpr int U = decltype(Uc)::value;
-        constexpr int SA = U & 1, SW = U, SET = (U + 1) & 3;
-        gload_wait_n<3 + 2 * NW>();
+        constexpr int SA = U & 1, SW = U % WS, SET = (U + 1) % NA;
+        gload_wait_n<INFLIGHT>();
         __syncthreads();
-        gload_pin(ra[SET]);
-        Frag ah, al, bh[NJ], bl[NJ];
-        ah.u = *(const uint4*)(fA + SA * A_BYTES + ohi);
-        al.u = *(const uint4*)(fA + SA * A_BYTES + olo);
+        gload_pin(ra[SET][0]);
+        gload_pin(ra[SET][1]);
+        Frag ah[2], al[2], bh[2][NJ], bl[2][NJ];
+        if (!(pl.ablate & 64))
 #pragma unroll
-        for (int q = 0; q < NJ; ++q) {
-            bh[q].u = *(const uint4*)(fW + SW * W_BYTES + q * 32 * ROWB + ohi);
-            bl[q].u = *(const uint4*)(fW + SW * W_BYTES + q * 32 * ROWB + olo);
+        for (int ks = 0; ks < 2; ++ks) {
+            ah[ks].u = *(const uint4*)(fA + SA * A_BYTES + ks * (TM * ROWB) + ohi);
+            al[ks].u = *(const uint4*)(fA + SA * A_BYTES + ks * (TM * ROWB) + olo);
+#pragma unroll
+            for (int q = 0; q < NJ; ++q) {
+                bh[ks][q].u = *(const uint4*)(fW + SW * W_BYTES + ks * (TN * ROWB) + q * 32 * ROWB + ohi);
+                bl[ks][q].u = *(const uint4*)(fW + SW * W_BYTES + ks * (TN * ROWB) + q * 32 * ROWB + olo);
+            }
         }
-        if (t + 1 < ntile) write_a(SA ^ 1, ra[SET], rz[SET]);    // tile t+1: registers -> LDS (the set is then free for tile t+5)
-        if (t < ntile) {
+        if (t + 1 < ntile && !(pl.ablate & 128)) write_a(SA ^ 1, ra[SET]);             // tile t+1: registers -> LDS (the set is then free for tile t+1+NA)
+        if (t < ntile && !(pl.ablate & 32)) {
 #pragma unroll
-            for (int q = 0; q < NJ; ++q) acl[q] = mfma_pair<PAIR>(al.u, bh[q].u, acl[q]);
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int q = 0; q < NJ; ++q) acc[q] = mfma_pair<PAIR>(ah.u, bh[q].u, acc[q]);
+                for (int q = 0; q < NJ; ++q) acl[q] = mfma_pair<PAIR>(al[ks].u, bh[ks][q].u, acl[q]);
 #pragma unroll
-            for (int q = 0; q < NJ; ++q) acl[q] = mfma_pair<PAIR>(ah.u, bl[q].u, acl[q]);
+                for (int q = 0; q < NJ; ++q) acc[q] = mfma_pair<PAIR>(ah[ks].u, bh[ks][q].u, acc[q]);
+#pragma unroll
+                for (int q = 0; q < NJ; ++q) acl[q] = mfma_pair<PAIR>(ah[ks].u, bl[ks][q].u, acl[q]);
+            }
         }
-        dma_w((U + 3) & 3);                                      // tile t + 3 -> stage (t + 3) % 4 (tile t - 1's: every wave is past its reads)
-        load_a(ra[SET], rz[SET]);                                // tile t + 5
+        dma_w((U + DW) % WS);                                    // tile t + DW -> the stage of tile t - 1: every wave is past its reads
+        load_a(ra[SET]);                                         // tile t + 1 + NA
         conv_facts();                                            // tile t + 2
     };
-    for (int t = 0; t < ((pl.ablate & 4) ? 0 : ntile); t += 4) {
+    for (int t = 0; t < ((pl.ablate & 4) ? 0 : ntile); t += UNROLL) {
         step(std::integral_constant<int, 0>{}, t);
         step(std::integral_constant<int, 1>{}, t + 1);
         step(std::integral_constant<int, 2>{}, t + 2);
         step(std::integral_constant<int, 3>{}, t + 3);
+        if constexpr (UNROLL == 6) {
+            step(std::integral_constant<int, 4>{}, t + 4);
+            step(std::integral_constant<int, 5>{}, t + 5);
+        }
     }
     gload_wait_n<0>();                 // (the re-requested tiles past the end: nothing may land in LDS or in registers after this point)
-    asm volatile("" ::"v"(ra[0]), "v"(ra[1]), "v"(ra[2]), "v"(ra[3]));
+#pragma unroll
+    for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i][0]), "v"(ra[i][1]));
 #pragma unroll
     for (int q = 0; q < NJ; ++q)
 #pragma unroll
@@ -438,12 +502,12 @@ struct BjBatch {
 static_assert(sizeof(BjBatch) <= 3840, "BjBatch travels as a kernel argument (4 KB limit)");
 
 template <int NJ, int PAIR>
-__global__ void __launch_bounds__(NT, 4) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
+__global__ void __launch_bounds__(NT, 2) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bj_body<NJ, PAIR>(a, pl, blockIdx.x, smem);
 }
 template <int NJ, int PAIR>
-__global__ void __launch_bounds__(NT, 4) gemm_bj_multi_kernel(const BjBatch b) {
+__global__ void __launch_bounds__(NT, 2) gemm_bj_multi_kernel(const BjBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
@@ -455,8 +519,14 @@ std::atomic<bool> bj_setup_done[64];
 
 typedef void (*bj_kernel_t)(const gast_gemm_args, const BjPlan);
 typedef void (*bj_multi_kernel_t)(const BjBatch);
-bj_kernel_t bj_kernel(int, int pair) { return pair == 2 ? gemm_bj_kernel<1, 2> : gemm_bj_kernel<1, 1>; }
-bj_multi_kernel_t bj_multi_kernel(int, int pair) { return pair == 2 ? gemm_bj_multi_kernel<1, 2> : gemm_bj_multi_kernel<1, 1>; }
+bj_kernel_t bj_kernel(int nj, int pair) {
+    if (pair == 2) return nj == 1 ? gemm_bj_kernel<1, 2> : gemm_bj_kernel<2, 2>;
+    return nj == 1 ? gemm_bj_kernel<1, 1> : gemm_bj_kernel<2, 1>;
+}
+bj_multi_kernel_t bj_multi_kernel(int nj, int pair) {
+    if (pair == 2) return nj == 1 ? gemm_bj_multi_kernel<1, 2> : gemm_bj_multi_kernel<2, 2>;
+    return nj == 1 ? gemm_bj_multi_kernel<1, 1> : gemm_bj_multi_kernel<2, 1>;
+}
 int bj_lds_bytes(int ntab, int nj) { return off_tab(nj) + 2 * ntab * 4; }
 
 void bj_setup() {
@@ -464,7 +534,7 @@ void bj_setup() {
     hipGetDevice(&dev);
     dev &= 63;
     if (bj_setup_done[dev].load(std::memory_order_acquire)) return;
-    for (int nj = 1; nj <= 1; ++nj)
+    for (int nj = 1; nj <= 2; ++nj)
         for (int pair = 1; pair <= 2; ++pair) {
             const hipError_t e1 = hipFuncSetAttribute((const void*)bj_kernel(nj, pair), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
             const hipError_t e2 = hipFuncSetAttribute((const void*)bj_multi_kernel(nj, pair), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
@@ -475,7 +545,7 @@ void bj_setup() {
         }
     bj_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BJ_DEBUG")) {
-        for (int nj = 1; nj <= 1; ++nj) {
+        for (int nj = 1; nj <= 2; ++nj) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bj_kernel(nj, 1), NT, bj_lds_bytes(0, nj));
             hipFuncAttributes fa;
@@ -512,7 +582,7 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
-    if (ntab > max_tab(1)) return 0;
+    if (ntab > max_tab(2)) return 0;
     if (a.epi < 0 || a.epi > GAST_EPI_BNRELU_BWD) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
@@ -520,22 +590,17 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
     if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || rowsC * a.ldc2 * 4 >= 0x7fffffffL)) return 0;
     if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
-    // Where this kernel is used (measured on MI355X at M = 2 176, scripts/gemm_table.py bf16x3: isolated launch, this kernel vs gemm.hip's
-    // split-K pair).  A K step of this kernel costs ~0.5 us whatever the tile does in it (every variant tried -- 32 / 64 values per step,
-    // 8 / 16 waves, 2 / 4 k-groups, one or two blocks per CU, a third of the VALU work removed -- lands there: DESIGN.md section 9), so it
-    // wins where the split-K pair's fixed costs dominate -- sum K <= 1024: 26 / 44 / 45 / 26 / 46 us against 34 / 52 / 52 / 34 / 61 --
-    // and loses on the long-K shapes (K = 1536: 48 vs 40, K = 3592: 80 vs 62) and on very wide outputs (N = 5C + 8: 1 394 tiles, 62 vs
-    // 44 without any split).  GAST_GEMM_BJ_ALL=1: every eligible shape (kernel tests).
-    static const int all_shapes = getenv("GAST_GEMM_BJ_ALL") ? atoi(getenv("GAST_GEMM_BJ_ALL")) : 0;
-    static const int max_k = getenv("GAST_GEMM_BJ_MAX_K") ? atoi(getenv("GAST_GEMM_BJ_MAX_K")) : 1024;
-    static const int min_k = getenv("GAST_GEMM_BJ_MIN_K") ? atoi(getenv("GAST_GEMM_BJ_MIN_K")) : 64;
-    static const int max_tiles = getenv("GAST_GEMM_BJ_MAX_TILES") ? atoi(getenv("GAST_GEMM_BJ_MAX_TILES")) : 600;
-    if (!all_shapes) {
-        int ksum = 0;
-        for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
-        if (ksum > max_k || ksum < min_k || ((Ml + TM - 1) / TM) * ((a.N + 63) / 64) > max_tiles) return 0;
-    }
     pl.M = (int)Ml;
+    pl.ntile = 0;
+    pl.segfull = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        pl.ntile += (a.seg[s].K + KS - 1) / KS;
+        // does the segment's row map send EVERY frame of the domain to a frame of its tensor?  (then no tile of it has zero rows)
+        const gast_rowmap& mp = a.seg[s].map;
+        const long lo = mp.t_stride >= 0 ? mp.t_off : (long)(a.Tn - 1) * mp.t_stride + mp.t_off;
+        const long hi = mp.t_stride >= 0 ? (long)(a.Tn - 1) * mp.t_stride + mp.t_off : mp.t_off;
+        if (lo >= 0 && hi < mp.T_total) pl.segfull |= 1 << s;
+    }
     pl.tilesM = (pl.M + TM - 1) / TM;
     pl.ntab = ntab;
     pl.nj = 0;
@@ -545,7 +610,15 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     return 1;
 }
 
-static int bj_pick_nj(const gast_gemm_args*, const BjPlan*, int) { return 1; }      // (one tile width: 64 columns)
+// tile width of a launch: 64 columns while the grid fits one round of resident blocks (one per CU), else 128
+static int bj_pick_nj(const gast_gemm_args* args, const BjPlan* pls, int n) {
+    static const int nj_env = getenv("GAST_GEMM_BJ_NJ") ? atoi(getenv("GAST_GEMM_BJ_NJ")) : 0;
+    static const int max_blocks = getenv("GAST_GEMM_BJ_BLOCKS") ? atoi(getenv("GAST_GEMM_BJ_BLOCKS")) : 288;
+    if (nj_env == 1 || nj_env == 2) return nj_env;
+    long blocks = 0;
+    for (int d = 0; d < n; ++d) blocks += (long)pls[d].tilesM * ((args[d].N + 63) / 64);
+    return blocks <= max_blocks ? 1 : 2;
+}
 
 int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hipStream_t st) {
     bj_setup();

@@ -42,6 +42,7 @@ class x3_mode:
 def ops():
     import os
     os.environ.setdefault('GAST_GEMM_BIG_ALL', '1')     # kernel tests: every eligible shape on the large-M kernel (read once by the library)
+    os.environ.setdefault('GAST_GEMM_BJ_ALL', '1')      # ... and every eligible small-M shape on the M = B*J kernel (the product uses it where it wins)
     from conftest import poison_allocations
     from gast_hip.binding import HipOps, set_h16
     poison_allocations()           # (GAST_TEST_POISON=1 only)
