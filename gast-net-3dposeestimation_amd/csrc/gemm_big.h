@@ -30,6 +30,8 @@ struct BjPlan {
     int pair;                     // 1 = bf16 hi/lo, 2 = fp16 hi/lo
     int ntab;
     int taboff[GAST_MAX_SEG];
+    int fast;                     // every segment's K a multiple of 128 and no zero rows: the lean K loop (bj_body_fast)
+    int ntile32;                  // 32-value K steps over all segments
     int ablate;                   // GAST_GEMM_BJ_ABLATE (profiling aid, results are wrong when set): 1 no statistics atomics, 2 no epilogue, 4 no K loop
 };
 __attribute__((visibility("hidden"))) int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl);

@@ -40,6 +40,14 @@ constexpr int w_bytes(int nj) { return KG * tn_of(nj) * ROWB; }          // 8 KB
 constexpr int off_tab(int nj) { return OFF_W + WS * w_bytes(nj); }
 constexpr int LDS_BLOCK = 64 * 1024;             // two blocks per CU with room to spare
 constexpr int max_tab(int nj) { return (LDS_BLOCK - off_tab(nj)) / 8; }
+// the lean loop's pipeline depth: weight stages = activation register sets = unroll period (a multiple of 4)
+#ifndef GAST_BJ_DEPTH
+#define GAST_BJ_DEPTH 4
+#endif
+constexpr int FD = GAST_BJ_DEPTH;
+constexpr int off_tab_fast() { return OFF_W + FD * w_bytes(1); }
+constexpr int LDS_BLOCK_FAST = FD == 4 ? LDS_BLOCK : 100 * 1024;
+constexpr int max_tab_fast() { return (LDS_BLOCK_FAST - off_tab_fast()) / 8; }
 
 template <int OFF>
 __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_wave_base) {
@@ -47,6 +55,13 @@ __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_
 }
 __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* sbase) {
     asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
+}
+
+// a wave-uniform pointer the compiler's divergence analysis may have lost track of (loop-carried through a lambda): scalar registers
+__device__ __forceinline__ const char* uni(const char* p) {
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
 }
 
 struct Frag { uint4 u; };
@@ -170,6 +185,37 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
     }
 }
 
+// ---- the two k-groups' accumulators meet: group g keeps registers 8 g .. 8 g + 7 (rows 16 g .. 16 g + 15 of the wave tile) and hands the
+// other half over through LDS ([8 NJ][256] floats per direction, conflict-free); then the epilogue.  Called behind a barrier that
+// every wave reaches after its last fragment read.
+template <int NJ>
+__device__ __forceinline__ void bj_finish(const gast_gemm_args& a, const BjPlan& pl, unsigned char* smem, f32x16 (&acc)[NJ], int m0, int n0, int mt) {
+    const int tid = threadIdx.x, kg = tid >> 8;
+    {
+        float* const xch = (float*)(smem + OFF_A);
+        const int t256 = tid & 255;
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xch[((kg * NJ + q) * 8 + r) * 256 + t256] = acc[q][8 * (1 - kg) + r];
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < NJ; ++q)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                const float o = xch[(((1 - kg) * NJ + q) * 8 + r) * 256 + t256];
+                // (always group 0's sum + group 1's sum, whichever group finishes the row)
+                acc[q][8 * kg + r] = kg == 0 ? acc[q][8 * kg + r] + o : o + acc[q][8 * kg + r];
+            }
+    }
+    if (pl.ablate & 2) { if (acc[0][0] == 12345.678f) ((float*)a.C)[0] = acc[0][5]; return; }
+    const int v = a.epi == GAST_EPI_BNRELU_BWD ? ((a.xdrop && a.drop.thresh != 0) ? 3 : 2) : a.epi;
+    if (v == 0) bj_epilogue<0, NJ>(a, pl, smem, acc, m0, n0, mt);
+    else if (v == 1) bj_epilogue<1, NJ>(a, pl, smem, acc, m0, n0, mt);
+    else if (v == 2) bj_epilogue<2, NJ>(a, pl, smem, acc, m0, n0, mt);
+    else bj_epilogue<3, NJ>(a, pl, smem, acc, m0, n0, mt);
+}
+
 // PAIR: 1 = bf16 hi/lo pairs (GAST_F32X3), 2 = fp16 pairs (GAST_F32X3H: forward epilogues, images of the f16 kind)
 //
 // The K loop.  Three operand streams run ahead of the MFMAs, each with its own tile generator in scalar registers (a queue of full
@@ -259,7 +305,7 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
         // (K tail: chunks past K re-read the step's first chunk and are zeroed by the conversion; branch-free -- three VALU
         //  instructions -- so that the load is ONE instruction behind the address arithmetic on every path)
         const bool kin = ga.k0 + c8 * 4 < ga.K;
-        gload16s(r, offA - (kin ? 0u : (uint32_t)c8 * 16u), A_l + ga.k0 * 4);
+        gload16s(r, offA - (kin ? 0u : (uint32_t)c8 * 16u), uni(A_l + ga.k0 * 4));
         z = zrow || !kin;
         if (advance(ga)) enter_a();
     };
@@ -276,7 +322,7 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
         // this wave's k-group of the step; a step whose second half lies past the segment's last 16-value group re-reads the first
         // one (the activations of that half are written as zeros)
         const int g = (gw.k0 >> 4) + kgW;
-        const char* wbase = W_l + (long)(g * 16 < gw.K ? g : (gw.k0 >> 4)) * ldg_l;
+        const char* wbase = uni(W_l + (long)(g * 16 < gw.K ? g : (gw.k0 >> 4)) * ldg_l);
         const uint32_t sW = sW0 + stage * W_BYTES;
         glds16<0>(offW, wbase, sW);
         if (NW == 2) glds16<1024>(offW, wbase, sW);
@@ -402,31 +448,238 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
         for (int r = 0; r < 16; ++r) acc[q][r] += acl[q][r];
     __syncthreads();
 
-    // ---- the two k-groups' accumulators meet: group g keeps registers 8 g .. 8 g + 7 (rows 16 g .. 16 g + 15 of the wave tile) and
-    // hands the other half over through LDS ([8 NJ][256] floats per direction, conflict-free)
+    bj_finish<NJ>(a, pl, smem, acc, m0, n0, mt);
+}
+
+// The same kernel for the shapes the stage is made of -- every segment's K a multiple of 128, no zero rows (pl.fast) -- with a K
+// loop of a THIRD of the instructions.  SQ counters of the general loop above (profiles/r06_pmc_gemm_bj.txt): ~120 instructions per
+// wave and 32-value step for 3 MFMAs, a wave active (issuing) a third of its cycles, L2 read latency 340 cycles at a 74 % hit rate --
+// the loop is bound by its own instruction stream (a wave issues in order, ~4.5 cycles per instruction), not by memory.  Here the
+// three operand streams advance in GROUPS of four steps: inside a group every address is (group base + compile-time offset), a
+// stream looks at its segment once per four steps (in the one sub-step where its look-ahead crosses a group boundary), and there is
+// no tail / zero-row / past-the-end handling at all (K steps come in fours).
+template <int OFF>
+__device__ __forceinline__ void gload16s_o(u32x4& dst, uint32_t voff, const void* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+}
+template <int PAIR>
+__device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPlan& pl, int blk, unsigned char* smem) {
+    constexpr int NJ = 1, TN = tn_of(NJ), W_BYTES = w_bytes(NJ), OFF_TAB = off_tab_fast(), NW = 1;
+    static_assert(FD % 4 == 0 && FD >= 4, "pipeline depth");
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kg = w >> 2, wr = (w >> 1) & 1, wc = w & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int lb = xcd_remap(blk, pl.tilesM * pl.tilesN);
+    int mt, nt;
+    if (pl.M >= a.N) { mt = lb / pl.tilesN; nt = lb - mt * pl.tilesN; }
+    else { nt = lb / pl.tilesM; mt = lb - nt * pl.tilesM; }
+    const int m0 = mt * TM, n0 = nt * TN;
+    int* const sCrow = (int*)smem;
+    int* const sAdd = sCrow + TM;
+    const int nseg = a.nseg;
+    const int ra_row = tid >> 3, c8 = tid & 7, kgA = c8 >> 2, cA = c8 & 3;
+    const int TJ = a.Tn * a.J;
+    int pb, pt, pj;
     {
-        float* const xch = (float*)(smem + OFF_A);
-        const int t256 = tid & 255;
-#pragma unroll
-        for (int q = 0; q < NJ; ++q)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) xch[((kg * NJ + q) * 8 + r) * 256 + t256] = acc[q][8 * (1 - kg) + r];
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < NJ; ++q)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                const float o = xch[(((1 - kg) * NJ + q) * 8 + r) * 256 + t256];
-                // (always group 0's sum + group 1's sum, whichever group finishes the row)
-                acc[q][8 * kg + r] = kg == 0 ? acc[q][8 * kg + r] + o : o + acc[q][8 * kg + r];
-            }
+        const int m = m0 + ra_row;                   // (pl.fast: M is a multiple of the tile, every row exists)
+        pb = m / TJ; const int rem = m - pb * TJ; pt = rem / a.J; pj = rem - pt * a.J;
     }
-    if (pl.ablate & 2) { if (acc[0][0] == 12345.678f) ((float*)a.C)[0] = acc[0][5]; return; }
-    const int v = a.epi == GAST_EPI_BNRELU_BWD ? ((a.xdrop && a.drop.thresh != 0) ? 3 : 2) : a.epi;
-    if (v == 0) bj_epilogue<0, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else if (v == 1) bj_epilogue<1, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else if (v == 2) bj_epilogue<2, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else bj_epilogue<3, NJ>(a, pl, smem, acc, m0, n0, mt);
+    if (c8 == 0) {
+        sCrow[ra_row] = (int)map_row(a.cmap, pb, pt, pj, a.J);
+        sAdd[ra_row] = a.addend ? (int)map_row(a.addmap, pb, pt, pj, a.J) : -1;
+    }
+    // ---- activation loads: group base (scalar) + the thread's byte offset; groups of 4 steps = 128 values = 512 bytes
+    int a_seg = 0, a_grp = a.seg[0].K >> 7;
+    const char* a_ptr = (const char*)a.seg[0].A;
+    uint32_t offA;
+    auto a_row = [&](const gast_gemm_seg& sg) {      // (pl.fast: every frame of the domain maps into the segment's tensor)
+        const uint32_t srow = (uint32_t)((pb * sg.map.T_total + pt * sg.map.t_stride + sg.map.t_off) * a.J + pj);
+        offA = (srow * (uint32_t)sg.lda + c8 * 4) * 4u;
+    };
+    a_row(a.seg[0]);
+    auto a_next_group = [&]() {
+        a_ptr += 512;
+        if (--a_grp == 0) {
+            if (a_seg + 1 < nseg) {
+                ++a_seg;
+                const gast_gemm_seg& sg = a.seg[a_seg];
+                a_ptr = (const char*)sg.A;
+                a_grp = sg.K >> 7;
+                a_row(sg);
+            } else { a_ptr -= 512; a_grp = 1; }      // past the last group: the last group again
+        }
+    };
+    u32x4 ra[FD];
+    // ---- weights: running pointer of the next step's 16-value group of this wave's k-group; a step is 2 groups further
+    const int r16 = lane >> 2, s4 = lane & 3;
+    const int kgW = __builtin_amdgcn_readfirstlane(w >> 2), pieceW = __builtin_amdgcn_readfirstlane((w & 3) * NW);
+    const uint32_t offW = (uint32_t)(n0 + pieceW * 16 + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
+    const uint32_t sW0 = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + kgW * (TN * ROWB) + pieceW * 1024);
+    int w_seg = 0, w_grp = a.seg[0].K >> 7;
+    long w_step = (long)a.seg[0].ldwx * 4;           // bytes per step: two 16-value groups of ldwx 16-bit elements
+    const char* w_cur = (const char*)a.seg[0].Wx + (w_step >> 1) * kgW;
+    auto dma_w = [&](int stage) {
+        glds16<0>(offW, uni(w_cur), sW0 + stage * W_BYTES);
+        w_cur += w_step;
+    };
+    auto w_next_group = [&]() {                      // (called when the next request is the first step of a new group)
+        if (--w_grp == 0) {
+            if (w_seg + 1 < nseg) {
+                ++w_seg;
+                w_grp = a.seg[w_seg].K >> 7;
+                w_step = (long)a.seg[w_seg].ldwx * 4;
+                w_cur = (const char*)a.seg[w_seg].Wx + (w_step >> 1) * kgW;
+            } else { w_cur -= 4 * w_step; w_grp = 1; }
+        }
+    };
+    // ---- conversion facts: prologue of the segment? + the LDS address of the thread's scale / shift values of the group
+    int c_seg = 0, c_grp = a.seg[0].K >> 7;
+    bool c_pro = pl.taboff[0] >= 0;
+    const int tab_sh = pl.ntab * 4;
+    int tabv = OFF_TAB + (c_pro ? pl.taboff[0] : 0) * 4 + c8 * 16;
+    auto c_next_group = [&]() {
+        tabv += 512;
+        if (--c_grp == 0) {
+            if (c_seg + 1 < nseg) {
+                ++c_seg;
+                c_grp = a.seg[c_seg].K >> 7;
+                c_pro = pl.taboff[c_seg] >= 0;
+                tabv = OFF_TAB + (c_pro ? pl.taboff[c_seg] : 0) * 4 + c8 * 16;
+            } else { tabv -= 512; c_grp = 1; }
+        }
+    };
+    float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    bool t_pro = false;                              // prologue flag of the tile whose scale / shift are held
+    auto fetch_tab = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        t_pro = c_pro;
+        if (c_pro) {
+            tsc = *(const float4*)(smem + tabv + J * 128);
+            tsh = *(const float4*)(smem + tabv + tab_sh + J * 128);
+        }
+    };
+    const int wa_key = (ra_row >> 2) & 3;
+    const int wa_base = OFF_A + kgA * (TM * ROWB) + ra_row * ROWB + (cA & 1) * 8;
+    const int wa_hi = wa_base + (((cA >> 1) ^ wa_key) << 4), wa_lo = wa_base + (((2 + (cA >> 1)) ^ wa_key) << 4);
+    auto write_a = [&](int stage, const u32x4& r) {
+        float x0 = __uint_as_float(r.x), x1 = __uint_as_float(r.y), x2 = __uint_as_float(r.z), x3 = __uint_as_float(r.w);
+        if (t_pro) {         // BN + ReLU prologue
+            x0 = fmaxf(fmaf(x0, tsc.x, tsh.x), 0.f);
+            x1 = fmaxf(fmaf(x1, tsc.y, tsh.y), 0.f);
+            x2 = fmaxf(fmaf(x2, tsc.z, tsh.z), 0.f);
+            x3 = fmaxf(fmaf(x3, tsc.w, tsh.w), 0.f);
+        }
+        uint2 h, l;
+        split_pair4<PAIR>(x0, x1, x2, x3, h, l);
+        *(uint2*)(smem + stage * A_BYTES + wa_hi) = h;
+        *(uint2*)(smem + stage * A_BYTES + wa_lo) = l;
+    };
+    const int ntile = pl.ntile32;                    // (a multiple of 4)
+    f32x16 acc[NJ], acl[NJ];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acl[0][r] = 0.f; }
+    const int fkey = (li >> 2) & 3;
+    const int ohi = li * ROWB + ((lh ^ fkey) << 4), olo = li * ROWB + (((2 + lh) ^ fkey) << 4);
+    const unsigned char* const fA = smem + OFF_A + kg * (TM * ROWB) + wr * 32 * ROWB;
+    const unsigned char* const fW = smem + OFF_W + kg * (TN * ROWB) + wc * (TN / 2) * ROWB;
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---- pipeline fill: W(0), A(0), A(1) first (the first wait needs exactly these), then W(j), A(j + 1) for j = 1 .. FD - 2;
+    // tile j is step j & 3 of group j >> 2
+    auto load_tile = [&](auto Jc, u32x4& r) {
+        constexpr int J = decltype(Jc)::value;
+        if (J != 0 && (J & 3) == 0) a_next_group();
+        gload16s_o<(J & 3) * 128>(r, offA, uni(a_ptr));
+    };
+    auto dma_tile = [&](auto Jc) {
+        constexpr int J = decltype(Jc)::value;
+        if (J != 0 && (J & 3) == 0) w_next_group();
+        dma_w(J % FD);
+    };
+    dma_tile(I0{});
+    load_tile(I0{}, ra[0]);
+    load_tile(I1{}, ra[1]);
+    dma_tile(I1{}); load_tile(I2{}, ra[2]);
+    dma_tile(I2{}); load_tile(I3{}, ra[3]);
+    if constexpr (FD == 8) {
+        dma_tile(std::integral_constant<int, 3>{}); load_tile(std::integral_constant<int, 4>{}, ra[4]);
+        dma_tile(std::integral_constant<int, 4>{}); load_tile(std::integral_constant<int, 5>{}, ra[5]);
+        dma_tile(std::integral_constant<int, 5>{}); load_tile(std::integral_constant<int, 6>{}, ra[6]);
+        dma_tile(std::integral_constant<int, 6>{}); load_tile(std::integral_constant<int, 7>{}, ra[7]);
+    }
+    {
+        float* const sSc = (float*)(smem + OFF_TAB);
+        float* const sSh = sSc + pl.ntab;
+        for (int s = 0; s < nseg; ++s) {
+            if (pl.taboff[s] >= 0) {
+                const float* sc = a.seg[s].scale;
+                const float* sh = a.seg[s].shift;
+                for (int k = tid; k < a.seg[s].K; k += NT) { sSc[pl.taboff[s] + k] = sc[k]; sSh[pl.taboff[s] + k] = sh[k]; }
+            }
+        }
+    }
+    gload_wait_n<(FD - 2) * (NW + 1)>();               // everything but W(0), A(0), A(1)
+    __syncthreads();
+    gload_pin(ra[0]);
+    gload_pin(ra[1]);
+    fetch_tab(I0{});                                   // tile 0
+    write_a(0, ra[0]);
+    load_tile(std::integral_constant<int, FD>{}, ra[0]);      // tile FD = the first step of a new group
+    fetch_tab(I1{});                                   // tile 1 (converted by step 0)
+
+    // step t = FD g + U.  Stage / register-set indices are compile-time; so are the streams' positions inside their groups of four:
+    // activations tile t + 1 + FD = step (U + 1) % 4 of its group, weights tile t + FD - 1 = step (U + 3) % 4, facts tile t + 2.
+    // In flight at the top: the weights of tiles t+1 .. t+FD-2 and the activations of tiles t+2 .. t+FD.
+    auto step = [&](auto Uc, bool wr_next, bool do_mma) {
+        constexpr int U = decltype(Uc)::value;
+        constexpr int SA = U & 1, SW = U % FD, SET = (U + 1) % FD;
+        gload_wait_n<(FD - 2) * NW + (FD - 1)>();
+        __syncthreads();
+        gload_pin(ra[SET]);
+        Frag ah, al, bh, bl;
+        ah.u = *(const uint4*)(fA + SA * A_BYTES + ohi);
+        al.u = *(const uint4*)(fA + SA * A_BYTES + olo);
+        bh.u = *(const uint4*)(fW + SW * W_BYTES + ohi);
+        bl.u = *(const uint4*)(fW + SW * W_BYTES + olo);
+        if (wr_next) write_a(SA ^ 1, ra[SET]);
+        if (do_mma) {
+            acl[0] = mfma_pair<PAIR>(al.u, bh.u, acl[0]);
+            acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
+            acl[0] = mfma_pair<PAIR>(ah.u, bl.u, acl[0]);
+        }
+        if ((U & 3) == 1) w_next_group();
+        dma_w((U + FD - 1) % FD);
+        if ((U & 3) == 3) a_next_group();
+        gload16s_o<((U + 1) & 3) * 128>(ra[SET], offA, uni(a_ptr));
+        if ((U & 3) == 2) c_next_group();
+        fetch_tab(std::integral_constant<int, (U + 2) & 3>{});
+    };
+    for (int t = 0; t < ((pl.ablate & 4) ? 0 : ntile); t += FD) {
+        if constexpr (FD == 4) {
+            step(I0{}, true, true);
+            step(I1{}, true, true);
+            step(I2{}, true, true);
+            step(I3{}, t + 4 < ntile, true);
+        } else {
+            const bool more = t + 4 < ntile;           // (K steps come in fours: the second half of the trip may lie past the end)
+            step(I0{}, true, true);
+            step(I1{}, true, true);
+            step(I2{}, true, true);
+            step(I3{}, more, true);
+            step(std::integral_constant<int, 4>{}, more, more);
+            step(std::integral_constant<int, 5>{}, more, more);
+            step(std::integral_constant<int, 6>{}, more, more);
+            step(std::integral_constant<int, 7>{}, more && t + 8 < ntile, more);
+        }
+    }
+    gload_wait_n<0>();
+#pragma unroll
+    for (int i = 0; i < FD; ++i) asm volatile("" ::"v"(ra[i]));
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += acl[0][r];
+    __syncthreads();
+    bj_finish<NJ>(a, pl, smem, acc, m0, n0, mt);
 }
 
 struct BjBatch {
@@ -437,17 +690,19 @@ struct BjBatch {
 };
 static_assert(sizeof(BjBatch) <= 3840, "BjBatch travels as a kernel argument (4 KB limit)");
 
-template <int NJ, int PAIR>
-__global__ void __launch_bounds__(NT, 4) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
+template <int NJ, int PAIR, bool FAST>
+__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : 4) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    bj_body<NJ, PAIR>(a, pl, blockIdx.x, smem);
+    if constexpr (FAST) bj_body_fast<PAIR>(a, pl, blockIdx.x, smem);
+    else bj_body<NJ, PAIR>(a, pl, blockIdx.x, smem);
 }
-template <int NJ, int PAIR>
-__global__ void __launch_bounds__(NT, 4) gemm_bj_multi_kernel(const BjBatch b) {
+template <int NJ, int PAIR, bool FAST>
+__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : 4) gemm_bj_multi_kernel(const BjBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    bj_body<NJ, PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    if constexpr (FAST) bj_body_fast<PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    else bj_body<NJ, PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
 inline bool aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
@@ -455,32 +710,38 @@ std::atomic<bool> bj_setup_done[64];
 
 typedef void (*bj_kernel_t)(const gast_gemm_args, const BjPlan);
 typedef void (*bj_multi_kernel_t)(const BjBatch);
-bj_kernel_t bj_kernel(int, int pair) { return pair == 2 ? gemm_bj_kernel<1, 2> : gemm_bj_kernel<1, 1>; }
-bj_multi_kernel_t bj_multi_kernel(int, int pair) { return pair == 2 ? gemm_bj_multi_kernel<1, 2> : gemm_bj_multi_kernel<1, 1>; }
-int bj_lds_bytes(int ntab, int nj) { return off_tab(nj) + 2 * ntab * 4; }
+bj_kernel_t bj_kernel(int fast, int pair) {
+    if (fast) return pair == 2 ? gemm_bj_kernel<1, 2, true> : gemm_bj_kernel<1, 1, true>;
+    return pair == 2 ? gemm_bj_kernel<1, 2, false> : gemm_bj_kernel<1, 1, false>;
+}
+bj_multi_kernel_t bj_multi_kernel(int fast, int pair) {
+    if (fast) return pair == 2 ? gemm_bj_multi_kernel<1, 2, true> : gemm_bj_multi_kernel<1, 1, true>;
+    return pair == 2 ? gemm_bj_multi_kernel<1, 2, false> : gemm_bj_multi_kernel<1, 1, false>;
+}
+int bj_lds_bytes(int ntab, int fast) { return (fast ? off_tab_fast() : off_tab(1)) + 2 * ntab * 4; }
 
 void bj_setup() {
     int dev = 0;
     hipGetDevice(&dev);
     dev &= 63;
     if (bj_setup_done[dev].load(std::memory_order_acquire)) return;
-    for (int nj = 1; nj <= 1; ++nj)
+    for (int fast = 0; fast <= 1; ++fast)
         for (int pair = 1; pair <= 2; ++pair) {
-            const hipError_t e1 = hipFuncSetAttribute((const void*)bj_kernel(nj, pair), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
-            const hipError_t e2 = hipFuncSetAttribute((const void*)bj_multi_kernel(nj, pair), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BLOCK);
+            const hipError_t e1 = hipFuncSetAttribute((const void*)bj_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
+            const hipError_t e2 = hipFuncSetAttribute((const void*)bj_multi_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
             if (e1 != hipSuccess || e2 != hipSuccess) {
-                fprintf(stderr, "gast_hip: gemm_bj set-up failed for NJ %d pair %d: %s\n", nj, pair, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+                fprintf(stderr, "gast_hip: gemm_bj set-up failed for fast %d pair %d: %s\n", fast, pair, hipGetErrorString(e1 != hipSuccess ? e1 : e2));
                 (void)hipGetLastError();
             }
         }
     bj_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BJ_DEBUG")) {
-        for (int nj = 1; nj <= 1; ++nj) {
+        for (int fast = 0; fast <= 1; ++fast) {
             int nb = -1;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bj_kernel(nj, 1), NT, bj_lds_bytes(0, nj));
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bj_kernel(fast, 1), NT, bj_lds_bytes(0, fast));
             hipFuncAttributes fa;
-            (void)hipFuncGetAttributes(&fa, (const void*)bj_kernel(nj, 1));
-            fprintf(stderr, "gemm_bj NJ %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", nj, nb, bj_lds_bytes(0, nj), fa.numRegs, (size_t)fa.localSizeBytes);
+            (void)hipFuncGetAttributes(&fa, (const void*)bj_kernel(fast, 1));
+            fprintf(stderr, "gemm_bj fast %d: %d blocks/CU at %d B LDS, %d regs, %zu B scratch\n", fast, nb, bj_lds_bytes(0, fast), fa.numRegs, (size_t)fa.localSizeBytes);
         }
     }
 }
@@ -512,7 +773,7 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
             if (pl.taboff[s] < 0) { pl.taboff[s] = ntab; ntab += (g.K + 3) / 4 * 4; }
         }
     }
-    if (ntab > max_tab(1)) return 0;
+    if (ntab > max_tab(1) || ntab > max_tab_fast()) return 0;
     if (a.epi < 0 || a.epi > GAST_EPI_BNRELU_BWD) return 0;
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
@@ -520,22 +781,27 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
     if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || rowsC * a.ldc2 * 4 >= 0x7fffffffL)) return 0;
     if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
-    // Where this kernel is used (measured on MI355X at M = 2 176, scripts/gemm_table.py bf16x3: isolated launch, this kernel vs gemm.hip's
-    // split-K pair).  A K step of this kernel costs ~0.5 us whatever the tile does in it (every variant tried -- 32 / 64 values per step,
-    // 8 / 16 waves, 2 / 4 k-groups, one or two blocks per CU, a third of the VALU work removed -- lands there: DESIGN.md section 9), so it
-    // wins where the split-K pair's fixed costs dominate -- sum K <= 1024: 26 / 44 / 45 / 26 / 46 us against 34 / 52 / 52 / 34 / 61 --
-    // and loses on the long-K shapes (K = 1536: 48 vs 40, K = 3592: 80 vs 62) and on very wide outputs (N = 5C + 8: 1 394 tiles, 62 vs
-    // 44 without any split).  GAST_GEMM_BJ_ALL=1: every eligible shape (kernel tests).
-    static const int all_shapes = getenv("GAST_GEMM_BJ_ALL") ? atoi(getenv("GAST_GEMM_BJ_ALL")) : 0;
-    static const int max_k = getenv("GAST_GEMM_BJ_MAX_K") ? atoi(getenv("GAST_GEMM_BJ_MAX_K")) : 1024;
-    static const int min_k = getenv("GAST_GEMM_BJ_MIN_K") ? atoi(getenv("GAST_GEMM_BJ_MIN_K")) : 64;
-    static const int max_tiles = getenv("GAST_GEMM_BJ_MAX_TILES") ? atoi(getenv("GAST_GEMM_BJ_MAX_TILES")) : 600;
-    if (!all_shapes) {
-        int ksum = 0;
-        for (int s = 0; s < a.nseg; ++s) ksum += a.seg[s].K;
-        if (ksum > max_k || ksum < min_k || ((Ml + TM - 1) / TM) * ((a.N + 63) / 64) > max_tiles) return 0;
-    }
     pl.M = (int)Ml;
+    // the lean K loop (bj_body_fast): K steps in groups of four for every segment, no zero rows anywhere
+    static const int fast_ok = getenv("GAST_GEMM_BJ_FAST") ? atoi(getenv("GAST_GEMM_BJ_FAST")) : 1;
+    pl.fast = fast_ok && Ml % TM == 0;
+    pl.ntile32 = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        const gast_rowmap& mp = a.seg[s].map;
+        const long lo = mp.t_stride >= 0 ? mp.t_off : (long)(a.Tn - 1) * mp.t_stride + mp.t_off;
+        const long hi = mp.t_stride >= 0 ? (long)(a.Tn - 1) * mp.t_stride + mp.t_off : mp.t_off;
+        if (a.seg[s].K % 128 || lo < 0 || hi >= mp.T_total) pl.fast = 0;
+        pl.ntile32 += (a.seg[s].K + 31) / 32;
+    }
+    // Where this kernel is used (measured on MI355X at M = 2 176, scripts/gemm_table.py bf16x3: one launch per graph replay, this kernel
+    // against gemm.hip's split-K pair): with the lean loop it wins or ties on every shape of the stage whose K steps come in fours and
+    // whose grid is at most ~2 blocks per CU -- 24 / 39 / 47 / 41 / 25 / 42 us against 34 / 52 / 54 / 52 / 34 / 61 (K <= 1024), 40 / 54 /
+    // 21 against 40 / 53 / 22 (K = 1536, the N = 3 output layer) -- and saves the finish launch and the workspace round trip either way.
+    // It loses on N = 5C + 8 (1 394 tiles: 56 vs 44 without any split) and, through the general loop, on K = 8 (27 vs 18) and K = 3 592
+    // (82 vs 62): those stay on gemm.hip.  GAST_GEMM_BJ_ALL=1: every eligible shape (kernel tests).
+    static const int all_shapes = getenv("GAST_GEMM_BJ_ALL") ? atoi(getenv("GAST_GEMM_BJ_ALL")) : 0;
+    static const int max_tiles = getenv("GAST_GEMM_BJ_MAX_TILES") ? atoi(getenv("GAST_GEMM_BJ_MAX_TILES")) : 600;
+    if (!all_shapes && (!pl.fast || ((Ml + TM - 1) / TM) * ((a.N + 63) / 64) > max_tiles)) return 0;
     pl.tilesM = (pl.M + TM - 1) / TM;
     pl.ntab = ntab;
     pl.nj = 0;
@@ -553,18 +819,20 @@ int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hi
     BjBatch b;
     b.n = n;
     b.first[0] = 0;
-    int ntab = 0;
+    int ntab = 0, fast = 1;
+    for (int d = 0; d < n; ++d) fast &= pls[d].fast;          // (one kernel per launch: the lean loop when every job qualifies)
     for (int d = 0; d < n; ++d) {
         if (pls[d].pair != pair) return GAST_EINVAL;
         pls[d].nj = nj;
+        pls[d].fast = fast;
         pls[d].tilesN = (args[d].N + tn_of(nj) - 1) / tn_of(nj);
         b.a[d] = args[d];
         b.pl[d] = pls[d];
         b.first[d + 1] = b.first[d] + pls[d].tilesM * pls[d].tilesN;
         if (pls[d].ntab > ntab) ntab = pls[d].ntab;
     }
-    if (n == 1) hipLaunchKernelGGL(bj_kernel(nj, pair), dim3(b.first[1]), dim3(NT), bj_lds_bytes(ntab, nj), st, b.a[0], b.pl[0]);
-    else hipLaunchKernelGGL(bj_multi_kernel(nj, pair), dim3(b.first[n]), dim3(NT), bj_lds_bytes(ntab, nj), st, b);
+    if (n == 1) hipLaunchKernelGGL(bj_kernel(fast, pair), dim3(b.first[1]), dim3(NT), bj_lds_bytes(ntab, fast), st, b.a[0], b.pl[0]);
+    else hipLaunchKernelGGL(bj_multi_kernel(fast, pair), dim3(b.first[n]), dim3(NT), bj_lds_bytes(ntab, fast), st, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }

@@ -504,6 +504,10 @@ GEMM_BJ_CASES = GEMM_CASES + GEMM_SMALL_X3_CASES + [
     ('bj_scatter_taps_add', (50, 1, 17), 192, [(256, 1, 1, 0, 0)], 2, True, False),
     ('bj_wide_n2568', (33, 1, 17), 2568, [(128, 1, 1, 0, 0)], 0, False, True),
     ('bj_two_pro_tables', (20, 3, 15), 100, [(200, 3, 1, 0, 1), (72, 5, 1, 2, 1), (40, 3, 1, 0, 0)], 1, True, 'neg'),
+    # the lean K loop (every K a multiple of 128, rows a multiple of 64, full row maps): prologue / plain segments mixed, taps, both epilogues
+    ('bj_fast_pro_mix', (64, 2, 17), 96, [(128, 4, 1, 1, 1), (384, 2, 1, 0, 0), (128, 4, 2, 0, 1)], 1, False, 'neg'),
+    ('bj_fast_concat_bwd_add', (128, 1, 17), 192, [(256, 1, 1, 0, 0), (128, 3, 1, 2, 0)], 2, True, False),
+    ('bj_fast_one_group', (64, 1, 17), 64, [(128, 1, 1, 0, 1)], 1, False, True),
 ]
 
 
