@@ -56,8 +56,8 @@ CONFIGS = {
                  '(final width 1024 as in the shipped 81-frame checkpoints)'),
     'cfg3': dict(J=19, arc=[3, 3, 3], channels=128, batch=64, what='configs[3]: 19-joint body+foot, arc 3,3,3, B=512 over 8 GPUs = 64 per GPU'),
     'cfg4': dict(J=15, arc=[3, 3, 3], channels=128, batch=4, what='configs[4]: HumanEva-15, arc 3,3,3, B=32 over 8 GPUs = 4 per GPU -- reported in '
-                 'bf16x3 unless --dtype fp8 is given: the mixed-fp8 mode exists (forward GEMMs on e4m3 MFMA) but does not meet any parity bound '
-                 'in train mode (3 mantissa bits through 13 BatchNorm\'d layers: outputs move by 0.4 on a range of 1.15; parity.pass = false)'),
+                 'bf16x3: "mixed fp8" is not offered as a mode (e4m3 forward operands through 13 BatchNorm\'d layers move train-mode outputs by 0.4 on a '
+                 'range of 1.15; the kernel-level fp8-operand GEMM stays in the library as a tested building block, DESIGN.md section 8)'),
     # not a BASELINE.json config: the shipped 243-frame shape (reference reconstruction.py:225-227, trainval.py -arc 3,3,3,3,3 -ch 32)
     'cfg243': dict(J=17, arc=[3, 3, 3, 3, 3], channels=32, batch=128, what='243-frame model: 17 joints, arc 3,3,3,3,3 (RF 243), channels=32, B=128'),
 }
@@ -136,7 +136,8 @@ class KernelTimer:
 
     def classify(self, name, a, k):
         """which kernel / plan step a gast_gemm(+_multi) call is: 'big' (gemm_big_kernel: the large-M GAST_F32X3 kernel -- the single
-        dominant kernel of the step), 'small' (gemm_kernel + split-K finish: the M = B*J stage), and for the temporal convolution of the
+        dominant kernel of the step), 'bj' (gemm_bj_kernel: the M = B*J stage's regular shapes, round 6), 'small' (gemm_kernel + split-K
+        finish: what is left of that stage), and for the temporal convolution of the
         north star's "conv path": 'conv_fwd' (k taps of one BatchNorm'd tensor as K segments) / 'conv_dgrad' (its input gradient)"""
         try:
             if name == 'gemm_multi':
@@ -145,7 +146,7 @@ class KernelTimer:
                 big = self.ops.gemm_path(j0.pop('dom'), j0.pop('N'), j0.pop('segs'), j0.pop('C_'), j0.pop('cmap'), **j0)
                 taps = len(jobs) >= 2 and all(len(j['segs']) == 1 and j['segs'][0]['A'].data_ptr() == jobs[0]['segs'][0]['A'].data_ptr()
                                               and j.get('epi', 0) == 2 for j in jobs)
-                return ('big' if big else 'small'), ('conv_dgrad' if taps else None)
+                return ({1: 'big', 2: 'bj'}.get(big, 'small')), ('conv_dgrad' if taps else None)
             big = self.ops.gemm_path(*a, **k)
             segs = a[2]
             same = len(segs) >= 2 and all(sg['A'].data_ptr() == segs[0]['A'].data_ptr() for sg in segs)
@@ -154,7 +155,7 @@ class KernelTimer:
                 conv = 'conv_fwd'
             elif same and k.get('addend') is not None:
                 conv = 'conv_dgrad'
-            return ('big' if big else 'small'), conv
+            return ({1: 'big', 2: 'bj'}.get(big, 'small')), conv
         except Exception:
             return 'small', None
 
@@ -389,10 +390,10 @@ def cpu_reference_forward(state, adj, fw, channels, x, y3d):
 
 def stock_gpu_baseline(full=False):
     """SURVEY.md section 8(d) "extra comparator": the same model through stock PyTorch-ROCm operators on this GPU (what
-    `model.cuda()` of the reference gives a user): eager launches, fp32 (3 steps after a warm-up: part of the default N = 1 line) and,
-    with --stock-baseline, autocast-bf16 and a longer sample."""
+    `model.cuda()` of the reference gives a user): eager launches, fp32 and torch.autocast(bfloat16) (3 steps each after a warm-up: part of
+    the default N = 1 line; --stock-baseline: a longer sample)."""
     out = {}
-    for tag, ac in ((('fp32', False), ('autocast_bf16', True)) if full else (('fp32', False),)):
+    for tag, ac in (('fp32', False), ('autocast_bf16', True)):
         n, dt = _stock_steps('cuda', ac, 128, 10.0 if full else 0.0, 10 if full else 3, min_steps=3)
         out[tag] = dict(ms_per_step=round(dt / n * 1e3, 2), sequences_per_s=round(128 * n / dt, 1), steps=n)
     out['note'] = ('oracle restatement on stock ATen/MIOpen/rocBLAS operators (oracle/torch_ops.py), eager, '
@@ -406,7 +407,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32', 'fp8', 'f16'])
+    ap.add_argument('--dtype', default=os.environ.get('GAST_HIP_DTYPE', 'bf16x3'), choices=['bf16', 'bf16x3', 'fp32', 'f16'])
     ap.add_argument('--variant', default='dilated', choices=['dilated', 'strided'])
     ap.add_argument('--config', default='cfg1', choices=sorted(CONFIGS), help='BASELINE.json configs[1..4] (cfg1 is the metric) or cfg243, the shipped 243-frame shape')
     ap.add_argument('--batch', type=int, default=None, help='per-GPU batch (default: the config\'s)')
@@ -844,6 +845,37 @@ def main():
                                       'softmax / master weights / parameter gradients; activation gradients travel x%g (loss scale)'
                                       % float(os.environ.get('GAST_F16_LOSS_SCALE', '4096')),
                         'note': 'same model, batch and step as `value`, own hipGraph'})
+            # the 16-bit counterpart of `forward_only` (north_star: >= 60 % of the roofline on the forward): train-mode forward under
+            # no_grad, own hipGraph, 20 replays in one event pair; roofline from the 16-bit bytes of SURVEY.md App. C
+            try:
+                with torch.no_grad():
+                    for _ in range(3):
+                        fm(x)
+                    torch.cuda.synchronize()
+                    fgf = torch.cuda.CUDAGraph()
+                    with _capture(fgf):
+                        fm(x)
+                    for _ in range(3):
+                        fgf.replay()
+                    fe0, fe1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    fe0.record()
+                    for _ in range(20):
+                        fgf.replay()
+                    fe1.record()
+                    torch.cuda.synchronize()
+                ffwd = fe0.elapsed_time(fe1) / 20
+                if args.config == 'cfg1' and C == 128:
+                    froof = max(793.4e6 * (B / 128.0) / (HBM_PEAK_GBS * 1e9), 160.7e9 * (B / 128.0) / (MFMA_PEAK_TFLOPS['f16'] * 1e12)) * 1e3
+                    f16['forward_only'] = {'ms': round(ffwd, 4), 'sequences_per_s': round(B / ffwd * 1e3, 1), 'roofline_ms': round(froof, 4),
+                                           'frac_of_roofline': round(froof / ffwd, 4),
+                                           'note': 'train-mode forward of the 16-bit mode, own hipGraph; roofline = max(HBM, MFMA) of the '
+                                                   '16-bit algorithmic work of SURVEY.md App. C (793.4 MB, 160.7 GFLOP per B = 128 forward)'}
+                    f16['roofline'] = {'bound': 'hbm', 'achieved': round(793.4e6 * (B / 128.0) / (ffwd * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                       'frac': round(793.4e6 * (B / 128.0) / (ffwd * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), 'traffic': None,
+                                       'what': 'whole forward pass (all kernels), algorithmic 16-bit bytes / measured forward time'}
+                del fgf
+            except Exception as e:   # noqa: BLE001
+                f16['forward_only'] = {'error': str(e).splitlines()[0][:160]}
             del fm, fsync, fopt, fg
         except Exception as e:   # noqa: BLE001 -- never lose the bench line to this leg
             f16 = {'error': str(e).splitlines()[0][:200]}
@@ -936,11 +968,13 @@ def main():
                     peak, unit = peak_tf, 'TFLOP/s'
                 traffic, tsrc = None, None
                 try:     # HBM bytes per launch from the committed rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected)
-                    pmc_name = next(n for n in ('r05_pmc_hbm_bytes_%s.json' % args.dtype, 'r04_pmc_hbm_bytes_%s.json' % args.dtype, 'r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
+                    if args.config != 'cfg1' or args.variant != 'dilated':
+                        raise LookupError('the committed counter passes are of the configs[1] workload: traffic stays null for any other')
+                    pmc_name = next(n for n in ('r06_pmc_hbm_bytes_%s.json' % args.dtype, 'r05_pmc_hbm_bytes_%s.json' % args.dtype, 'r04_pmc_hbm_bytes_%s.json' % args.dtype, 'r03_pmc_hbm_bytes_%s.json' % args.dtype, 'r02_pmc_hbm_bytes_%s.json' % args.dtype)
                                     if os.path.exists(os.path.join(ROOT, 'profiles', n)))      # counters of the committed kernels, newest round first
                     pmc = json.load(open(os.path.join(ROOT, 'profiles', pmc_name)))
                     GEMM_K = ('gemm_kernel<', 'gemm_multi_kernel<', 'gemm_big_kernel<', 'gemm_big_multi_kernel<', 'splitk_finish_kernel<',
-                              'splitk_finish_multi_kernel<')
+                              'splitk_finish_multi_kernel<', 'gemm_bj_kernel<', 'gemm_bj_multi_kernel<')
                     fam = [v for k, v in pmc.items() if k.startswith(GEMM_K)]
                     # bytes of the family per step / gast_gemm(+_multi) API launches per step (a multi call may be two grids)
                     calls = pmc['_meta']['steps'] * gm['launches'] / tsteps
@@ -973,12 +1007,40 @@ def main():
                             'frac_of_mfma_peak': round(flo * mult / (msl * 1e-3) / 1e12 / (2500.0 if args.dtype != 'fp32' else 157.0), 4)}
                 by_kernel = {}
                 for key, pred, label in (('gemm_big_kernel', lambda r: r[6] == 'big', 'the large-M GAST_F32X3 kernel (csrc/gemm_big.hip): the single dominant kernel of the step'),
-                                         ('gemm_kernel+splitk_finish', lambda r: r[6] == 'small', 'the M = B*J stage and the 3-column output layer (csrc/gemm.hip, split-K + finish)'),
+                                         ('gemm_bj_kernel', lambda r: r[6] == 'bj', 'the M = B*J stage on the in-block split-K kernel (csrc/gemm_bj.hip, round 6): every shape of the stage whose K steps come in fours'),
+                                         ('gemm_kernel+splitk_finish', lambda r: r[6] == 'small', 'what stays on csrc/gemm.hip (split-K + finish): K = 8, K = 5C + 8 + 2C, N = 5C + 8 of the M = B*J stage'),
                                          ('temporal_conv_fwd', lambda r: r[7] == 'conv_fwd', 'forward dilated temporal convolutions (k taps of one BatchNorm\'d tensor as K segments; reference gast_net.py:173)'),
                                          ('temporal_conv_dgrad', lambda r: r[7] == 'conv_dgrad', 'their input gradients (gather GEMM / disjoint-tap scatter GEMMs)')):
                     v = klass(pred, label)
                     if v:
                         by_kernel[key] = v
+                if 'gemm_big_kernel' in by_kernel and args.dtype == 'bf16x3':
+                    # the vendor bar: ONE plain bf16 product of the kernel's largest shape through torch.mm (hipBLASLt / rocBLAS),
+                    # no prologue / statistics / fp32 I/O -- gemm_big does THREE such products plus those per launch
+                    try:
+                        big = max((r for r in timer.calls if r[6] == 'big' and r[0] == 'gemm'), key=lambda r: r[8])
+                        dom_, N_, segs_ = big[2][0], big[2][1], big[2][2]
+                        M_, K_ = dom_[0] * dom_[1] * dom_[2], sum(sg['K'] for sg in segs_)
+                        Av = torch.randn(M_, K_, device=dev, dtype=torch.bfloat16)
+                        Wv = torch.randn(N_, K_, device=dev, dtype=torch.bfloat16)
+                        for _ in range(3):
+                            Av @ Wv.t()
+                        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        ev0.record()
+                        for _ in range(20):
+                            Av @ Wv.t()
+                        ev1.record()
+                        torch.cuda.synchronize()
+                        vus = ev0.elapsed_time(ev1) / 20 * 1e3
+                        ours = timer.replay_only('gemm', pred=lambda r: r is big)
+                        by_kernel['gemm_big_kernel'].update({'vendor_bf16_us': round(vus, 1), 'vendor_shape': 'M=%d N=%d K=%d' % (M_, N_, K_),
+                                                             'this_kernel_us_same_shape': round(ours * 1e3, 1) if ours else None,
+                                                             'x3_over_vendor': round(ours * 1e3 / vus, 2) if ours else None,
+                                                             'vendor_note': 'torch.mm in bf16 (hipBLASLt/rocBLAS), ONE product, no prologue / epilogue; '
+                                                                            'this kernel: three split products + BN prologue + statistics + fp32 I/O'})
+                        del Av, Wv
+                    except Exception as e:      # noqa: BLE001
+                        by_kernel['gemm_big_kernel']['vendor_error'] = str(e).splitlines()[0][:160]
                 out['roofline_by_kernel'] = by_kernel
                 out['roofline'] = {'kernel': ('gemm_big_kernel (large-M GAST_F32X3) + gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; '
                                               'incl. split-K finish)' if args.dtype == 'bf16x3' else 'gemm_kernel / gemm_multi_kernel<%s> (gast_gemm, gast_gemm_multi; incl. split-K finish)') % args.dtype, 'bound': bound, 'achieved': round(ach, 2),
@@ -990,7 +1052,7 @@ def main():
                                    'alg_mb_per_launch': round(gm['bytes'] / gm['launches'] / 1e6, 3)}
             out['kernels_note'] = ('per-op durations from an EAGER pass with a HIP-event pair around every launch (events cannot be recorded inside a '
                                    'replayed graph): the GPU clocks down between eager launches, so the column sums to more than ms_per_step; '
-                                   'the replayed step itself is broken down in profiles/r05_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
+                                   'the replayed step itself is broken down in profiles/r06_*_step_summary.txt / _timeline.txt (rocprofv3 --kernel-trace)')
             out['kernels'] = {k: {'launches_per_step': v['launches'] / tsteps, 'ms_per_step': round(v['ms'] / tsteps, 4),
                                   'roofline_ms_per_step': round(v['roof_ms'] / tsteps, 4)} for k, v in sorted(agg.items(), key=lambda kv: -kv[1]['ms'])}
             out['kernels_ms_per_step_total'] = round(sum(v['ms'] for v in agg.values()) / tsteps, 4)
@@ -1015,6 +1077,8 @@ def main():
                 out['stock_pytorch_rocm'] = stock_gpu_baseline(full=args.stock_baseline)
                 sp_ = out['stock_pytorch_rocm']['fp32']['sequences_per_s']
                 out['stock_pytorch_rocm']['this_path_over_stock_fp32'] = round(value / sp_, 1) if sp_ else None
+                sa_ = out['stock_pytorch_rocm'].get('autocast_bf16', {}).get('sequences_per_s')
+                out['stock_pytorch_rocm']['this_path_over_stock_autocast_bf16'] = round(value / sa_, 1) if sa_ else None
             except Exception as e:   # noqa: BLE001 -- never lose the bench line to this leg
                 out['stock_pytorch_rocm'] = {'error': str(e).splitlines()[0][:200]}
         if collective:

@@ -49,12 +49,18 @@ constexpr int off_tab_fast() { return OFF_W + FD * w_bytes(1); }
 constexpr int LDS_BLOCK_FAST = FD == 4 ? LDS_BLOCK : 100 * 1024;
 constexpr int max_tab_fast() { return (LDS_BLOCK_FAST - off_tab_fast()) / 8; }
 
+// The scalar base of these loads may reach the statement through v_readfirstlane (uni() below: a pointer the compiler kept in vector
+// registers).  gfx9 needs 5 wait states between a VALU write of an SGPR and a VMEM instruction that reads it; hipcc inserts them for the
+// code it generates but cannot see inside an inline-asm statement -- without the s_nop the load uses the OLD register content, i.e. a wild
+// address (the memory access faults that came and went with unrelated code changes in rounds 5 and 6: 204 such pairs in the build of
+// this file that faulted, none in the next one -- scripts/asm_load_hazard.py --sgpr).  The wait states are part of
+// the statement: the order no longer depends on what the scheduler puts in front.
 template <int OFF>
 __device__ __forceinline__ void glds16(uint32_t voff, const void* sbase, uint32_t lds_wave_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(lds_wave_base), "n"(OFF) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3" ::"v"(voff), "s"(sbase), "s"(lds_wave_base), "n"(OFF) : "memory", "m0");
 }
 __device__ __forceinline__ void gload16s(u32x4& dst, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory");
 }
 
 // a wave-uniform pointer the compiler's divergence analysis may have lost track of (loop-carried through a lambda): scalar registers
@@ -460,7 +466,7 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
 // no tail / zero-row / past-the-end handling at all (K steps come in fours).
 template <int OFF>
 __device__ __forceinline__ void gload16s_o(u32x4& dst, uint32_t voff, const void* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
 template <int PAIR>
 __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPlan& pl, int blk, unsigned char* smem) {
@@ -718,7 +724,11 @@ bj_multi_kernel_t bj_multi_kernel(int fast, int pair) {
     if (fast) return pair == 2 ? gemm_bj_multi_kernel<1, 2, true> : gemm_bj_multi_kernel<1, 1, true>;
     return pair == 2 ? gemm_bj_multi_kernel<1, 2, false> : gemm_bj_multi_kernel<1, 1, false>;
 }
-int bj_lds_bytes(int ntab, int fast) { return (fast ? off_tab_fast() : off_tab(1)) + 2 * ntab * 4; }
+int bj_lds_bytes(int ntab, int fast) {
+    static const int pad = getenv("GAST_GEMM_BJ_LDS_PAD") ? atoi(getenv("GAST_GEMM_BJ_LDS_PAD")) : 0;      // (occupancy experiments: fewer blocks per CU)
+    const int n = (fast ? off_tab_fast() : off_tab(1)) + 2 * ntab * 4 + pad;
+    return n > LDS_BLOCK ? LDS_BLOCK : n;
+}
 
 void bj_setup() {
     int dev = 0;

@@ -34,7 +34,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n, const int* __restrict__ step,
-                                                   float lr, float beta1, float beta2, float eps, float wd, float gscale) {
+                                                   float lr, float beta1, float beta2, float eps, float wd, float gscale,
+                                                   const int* __restrict__ skip) {
+    if (skip && *skip) return;          // (non-finite gradient detected by the caller: the whole update is skipped, loss-scaled 16-bit mode)
     // (Round 4 tried to fold the step increment into this kernel -- every block computing with step + 1 and the last block to take a
     // ticket storing it back: 4096 device-scope atomics on ONE address cost 194 us (~47 ns each, serialised at the memory side), against
     // 4.6 us for the one-thread increment kernel.  Same-address atomics from every block of a grid are never cheap on this chip.)
@@ -60,7 +62,7 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
-__global__ void step_inc_kernel(int* step) { *step += 1; }
+__global__ void step_inc_kernel(int* step, const int* skip) { if (!(skip && *skip)) *step += 1; }
 
 // ---- pass prologue ("prep"): everything a forward or backward pass needs before its first real kernel, as ONE launch -- the
 // zero fills of the accumulation arenas / gradient buffers (up to GAST_PREP_MAX_ZERO regions), the dropout seed bump + its
@@ -137,15 +139,20 @@ __global__ void __launch_bounds__(1024) mpjpe_kernel(const float* __restrict__ p
 
 extern "C" int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                               float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream) {
+    return gast_adam_step_guarded(p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, nullptr, stream);
+}
+
+extern "C" int gast_adam_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
+                                      float beta2, float eps, float weight_decay, float grad_scale, const int* skip, gast_stream_t stream) {
     if (!p || !g || !m || !v || !step || n < 1) return GAST_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return GAST_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step, skip);
     long nb = ((n >> 2) + 255) / 256;
     if (nb > 256 * 16) nb = 256 * 16;
     if (nb < 1) nb = 1;
     hipLaunchKernelGGL(adam_kernel, dim3((int)nb), dim3(256), 0, st, p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, weight_decay,
-                       grad_scale);
+                       grad_scale, skip);
     GAST_CHECK_LAUNCH();
     return 0;
 }

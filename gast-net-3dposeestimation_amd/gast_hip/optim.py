@@ -14,12 +14,21 @@ from gast_hip.packer import note_raw_parameter_write
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, ops=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, amsgrad=False, ops=None, skip_nonfinite=None):
+        """skip_nonfinite: skip the whole update (parameters, moments, step counter) when the flat gradient holds an inf / NaN, and count
+        it in `skipped_steps` -- what torch.cuda.amp.GradScaler does around an optimizer.  Default: on in the loss-scaled 16-bit mode
+        (GAST_HIP_DTYPE=f16, where an overflow of the scaled activation gradients shows up exactly like that), off otherwise.  The check
+        and the counter stay on the device (hipGraph-capturable); the loss scale itself is static (GAST_F16_LOSS_SCALE)."""
         if lr < 0 or eps < 0 or not (0 <= betas[0] < 1) or not (0 <= betas[1] < 1) or weight_decay < 0:
             raise ValueError('invalid Adam hyper-parameters')
         defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad)
         super().__init__(params, defaults)
         self._ops = ops
+        if skip_nonfinite is None:
+            import os
+            skip_nonfinite = os.environ.get('GAST_HIP_DTYPE', '').lower() == 'f16'
+        self.skip_nonfinite = bool(skip_nonfinite)
+        self.skipped_steps = None      # device int64 counter (created with the first guarded step)
         self.grad_scale = 1.0      # gradients are multiplied by this inside the update kernel (1/world after a SUM all-reduce)
         self._flat = []
         for group in self.param_groups:
@@ -106,9 +115,15 @@ class FlatAdam(torch.optim.Optimizer):
                                        'build the optimizer after the model is on its device')
             G = self._grad_buffer(st)
             b1, b2 = group['betas']
+            skip = None
+            if self.skip_nonfinite:
+                skip = torch.logical_not(torch.isfinite(G).all()).to(torch.int32).reshape(1)
+                if self.skipped_steps is None:
+                    self.skipped_steps = torch.zeros(1, dtype=torch.int64, device=G.device)
+                self.skipped_steps += skip
             self._get_ops().adam_step(st['P'], G, st['m'], st['v'], st['vmax'] if group['amsgrad'] else None, st['step'],
                                       float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
-                                      grad_scale=float(self.grad_scale))
+                                      grad_scale=float(self.grad_scale), skip=skip)
             note_raw_parameter_write()      # (the kernel writes parameter memory behind torch's version counters)
         return loss
 

@@ -188,6 +188,9 @@ class CausalStream:
         if tuple(frame.shape) != (self.B_user, self.J, self.F):
             raise RuntimeError('CausalStream.push: expected a frame of shape %s, got %s' % ((self.B_user, self.J, self.F), tuple(frame.shape)))
         with torch.cuda.device(self.dev), torch.no_grad():
+            ops = self.engine.ops
+            if self.dt != torch.float32 and hasattr(ops, 'set_h16'):
+                ops.set_h16(self.dt)      # (the storage flavour is per THREAD: a stream pushed from another thread than the one that built it)
             self.x_in.copy_(frame)
             if not self.use_graph:
                 self._step()

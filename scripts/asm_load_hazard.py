@@ -10,6 +10,13 @@ instruction that names a register of a still-outstanding inline-asm load before 
 
   hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only csrc/gemm.hip -o /tmp/gemm.s && python scripts/asm_load_hazard.py /tmp/gemm.s
   ... asm_load_hazard.py --strict /tmp/gemm.s     (compiler-inserted waits do not count: see scan())
+Second screen (round 6), `--sgpr`: the gfx9 data hazard "VALU writes an SGPR -> VMEM reads that SGPR" needs 5 wait states.  hipcc's hazard
+recognizer inserts them for the instructions it generates, but it cannot see INSIDE an inline-asm statement: when the scalar base of
+gload16s / glds16 reaches the statement through v_readfirstlane (a pointer the divergence analysis kept in vector registers), nothing
+separates the VALU write from the asm's global_load.  The load then uses the OLD register content -- a wild address: the "memory access
+fault that comes and goes with unrelated code changes" of rounds 5 and 6.  Reported: every inline-asm VMEM instruction whose saddr pair
+was written by a VALU instruction fewer than 5 instruction slots (s_nop N counts N + 1) earlier in layout order.
+
 Linear scan (blocks are walked in layout order; loads issued inside a loop are forgotten at its exit block), so a report is a lead to read, not a proof; no report on a loop whose
 layout order is its execution order is strong evidence.  Exit code 1 when anything was reported.
 """
@@ -90,8 +97,70 @@ def scan(path):
     return reports
 
 
+SREG = re.compile(r'\bs(\d+)\b|\bs\[(\d+):(\d+)\]')
+
+
+def sregs(tok):
+    out = set()
+    for m in SREG.finditer(tok):
+        if m.group(1) is not None:
+            out.add(int(m.group(1)))
+        else:
+            out.update(range(int(m.group(2)), int(m.group(3)) + 1))
+    return out
+
+
+def scan_sgpr(path):
+    """VALU write of an SGPR followed by an inline-asm VMEM read of it with fewer than 5 wait states in between"""
+    fn, in_asm, reports = None, False, []
+    recent = []          # (wait states elapsed since, sgprs written by a VALU instruction, line, text)
+    for ln, line in enumerate(open(path, errors='replace'), 1):
+        if re.match(r'^[_A-Za-z][\w$.]*:\s*(;.*)?$', line) and not line.startswith('.L'):
+            fn, recent = line.split(':')[0], []
+            continue
+        st = line.strip()
+        if st.startswith(';;#ASMSTART'):
+            in_asm = True
+            continue
+        if st.startswith(';;#ASMEND'):
+            in_asm = False
+            continue
+        s_ = line.split(';')[0].strip()
+        if not s_ or s_.startswith('.') or s_.endswith(':'):
+            continue
+        op = s_.split()[0]
+        if in_asm and VMEM.match(s_):
+            ops = s_.split(None, 1)[1] if ' ' in s_ else ''
+            used = sregs(ops)
+            for age, wr, wl, wt in recent:
+                if age < 5 and used & wr:
+                    reports.append((fn, ln, s_, 'saddr s%s written %d wait state(s) earlier by: %s (line %d)' % (sorted(used & wr), age, wt, wl)))
+        step = 1
+        m = re.match(r's_nop\s+(\d+)', s_)
+        if m:
+            step = int(m.group(1)) + 1
+        recent = [(a + step, w, l, t) for a, w, l, t in recent if a + step < 8]
+        if op.startswith('v_'):
+            dst = s_.split(None, 1)[1].split(',')[0] if ' ' in s_ else ''
+            w = sregs(dst)
+            if op.startswith('v_cmp') and not w and 'vcc' not in dst:
+                w = set()
+            if w:
+                recent.append((0, w, ln, s_))
+    return reports
+
+
 if __name__ == '__main__':
     bad = 0
+    if '--sgpr' in sys.argv:
+        sys.argv.remove('--sgpr')
+        for p in sys.argv[1:]:
+            rep = scan_sgpr(p)
+            for fn, ln, s, why in rep[:400]:
+                print('%s:%d  %s\n    in %s   %s' % (p, ln, s, fn, why))
+            print('%s: %d VALU->SGPR->VMEM hazard(s) inside inline asm' % (p, len(rep)))
+            bad += len(rep)
+        sys.exit(1 if bad else 0)
     if '--strict' in sys.argv:
         STRICT = True
         sys.argv.remove('--strict')

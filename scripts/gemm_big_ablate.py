@@ -20,6 +20,10 @@ for K in Ks:
 C = torch.empty(M, N).cuda()
 part = torch.zeros((M + 127) // 128, N, 2).cuda()
 kw = dict(epi=epi, partials=part if epi else None)
+if os.environ.get('GAST_PRINT_ADDR'):      # (fault hunting: where every operand lives)
+    for i, sg in enumerate(segs):
+        print('seg %d: A %#x..%#x  W %#x..%#x  image %#x..%#x' % (i, sg['A'].data_ptr(), sg['A'].data_ptr() + sg['A'].numel() * 4, sg['W'].t.data_ptr(), sg['W'].t.data_ptr() + sg['W'].t.numel() * 4, sg['W'].img.data_ptr(), sg['W'].img.data_ptr() + sg['W'].img.numel() * 2), flush=True)
+    print('C %#x..%#x  partials %#x..%#x' % (C.data_ptr(), C.data_ptr() + C.numel() * 4, part.data_ptr(), part.data_ptr() + part.numel() * 4), flush=True)
 assert ops.gemm_path((B, T, J), N, segs, C, RowMap(T, 1, 0), **kw) == 1
 for _ in range(3): ops.gemm((B, T, J), N, segs, C, RowMap(T, 1, 0), **kw)
 torch.cuda.synchronize()

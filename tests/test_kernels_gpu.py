@@ -581,6 +581,68 @@ def test_gemm_bj_second_output(ops, case):
     _assert_bit_equal(bufs[2].view(bufs[2].shape[0], -1), part_ref.view(part_ref.shape[0], -1), 'column sums')
 
 
+GUARD_CASES = [
+    # M = 1 (mod 128) rows, every K = 16 (mod 32): the last row tile holds one row, every segment ends in half a K step
+    ('guard_small_m', (1, 43, 3), 72, [(48, 43, 1, 0, 1), (80, 45, 1, 2, 0)], 1, False, True),              # M = 129
+    ('guard_bwd_m', (5, 7, 11), 136, [(112, 7, 1, 0, 0)], 2, True, False),                                    # M = 385
+    ('guard_big_m', (1, 2731, 3), 96, [(48, 2731, 1, 0, 1), (176, 2735, 1, 4, 0)], 1, False, 'neg'),         # M = 8193: the large-M kernel
+]
+
+
+@pytest.mark.parametrize('images', [False, True], ids=['fp32_operands', 'images'])
+@pytest.mark.parametrize('case', GUARD_CASES, ids=[c[0] for c in GUARD_CASES])
+def test_gemm_guard_bands(ops, case, images):
+    """ragged shapes on every GEMM kernel (gemm.hip without images, gemm_bj.hip / gemm_big.hip with) with the OUTPUT,
+    the second output and the column statistics each carved out of a NaN-filled arena -- 4 KB guard bands on both sides must come back
+    untouched -- and every activation / weight operand ending exactly at the end of its allocation (an over-read of the last row or
+    the last K step leaves the tensor).  Results against the contract."""
+    name, dom, N, segdefs, epi, use_add, use_bias = case
+    B, Tn, J = dom
+    M = B * Tn * J
+    assert M % 128 == 1 and all(sd[0] % 32 == 16 for sd in segdefs)
+    jd, jh, bufs = _gemm_case(case, torch.float32)
+    Cd, Ch, pd, ph = bufs
+    G = 1024                                             # guard band: 1024 floats
+    rowsC, ldc = Cd.shape
+    sizes = [rowsC * ldc, rowsC * ldc if epi == 2 else 0, pd.numel() if pd is not None else 0]
+    arena = torch.full((sum(sizes) + G * (len(sizes) + 1),), float('nan')).cuda()
+    offs, o = [], G
+    for n in sizes:
+        offs.append(o)
+        o += n + G
+    Cg = arena[offs[0]:offs[0] + sizes[0]].view(rowsC, ldc)
+    Cg.fill_(7.0)
+    jd['C_'] = Cg[:, :N]
+    C2g = None
+    if epi == 2:
+        C2g = arena[offs[1]:offs[1] + sizes[1]].view(rowsC, ldc)
+        C2g.fill_(7.0)
+        jd['C2'] = C2g[:, :N]
+    if pd is not None:
+        pg = arena[offs[2]:offs[2] + sizes[2]].view(pd.shape)
+        pg.zero_()
+        jd['partials'] = pg
+    with x3_mode(ops, 'x3'):
+        if images:
+            _with_images(ops, jd)
+            assert ops.gemm_path(**jd) == (1 if M >= 8192 else 2)
+        ops.gemm(**jd)
+    torch.cuda.synchronize()
+    kc.gemm(**jh)
+    a = arena.cpu()
+    inside = torch.zeros(a.numel(), dtype=torch.bool)
+    for of, n in zip(offs, sizes):
+        inside[of:of + n] = True
+    assert bool(torch.isnan(a[~inside]).all()), 'a guard band was written: elements %s' % (~inside & ~torch.isnan(a)).nonzero()[:8].flatten().tolist()
+    got = Cg.cpu().numpy()
+    close(got[:, :N], Ch[:, :N], torch.float32, name + ' C', fp32=1e-4)
+    assert np.all(got[:, N:] == 7.0), 'wrote outside the N columns'
+    if C2g is not None:
+        assert np.all(C2g.cpu().numpy()[:, N:] == 7.0)
+    if pd is not None:
+        close(host(jd['partials']).sum(axis=0), ph.sum(axis=0), torch.float32, name + ' partial totals', fp32=2e-4)
+
+
 def test_x3_image_layout(ops):
     """k-group-major image: img[k>>4][r][k&15] = bf16(w), [...][16 + (k&15)] = bf16(w - hi); zero K padding and zero rows behind"""
     gen = torch.Generator().manual_seed(11)

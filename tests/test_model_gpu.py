@@ -563,6 +563,37 @@ def test_cpu_input_raises_loudly():
         m(torch.zeros(1, 9, 17, 2))
 
 
+def test_flat_adam_skips_a_step_with_a_nonfinite_gradient():
+    """FlatAdam(skip_nonfinite=True) -- the default in the loss-scaled 16-bit mode: an inf / NaN anywhere in the flat gradient leaves
+    parameters, moments and the step counter untouched and is counted on the device; finite gradients update as without the guard."""
+    from gast_hip.optim import FlatAdam
+    gen = torch.Generator().manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(37, 5, generator=gen).cuda()), torch.nn.Parameter(torch.randn(11, generator=gen).cuda())]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, opt_ref = FlatAdam(ps, lr=1e-2, amsgrad=True, skip_nonfinite=True), FlatAdam(ref, lr=1e-2, amsgrad=True, skip_nonfinite=False)
+    for step in range(4):
+        grads = [torch.randn(p.shape, generator=gen).cuda() for p in ps]
+        bad = step == 1
+        opt.zero_grad()
+        for p, g in zip(ps, grads):
+            p.grad.copy_(g)
+        if bad:
+            ps[1].grad[3] = float('inf')
+        before = [p.detach().clone() for p in ps]
+        opt.step()
+        if bad:
+            assert all(torch.equal(a, p.detach()) for a, p in zip(before, ps)), 'a skipped step must not touch the parameters'
+        else:
+            opt_ref.zero_grad()
+            for p, g in zip(ref, grads):
+                p.grad.copy_(g)
+            opt_ref.step()
+    assert int(opt.skipped_steps.item()) == 1
+    assert int(opt._flat[0]['step'].item()) == 3 == int(opt_ref._flat[0]['step'].item())
+    for a, b in zip(ps, ref):
+        assert torch.equal(a.detach(), b.detach())
+
+
 def test_training_trajectory_matches_reference(mode2):
     """P6: 12 training steps -- this model + gast_hip.loss.mpjpe + gast_hip.optim.FlatAdam(amsgrad), in fp32 and in
     bf16x3 (the arithmetic bench.py times: "MPJPE within 0.1 mm of reference" must hold for the timed mode) --
