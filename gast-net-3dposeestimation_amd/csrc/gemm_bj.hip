@@ -468,7 +468,10 @@ template <int OFF>
 __device__ __forceinline__ void gload16s_o(u32x4& dst, uint32_t voff, const void* sbase) {
     asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=&v"(dst) : "v"(voff), "s"(sbase), "n"(OFF) : "memory");
 }
-template <int PAIR>
+// CHAINS = 2: the correction products accumulate in a register set of their own (two independent MFMA chains per step: what a lone
+// block per CU wants); CHAINS = 1: one accumulator, 80 registers -- three blocks per CU, for the grids that do not fit two per CU
+// (measured: N = 1024 launches 55 -> 50 and 47 -> 43 us; the 34-block output layer 22 -> 27 us with it, so it keeps two chains)
+template <int PAIR, int CHAINS>
 __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPlan& pl, int blk, unsigned char* smem) {
     constexpr int NJ = 1, TN = tn_of(NJ), W_BYTES = w_bytes(NJ), OFF_TAB = off_tab_fast(), NW = 1;
     static_assert(FD % 4 == 0 && FD >= 4, "pipeline depth");
@@ -581,9 +584,9 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         *(uint2*)(smem + stage * A_BYTES + wa_lo) = l;
     };
     const int ntile = pl.ntile32;                    // (a multiple of 4)
-    f32x16 acc[NJ], acl[NJ];
+    f32x16 acc[NJ], acl[CHAINS == 2 ? NJ : 1];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acl[0][r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; if (CHAINS == 2) acl[0][r] = 0.f; }
     const int fkey = (li >> 2) & 3;
     const int ohi = li * ROWB + ((lh ^ fkey) << 4), olo = li * ROWB + (((2 + lh) ^ fkey) << 4);
     const unsigned char* const fA = smem + OFF_A + kg * (TM * ROWB) + wr * 32 * ROWB;
@@ -650,9 +653,15 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         bl.u = *(const uint4*)(fW + SW * W_BYTES + olo);
         if (wr_next) write_a(SA ^ 1, ra[SET]);
         if (do_mma) {
-            acl[0] = mfma_pair<PAIR>(al.u, bh.u, acl[0]);
-            acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
-            acl[0] = mfma_pair<PAIR>(ah.u, bl.u, acl[0]);
+            if constexpr (CHAINS == 2) {
+                acl[0] = mfma_pair<PAIR>(al.u, bh.u, acl[0]);
+                acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
+                acl[0] = mfma_pair<PAIR>(ah.u, bl.u, acl[0]);
+            } else {       // small terms first
+                acc[0] = mfma_pair<PAIR>(al.u, bh.u, acc[0]);
+                acc[0] = mfma_pair<PAIR>(ah.u, bl.u, acc[0]);
+                acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
+            }
         }
         if ((U & 3) == 1) w_next_group();
         dma_w((U + FD - 1) % FD);
@@ -682,8 +691,10 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
     gload_wait_n<0>();
 #pragma unroll
     for (int i = 0; i < FD; ++i) asm volatile("" ::"v"(ra[i]));
+    if constexpr (CHAINS == 2) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][r] += acl[0][r];
+        for (int r = 0; r < 16; ++r) acc[0][r] += acl[0][r];
+    }
     __syncthreads();
     bj_finish<NJ>(a, pl, smem, acc, m0, n0, mt);
 }
@@ -696,18 +707,18 @@ struct BjBatch {
 };
 static_assert(sizeof(BjBatch) <= 3840, "BjBatch travels as a kernel argument (4 KB limit)");
 
-template <int NJ, int PAIR, bool FAST>
-__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : 4) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
+template <int NJ, int PAIR, int FAST>      // FAST: 0 general loop, 1 lean loop (two chains, two blocks per CU), 2 lean loop (one chain, three blocks per CU)
+__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : (FAST == 2 ? 6 : 4)) gemm_bj_kernel(const gast_gemm_args a, const BjPlan pl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    if constexpr (FAST) bj_body_fast<PAIR>(a, pl, blockIdx.x, smem);
+    if constexpr (FAST != 0) bj_body_fast<PAIR, FAST == 2 ? 1 : 2>(a, pl, blockIdx.x, smem);
     else bj_body<NJ, PAIR>(a, pl, blockIdx.x, smem);
 }
-template <int NJ, int PAIR, bool FAST>
-__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : 4) gemm_bj_multi_kernel(const BjBatch b) {
+template <int NJ, int PAIR, int FAST>
+__global__ void __launch_bounds__(NT, (FAST && FD > 4) ? 2 : (FAST == 2 ? 6 : 4)) gemm_bj_multi_kernel(const BjBatch b) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int d = 0;
     while (d + 1 < b.n && (int)blockIdx.x >= b.first[d + 1]) ++d;
-    if constexpr (FAST) bj_body_fast<PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
+    if constexpr (FAST != 0) bj_body_fast<PAIR, FAST == 2 ? 1 : 2>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
     else bj_body<NJ, PAIR>(b.a[d], b.pl[d], blockIdx.x - b.first[d], smem);
 }
 
@@ -717,12 +728,14 @@ std::atomic<bool> bj_setup_done[64];
 typedef void (*bj_kernel_t)(const gast_gemm_args, const BjPlan);
 typedef void (*bj_multi_kernel_t)(const BjBatch);
 bj_kernel_t bj_kernel(int fast, int pair) {
-    if (fast) return pair == 2 ? gemm_bj_kernel<1, 2, true> : gemm_bj_kernel<1, 1, true>;
-    return pair == 2 ? gemm_bj_kernel<1, 2, false> : gemm_bj_kernel<1, 1, false>;
+    if (fast == 2) return pair == 2 ? gemm_bj_kernel<1, 2, 2> : gemm_bj_kernel<1, 1, 2>;
+    if (fast) return pair == 2 ? gemm_bj_kernel<1, 2, 1> : gemm_bj_kernel<1, 1, 1>;
+    return pair == 2 ? gemm_bj_kernel<1, 2, 0> : gemm_bj_kernel<1, 1, 0>;
 }
 bj_multi_kernel_t bj_multi_kernel(int fast, int pair) {
-    if (fast) return pair == 2 ? gemm_bj_multi_kernel<1, 2, true> : gemm_bj_multi_kernel<1, 1, true>;
-    return pair == 2 ? gemm_bj_multi_kernel<1, 2, false> : gemm_bj_multi_kernel<1, 1, false>;
+    if (fast == 2) return pair == 2 ? gemm_bj_multi_kernel<1, 2, 2> : gemm_bj_multi_kernel<1, 1, 2>;
+    if (fast) return pair == 2 ? gemm_bj_multi_kernel<1, 2, 1> : gemm_bj_multi_kernel<1, 1, 1>;
+    return pair == 2 ? gemm_bj_multi_kernel<1, 2, 0> : gemm_bj_multi_kernel<1, 1, 0>;
 }
 int bj_lds_bytes(int ntab, int fast) {
     static const int pad = getenv("GAST_GEMM_BJ_LDS_PAD") ? atoi(getenv("GAST_GEMM_BJ_LDS_PAD")) : 0;      // (occupancy experiments: fewer blocks per CU)
@@ -735,7 +748,7 @@ void bj_setup() {
     hipGetDevice(&dev);
     dev &= 63;
     if (bj_setup_done[dev].load(std::memory_order_acquire)) return;
-    for (int fast = 0; fast <= 1; ++fast)
+    for (int fast = 0; fast <= 2; ++fast)
         for (int pair = 1; pair <= 2; ++pair) {
             const hipError_t e1 = hipFuncSetAttribute((const void*)bj_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
             const hipError_t e2 = hipFuncSetAttribute((const void*)bj_multi_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
@@ -746,7 +759,7 @@ void bj_setup() {
         }
     bj_setup_done[dev].store(true, std::memory_order_release);
     if (getenv("GAST_GEMM_BJ_DEBUG")) {
-        for (int fast = 0; fast <= 1; ++fast) {
+        for (int fast = 0; fast <= 2; ++fast) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)bj_kernel(fast, 1), NT, bj_lds_bytes(0, fast));
             hipFuncAttributes fa;
@@ -830,11 +843,14 @@ int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hi
     b.n = n;
     b.first[0] = 0;
     int ntab = 0, fast = 1;
-    for (int d = 0; d < n; ++d) fast &= pls[d].fast;          // (one kernel per launch: the lean loop when every job qualifies)
+    long blocks = 0;
+    for (int d = 0; d < n; ++d) { fast &= pls[d].fast; blocks += (long)pls[d].tilesM * ((args[d].N + 63) / 64); }      // (one kernel per launch: the lean loop when every job qualifies)
+    static const int occ3_blocks = getenv("GAST_GEMM_BJ_OCC3_BLOCKS") ? atoi(getenv("GAST_GEMM_BJ_OCC3_BLOCKS")) : 512;
+    if (fast && FD == 4 && blocks > occ3_blocks) fast = 2;          // more blocks than two per CU: the 80-register variant, three per CU
     for (int d = 0; d < n; ++d) {
         if (pls[d].pair != pair) return GAST_EINVAL;
         pls[d].nj = nj;
-        pls[d].fast = fast;
+        pls[d].fast = fast != 0;
         pls[d].tilesN = (args[d].N + tn_of(nj) - 1) / tn_of(nj);
         b.a[d] = args[d];
         b.pl[d] = pls[d];

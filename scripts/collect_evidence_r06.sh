@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-5 evidence (run through gpurun): the driver's default bench line, the replayed step and the forward-only graph launch by launch
+# Round-6 evidence (run through gpurun): the driver's default bench line, the replayed step and the forward-only graph launch by launch
 # (rocprofv3 --kernel-trace), per-kernel stats, the HBM-byte and MFMA-utilisation counter passes (separate --pmc runs), two more default
-# lines for the median, the other configurations.  Everything lands in gpurun_out/r05_evidence; copy what is cited into profiles/.
+# lines for the median, the other configurations.  Everything lands in gpurun_out/r06_evidence; copy what is cited into profiles/.
 cd /tmp && export TMPDIR=/tmp
 R="$GRAFT_REPO_ROOT"; cd "$R"
-O=$R/gpurun_out/r05_evidence; mkdir -p $O
+O=$R/gpurun_out/r06_evidence; mkdir -p $O
 if [ "$ONLY" != trace ] && [ "$ONLY" != prof ]; then
 timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err
 tail -c 400 $O/bench_default.json; echo
@@ -59,8 +59,8 @@ timeout 300 python bench.py --force-collective --no-cpu-baseline --no-kernel-tim
 tail -c 600 $O/bench_force_collective.json; echo
 # LDS bank-conflict counters per kernel (its own --pmc run)
 bash scripts/pmc_lds.sh $O > /dev/null 2>&1; head -12 $O/pmc_lds_summary.txt
-# the opt-in lazy finalize next to the default on the same box
-bash scripts/ab_env.sh $O/ab_lazy base= lazy=GAST_LAZY_BN=1 nofuse=GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0 | tee $O/ab_lazy.txt
+# the M = B*J kernel (gemm_bj.hip) off / on every eligible shape, next to the default on the same box
+bash scripts/ab_env.sh $O/ab_bj base= nobj=GAST_GEMM_BJ=0 allbj=GAST_GEMM_BJ_ALL=1 | tee $O/ab_bj.txt
 # the 16-bit mode: the replayed f16 step per kernel, and its round-5 kernels (16-bit gemm_big / wgrad_wide) switched off on the same box
 GAST_HIP_DTYPE=f16 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_f16 -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 8 --warmup 2 > $O/trace_f16.log 2>&1
 python scripts/trace_step.py $(find /tmp/prof_f16 -name "*kernel_trace.csv" | head -1) 3 > $O/f16_step_summary.txt

@@ -831,6 +831,8 @@ def test_wide_wgrad_bf16_storage(ops):
                                                ('GAST_GEMM_BIG_NI=2', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_NI=4', 'test_gemm_big_x3', None),
                                                ('GAST_GEMM_BIG_MW=4', 'test_gemm_big_x3', None),
+                                               ('GAST_GEMM_BJ_OCC3_BLOCKS=0', 'test_gemm_bj', None),      # the 80-register lean loop (three blocks per CU) on every regular shape
+                                               ('GAST_GEMM_BJ_FAST=0', 'test_gemm_bj', None),             # the general loop on every shape
                                                ('GAST_ATTN_MFMA=0', 'test_attention and bf16', None)])
 def test_optin_kernel_variants(knob, select, npass):
     """Kernel variants behind environment switches (read once per process by the library): 256x256 weight-gradient tiles (forced on
