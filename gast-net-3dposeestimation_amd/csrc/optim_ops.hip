@@ -32,11 +32,39 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     p -= c.step_size * (m / denom);
 }
 
+// GAST_NONFINITE_FLAGS per-block verdicts of gast_nonfinite_scan (every block writes its own word on every call: nothing to reset);
+// block-uniform: is any of them set?  (nullptr: no guard)
+__device__ __forceinline__ bool skip_any(const int* __restrict__ skip) {
+    if (!skip) return false;
+    int bad = 0;
+    for (int i = threadIdx.x & 63; i < GAST_NONFINITE_FLAGS; i += 64) bad |= skip[i];
+    return __any(bad != 0);
+}
+
+// flags[b] = 1 when block b's slice of g holds an inf / NaN (exponent bits all ones), else 0
+__global__ void __launch_bounds__(256) nonfinite_scan_kernel(const float* __restrict__ g, long n, int* __restrict__ flags) {
+    __shared__ int sbad;
+    if (threadIdx.x == 0) sbad = 0;
+    __syncthreads();
+    const long n4 = n >> 2;
+    unsigned bad = 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const uint4 v = ((const uint4*)g)[i];
+        bad |= ((v.x & 0x7f800000u) == 0x7f800000u) | ((v.y & 0x7f800000u) == 0x7f800000u) | ((v.z & 0x7f800000u) == 0x7f800000u) |
+               ((v.w & 0x7f800000u) == 0x7f800000u);
+    }
+    if (blockIdx.x == 0)
+        for (long i = (n4 << 2) + threadIdx.x; i < n; i += 256) bad |= (__float_as_uint(g[i]) & 0x7f800000u) == 0x7f800000u;
+    if (bad) sbad = 1;               // (benign race: every writer stores 1)
+    __syncthreads();
+    if (threadIdx.x == 0) flags[blockIdx.x] = sbad;
+}
+
 __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, float* __restrict__ vmax, long n, const int* __restrict__ step,
                                                    float lr, float beta1, float beta2, float eps, float wd, float gscale,
                                                    const int* __restrict__ skip) {
-    if (skip && *skip) return;          // (non-finite gradient detected by the caller: the whole update is skipped, loss-scaled 16-bit mode)
+    if (skip_any(skip)) return;         // (non-finite gradient detected by gast_nonfinite_scan: the whole update is skipped, loss-scaled 16-bit mode)
     // (Round 4 tried to fold the step increment into this kernel -- every block computing with step + 1 and the last block to take a
     // ticket storing it back: 4096 device-scope atomics on ONE address cost 194 us (~47 ns each, serialised at the memory side), against
     // 4.6 us for the one-thread increment kernel.  Same-address atomics from every block of a grid are never cheap on this chip.)
@@ -62,7 +90,13 @@ __global__ void __launch_bounds__(256) adam_kernel(float* __restrict__ p, const 
     }
 }
 
-__global__ void step_inc_kernel(int* step, const int* skip) { if (!(skip && *skip)) *step += 1; }
+__global__ void __launch_bounds__(64) step_inc_kernel(int* step, const int* skip, long long* skipped) {
+    const bool sk = skip_any(skip);
+    if (threadIdx.x == 0) {
+        if (!sk) *step += 1;
+        else if (skipped) *skipped += 1;
+    }
+}
 
 // ---- pass prologue ("prep"): everything a forward or backward pass needs before its first real kernel, as ONE launch -- the
 // zero fills of the accumulation arenas / gradient buffers (up to GAST_PREP_MAX_ZERO regions), the dropout seed bump + its
@@ -139,15 +173,23 @@ __global__ void __launch_bounds__(1024) mpjpe_kernel(const float* __restrict__ p
 
 extern "C" int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                               float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream) {
-    return gast_adam_step_guarded(p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, nullptr, stream);
+    return gast_adam_step_guarded(p, g, m, v, vmax, n, step, lr, beta1, beta2, eps, weight_decay, grad_scale, nullptr, nullptr, stream);
+}
+
+extern "C" int gast_nonfinite_scan(const float* g, long n, int* flags, gast_stream_t stream) {
+    if (!g || !flags || n < 1 || ((uintptr_t)g & 15)) return GAST_EINVAL;
+    hipLaunchKernelGGL(nonfinite_scan_kernel, dim3(GAST_NONFINITE_FLAGS), dim3(256), 0, (hipStream_t)stream, g, n, flags);
+    GAST_CHECK_LAUNCH();
+    return 0;
 }
 
 extern "C" int gast_adam_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
-                                      float beta2, float eps, float weight_decay, float grad_scale, const int* skip, gast_stream_t stream) {
+                                      float beta2, float eps, float weight_decay, float grad_scale, const int* skip, long long* skipped,
+                                      gast_stream_t stream) {
     if (!p || !g || !m || !v || !step || n < 1) return GAST_EINVAL;
     if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v | (uintptr_t)vmax) & 15) return GAST_EALIGN;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, st, step, skip);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, st, step, skip, skipped);
     long nb = ((n >> 2) + 255) / 256;
     if (nb > 256 * 16) nb = 256 * 16;
     if (nb < 1) nb = 1;

@@ -237,7 +237,8 @@ def load_library(h16=torch.bfloat16):
         'gast_unfold': [vp, ci, ci, vp, vp],
         'gast_mpjpe': [vp, vp, cl, ci, vp, vp, vp],
         'gast_adam_step': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp],
-        'gast_adam_step_guarded': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp, vp],
+        'gast_adam_step_guarded': [vp, vp, vp, vp, vp, cl, vp, cf, cf, cf, cf, cf, cf, vp, vp, vp],
+        'gast_nonfinite_scan': [vp, cl, vp, vp],
         'gast_null_launch': [vp],
         'gast_prep': [C.POINTER(_PrepArgs), vp],
         'gast_chunk_gather': [vp, vp, vp, vp, vp, cl, ci, ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, vp],
@@ -262,7 +263,7 @@ EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_s
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_bn', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
-                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_adam_step_guarded', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
+                    'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_adam_step_guarded', 'gast_nonfinite_scan', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
 
 def _check(rc, what):
@@ -881,11 +882,21 @@ class HipOps:
         self.launches += 1
         _check(self.lib.gast_mpjpe(_p(pred), _p(target), rows, D, _p(loss), _p(dirs), _stream()), 'gast_mpjpe')
 
-    def adam_step(self, p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, skip=None):
-        """skip: optional device int32; non-zero = leave parameters, moments and the step counter alone (non-finite gradient)"""
+    NONFINITE_FLAGS = 256
+
+    def nonfinite_scan(self, g, flags):
+        """flags (NONFINITE_FLAGS int32): one verdict per block of the scan -- 1 when its slice of the flat fp32 buffer g holds an inf / NaN"""
+        if flags.numel() < self.NONFINITE_FLAGS or flags.dtype != torch.int32 or g.dtype != torch.float32:
+            raise RuntimeError('gast_hip: nonfinite_scan needs %d int32 flag words and an fp32 buffer' % self.NONFINITE_FLAGS)
+        self.launches += 1
+        _check(self.lib.gast_nonfinite_scan(_p(g), g.numel(), _p(flags), _stream()), 'gast_nonfinite_scan')
+
+    def adam_step(self, p, g, m, v, vmax, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, skip=None, skipped=None):
+        """skip: optional flag words of nonfinite_scan; any set = leave parameters, moments and the step counter alone and count the
+        step in `skipped` (device int64)"""
         self.launches += 2
         _check(self.lib.gast_adam_step_guarded(_p(p), _p(g), _p(m), _p(v), _p(vmax), p.numel(), _p(step), lr, beta1, beta2, eps,
-                                               weight_decay, grad_scale, _p(skip), _stream()), 'gast_adam_step')
+                                               weight_decay, grad_scale, _p(skip), _p(skipped), _stream()), 'gast_adam_step')
 
     def chunk_gather(self, poses2d, poses3d, cams, seq_off, pairs, first_pair, B, chunk, pad, causal_shift, perm2d, perm3d, out2d, out3d,
                      outcam):

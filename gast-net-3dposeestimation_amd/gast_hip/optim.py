@@ -116,14 +116,16 @@ class FlatAdam(torch.optim.Optimizer):
             G = self._grad_buffer(st)
             b1, b2 = group['betas']
             skip = None
+            ops = self._get_ops()
             if self.skip_nonfinite:
-                skip = torch.logical_not(torch.isfinite(G).all()).to(torch.int32).reshape(1)
                 if self.skipped_steps is None:
                     self.skipped_steps = torch.zeros(1, dtype=torch.int64, device=G.device)
-                self.skipped_steps += skip
-            self._get_ops().adam_step(st['P'], G, st['m'], st['v'], st['vmax'] if group['amsgrad'] else None, st['step'],
-                                      float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
-                                      grad_scale=float(self.grad_scale), skip=skip)
+                    self._flags = torch.zeros(ops.NONFINITE_FLAGS, dtype=torch.int32, device=G.device)
+                skip = self._flags
+                ops.nonfinite_scan(G, skip)          # one launch over the flat gradient: a verdict per block, read by the update kernel
+            ops.adam_step(st['P'], G, st['m'], st['v'], st['vmax'] if group['amsgrad'] else None, st['step'],
+                          float(group['lr']), float(b1), float(b2), float(group['eps']), float(group['weight_decay']),
+                          grad_scale=float(self.grad_scale), skip=skip, skipped=self.skipped_steps if skip is not None else None)
             note_raw_parameter_write()      # (the kernel writes parameter memory behind torch's version counters)
         return loss
 

@@ -415,11 +415,15 @@ int gast_mpjpe(const float* pred, const float* target, long rows, int D, float* 
  * and supplies the bias corrections.  16-byte aligned buffers. */
 int gast_adam_step(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
                    float beta2, float eps, float weight_decay, float grad_scale, gast_stream_t stream);
-/* The same behind a guard: `skip` (nullable) points at a device int32; a non-zero value makes the call a no-op -- parameters, moments and
- * *step untouched.  The loss-scaled 16-bit mode sets it when the unscaled gradient holds an inf / NaN (an overflow of the scaled
- * activation gradients), like torch.cuda.amp.GradScaler's skipped steps (the reference trains in fp32 and has no such step). */
+/* The same behind a guard (the loss-scaled 16-bit mode; like torch.cuda.amp.GradScaler's skipped steps -- the reference trains in fp32 and
+ * has no such step).  gast_nonfinite_scan: flags[b] = 1 when block b's slice of the flat gradient holds an inf / NaN, else 0, for all
+ * GAST_NONFINITE_FLAGS blocks (every word is rewritten on every call).  gast_adam_step_guarded: `skip` (nullable) points at those words;
+ * when any is set the call is a no-op -- parameters, moments and *step untouched -- and *skipped (nullable, device int64) is incremented. */
+#define GAST_NONFINITE_FLAGS 256
+int gast_nonfinite_scan(const float* g, long n, int* flags, gast_stream_t stream);
 int gast_adam_step_guarded(float* p, const float* g, float* m, float* v, float* vmax, long n, int* step, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, float grad_scale, const int* skip, gast_stream_t stream);
+                           float beta2, float eps, float weight_decay, float grad_scale, const int* skip, long long* skipped,
+                           gast_stream_t stream);
 
 /* Pass prologue, ONE launch: zero-fill up to GAST_PREP_MAX_ZERO regions (16-byte aligned, sizes multiples of 16: the accumulation
  * arena of the pass, the flat gradient buffer, the packed-gradient scratch), optionally advance the dropout seed (*seed_out =
