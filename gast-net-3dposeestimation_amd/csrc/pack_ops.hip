@@ -19,97 +19,141 @@ __device__ __forceinline__ float load_any(const void* p, long idx, int is_bf16) 
     return is_bf16 ? bf2f(((const bf16_t*)p)[idx]) : ((const float*)p)[idx];
 }
 
-// one block = one 32x32 tile of one job; 256 threads = 32 x 8.
+// one block = TQ 32x32 tiles (consecutive entries of the tile table, any jobs); 256 threads = 32 x 8 per tile.
 // CJ: 10 words per job (gast_strided_copy) or 16 (gast_pack_all: + the pre-split image of the packed operand the tile lands in --
 // words 10..15 = image word, ldimg (16-bit elements per k-group), element offset of the job's (0, 0) inside the operand, columns K
 // of the operand, fp16-pair flag, reserved; image word 0 = none): the tile is then ALSO written as 16-bit hi/lo pairs in the
 // k-group-major layout of gast_x3_image_multi, so the large-M GEMM's weight images no longer need a pass of their own over the
 // packed fp32 operands (x3_image_kernel: 30 us per step + its graph-node boundary).
 constexpr int CJ_WORDS_X = 16;
+// Round 6: a block runs TQ tiles with the loads of all of them in flight together.  One tile per block was bound by its chain of
+// dependent loads (tile entry -> job words -> element: ~7 us per block lifetime, 12 564 blocks of 4 KB for pack_all = 44 us per step at
+// 1.9 TB/s); the tables and the per-element arithmetic are unchanged, so the operands and images are bit-equal.
+constexpr int TQ = 4;
+struct TileJob {
+    const char* src; char* dst;
+    int R, S, r0, c0, flags;
+    long srs, scs, drs, dcs;
+    const long* j;
+};
 template <int CJ>
-__device__ __forceinline__ void copy_tile(const long* __restrict__ jobs, const int* __restrict__ t, const long* bases, float (*tile)[TILE + 1]) {
+__device__ __forceinline__ TileJob tile_job(const long* __restrict__ jobs, const int* __restrict__ t, const long* bases) {
+    TileJob q;
     const long* j = jobs + (long)t[0] * CJ;
-    const char* src = (const char*)(bases[j[0] & 7] + (j[0] >> 4));     // (element-size independent) byte address
-    char* dst = (char*)(bases[j[1] & 7] + (j[1] >> 4));
-    const int R = (int)j[2], S = (int)j[3];
-    const long srs = j[4], scs = j[5], drs = j[6], dcs = j[7];
-    const int flags = (int)j[8];
-    const int src_bf16 = flags & 1, dst_bf16 = (flags >> 1) & 1, accumulate = (flags >> 2) & 1, zero_fill = (flags >> 3) & 1;
-    const int r0 = t[1] * TILE, c0 = t[2] * TILE;
+    q.j = j;
+    q.src = (const char*)(bases[j[0] & 7] + (j[0] >> 4));     // (element-size independent) byte address
+    q.dst = (char*)(bases[j[1] & 7] + (j[1] >> 4));
+    q.R = (int)j[2]; q.S = (int)j[3];
+    q.srs = j[4]; q.scs = j[5]; q.drs = j[6]; q.dcs = j[7];
+    q.flags = (int)j[8];
+    q.r0 = t[1] * TILE; q.c0 = t[2] * TILE;
+    return q;
+}
+template <int CJ>
+__device__ __forceinline__ void copy_tiles(const long* __restrict__ jobs, const int* __restrict__ tiles, int first, int ntiles, const long* bases,
+                                           float (*tile)[TILE][TILE + 1]) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    // read with the source-contiguous dimension on tx
-    const bool src_col_fast = (scs <= srs);
+    const int nq = min(TQ, ntiles - first);
+    TileJob tj[TQ];
 #pragma unroll
-    for (int i = 0; i < TILE; i += 8) {
-        int r = src_col_fast ? r0 + ty + i : r0 + tx;
-        int c = src_col_fast ? c0 + tx : c0 + ty + i;
-        float v = 0.f;
-        if (r < R && c < S && !zero_fill) v = load_any(src, r * srs + c * scs, src_bf16);
-        tile[r - r0][c - c0] = v;
+    for (int q = 0; q < TQ; ++q) tj[q] = tile_job<CJ>(jobs, tiles + (long)(first + (q < nq ? q : 0)) * 3, bases);
+    // read with the source-contiguous dimension on tx
+    float v[TQ][TILE / 8];
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+        const TileJob& J = tj[q];
+        const int src_bf16 = J.flags & 1, zero_fill = (J.flags >> 3) & 1;
+        const bool src_col_fast = (J.scs <= J.srs);
+#pragma unroll
+        for (int i = 0; i < TILE; i += 8) {
+            const int r = src_col_fast ? J.r0 + ty + i : J.r0 + tx;
+            const int c = src_col_fast ? J.c0 + tx : J.c0 + ty + i;
+            v[q][i / 8] = (q < nq && r < J.R && c < J.S && !zero_fill) ? load_any(J.src, r * J.srs + c * J.scs, src_bf16) : 0.f;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < TQ; ++q) {
+        const TileJob& J = tj[q];
+        const bool src_col_fast = (J.scs <= J.srs);
+#pragma unroll
+        for (int i = 0; i < TILE; i += 8) {
+            const int rl = src_col_fast ? ty + i : tx, cl = src_col_fast ? tx : ty + i;
+            tile[q][rl][cl] = v[q][i / 8];
+        }
     }
     __syncthreads();
-    const bool dst_col_fast = (dcs <= drs);
 #pragma unroll
-    for (int i = 0; i < TILE; i += 8) {
-        int r = dst_col_fast ? r0 + ty + i : r0 + tx;
-        int c = dst_col_fast ? c0 + tx : c0 + ty + i;
-        if (r < R && c < S) {
-            float v = tile[r - r0][c - c0];
-            long o = r * drs + c * dcs;
-            if (dst_bf16) ((bf16_t*)dst)[o] = f2bf(v);
-            else if (accumulate) ((float*)dst)[o] += v;
-            else ((float*)dst)[o] = v;
+    for (int q = 0; q < TQ; ++q) {
+        if (q >= nq) break;
+        const TileJob& J = tj[q];
+        const int dst_bf16 = (J.flags >> 1) & 1, accumulate = (J.flags >> 2) & 1;
+        const int R = J.R, S = J.S, r0 = J.r0, c0 = J.c0;
+        const long drs = J.drs, dcs = J.dcs;
+        char* dst = J.dst;
+        const bool dst_col_fast = (dcs <= drs);
+#pragma unroll
+        for (int i = 0; i < TILE; i += 8) {
+            int r = dst_col_fast ? r0 + ty + i : r0 + tx;
+            int c = dst_col_fast ? c0 + tx : c0 + ty + i;
+            if (r < R && c < S) {
+                float x = tile[q][r - r0][c - c0];
+                long o = r * drs + c * dcs;
+                if (dst_bf16) ((bf16_t*)dst)[o] = f2bf(x);
+                else if (accumulate) ((float*)dst)[o] += x;
+                else ((float*)dst)[o] = x;
+            }
         }
-    }
-    if constexpr (CJ == CJ_WORDS_X) {
-        if (j[10] == 0) return;
-        // image: thread = (line along the operand's row direction, quad of 4 consecutive K values).  The operand's K runs along the
-        // job's s when dcs == 1 and along its r when drs == 1 (a transposed twin); 4-aligned quads stay inside one 16-value k-group.
-        bf16_t* img = (bf16_t*)(bases[j[10] & 7] + (j[10] >> 4));
-        const long ldimg = j[11], rel = j[12];
-        const int Kop = (int)j[13], f16 = (int)j[14];
-        const int line = threadIdx.x >> 3, quad = threadIdx.x & 7;
-        const bool k_on_s = dcs == 1;
-        float x[4];
-        bool in[4];
-        long o0 = 0;
+        if constexpr (CJ == CJ_WORDS_X) {
+            const long* j = J.j;
+            if (j[10] == 0) continue;
+            // image: thread = (line along the operand's row direction, quad of 4 consecutive K values).  The operand's K runs along the
+            // job's s when dcs == 1 and along its r when drs == 1 (a transposed twin); 4-aligned quads stay inside one 16-value k-group.
+            bf16_t* img = (bf16_t*)(bases[j[10] & 7] + (j[10] >> 4));
+            const long ldimg = j[11], rel = j[12];
+            const int Kop = (int)j[13], f16 = (int)j[14];
+            const int line = threadIdx.x >> 3, quad = threadIdx.x & 7;
+            const bool k_on_s = dcs == 1;
+            float x[4];
+            bool in[4];
+            long o0 = 0;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int rl = k_on_s ? line : quad * 4 + q, cl = k_on_s ? quad * 4 + q : line;
-            in[q] = r0 + rl < R && c0 + cl < S;
-            x[q] = in[q] ? tile[rl][cl] : 0.f;
-            if (q == 0) o0 = rel + (long)(r0 + rl) * drs + (long)(c0 + cl) * dcs;
-        }
-        if (!in[0]) return;          // (validity is monotone along the quad)
-        const long row = o0 / Kop;
-        const int k = (int)(o0 - row * Kop);
-        uint2 h, l;
-        if (f16) split_pair4<2>(x[0], x[1], x[2], x[3], h, l);
-        else split_pair4<1>(x[0], x[1], x[2], x[3], h, l);
-        bf16_t* o = img + (long)(k >> 4) * ldimg + row * 32 + (k & 15);
-        if (in[3] && (k & 3) == 0) {
-            *(uint2*)o = h;
-            *(uint2*)(o + 16) = l;
-        } else {
-            // ragged quad (a 2-row head block of an 8-channel model, a K offset that is not a multiple of 4): value by value -- the
-            // neighbouring K positions belong to other jobs
-            const bf16_t* hp = (const bf16_t*)&h;
-            const bf16_t* lp = (const bf16_t*)&l;
+            for (int e = 0; e < 4; ++e) {
+                const int rl = k_on_s ? line : quad * 4 + e, cl = k_on_s ? quad * 4 + e : line;
+                in[e] = r0 + rl < R && c0 + cl < S;
+                x[e] = in[e] ? tile[q][rl][cl] : 0.f;
+                if (e == 0) o0 = rel + (long)(r0 + rl) * drs + (long)(c0 + cl) * dcs;
+            }
+            if (!in[0]) continue;          // (validity is monotone along the quad)
+            const long row = o0 / Kop;
+            const int k = (int)(o0 - row * Kop);
+            uint2 h, l;
+            if (f16) split_pair4<2>(x[0], x[1], x[2], x[3], h, l);
+            else split_pair4<1>(x[0], x[1], x[2], x[3], h, l);
+            bf16_t* o = img + (long)(k >> 4) * ldimg + row * 32 + (k & 15);
+            if (in[3] && (k & 3) == 0) {
+                *(uint2*)o = h;
+                *(uint2*)(o + 16) = l;
+            } else {
+                // ragged quad (a 2-row head block of an 8-channel model, a K offset that is not a multiple of 4): value by value -- the
+                // neighbouring K positions belong to other jobs
+                const bf16_t* hp = (const bf16_t*)&h;
+                const bf16_t* lp = (const bf16_t*)&l;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!in[q]) break;
-                const int kq = k + q;
-                bf16_t* oq = img + (long)(kq >> 4) * ldimg + row * 32 + (kq & 15);
-                oq[0] = hp[q];
-                oq[16] = lp[q];
+                for (int e = 0; e < 4; ++e) {
+                    if (!in[e]) break;
+                    const int kq = k + e;
+                    bf16_t* oq = img + (long)(kq >> 4) * ldimg + row * 32 + (kq & 15);
+                    oq[0] = hp[e];
+                    oq[16] = lp[e];
+                }
             }
         }
     }
 }
-__global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restrict__ jobs, const int* __restrict__ tiles,
+__global__ void __launch_bounds__(256) strided_copy_kernel(const long* __restrict__ jobs, const int* __restrict__ tiles, int ntiles,
                                                            const Bases bs) {
-    __shared__ float tile[TILE][TILE + 1];
-    copy_tile<CJ_WORDS>(jobs, tiles + (long)blockIdx.x * 3, bs.v, tile);
+    __shared__ float tile[TQ][TILE][TILE + 1];
+    copy_tiles<CJ_WORDS>(jobs, tiles, (int)blockIdx.x * TQ, ntiles, bs.v, tile);
 }
 
 // fold: v[k] = sum_m W[m][k] * w[m]  (k < C, m < Ci), a = sum_m w[m] * b[m]
@@ -192,12 +236,13 @@ __global__ void __launch_bounds__(256) fold_kernel(const long* __restrict__ jobs
 // are independent: a copy tile and a fold block never write the same element (operand or image).
 __global__ void __launch_bounds__(256) pack_all_kernel(const long* __restrict__ cjobs, const int* __restrict__ tiles, int ntiles,
                                                        const long* __restrict__ fjobs, int fold_by, const Bases bs) {
-    __shared__ float smem[TILE][TILE + 1];
-    if ((int)blockIdx.x < ntiles) {
-        copy_tile<CJ_WORDS_X>(cjobs, tiles + (long)blockIdx.x * 3, bs.v, smem);
+    __shared__ float smem[TQ][TILE][TILE + 1];
+    const int ncopy = (ntiles + TQ - 1) / TQ;
+    if ((int)blockIdx.x < ncopy) {
+        copy_tiles<CJ_WORDS_X>(cjobs, tiles, (int)blockIdx.x * TQ, ntiles, bs.v, smem);
         return;
     }
-    const int fb = blockIdx.x - ntiles;
+    const int fb = blockIdx.x - ncopy;
     fold_body<FJ_WORDS_X>(fjobs, bs.v, fb / fold_by, fb % fold_by, (float (*)[32])smem);
 }
 
@@ -244,7 +289,7 @@ extern "C" int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int 
     if (ntiles == 0) return 0;
     Bases b;
     for (int i = 0; i < 8; ++i) b.v[i] = bases[i];
-    hipLaunchKernelGGL(strided_copy_kernel, dim3(ntiles), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, tiles, b);
+    hipLaunchKernelGGL(strided_copy_kernel, dim3((ntiles + TQ - 1) / TQ), dim3(256), 0, (hipStream_t)stream, (const long*)jobs, tiles, ntiles, b);
     GAST_CHECK_LAUNCH();
     return 0;
 }
@@ -253,7 +298,7 @@ extern "C" int gast_pack_all(const int64_t* cjobs, const int32_t* tiles, int nti
                              const int64_t* bases, gast_stream_t stream) {
     if (!bases || ntiles < 0 || nfold < 0 || (ntiles && (!cjobs || !tiles)) || (nfold && (!fjobs || max_C < 1))) return GAST_EINVAL;
     const int fold_by = nfold ? (max_C + 31) / 32 : 1;
-    const long nblk = (long)ntiles + (long)nfold * fold_by;
+    const long nblk = (long)((ntiles + TQ - 1) / TQ) + (long)nfold * fold_by;
     if (nblk == 0) return 0;
     Bases b;
     for (int i = 0; i < 8; ++i) b.v[i] = bases[i];

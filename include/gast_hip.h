@@ -115,7 +115,8 @@ typedef struct {
     gast_rowmap addmap;
     int epi;              /* GAST_EPI_* */
     float* partials;      /* epi != PLAIN: [ceil(M/128)][N][2] fp32; fully overwritten by gast_gemm, ACCUMULATED into by the
-                           * split-K path of gast_gemm_ws (pass it zero-filled there) */
+                           * split-K paths of gast_gemm_ws -- the cross-block one and the in-block one of the M = B*J kernel
+                           * (gemm_bj.hip, two 64-row tiles add into one 128-row entry) -- so pass it zero-filled there */
     const void* X;        /* epi == BNRELU_BWD: pre-BN tensor addressed with cmap, [rows][ldx] */
     int ldx;
     const float* xscale;  /* [N] */
@@ -135,8 +136,11 @@ typedef struct {
 } gast_gemm_args;
 
 int gast_gemm(const gast_gemm_args* args, gast_stream_t stream);
-/* Same, with an fp32 workspace: GEMMs with few output tiles and a long K loop (the M = B*J rows of the last stage) split K
- * over up to 8 blocks per tile and a finish kernel applies bias / addend / epilogue.  ws_bytes >= gast_gemm_splitk_ws_bytes(M, N)
+/* Same, with an fp32 workspace: GEMMs with few output tiles and a long K loop (the M = B*J rows of the last stage) split K.
+ * Round 6: with pre-split weight images (GAST_F32X3 / GAST_F32X3H), M <= 8191 and at most 600 64x64 tiles the split happens INSIDE
+ * the block (two k-groups of four waves, accumulators exchanged through LDS in a fixed order, epilogue in the same launch; the
+ * workspace pointer only enables the path, nothing is written to it).  Otherwise K splits over up to 8 blocks per tile and a
+ * finish kernel applies bias / addend / epilogue.  ws_bytes >= gast_gemm_splitk_ws_bytes(M, N)
  * enables every split the heuristic may pick; a smaller or null workspace simply disables splitting. */
 int gast_gemm_ws(const gast_gemm_args* args, void* ws, long ws_bytes, gast_stream_t stream);
 /* n <= GAST_GEMM_MAX_BATCH independent GEMMs (same dtype / out_f32) in ONE grid: one launch and one tail for the thin GEMMs of a
