@@ -266,6 +266,126 @@ __global__ void __launch_bounds__(256) bnrelu_bwd_mask_kernel(const T* dY, int l
     }
 }
 
+// ------------------------------------------------------------------------------------------------ shrink layer (round 6)
+// Reference gast_net.py:99,176-178: shrink = Conv2d(2C * 2^(L-1), 3, 1, bias=False) on the M = B*T'*J rows that survive the temporal
+// stages.  With D = 3 output columns it is a row-wise dot product, not a GEMM: on the GEMM kernels it ran 34 blocks with a 32-step
+// serial K loop (20 us), its input gradient a K = 8 GEMM whose whole cost is the epilogue (19 us).
+//   forward   pred[r, d] = sum_k relu(scale[k] * O[r, k] + shift[k]) * W[d][k]            (fp32 out; a wave owns two rows)
+//   backward  dO[r, k] = [scale[k] * O[r, k] + shift[k] > 0] * sum_d dp[r, d] * W[d][k]  + the BatchNorm-backward column sums
+//             {sum dO, sum dO * O} of every SHRINK_ROWS-row block (same partial-row contract as GAST_EPI_BNRELU_BWD / gast_bnrelu_bwd_mask)
+constexpr int SHRINK_ROWS = 32;          // rows per block of the backward kernel (x 256 columns)
+constexpr int SHRINK_MAXD = 4;
+template <typename T>
+__global__ void __launch_bounds__(256) shrink_fwd_kernel(const T* __restrict__ O, int ldo, long rows, int K, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ W, int ldw, int D,
+                                                         float* __restrict__ pred, int ldp) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const long r0 = ((long)blockIdx.x * 4 + wv) * 2;
+    if (r0 >= rows) return;
+    const bool two = r0 + 1 < rows;
+    const T* o0 = O + r0 * ldo;
+    const T* o1 = O + (two ? r0 + 1 : r0) * ldo;
+    float acc[2][SHRINK_MAXD];
+#pragma unroll
+    for (int d = 0; d < SHRINK_MAXD; ++d) acc[0][d] = acc[1][d] = 0.f;
+    const int K4 = K >> 2;
+#pragma unroll 4
+    for (int k4 = lane; k4 < K4; k4 += 64) {
+        const int k = k4 * 4;
+        const float4 s = *(const float4*)(scale + k), h = *(const float4*)(shift + k);
+        float4 x0 = ld4(o0 + k), x1 = ld4(o1 + k);
+        x0.x = fmaxf(fmaf(x0.x, s.x, h.x), 0.f); x0.y = fmaxf(fmaf(x0.y, s.y, h.y), 0.f);
+        x0.z = fmaxf(fmaf(x0.z, s.z, h.z), 0.f); x0.w = fmaxf(fmaf(x0.w, s.w, h.w), 0.f);
+        x1.x = fmaxf(fmaf(x1.x, s.x, h.x), 0.f); x1.y = fmaxf(fmaf(x1.y, s.y, h.y), 0.f);
+        x1.z = fmaxf(fmaf(x1.z, s.z, h.z), 0.f); x1.w = fmaxf(fmaf(x1.w, s.w, h.w), 0.f);
+#pragma unroll
+        for (int d = 0; d < SHRINK_MAXD; ++d) {
+            if (d < D) {
+                const float4 w = ld4(W + (long)d * ldw + k);
+                acc[0][d] = fmaf(x0.w, w.w, fmaf(x0.z, w.z, fmaf(x0.y, w.y, fmaf(x0.x, w.x, acc[0][d]))));
+                acc[1][d] = fmaf(x1.w, w.w, fmaf(x1.z, w.z, fmaf(x1.y, w.y, fmaf(x1.x, w.x, acc[1][d]))));
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int d = 0; d < SHRINK_MAXD; ++d)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) acc[i][d] += __shfl_xor(acc[i][d], off);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < SHRINK_MAXD; ++d) {
+            if (d < D) {
+                pred[r0 * ldp + d] = acc[0][d];
+                if (two) pred[(r0 + 1) * ldp + d] = acc[1][d];
+            }
+        }
+    }
+}
+
+// block = (SHRINK_ROWS rows, 256 columns): 256 threads = 64 column quads x 4 row lanes, 8 rows per thread (all loads in flight)
+template <typename T>
+__global__ void __launch_bounds__(256) shrink_bwd_kernel(const T* __restrict__ dp, int lddp, const T* __restrict__ W, int ldw, int D,
+                                                         const T* __restrict__ O, int ldo, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, long rows, int K, T* __restrict__ dO, int lddo,
+                                                         float* __restrict__ partials) {
+    __shared__ float sred[4][64][8];
+    __shared__ float sdp[SHRINK_ROWS][SHRINK_MAXD];
+    const int tid = threadIdx.x, cq = tid & 63, rl = tid >> 6;
+    const long rb = (long)blockIdx.x * SHRINK_ROWS;
+    const int c = blockIdx.y * 256 + cq * 4;
+    if (tid < SHRINK_ROWS * SHRINK_MAXD) {
+        const int r = tid / SHRINK_MAXD, d = tid - r * SHRINK_MAXD;
+        sdp[r][d] = (rb + r < rows && d < D) ? Elem<T>::ld(dp + (rb + r) * lddp + d) : 0.f;
+    }
+    __syncthreads();
+    float4 a1 = make_float4(0, 0, 0, 0), a2 = make_float4(0, 0, 0, 0);
+    if (c < K) {
+        const float4 s = *(const float4*)(scale + c), h = *(const float4*)(shift + c);
+        float4 w[SHRINK_MAXD];
+#pragma unroll
+        for (int d = 0; d < SHRINK_MAXD; ++d) w[d] = d < D ? ld4(W + (long)d * ldw + c) : make_float4(0, 0, 0, 0);
+        float4 x[SHRINK_ROWS / 4];
+#pragma unroll
+        for (int i = 0; i < SHRINK_ROWS / 4; ++i) {
+            const long r = rb + rl + 4 * i;
+            x[i] = r < rows ? ld4(O + r * ldo + c) : make_float4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < SHRINK_ROWS / 4; ++i) {
+            const int rr = rl + 4 * i;
+            const long r = rb + rr;
+            if (r >= rows) continue;
+            float4 g = make_float4(0, 0, 0, 0);
+#pragma unroll
+            for (int d = 0; d < SHRINK_MAXD; ++d) {
+                const float p = sdp[rr][d];
+                g.x = fmaf(p, w[d].x, g.x); g.y = fmaf(p, w[d].y, g.y); g.z = fmaf(p, w[d].z, g.z); g.w = fmaf(p, w[d].w, g.w);
+            }
+            if (!(fmaf(x[i].x, s.x, h.x) > 0.f)) g.x = 0.f;
+            if (!(fmaf(x[i].y, s.y, h.y) > 0.f)) g.y = 0.f;
+            if (!(fmaf(x[i].z, s.z, h.z) > 0.f)) g.z = 0.f;
+            if (!(fmaf(x[i].w, s.w, h.w) > 0.f)) g.w = 0.f;
+            g = rnd4(g, (const T*)nullptr);
+            st4(dO + r * lddo + c, g);
+            a1.x += g.x; a1.y += g.y; a1.z += g.z; a1.w += g.w;
+            a2.x = fmaf(g.x, x[i].x, a2.x); a2.y = fmaf(g.y, x[i].y, a2.y); a2.z = fmaf(g.z, x[i].z, a2.z); a2.w = fmaf(g.w, x[i].w, a2.w);
+        }
+    }
+    float* sr = sred[rl][cq];
+    sr[0] = a1.x; sr[1] = a2.x; sr[2] = a1.y; sr[3] = a2.y; sr[4] = a1.z; sr[5] = a2.z; sr[6] = a1.w; sr[7] = a2.w;
+    __syncthreads();
+    if (rl == 0 && c < K) {
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = ((sred[0][cq][q] + sred[1][cq][q]) + sred[2][cq][q]) + sred[3][cq][q];
+        float* pp = partials + ((long)blockIdx.x * K + c) * 2;
+        *(float4*)pp = make_float4(o[0], o[1], o[2], o[3]);
+        *(float4*)(pp + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    }
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256) residual_fwd_kernel(const T* __restrict__ O, int ldo, gast_rowmap omap,
                                                            const float* __restrict__ scO, const float* __restrict__ shO,
@@ -720,6 +840,46 @@ extern "C" int gast_bnrelu_apply(int dtype, const void* X, int ldx, long rows, i
     else
         hipLaunchKernelGGL((bnrelu_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (const bf16_t*)X, ldx, rows, N, scale,
                            shift, (bf16_t*)Y, ldy, use_drop, salt, drop, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_shrink_fwd(int dtype, const void* O, int ldo, long rows, int K, const float* scale, const float* shift, const void* W,
+                               int ldw, int D, float* pred, int ldp, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !O || !scale || !shift || !W || !pred || rows < 1 || K < 4 || D < 1 || D > SHRINK_MAXD || ldp < D) return GAST_EINVAL;
+    const int epc = dtype == GAST_F32 ? 4 : 8;       // elements per 16 bytes
+    if (K % 4 || ldo % epc || ldw % epc || (((uintptr_t)O) & 15) || (((uintptr_t)W) & 15) || (((uintptr_t)scale) & 15) || (((uintptr_t)shift) & 15))
+        return GAST_EALIGN;
+    const unsigned grid = (unsigned)((rows + 7) / 8);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((shrink_fwd_kernel<float>), dim3(grid), dim3(256), 0, st, (const float*)O, ldo, rows, K, scale, shift, (const float*)W,
+                           ldw, D, pred, ldp);
+    else
+        hipLaunchKernelGGL((shrink_fwd_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)O, ldo, rows, K, scale, shift,
+                           (const bf16_t*)W, ldw, D, pred, ldp);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_shrink_bwd_blocks(long rows) { return (int)((rows + SHRINK_ROWS - 1) / SHRINK_ROWS); }
+
+extern "C" int gast_shrink_bwd(int dtype, const void* dp, int lddp, const void* W, int ldw, int D, const void* O, int ldo, const float* scale,
+                               const float* shift, long rows, int K, void* dO, int lddo, float* partials, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dp || !W || !O || !scale || !shift || !dO || !partials || rows < 1 || K < 4 || D < 1 || D > SHRINK_MAXD || lddp < D)
+        return GAST_EINVAL;
+    const int epc = dtype == GAST_F32 ? 4 : 8;
+    if (K % 4 || ldo % epc || lddo % epc || ldw % epc || (((uintptr_t)O) & 15) || (((uintptr_t)dO) & 15) || (((uintptr_t)W) & 15) ||
+        (((uintptr_t)scale) & 15) || (((uintptr_t)shift) & 15) || (((uintptr_t)partials) & 15))
+        return GAST_EALIGN;
+    const dim3 grid((unsigned)gast_shrink_bwd_blocks(rows), (unsigned)((K + 255) / 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((shrink_bwd_kernel<float>), grid, dim3(256), 0, st, (const float*)dp, lddp, (const float*)W, ldw, D, (const float*)O, ldo,
+                           scale, shift, rows, K, (float*)dO, lddo, partials);
+    else
+        hipLaunchKernelGGL((shrink_bwd_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dp, lddp, (const bf16_t*)W, ldw, D, (const bf16_t*)O,
+                           ldo, scale, shift, rows, K, (bf16_t*)dO, lddo, partials);
     GAST_CHECK_LAUNCH();
     return 0;
 }

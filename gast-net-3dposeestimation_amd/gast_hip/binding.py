@@ -222,6 +222,9 @@ def load_library(h16=torch.bfloat16):
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, cu, _Dropout, vp],
         'gast_bnrelu_bwd_mask': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
+        'gast_shrink_fwd': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, vp, ci, vp],
+        'gast_shrink_bwd_blocks': [cl],
+        'gast_shrink_bwd': [ci, vp, ci, vp, ci, ci, vp, ci, vp, vp, cl, ci, vp, ci, vp, vp],
         'gast_rowwise_blocks': [cl, ci],
         'gast_residual_fwd': [ci, vp, ci, _RowMap, vp, vp, vp, ci, vp, vp, ci, cu, _Dropout, ci, ci, ci, ci, vp, ci, vp],
         'gast_input_stats': [vp, cl, ci, vp, vp, vp],
@@ -261,7 +264,7 @@ def load_library(h16=torch.bfloat16):
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_f8_scale_multi', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_semch_agg_bwd_fuses_bn', 'gast_semch_agg_bwd_bn', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats', 'gast_rowsum_multi', 'gast_attn_bwd_deferred', 'gast_semch_agg_bwd_deferred',
                     'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
-                    'gast_bnrelu_bwd_mask', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
+                    'gast_bnrelu_bwd_mask', 'gast_shrink_fwd', 'gast_shrink_bwd_blocks', 'gast_shrink_bwd', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_bn', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_adam_step_guarded', 'gast_nonfinite_scan', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
 
@@ -723,6 +726,23 @@ class HipOps:
         _check(self.lib.gast_bnrelu_bwd_mask(_dt(X), _p(dY), _ld(dY), _p(X), _ld(X), rows, N, _p(scale), _p(shift),
                                              int(bool(use_drop)), int(salt), _drop(drop), _p(dz), _ld(dz), _p(partials), _stream()),
                'gast_bnrelu_bwd_mask')
+
+    def shrink_fwd(self, O, rows, K, scale, shift, W, pred):
+        """pred[r, :] = relu(scale*O[r, :] + shift) . W^T  (W [D][K] of O's dtype, pred fp32 [rows][D]): the shrink layer as ONE row-wise launch"""
+        W = W if torch.is_tensor(W) else W.t          # (an X3Weight / F8Weight wrapper: the plain operand)
+        self.launches += 1
+        _check(self.lib.gast_shrink_fwd(_dt(O), _p(O), _ld(O), rows, K, _p(scale), _p(shift), _p(W), _ld(W), W.shape[0], _p(pred), _ld(pred),
+                                        _stream()), 'gast_shrink_fwd')
+
+    def shrink_bwd_blocks(self, rows):
+        return self.lib.gast_shrink_bwd_blocks(int(rows))
+
+    def shrink_bwd(self, dp, W, O, rows, K, scale, shift, dO, partials):
+        """dO = [scale*O + shift > 0] * (dp[:, :D] . W) + the BatchNorm-backward column sums per row block (partials [shrink_bwd_blocks][K][2])"""
+        W = W if torch.is_tensor(W) else W.t
+        self.launches += 1
+        _check(self.lib.gast_shrink_bwd(_dt(O), _p(dp), _ld(dp), _p(W), _ld(W), W.shape[0], _p(O), _ld(O), _p(scale), _p(shift), rows, K,
+                                        _p(dO), _ld(dO), _p(partials), _stream()), 'gast_shrink_bwd')
 
     def residual_fwd(self, O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn):
         self.launches += 1

@@ -117,6 +117,7 @@ class Engine:
         self.za = ZeroArena()
         # (the HIP op set fuses the BatchNorm backward of dY / dE into their one reader; the numpy mirror of the tests has neither form)
         self.fuse_bn_bwd = bool(getattr(ops, 'fuses_bn_bwd', False))
+        self.shrink_rowwise = hasattr(ops, 'shrink_fwd') and os.environ.get('GAST_SHRINK_KERNEL', '1') not in ('0', '')
         self._pre = {}           # eval mode: pre-filled (scale, shift) views per BNState name
         self._side = {}          # device -> side stream for independent branches of the plan
         self._keep = []          # operands of side-stream launches, kept alive until the join
@@ -363,8 +364,12 @@ class Engine:
         PL = B * T[-1] * J
         Wsh = inp['shrink']   # [3][CL]
         pred = torch.empty(PL, 3, dtype=torch.float32, device=dev)
-        ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
-                                         scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
+        if self.shrink_rowwise:
+            # three output columns are a row-wise dot product, not a GEMM (round 6: 20 -> 6 us at B = 128; GAST_SHRINK_KERNEL=0: the GEMM)
+            ops.shrink_fwd(last['O'], PL, CL, last['bnO'].scale, last['bnO'].shift, Wsh, pred)
+        else:
+            ops.gemm((B, T[-1], J), 3, [dict(A=last['O'], K=CL, map=ident(T[-1]), W=Wsh, pro=PRO_BNRELU,
+                                             scale=last['bnO'].scale, shift=last['bnO'].shift)], pred, ident(T[-1]))
         sv.update(stages=stages, levels=levels)
         za.end()
         return pred.view(B, T[-1], J, 3), sv
@@ -574,12 +579,17 @@ class Engine:
             dp[:, :3] = (dpred.reshape(PL, 3) * ls if ls != 1.0 else dpred.reshape(PL, 3)).to(dt)
         self._wgrad((B, TL, J), dp, KP, ident(TL), [dict(Q=last['O'], S=CL, map=ident(TL), pro=PRO_BNRELU, scale=last['bnO'].scale,
                                                         shift=last['bnO'].shift, wcol0=0)], gout['shrink'], zero_first=False)
-        WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
         dO = self._new(PL, CL, dt, dev)
-        nb = ops.gemm_row_blocks(PL)
-        part = za.take((nb, CL, 2))
-        ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, partials=part,
-                 X=last['O'], xscale=last['bnO'].scale, xshift=last['bnO'].shift)
+        if self.shrink_rowwise:
+            nb = ops.shrink_bwd_blocks(PL)
+            part = za.take((nb, CL, 2))
+            ops.shrink_bwd(dp, inp['shrink'], last['O'], PL, CL, last['bnO'].scale, last['bnO'].shift, dO, part)
+        else:
+            WshT = inp['shrinkT']          # [CL][8], columns 3..7 zero
+            nb = ops.gemm_row_blocks(PL)
+            part = za.take((nb, CL, 2))
+            ops.gemm((B, TL, J), CL, [dict(A=dp, K=KP, map=ident(TL), W=WshT)], dO, ident(TL), epi=EPI_BNRELU_BWD, partials=part,
+                     X=last['O'], xscale=last['bnO'].scale, xshift=last['bnO'].shift)
         g = 'g%d.' % (L - 1)
         self._bn_backward(part, nb, 0, CL, last['bnO'], inp[g + 'cat_bn.weight'], grads, g + 'cat_bn', dO, last['O'], PL)
 

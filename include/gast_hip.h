@@ -351,6 +351,19 @@ int gast_bnrelu_bwd_mask(int dtype, const void* dY, int lddy, const void* X, int
                          const float* scale, const float* shift, int use_drop, uint32_t salt, gast_dropout drop,
                          void* dz, int lddz, float* partials, gast_stream_t stream);
 int gast_rowwise_blocks(long rows, int N);
+/* Shrink layer (reference gast_net.py:99,176-178: Conv2d(2C * 2^(L-1), 3, 1, bias=False) on the rows the temporal stages leave) as a
+ * row-wise dot product -- D <= 4 output columns are not a GEMM (round 6; gast_gemm accepts the same operation and is what the
+ * streaming path and the 16-bit fp8 experiments still use):
+ *   pred[r, d] = sum_k relu(scale[k] * O[r, k] + shift[k]) * W[d][k]      pred fp32 [rows][ldp], W [D][ldw] of the activation type
+ * and its input gradient with the BatchNorm-backward column sums of GAST_EPI_BNRELU_BWD:
+ *   dO[r, k] = [scale[k] * O[r, k] + shift[k] > 0] * sum_d dp[r, d] * W[d][k]
+ *   partials[gast_shrink_bwd_blocks(rows)][K][2] = {sum dO, sum dO * O} over each row block, fully overwritten.
+ * K % 4 == 0, 16-byte aligned rows. */
+int gast_shrink_fwd(int dtype, const void* O, int ldo, long rows, int K, const float* scale, const float* shift, const void* W, int ldw,
+                    int D, float* pred, int ldp, gast_stream_t stream);
+int gast_shrink_bwd_blocks(long rows);
+int gast_shrink_bwd(int dtype, const void* dp, int lddp, const void* W, int ldw, int D, const void* O, int ldo, const float* scale,
+                    const float* shift, long rows, int K, void* dO, int lddo, float* partials, gast_stream_t stream);
 /* Residual of a temporal block (gast_net.py:170-174 / :243-247):
  * Xn[m] = relu(scO*O[omap(m)] + shO) + keep/(1-p) * relu(sc2*T2[m] + sh2) */
 int gast_residual_fwd(int dtype, const void* O, int ldo, gast_rowmap omap, const float* scO, const float* shO,

@@ -458,6 +458,37 @@ def bnrelu_bwd_mask(dY, X, rows, N, scale, shift, use_drop, salt, drop, dz, part
     _rowwise_partials([d, d * x], rows, N, partials)
 
 
+SHRINK_ROWS = 32      # rows per partial block of gast_shrink_bwd (csrc/norm_ops.hip)
+
+
+def shrink_bwd_blocks(rows):
+    return (rows + SHRINK_ROWS - 1) // SHRINK_ROWS
+
+
+def shrink_fwd(O, rows, K, scale, shift, W, pred):
+    """gast_shrink_fwd: reference gast_net.py:99,176-178 -- shrink = Conv2d(2C * 2^(L-1), 3, 1, bias=False) applied to
+    relu(cat_bn(O)) of the last block: pred[r, d] = sum_k relu(scale[k] O[r, k] + shift[k]) W[d][k]"""
+    z = np.maximum(np.asarray(O[:rows, :K], np.float64) * np.asarray(scale, np.float64)[:K] + np.asarray(shift, np.float64)[:K], 0.0)
+    D = np.asarray(W).shape[0]
+    pred[:rows, :D] = z @ np.asarray(W, np.float64)[:, :K].T
+
+
+def shrink_bwd(dp, W, O, rows, K, scale, shift, dO, partials, round_fn=None):
+    """gast_shrink_bwd: input gradient of the same through the ReLU of cat_bn (gast_net.py:176 backward) and the BatchNorm-backward
+    column sums {sum dO, sum dO * O} of every SHRINK_ROWS-row block"""
+    x = np.asarray(O[:rows, :K], np.float64)
+    D = np.asarray(W).shape[0]
+    g = np.asarray(dp[:rows, :D], np.float64) @ np.asarray(W, np.float64)[:, :K]
+    d = np.where(x * np.asarray(scale, np.float64)[:K] + np.asarray(shift, np.float64)[:K] > 0, g, 0.0)
+    if round_fn is not None:
+        d = round_fn(d)
+    dO[:rows, :K] = d
+    for b in range(shrink_bwd_blocks(rows)):
+        sl = slice(b * SHRINK_ROWS, min(rows, (b + 1) * SHRINK_ROWS))
+        partials[b, :K, 0] = d[sl].sum(axis=0)
+        partials[b, :K, 1] = (d[sl] * x[sl]).sum(axis=0)
+
+
 def residual_fwd(O, omap, scO, shO, T2, sc2, sh2, use_drop, salt, drop, B, Tn, J, N, Xn, round_fn=None):
     rows = B * Tn * J
     orow = map_rows(omap, B, Tn, J)

@@ -1158,6 +1158,50 @@ def test_bn_finalize_multi(ops):
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('rows,K', [(2176, 1024), (2175, 512), (1, 64), (33, 2048 + 8), (70, 8)])
+def test_shrink_rowwise(ops, rows, K, dt):
+    """gast_shrink_fwd / gast_shrink_bwd (reference gast_net.py:99,176-178) against the numpy contract: full size of BASELINE configs[1]
+    (B*J = 2176 rows, 1024 channels), an odd row count (the wave that owns one row, the ragged last row block), a single row, a K that
+    is not a multiple of the 256-column block, K = 8."""
+    gen = torch.Generator().manual_seed(rows * 7 + K)
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
+    ld = K + 8
+    O = rand(gen, rows, ld).to(dt)
+    W = rand(gen, 3, K, scale=0.2).to(dt)
+    sc, sh = torch.rand(K, generator=gen) + 0.5, rand(gen, K, scale=0.5)
+    pred = torch.full((rows, 3), 7.0).cuda()
+    Od = O.cuda()
+    ops.shrink_fwd(Od[:, :K], rows, K, sc.cuda(), sh.cuda(), W.cuda(), pred)
+    ph = np.zeros((rows, 3))
+    kc.shrink_fwd(host(O), rows, K, host(sc), host(sh), host(W), ph)
+    close(host(pred), ph, torch.float32, 'shrink_fwd', fp32=2e-5)          # (fp32 output and accumulation in both storage types)
+    dp = torch.zeros(rows, 8)
+    dp[:, :3] = rand(gen, rows, 3)
+    dp = dp.to(dt)
+    dO = torch.full((rows, ld), 4.0).to(dt).cuda()
+    nb = ops.shrink_bwd_blocks(rows)
+    assert nb == kc.shrink_bwd_blocks(rows)
+    part = torch.full((nb, K, 2), 5.0).cuda()            # fully overwritten
+    ops.shrink_bwd(dp.cuda(), W.cuda(), Od[:, :K], rows, K, sc.cuda(), sh.cuda(), dO[:, :K], part)
+    dh = np.full((rows, ld), 4.0)
+    pth = np.zeros((nb, K, 2))
+    kc.shrink_bwd(host(dp), host(W), host(O), rows, K, host(sc), host(sh), dh, pth, round_fn=rnd)
+    close(host(dO), dh, dt, 'shrink_bwd dO')
+    close(host(part), pth, dt, 'shrink_bwd partials', fp32=1e-4, bf16=3e-2)
+
+
+def test_shrink_rejects_bad_arguments(ops):
+    O = torch.zeros(8, 64).cuda()
+    W = torch.zeros(3, 64).cuda()
+    v = torch.ones(64).cuda()
+    pred = torch.zeros(8, 3).cuda()
+    with pytest.raises(RuntimeError):
+        ops.shrink_fwd(O[:, :62], 8, 62, v, v, W, pred)                      # K % 4
+    with pytest.raises(RuntimeError):
+        ops.shrink_fwd(O, 8, 64, v, v, torch.zeros(5, 64).cuda(), torch.zeros(8, 5).cuda())      # D > 4
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
 @pytest.mark.parametrize('rows,N', [(301, 16), (1000, 128), (77, 2048 + 64), (5000, 8)])
 def test_rowwise_kernels(ops, rows, N, dt):
     from gast_hip.binding import Dropout, dropout_params
