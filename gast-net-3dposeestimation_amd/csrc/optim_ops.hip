@@ -132,8 +132,12 @@ __global__ void __launch_bounds__(256) prep_kernel(const PrepArgs p) {
     // pad job: dst[r][c] = c < cols_src ? src[r][c] : 0, one thread per destination row
     const long r = (long)(blk - p.first[a.nzero]) * 256 + tid;
     if (r < a.pad_rows) {
-        for (int c = 0; c < a.pad_cols_dst; ++c)
-            a.pad_dst[r * a.pad_cols_dst + c] = c < a.pad_cols_src ? a.pad_src[r * a.pad_cols_src + c] : 0.f;
+        const float sc = a.pad_scale != 0.f ? a.pad_scale : 1.f;
+        for (int c = 0; c < a.pad_cols_dst; ++c) {
+            const float v = c < a.pad_cols_src ? sc * a.pad_src[r * a.pad_cols_src + c] : 0.f;
+            if (a.pad_dst_h16) ((bf16_t*)a.pad_dst)[r * a.pad_cols_dst + c] = f2bf(v);
+            else a.pad_dst[r * a.pad_cols_dst + c] = v;
+        }
     }
 }
 __global__ void null_kernel() {}

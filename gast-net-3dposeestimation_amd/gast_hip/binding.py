@@ -104,7 +104,7 @@ PREP_MAX_ZERO = 6
 class _PrepArgs(C.Structure):
     _fields_ = [('zero', _ZeroJob * PREP_MAX_ZERO), ('nzero', C.c_int), ('seed_ctr', C.c_void_p), ('seed_out', C.c_void_p),
                 ('pad_src', C.c_void_p), ('pad_dst', C.c_void_p), ('pad_rows', C.c_long), ('pad_cols_src', C.c_int),
-                ('pad_cols_dst', C.c_int)]
+                ('pad_cols_dst', C.c_int), ('pad_scale', C.c_float), ('pad_dst_h16', C.c_int)]
 
 
 class _BnEvalJob(C.Structure):
@@ -636,6 +636,7 @@ class HipOps:
         a.scale, a.shift, a.mean, a.rstd = _p(j['scale']), _p(j['shift']), _p(j['mean']), _p(j['rstd'])
         a.centered = int(bool(j.get('centered', False)))
 
+    prep_pads_h16 = True  # gast_prep pads d loss / d pred into the 16-bit storage type, with the loss scale (round 6)
     fuses_bn_bwd = True  # semch_agg_bwd(bn=...) / expand_bwd(bn=...) apply the BatchNorm backward of their input gradient on load
 
     def bn_finalize_multi(self, jobs):
@@ -946,7 +947,7 @@ class HipOps:
 
     def prep(self, zero, seed=None, pad=None):
         """Pass prologue (gast_prep): zero-fill the tensors of `zero` (contiguous device tensors), seed = (counter, per-pass copy):
-        *copy = ++*counter (int32 / uint32 one-element tensors), pad = (src, dst, rows, cols_src, cols_dst): contiguous fp32.  One
+        *copy = ++*counter (int32 / uint32 one-element tensors), pad = (src, dst, rows, cols_src, cols_dst[, scale]): contiguous, fp32 source, fp32 or 16-bit destination.  One
         launch per PREP_MAX_ZERO regions; a region that is not 16-byte granular is zeroed by torch instead."""
         jobs = []
         for t in zero:
@@ -968,10 +969,12 @@ class HipOps:
             if first and seed is not None:
                 a.seed_ctr, a.seed_out = _p(seed[0]), _p(seed[1])
             if first and pad is not None:
-                src, dst, rows, cs, cd = pad
-                if src.dtype != torch.float32 or dst.dtype != torch.float32 or not src.is_contiguous() or not dst.is_contiguous():
-                    raise RuntimeError('gast_hip: prep pads contiguous fp32 tensors')
+                src, dst, rows, cs, cd = pad[:5]
+                if src.dtype != torch.float32 or dst.dtype not in (torch.float32, h16_dtype()) or not src.is_contiguous() or not dst.is_contiguous():
+                    raise RuntimeError('gast_hip: prep pads a contiguous fp32 tensor into fp32 or the 16-bit storage type')
                 a.pad_src, a.pad_dst, a.pad_rows, a.pad_cols_src, a.pad_cols_dst = _p(src), _p(dst), int(rows), int(cs), int(cd)
+                a.pad_scale = float(pad[5]) if len(pad) > 5 else 1.0
+                a.pad_dst_h16 = int(dst.dtype != torch.float32)
             if a.nzero or a.seed_ctr or a.pad_rows:
                 self.launches += 1
                 _check(self.lib.gast_prep(C.byref(a), _stream()), 'gast_prep')

@@ -569,9 +569,10 @@ class Engine:
         TL = T[-1]
         PL = B * TL * J
         KP = 8
-        if dt == f32 and dpred.dtype == f32 and dpred.is_contiguous():
-            dp = torch.empty(PL, KP, dtype=f32, device=dev)       # written whole (3 columns + zero padding) by the pass prologue
-            self._prep(arena, prep, pad=(dpred, dp, PL, 3, KP))
+        if dpred.dtype == f32 and dpred.is_contiguous() and (dt == f32 or getattr(ops, 'prep_pads_h16', False)):
+            # written whole (3 columns + zero padding, the 16-bit modes' loss scale and rounding) by the pass prologue
+            dp = torch.empty(PL, KP, dtype=dt, device=dev)
+            self._prep(arena, prep, pad=(dpred, dp, PL, 3, KP, self.loss_scale(dt)))
         else:
             self._prep(arena, prep)
             dp = za.take((PL, KP), dt)

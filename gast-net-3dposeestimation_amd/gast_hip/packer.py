@@ -83,10 +83,15 @@ def x3_forward_f16():
     return v != 'bf16'
 
 
-def h16_images():
-    """GAST_H16_IMAGES = 1 (default) | 0: the 16-bit modes keep a k-group-major layout image of every packed operand, so that their
-    large-M GEMMs take gemm_big.hip (round 5); 0 = the round-1..4 behaviour (every GEMM on the 128 x 128 kernel)."""
-    return os.environ.get('GAST_H16_IMAGES', '1') not in ('0', '')
+def h16_images(dt=None):
+    """GAST_H16_IMAGES = 1 | 0: the 16-bit modes keep a k-group-major layout image of every packed operand, so that their large-M GEMMs
+    take gemm_big.hip (round 5); 0 = the round-1..4 behaviour (every GEMM on the 128 x 128 kernel).  Default by storage type (round 6,
+    three boxes, profiles/r06_ab_f16_kernels.txt): bfloat16 ON (2.469 vs 2.503 ms), binary16 OFF (2.521 vs 2.543, 2.530 vs 2.568,
+    2.604 vs 2.627 ms: the large-M kernel only ties the 128 x 128 one there and the image launch is not free)."""
+    v = os.environ.get('GAST_H16_IMAGES')
+    if v is None:
+        return dt != torch.float16
+    return v not in ('0', '')
 
 
 class X3Weight:
@@ -279,7 +284,7 @@ class Packer:
         """Per (device, dtype, x3) persistent buffers + device job tables.  x3 (GAST_F32X3): every packed fp32 operand also gets a
         pre-split bf16 image (`Xb`), refreshed by ops.run_pack after the copy / fold launches."""
         f16fwd = bool(x3) and dt == torch.float32 and x3_forward_f16()
-        h16 = bool(h16) and dt != torch.float32 and not f8 and h16_images()
+        h16 = bool(h16) and dt != torch.float32 and not f8 and h16_images(dt)
         key = (str(dev), dt, bool(x3), bool(f8), f16fwd, h16)
         st = self._dev.get(key)
         ptrs = tuple(p.data_ptr() for p in self.params)

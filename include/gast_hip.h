@@ -445,7 +445,7 @@ int gast_adam_step_guarded(float* p, const float* g, float* m, float* v, float* 
 /* Pass prologue, ONE launch: zero-fill up to GAST_PREP_MAX_ZERO regions (16-byte aligned, sizes multiples of 16: the accumulation
  * arena of the pass, the flat gradient buffer, the packed-gradient scratch), optionally advance the dropout seed (*seed_out =
  * ++*seed_ctr: the per-pass copy the kernels of this pass -- and its backward -- read) and optionally pad d loss / d pred from
- * pad_cols_src to pad_cols_dst columns (pad_dst[r][c] = c < pad_cols_src ? pad_src[r][c] : 0, contiguous fp32, pad_rows rows;
+ * pad_cols_src to pad_cols_dst columns (pad_dst[r][c] = c < pad_cols_src ? pad_scale * pad_src[r][c] : 0, contiguous, fp32 source, pad_rows rows;
  * reference main.py:231-237: the 3 output coordinates, 8 columns for the shrink layer's gradient GEMMs).  Replaces the torch
  * fill / add / clone / slice-copy nodes at the head of a forward and of a backward pass. */
 #define GAST_PREP_MAX_ZERO 6
@@ -459,6 +459,8 @@ typedef struct {
     float* pad_dst;
     long pad_rows;
     int pad_cols_src, pad_cols_dst;
+    float pad_scale;         /* round 6: the copied values are multiplied by this (0 means 1: the loss scale of GAST_HIP_DTYPE=f16) */
+    int pad_dst_h16;         /* round 6: pad_dst holds the library's 16-bit storage type (bfloat16 / binary16 by build flavour) instead of fp32 */
 } gast_prep_args;
 int gast_prep(const gast_prep_args* args, gast_stream_t stream);
 

@@ -572,7 +572,8 @@ def stream_shift(buf, newest):
 
 def prep(zero, seed=None, pad=None):
     """gast_prep (pass prologue): zero-fill every array of `zero`; seed = (counter, copy): copy[0] = counter[0] = counter[0] + 1
-    (mod 2^32); pad = (src, dst, rows, cols_src, cols_dst): dst[r, c] = src[r, c] for c < cols_src, 0 beyond."""
+    (mod 2^32); pad = (src, dst, rows, cols_src, cols_dst[, scale]): dst[r, c] = scale * src[r, c] for c < cols_src, 0 beyond (the
+    caller rounds dst to the 16-bit storage type where the destination has one)."""
     for z in zero:
         z[...] = 0
     if seed is not None:
@@ -583,8 +584,8 @@ def prep(zero, seed=None, pad=None):
         ctr.reshape(-1)[0] = v
         copy.reshape(-1)[0] = v
     if pad is not None:
-        src, dst, rows, cs, cd = pad
+        src, dst, rows, cs, cd = pad[:5]
         d = dst.reshape(rows, cd)
         d[...] = 0
-        d[:, :cs] = src.reshape(rows, cs)
+        d[:, :cs] = src.reshape(rows, cs) * (pad[5] if len(pad) > 5 else 1.0)
 

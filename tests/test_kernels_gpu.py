@@ -111,6 +111,22 @@ def test_prep_matches_contract(ops):
     assert np.array_equal(dst_d.cpu().numpy(), rdst)
 
 
+def test_prep_pads_scaled_into_16_bit_storage(ops):
+    """gast_prep's pad job with a loss scale and a 16-bit destination (GAST_HIP_DTYPE=f16 / bf16: d loss / d pred arrives in fp32, the
+    shrink layer's gradient kernels read the storage type): scale * src rounded to the storage type, zero padding, nothing else."""
+    gen = torch.Generator().manual_seed(5)
+    src = torch.randn(301, 3, generator=gen) * 1e-4
+    dst = torch.full((301, 8), 7.0).to(H16).cuda()
+    ops.prep([], pad=(src.cuda(), dst, 301, 3, 8, 4096.0))
+    ref = np.zeros((301, 8), np.float32)
+    kc.prep([], pad=(src.numpy(), ref, 301, 3, 8, 4096.0))
+    assert np.array_equal(dst.float().cpu().numpy(), torch.from_numpy(ref).to(H16).float().numpy())
+    dst32 = torch.full((301, 8), 7.0).cuda()
+    ops.prep([], pad=(src.cuda(), dst32, 301, 3, 8, 0.5))
+    kc.prep([], pad=(src.numpy(), ref, 301, 3, 8, 0.5))
+    assert np.array_equal(dst32.cpu().numpy(), ref)
+
+
 # ------------------------------------------------------------------------------------------------ dropout stream
 def test_dropout_stream_matches_contract(ops):
     """bnrelu_bwd_mask with scale=1, shift=1 (always positive) exposes the keep mask exactly."""
