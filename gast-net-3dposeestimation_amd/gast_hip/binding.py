@@ -827,6 +827,7 @@ class HipOps:
         from gast_hip.packer import BASE_W
         wsize = st['Wb'].element_size()
         regions = sorted((off, r, c, n) for n, (off, r, c) in packer.W.regions.items())
+        noimg = st.get('Xb') is None          # (a state without images: every image word stays 0 = "none")
 
         def region_of(off):
             for o, r, c, n in regions:
@@ -840,7 +841,7 @@ class HipOps:
             dst_size = wsize if dst.base == BASE_W else 4
             flags = (1 if src_size == 2 else 0) | (2 if dst_size == 2 else 0)
             ext = [0, 0, 0, 0, 0, 0]
-            if dst.base == BASE_W:
+            if dst.base == BASE_W and not noimg:
                 roff, K, name = region_of(dst.off)
                 if dst.rs != 1 and dst.cs != 1:
                     raise RuntimeError('gast_hip: an operand destination must be K-contiguous or a transposed twin')
@@ -853,6 +854,11 @@ class HipOps:
         fw = []
         for j in packer.fold_jobs:
             wt = j['w']
+            if noimg:
+                fw += [(j['W'].data_ptr() << 4), ((wt.data_ptr() + j['woff'] * 4) << 4), (j['b'].data_ptr() << 4), j['Ci'], j['C'],
+                       self._word(j['row'], wsize), j['row'].cs, self._word(j['col'], wsize), j['col'].cs, self._word(j['bias'], 4),
+                       1 if wsize == 2 else 0, 0, 0, 0, 0, 0, 0, 0]
+                continue
             roff_r, K_r, name_r = region_of(j['row'].off)
             roff_c, K_c, name_c = region_of(j['col'].off)
             img_r, img_c = packer._image(st, name_r), packer._image(st, name_c)
@@ -987,9 +993,11 @@ class HipOps:
         dev = st['Wb'].device
         tb = self._tables(packer, st, dev)
         bases = self._bases(W=st['Wb'], F=st['Fb'])
-        if st.get('Xb') is not None and not st.get('h16img') and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
+        fused_ok = (st.get('Xb') is not None and not st.get('h16img')) or (st.get('Xb') is None and st.get('F8s') is None)
+        if fused_ok and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
             # GAST_F32X3: operands, folds and their pre-split images in ONE launch (gast_pack_all; GAST_PACK_FUSED=0: the three
-            # launches of rounds 2-3)
+            # launches of rounds 2-3).  Round 6: also the states WITHOUT images (fp32, binary16 storage): copy tiles and fold blocks
+            # in one grid, image words zero
             px = tb.get('packx')
             if px is None:
                 px = tb['packx'] = self._packx_tables(packer, st, dev)

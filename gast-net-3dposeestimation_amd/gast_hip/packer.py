@@ -84,14 +84,13 @@ def x3_forward_f16():
 
 
 def h16_images(dt=None):
-    """GAST_H16_IMAGES = 1 | 0: the 16-bit modes keep a k-group-major layout image of every packed operand, so that their large-M GEMMs
-    take gemm_big.hip (round 5); 0 = the round-1..4 behaviour (every GEMM on the 128 x 128 kernel).  Default by storage type (round 6,
-    three boxes, profiles/r06_ab_f16_kernels.txt): bfloat16 ON (2.469 vs 2.503 ms), binary16 OFF (2.521 vs 2.543, 2.530 vs 2.568,
-    2.604 vs 2.627 ms: the large-M kernel only ties the 128 x 128 one there and the image launch is not free)."""
-    v = os.environ.get('GAST_H16_IMAGES')
-    if v is None:
-        return dt != torch.float16
-    return v not in ('0', '')
+    """GAST_H16_IMAGES = 1 (default) | 0: the 16-bit modes keep a k-group-major layout image of every packed operand, so that their
+    large-M GEMMs take gemm_big.hip (round 5); 0 = the round-1..4 behaviour (every GEMM on the 128 x 128 kernel).  Round 6 measured
+    the switch again on four boxes (profiles/r06_ab_f16_kernels.txt): bfloat16 storage is faster WITH images (2.469 vs 2.503 ms),
+    binary16 20 - 40 us faster WITHOUT (2.521 vs 2.543, 2.530 vs 2.568, 2.604 vs 2.627) -- but without them configs[2] moves from
+    9.66e-3 to 1.0009e-2 against the float64 oracle, across the north star's 1e-2 bound (the 128 x 128 kernel sums a K tile in a
+    different order).  Parity first: the images stay on for both storage types."""
+    return os.environ.get('GAST_H16_IMAGES', '1') not in ('0', '')
 
 
 class X3Weight:

@@ -64,4 +64,4 @@ bash scripts/ab_env.sh $O/ab_bj base= nobj=GAST_GEMM_BJ=0 allbj=GAST_GEMM_BJ_ALL
 # the 16-bit mode: the replayed f16 step per kernel, and its round-5 kernels (16-bit gemm_big / wgrad_wide) switched off on the same box
 GAST_HIP_DTYPE=f16 timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_f16 -- python bench.py --no-cpu-baseline --no-parity --no-kernel-timer --no-eager --no-twin --no-f16 --no-stock-baseline --steps 8 --warmup 2 > $O/trace_f16.log 2>&1
 python scripts/trace_step.py $(find /tmp/prof_f16 -name "*kernel_trace.csv" | head -1) 3 > $O/f16_step_summary.txt
-bash scripts/ab_env.sh $O/ab_f16 "r4kernels=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=0,GAST_WGRAD_H16_WIDE=0" "images=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=1" "default=GAST_HIP_DTYPE=f16" | tee $O/ab_f16.txt
+bash scripts/ab_env.sh $O/ab_f16 "r4kernels=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=0,GAST_WGRAD_H16_WIDE=0" "noimages=GAST_HIP_DTYPE=f16,GAST_H16_IMAGES=0" "default=GAST_HIP_DTYPE=f16" | tee $O/ab_f16.txt
