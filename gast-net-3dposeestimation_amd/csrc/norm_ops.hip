@@ -116,10 +116,14 @@ struct BnBwdFinBatch { gast_bn_bwd_fin_job j[GAST_BN_MAX_BATCH]; };
 __global__ void __launch_bounds__(256) bn_bwd_finalize_multi_kernel(const BnBwdFinBatch b) { bn_bwd_finalize_body(b.j[blockIdx.y]); }
 
 // ------------------------------------------------------------------------------------------------ elementwise
-template <typename T>
+// FR (round 6): rows = B * T_total * J and only the frames whose bit is set in `frames` carry a gradient -- the others are known to be zero
+// and are NOT read (they need not even be initialised): the input gradient of the last dilated level reaches 3 of its 19 input frames
+// (reference gast_net.py:173, T' = 1), and both the zero fill of the rest and its read-back were at the HBM roofline.
+template <typename T, bool FR = false>
 __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, int lddz, const T* __restrict__ X, int ldx, long rows, int N,
                                                            const float* ka, const float* kb,
-                                                           const float* kc, int TPR, int RB) {
+                                                           const float* kc, int TPR, int RB, int T_total = 1, int J = 1,
+                                                           unsigned long long frames = 0) {
     const int tid = threadIdx.x, slot = tid / TPR, ct = tid - slot * TPR;
     if (slot >= RB) return;
     const int N4 = N >> 2;
@@ -127,7 +131,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(T* __restrict__ dz, i
         const int c = cg * 4;
         const float4 a = *(const float4*)(ka + c), b = *(const float4*)(kb + c), k = *(const float4*)(kc + c);
         for (long r = (long)blockIdx.x * RB + slot; r < rows; r += (long)gridDim.x * RB) {
-            float4 d = ld4(dz + r * lddz + c), x = ld4(X + r * ldx + c);
+            const bool live = !FR || ((frames >> (unsigned)((r / J) % T_total)) & 1ull);
+            float4 d = live ? ld4(dz + r * lddz + c) : make_float4(0, 0, 0, 0), x = ld4(X + r * ldx + c);
             d.x = fmaf(a.x, d.x, fmaf(b.x, x.x, k.x));
             d.y = fmaf(a.y, d.y, fmaf(b.y, x.y, k.y));
             d.z = fmaf(a.z, d.z, fmaf(b.z, x.z, k.z));
@@ -824,6 +829,23 @@ extern "C" int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, i
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz, (const bf16_t*)X,
                            ldx, rows, N, ka, kb, kc, c.TPR, c.RB);
+    GAST_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int gast_bn_bwd_apply_frames(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N, const float* ka,
+                                        const float* kb, const float* kc, int T_total, int J, unsigned long long frames, gast_stream_t stream) {
+    if (bad_dtype(dtype) || !dz || !X || !ka || !kb || !kc || rows < 1 || T_total < 1 || T_total > 64 || J < 1 || rows % ((long)T_total * J))
+        return GAST_EINVAL;
+    if (N % 4 || lddz % 4 || ldx % 4) return GAST_EALIGN;
+    RowCfg c = row_cfg(N);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == GAST_F32)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<float, true>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (float*)dz, lddz, (const float*)X, ldx,
+                           rows, N, ka, kb, kc, c.TPR, c.RB, T_total, J, frames);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t, true>), dim3(row_blocks(rows, N)), dim3(256), 0, st, (bf16_t*)dz, lddz, (const bf16_t*)X,
+                           ldx, rows, N, ka, kb, kc, c.TPR, c.RB, T_total, J, frames);
     GAST_CHECK_LAUNCH();
     return 0;
 }

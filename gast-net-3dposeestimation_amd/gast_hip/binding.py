@@ -220,6 +220,7 @@ def load_library(h16=torch.bfloat16):
         'gast_bn_bwd_fused_multi': [ci, C.POINTER(_BnBwdJob), ci, vp],
         'gast_bn_bwd_finalize': [vp, ci, ci, ci, ci, cd, vp, vp, vp, vp, vp, vp, vp, vp, vp],
         'gast_bn_bwd_apply': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, vp],
+        'gast_bn_bwd_apply_frames': [ci, vp, ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, C.c_ulonglong, vp],
         'gast_bnrelu_apply': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, cu, _Dropout, vp],
         'gast_bnrelu_bwd_mask': [ci, vp, ci, vp, ci, cl, ci, vp, vp, ci, cu, _Dropout, vp, ci, vp, vp],
         'gast_shrink_fwd': [ci, vp, ci, cl, ci, vp, vp, vp, ci, ci, vp, ci, vp],
@@ -263,7 +264,7 @@ def load_library(h16=torch.bfloat16):
 
 EXPORTED_SYMBOLS = ['gast_gemm', 'gast_gemm_ws', 'gast_gemm_multi', 'gast_gemm_splitk_ws_bytes', 'gast_gemm_row_blocks', 'gast_gemm_path', 'gast_f8_scale_multi', 'gast_x3_image_multi', 'gast_x3_image_ld', 'gast_wgrad', 'gast_wgrad_multi', 'gast_semch_adj_fwd', 'gast_semch_adj_bwd', 'gast_semch_adj_multi',
                     'gast_semch_agg_fwd', 'gast_semch_agg_blocks', 'gast_semch_agg_bwd', 'gast_semch_agg_bwd_ws_floats', 'gast_semch_agg_bwd_fuses_bn', 'gast_semch_agg_bwd_bn', 'gast_attn_fwd', 'gast_attn_bwd', 'gast_attn_bwd_ws_floats', 'gast_rowsum_multi', 'gast_attn_bwd_deferred', 'gast_semch_agg_bwd_deferred',
-                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bnrelu_apply',
+                    'gast_bn_finalize', 'gast_bn_finalize_multi', 'gast_bn_eval', 'gast_bn_eval_multi', 'gast_bn_bwd_finalize', 'gast_bn_bwd_finalize_multi', 'gast_bn_bwd_fused_multi', 'gast_bn_bwd_apply', 'gast_bn_bwd_apply_frames', 'gast_bnrelu_apply',
                     'gast_bnrelu_bwd_mask', 'gast_shrink_fwd', 'gast_shrink_bwd_blocks', 'gast_shrink_bwd', 'gast_rowwise_blocks', 'gast_residual_fwd', 'gast_input_stats',
                     'gast_input_stats_blocks', 'gast_expand_fwd', 'gast_expand_bwd', 'gast_expand_bwd_bn', 'gast_expand_bwd_ws_floats', 'gast_colsum', 'gast_strided_copy', 'gast_pack_all', 'gast_fold',
                     'gast_unfold', 'gast_mpjpe', 'gast_adam_step', 'gast_adam_step_guarded', 'gast_nonfinite_scan', 'gast_prep', 'gast_null_launch', 'gast_chunk_gather', 'gast_stream_shift_multi', 'gast_version']
@@ -712,6 +713,13 @@ class HipOps:
     def bn_bwd_apply(self, dz, X, rows, N, ka, kb, kc):
         self.launches += 1
         _check(self.lib.gast_bn_bwd_apply(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), _stream()), 'gast_bn_bwd_apply')
+
+    def bn_bwd_apply_frames(self, dz, X, rows, N, ka, kb, kc, T_total, J, frames):
+        """bn_bwd_apply for rows = B * T_total * J of which only the frames in the bit mask `frames` carry a gradient: the rest of dz is
+        taken as zero without being read (it may be uninitialised)"""
+        self.launches += 1
+        _check(self.lib.gast_bn_bwd_apply_frames(_dt(dz), _p(dz), _ld(dz), _p(X), _ld(X), rows, N, _p(ka), _p(kb), _p(kc), int(T_total), int(J),
+                                                 int(frames), _stream()), 'gast_bn_bwd_apply_frames')
 
     def bnrelu_apply(self, X, rows, N, scale, shift, Y, use_drop=False, salt=0, drop=None):
         """Y = drop(relu(scale*X + shift)); the dropout stream `salt` is indexed by the element offset in X."""

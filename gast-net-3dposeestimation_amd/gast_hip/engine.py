@@ -480,13 +480,13 @@ class Engine:
             self.ops.rowsum_multi(self._finq)
             self._finq = []
 
-    def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None):
+    def _bn_backward(self, partials, nblk, col0, n, st, gamma, gout, key, dz, Xpre, rows, off=0, dzcol=None, frames=None):
         """finalize {sum dz, sum dz*x} -> dgamma/dbeta (ACCUMULATED into their destinations: the gradient buffers arrive zeroed or
         hold a running sum) + coefficients, then dz <- dx in place."""
         d = dz if dzcol is None else dz[:, dzcol:dzcol + n]
         xx = Xpre if dzcol is None else Xpre[:, dzcol:dzcol + n]
         self._bn_backward_group([dict(partials=partials, nblk=nblk, col0=col0, n=n, st=st, off=off, gamma=gamma, key=key, dz=d, X=xx,
-                                      rows=rows)], gout)
+                                      rows=rows, frames=frames)], gout)
 
     def _bn_backward_group(self, items, gout, one_apply=None):
         """items: dicts(partials, nblk, col0, n, st, off, gamma, key, dz, X, rows[, dzcol]) -- BatchNorm backward passes whose
@@ -531,7 +531,10 @@ class Engine:
         o = 0
         for it in items:
             n = it['n']
-            ops.bn_bwd_apply(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n])
+            if it.get('frames') is not None:       # (T_total, J, bit mask): only these frames of dz were written, the rest counts as zero
+                ops.bn_bwd_apply_frames(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n], *it['frames'])
+            else:
+                ops.bn_bwd_apply(it['dz'], it['X'], it['rows'], n, ka[o:o + n], kb[o:o + n], kc[o:o + n])
             o += n
 
     def backward(self, sv, inp, dpred, gout, stage_done=None, prep=None):
@@ -650,6 +653,7 @@ class Engine:
             # ... and input gradient, fused with the residual branch and the ReLU/BN backward of the previous block's output
             WcT = [inp[lk + 'convT'][tap * C:(tap + 1) * C] for tap in range(k)]     # [tap][cin][cout]
             pg = 'g%d.' % (s - 1)
+            dO_frames = None
             if sp.strided:
                 covered = k * Tn == Tp
                 dOp = self._new(Pp, C, dt, dev) if covered else za.take((Pp, C), dt)
@@ -669,7 +673,12 @@ class Engine:
                 # the input domain whose rows are mostly zero (arc 3,3,3, last level: 3 x 1.1 GFLOP instead of 65 GFLOP).  Frames
                 # no tap reaches keep the zero of the arena: their gradient before the BatchNorm backward is exactly zero.
                 d = sp.tapstep[s]
-                dOp = za.take((Pp, C), dt)
+                # (round 6) ... unless the BatchNorm-backward apply can be told which frames were written: then nothing is zero-filled
+                # and nothing zero is read back (84.7 MB each way at B = 128)
+                sparse = hasattr(ops, 'bn_bwd_apply_frames') and Tp <= 64 and Pp > FUSED_BN_BWD_ROWS and \
+                    os.environ.get('GAST_SPARSE_TAP_GRAD', '1') not in ('0', '')
+                dO_frames = (Tp, J, sum(1 << (tap * d + t) for tap in range(k) for t in range(Tn))) if sparse else None
+                dOp = self._new(Pp, C, dt, dev) if sparse else za.take((Pp, C), dt)
                 nbt = ops.gemm_row_blocks(P)
                 partO = za.take((k * nbt, C, 2))
                 res_off = lv['resmap'].t_off
@@ -688,7 +697,8 @@ class Engine:
                 self._gemm_chunked((B, Tp, J), C, segs, dOp, ident(Tp), addend=dX, addmap=RowMap(Tn, 1, -lv['resmap'].t_off),
                                    epi=EPI_BNRELU_BWD, partials=partO, X=prev['O'], xscale=prev['bnO'].scale,
                                    xshift=prev['bnO'].shift)
-            self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp)
+            self._bn_backward(partO, nbo, 0, C, prev['bnO'], inp[pg + 'cat_bn.weight'], grads, pg + 'cat_bn', dOp, prev['O'], Pp,
+                              frames=dO_frames)
             dO = dOp
             self._wgrad_flush()
             if stage_done is not None:

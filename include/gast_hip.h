@@ -341,6 +341,11 @@ int gast_bn_bwd_finalize(const float* partials, int nblk, int ncol_total, int co
 /* dz <- ka*dz + kb*x + kc (in place) */
 int gast_bn_bwd_apply(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N,
                       const float* ka, const float* kb, const float* kc, gast_stream_t stream);
+/* The same for a tensor of rows = B * T_total * J of which only the frames t with bit t of `frames` set carry a gradient (T_total <= 64): the
+ * other rows of dz are taken as zero WITHOUT being read -- they may be uninitialised -- and receive kb*X + kc.  The input gradient of
+ * the last dilated temporal level (reference gast_net.py:173 with T' = 1) reaches k of its input frames only. */
+int gast_bn_bwd_apply_frames(int dtype, void* dz, int lddz, const void* X, int ldx, long rows, int N, const float* ka, const float* kb,
+                             const float* kc, int T_total, int J, unsigned long long frames, gast_stream_t stream);
 /* Y = drop(relu(scale*X + shift)); dropout (use_drop != 0) uses stream `salt` indexed by the element offset in X.  Materialises
  * the post-activation of the local / global branch (gast_net.py:24-27) once, so that the G4 GEMM, its weight gradient and the
  * branch input gradients need neither the BatchNorm prologue nor the dropout hash (mask = [Y > 0], see epi_scale). */

@@ -417,6 +417,15 @@ def bn_bwd_apply(dz, X, rows, N, ka, kb, kc, round_fn=None):
     dz[:rows, :N] = round_fn(v) if round_fn else v
 
 
+def bn_bwd_apply_frames(dz, X, rows, N, ka, kb, kc, T_total, J, frames, round_fn=None):
+    """gast_bn_bwd_apply_frames: rows = B * T_total * J; the rows of frames whose bit is clear in `frames` count as zero whatever they hold"""
+    t = (np.arange(rows) // J) % T_total
+    live = np.array([(int(frames) >> tt) & 1 for tt in range(T_total)], bool)[t]
+    d = np.where(live[:, None], np.asarray(dz[:rows, :N], np.float64), 0.0)
+    v = np.asarray(ka, np.float64)[:N] * d + np.asarray(kb, np.float64)[:N] * X[:rows, :N] + np.asarray(kc, np.float64)[:N]
+    dz[:rows, :N] = round_fn(v) if round_fn else v
+
+
 def bnrelu_apply(X, rows, N, scale, shift, Y, round_fn=None, use_drop=False, salt=0, drop=None):
     """drop = (seed, thresh, inv_keep); the stream is indexed by the element offset in X (row * ld(X) + col)."""
     v = np.maximum(np.asarray(X[:rows, :N], np.float64) * np.asarray(scale, np.float64)[:N] + np.asarray(shift, np.float64)[:N], 0)

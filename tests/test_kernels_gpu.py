@@ -1174,6 +1174,32 @@ def test_bn_finalize_multi(ops):
 
 
 @pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
+@pytest.mark.parametrize('B,T,J,N,frames', [(7, 19, 17, 512, (0, 9, 18)), (3, 64, 15, 64, (63,)), (2, 5, 19, 8, (0, 1, 2, 3, 4)), (4, 3, 17, 1032, ())])
+def test_bn_bwd_apply_frames(ops, B, T, J, N, frames, dt):
+    """gast_bn_bwd_apply_frames: the rows of the frames outside the mask are NaN here -- they must not be read -- and come out as kb*x + kc;
+    a full mask equals gast_bn_bwd_apply, an empty one is a pure function of X."""
+    gen = torch.Generator().manual_seed(B * 100 + T)
+    rnd = (lambda v: v) if dt == torch.float32 else (lambda v: host(torch.from_numpy(v).to(H16)))
+    rows, ld = B * T * J, N + 8
+    mask = sum(1 << t for t in frames)
+    X = rand(gen, rows, ld).to(dt)
+    ka, kb, kcc = rand(gen, N), rand(gen, N, scale=0.1), rand(gen, N, scale=0.1)
+    dz = rand(gen, rows, ld).to(dt)
+    t_of = (torch.arange(rows) // J) % T
+    dead = torch.tensor([t not in frames for t in range(T)])[t_of]
+    dzd = dz.clone()
+    dzd[dead] = float('nan')
+    dzd = dzd.cuda()
+    ops.bn_bwd_apply_frames(dzd[:, :N], X.cuda()[:, :N], rows, N, ka.cuda(), kb.cuda(), kcc.cuda(), T, J, mask)
+    dzh = host(dz)
+    kc.bn_bwd_apply_frames(dzh[:, :N], host(X)[:, :N], rows, N, host(ka), host(kb), host(kcc), T, J, mask, round_fn=rnd)
+    got = host(dzd)
+    assert np.isfinite(got[:, :N]).all(), 'a dead frame was read'
+    close(got[:, :N], dzh[:, :N], dt, 'bn_bwd_apply_frames')
+    assert np.isnan(got[dead.numpy()][:, N:]).all() or not dead.any()          # (the columns past N are untouched)
+
+
+@pytest.mark.parametrize('dt', DTYPES, ids=['f32', 'bf16'])
 @pytest.mark.parametrize('rows,K', [(2176, 1024), (2175, 512), (1, 64), (33, 2048 + 8), (70, 8)])
 def test_shrink_rowwise(ops, rows, K, dt):
     """gast_shrink_fwd / gast_shrink_bwd (reference gast_net.py:99,176-178) against the numpy contract: full size of BASELINE configs[1]
