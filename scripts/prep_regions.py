@@ -1,3 +1,5 @@
+"""Sizes of the regions the pass prologues (gast_prep) zero-fill in one training step (GPU box): how the 84.7 MB zero fill of the last
+dilated level's input gradient was found (round 6, gast_bn_bwd_apply_frames).  Usage: python scripts/prep_regions.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, 'gast-net-3dposeestimation_amd')):
