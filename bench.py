@@ -649,6 +649,7 @@ def main():
     barrier()
     _sync()
     elapsed = time.perf_counter() - t0
+    gc.unfreeze()
     per_rank_ms = None
     if collective:
         tt = torch.zeros(world, dtype=torch.float64, device=dev)
