@@ -1043,15 +1043,19 @@ def test_fused_parameter_packing_equals_the_three_launch_path(ch, arc, variant, 
 
 
 
-@pytest.mark.parametrize('switch', ['GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0'], ids=['round4_plan'])
-def test_round5_plan_switches_agree_with_the_default(switch, mode2, monkeypatch):
+@pytest.mark.parametrize('switch,frames', [('GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0', 27),
+                                           ('GAST_SPARSE_TAP_GRAD=0,GAST_SHRINK_KERNEL=0', 27), ('GAST_SPARSE_TAP_GRAD=0,GAST_SHRINK_KERNEL=0', 29)],
+                         ids=['round4_plan', 'round5_tail', 'round5_tail_T29'])
+def test_round5_plan_switches_agree_with_the_default(switch, frames, mode2, monkeypatch):
     """The bisecting switches that restore the round-4 plan (stand-alone bn_bwd_apply over dY / dE, materialised first-block input) compute the same training step as the
     default plan: same arithmetic, same order inside every kernel -- the only run-to-run freedom is the order of the split reductions, so
-    the comparison is at round-off level, not bitwise."""
+    the comparison is at round-off level, not bitwise.  round5_tail (round 6): the last level's input gradient in the zero-filled arena with
+    a dense BatchNorm-backward apply instead of gast_bn_bwd_apply_frames, the shrink layer through gast_gemm; T = 29 leaves THREE output
+    frames at the last level, so the mask of written frames has three runs of three (t, t + 9, t + 18)."""
     cfg = dict(J=17, parents=PARENTS[17], arc=[3, 3, 3], channels=64, causal=False, variant='dilated')
     gen = torch.Generator().manual_seed(41)
-    x = (torch.rand(96, 27, 17, 2, generator=gen) * 2 - 1).cuda()          # (96 x 27 x 17 rows: the large-M kernels and the fused consumers run)
-    y3d = (torch.randn(96, 1, 17, 3, generator=gen) * 0.3).cuda()
+    x = (torch.rand(96, frames, 17, 2, generator=gen) * 2 - 1).cuda()      # (96 x 27 x 17 rows: the large-M kernels and the fused consumers run)
+    y3d = (torch.randn(96, frames - 26, 17, 3, generator=gen) * 0.3).cuda()
     res = {}
     for name, envs in (('default', ''), ('switched', switch)):
         for kv in switch.split(','):
@@ -1071,6 +1075,11 @@ def test_round5_plan_switches_agree_with_the_default(switch, mode2, monkeypatch)
     assert float((ya - yb).abs().max()) < 2e-6 * max(1.0, float(ya.abs().max()))
     gmax = max(float(v.abs().max()) for v in ga.values())
     for k in ga:
-        assert float((ga[k] - gb[k]).abs().max()) < 2e-5 * gmax + 2e-4 * float(ga[k].abs().max()), k
+        # T = 29 with this seed has one ReLU input within round-off of zero: two runs of the SAME plan land on either side of it (the split
+        # reductions are atomics) and their gradients then differ by ~5e-4 of the largest one (measured, default plan against itself, six runs
+        # in one process: bimodal -- 0.01 x or 17 - 26 x the tight tolerance, no NaN with poisoned allocations).  The case is there for the mask of written frames -- a wrong mask
+        # is an O(1) error in every gradient below the last level -- so it gets a bound above that flip.
+        tol = 2e-3 * gmax if frames != 27 else 2e-5 * gmax + 2e-4 * float(ga[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) < tol, k
     for k in ba:
         assert torch.allclose(ba[k].float(), bb[k].float(), rtol=1e-5, atol=1e-6), k
