@@ -126,6 +126,22 @@ __device__ __forceinline__ void copy_tiles(const long* __restrict__ jobs, const 
             if (!in[0]) continue;          // (validity is monotone along the quad)
             const long row = o0 / Kop;
             const int k = (int)(o0 - row * Kop);
+            if (f16 == 2) {
+                // layout image of a 16-BIT operand (round 5 kind 2; fused into this launch in round 6): the stored values themselves,
+                // img[(k >> 5) * ldimg + row * 32 + (k & 31)]
+                if (in[3] && (k & 3) == 0) {
+                    bf16_t* o = img + (long)(k >> 5) * ldimg + row * 32 + (k & 31);
+                    *(uint2*)o = make_uint2((uint32_t)f2bf(x[0]) | ((uint32_t)f2bf(x[1]) << 16), (uint32_t)f2bf(x[2]) | ((uint32_t)f2bf(x[3]) << 16));
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (!in[e]) break;
+                        const int kq = k + e;
+                        img[(long)(kq >> 5) * ldimg + row * 32 + (kq & 31)] = f2bf(x[e]);
+                    }
+                }
+                continue;
+            }
             uint2 h, l;
             if (f16) split_pair4<2>(x[0], x[1], x[2], x[3], h, l);
             else split_pair4<1>(x[0], x[1], x[2], x[3], h, l);
@@ -202,6 +218,16 @@ __device__ __forceinline__ void fold_body(const long* __restrict__ jobs, const l
         if (dst_bf16) { ((bf16_t*)d_row)[k * ds_row] = f2bf(v); ((bf16_t*)d_col)[k * ds_col] = f2bf(v); }
         else { ((float*)d_row)[k * ds_row] = v; ((float*)d_col)[k * ds_col] = v; }
         if constexpr (FJ == FJ_WORDS_X) {
+            if (j[17]) {         // layout images of 16-bit operands (kind 2): the stored value, 32 K positions per 64-byte row
+                if (j[12]) {
+                    bf16_t* ir = (bf16_t*)(bases[j[12] & 7] + (j[12] >> 4));
+                    ir[(long)(k >> 5) * j[13] + (k & 31)] = f2bf(v);
+                }
+                if (j[14]) {
+                    bf16_t* ic = (bf16_t*)(bases[j[14] & 7] + (j[14] >> 4));
+                    ic[(long)k * 32] = f2bf(v);
+                }
+            } else {
             if (j[12]) {         // images: the row destination is K positions k0 + k of one operand row ...
                 bf16_t* ir = (bf16_t*)(bases[j[12] & 7] + (j[12] >> 4));      // (address of K position 0 of that row in k-group 0)
                 bf16_t hi, lo;
@@ -217,6 +243,7 @@ __device__ __forceinline__ void fold_body(const long* __restrict__ jobs, const l
                 bf16_t* o = ic + (long)k * 32;
                 o[0] = hi;
                 o[16] = lo;
+            }
             }
         }
     }

@@ -836,6 +836,7 @@ class HipOps:
         wsize = st['Wb'].element_size()
         regions = sorted((off, r, c, n) for n, (off, r, c) in packer.W.regions.items())
         noimg = st.get('Xb') is None          # (a state without images: every image word stays 0 = "none")
+        h16img = bool(st.get('h16img'))       # (16-bit storage: layout images, kind 2, 32 K positions per row; some operands have none)
 
         def region_of(off):
             for o, r, c, n in regions:
@@ -849,12 +850,12 @@ class HipOps:
             dst_size = wsize if dst.base == BASE_W else 4
             flags = (1 if src_size == 2 else 0) | (2 if dst_size == 2 else 0)
             ext = [0, 0, 0, 0, 0, 0]
-            if dst.base == BASE_W and not noimg:
+            if dst.base == BASE_W and not noimg and (not h16img or packer._h16_ok(region_of(dst.off)[2])):
                 roff, K, name = region_of(dst.off)
                 if dst.rs != 1 and dst.cs != 1:
                     raise RuntimeError('gast_hip: an operand destination must be K-contiguous or a transposed twin')
                 img = packer._image(st, name)
-                ext = [(img.data_ptr() << 4) | 0, img.stride(0), dst.off - roff, K, int(packer._f16(st, name)), 0]
+                ext = [(img.data_ptr() << 4) | 0, img.stride(0), dst.off - roff, K, 2 if h16img else int(packer._f16(st, name)), 0]
             words += [self._word(src, src_size), self._word(dst, dst_size), R, S, src.rs, src.cs, dst.rs, dst.cs, flags, 0] + ext
             for tr in range((R + 31) // 32):
                 for tc in range((S + 31) // 32):
@@ -869,11 +870,23 @@ class HipOps:
                 continue
             roff_r, K_r, name_r = region_of(j['row'].off)
             roff_c, K_c, name_c = region_of(j['col'].off)
-            img_r, img_c = packer._image(st, name_r), packer._image(st, name_c)
             row_r, k0_r = divmod(j['row'].off - roff_r, K_r)          # the row destination: operand row, first K position (0)
             row_c, k_c = divmod(j['col'].off - roff_c, K_c)           # the column destination: first operand row (0), K position
             if k0_r != 0 or row_c != 0 or j['row'].cs != 1 or j['col'].cs != K_c:
                 raise RuntimeError('gast_hip: unexpected fold destination layout')
+            if h16img:
+                ir = ic = ld_r = 0
+                if packer._h16_ok(name_r):
+                    img_r = packer._image(st, name_r)
+                    ir, ld_r = img_r.data_ptr() + 2 * (row_r * 32), img_r.stride(0)
+                if packer._h16_ok(name_c):
+                    img_c = packer._image(st, name_c)
+                    ic = img_c.data_ptr() + 2 * ((k_c >> 5) * img_c.stride(0) + (k_c & 31))
+                fw += [(j['W'].data_ptr() << 4), ((wt.data_ptr() + j['woff'] * 4) << 4), (j['b'].data_ptr() << 4), j['Ci'], j['C'],
+                       self._word(j['row'], wsize), j['row'].cs, self._word(j['col'], wsize), j['col'].cs, self._word(j['bias'], 4),
+                       1 if wsize == 2 else 0, 0, (ir << 4), ld_r, (ic << 4), 0, 0, 1]
+                continue
+            img_r, img_c = packer._image(st, name_r), packer._image(st, name_c)
             ir = img_r.data_ptr() + 2 * (row_r * 32)
             ic = img_c.data_ptr() + 2 * ((k_c >> 4) * img_c.stride(0) + (k_c & 15))
             fw += [(j['W'].data_ptr() << 4), ((wt.data_ptr() + j['woff'] * 4) << 4), (j['b'].data_ptr() << 4), j['Ci'], j['C'],
@@ -1001,11 +1014,11 @@ class HipOps:
         dev = st['Wb'].device
         tb = self._tables(packer, st, dev)
         bases = self._bases(W=st['Wb'], F=st['Fb'])
-        fused_ok = (st.get('Xb') is not None and not st.get('h16img')) or (st.get('Xb') is None and st.get('F8s') is None)
+        fused_ok = st.get('Xb') is not None or st.get('F8s') is None
         if fused_ok and os.environ.get('GAST_PACK_FUSED', '1') not in ('0', ''):
             # GAST_F32X3: operands, folds and their pre-split images in ONE launch (gast_pack_all; GAST_PACK_FUSED=0: the three
-            # launches of rounds 2-3).  Round 6: also the states WITHOUT images (fp32, binary16 storage): copy tiles and fold blocks
-            # in one grid, image words zero
+            # launches of rounds 2-3).  Round 6: also the states WITHOUT images (fp32): copy tiles and fold blocks in one grid, image
+            # words zero -- and the 16-bit states, whose LAYOUT images (kind 2) are written by the same tiles
             px = tb.get('packx')
             if px is None:
                 px = tb['packx'] = self._packx_tables(packer, st, dev)

@@ -418,10 +418,11 @@ int gast_colsum(int dtype, const void* X, int ldx, long rows, int N, float* out,
 int gast_strided_copy(const int64_t* jobs, const int32_t* tiles, int ntiles, const int64_t* bases, gast_stream_t stream);
 /* The whole parameter packing of a step in ONE launch (round 4; was gast_strided_copy + gast_fold + gast_x3_image_multi): copy jobs of
  * 16 int64 = the 10 words above + {image word (0: none), ldimg, element offset of the job's element (0, 0) inside its packed operand,
- * columns K of that operand, fp16-pair flag, reserved} -- the tile is also written into the operand's pre-split image (layout of
- * gast_x3_image_multi; the destination must be K-contiguous or a transposed twin, i.e. one of its strides 1) -- and fold jobs of 18
- * int64 = the 12 words above + {image word of K position 0 of the destination row (k-group 0), its ldimg, image word of the
- * destination column's K position in operand row 0, reserved, fp16-pair flags (bit 0 row, bit 1 column), reserved}. */
+ * columns K of that operand, image kind (gast_x3_image_job.f16: 0 bf16 pairs, 1 fp16 pairs, 2 = round 6: the layout image of a 16-bit
+ * operand), reserved} -- the tile is also written into the operand's image (layout of gast_x3_image_multi; the destination must be
+ * K-contiguous or a transposed twin, i.e. one of its strides 1) -- and fold jobs of 18 int64 = the 12 words above + {image word of K
+ * position 0 of the destination row (k-group 0), its ldimg, image word of the destination column's K position in operand row 0,
+ * reserved, fp16-pair flags (bit 0 row, bit 1 column), 1 = both images are layout images of 16-bit operands (kind 2)}. */
 int gast_pack_all(const int64_t* cjobs, const int32_t* tiles, int ntiles, const int64_t* fjobs, int nfold, int max_C,
                   const int64_t* bases, gast_stream_t stream);
 int gast_fold(const int64_t* jobs, int njobs, int max_C, const int64_t* bases, gast_stream_t stream);      /* max_C  = largest C of the jobs */

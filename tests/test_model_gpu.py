@@ -1043,6 +1043,39 @@ def test_fused_parameter_packing_equals_the_three_launch_path(ch, arc, variant, 
 
 
 
+@pytest.mark.parametrize('ch,arc,variant', [(16, [3, 3], 'dilated'), (8, [3, 3, 3], 'dilated'), (32, [3, 3], 'strided')])
+def test_fused_parameter_packing_16_bit_layout_images(ch, arc, variant, monkeypatch):
+    """The same for the 16-bit storage modes (round 6): gast_pack_all writes the packed 16-bit operands, the fp32 values and the LAYOUT
+    images (kind 2, 32 K positions per 64-byte row) the large-M kernel streams, bit for bit what gast_strided_copy + gast_fold +
+    gast_x3_image_multi wrote -- including the operands that have no image (K not a multiple of 8) and the 8-channel model's ragged quads."""
+    from gast_hip.packer import Packer
+    from gast_hip.binding import h16_dtype
+    monkeypatch.setenv('GAST_HIP_DTYPE', 'bf16')
+    monkeypatch.setenv('GAST_H16_IMAGES', '1')
+    cfg = dict(J=17, parents=PARENTS[17], arc=arc, channels=ch, causal=False, variant=variant)
+    torch.manual_seed(11)
+    m = build(cfg).cuda()
+    gen = torch.Generator().manual_seed(2)
+    _random_state(m, gen)
+    ops = m._runner.engine.ops
+    packer = Packer(m, m._runner.spec)
+    got = {}
+    for fused in ('0', '1'):
+        monkeypatch.setenv('GAST_PACK_FUSED', fused)
+        st = packer.state(torch.device('cuda', 0), h16_dtype(), x3=False)
+        assert st.get('h16img') and st['Xb'] is not None
+        for k in ('Wb', 'Fb', 'Xb'):
+            st[k].zero_()
+        st['tables'] = None
+        ops.run_pack(packer, st)
+        torch.cuda.synchronize()
+        got[fused] = {k: st[k].clone() for k in ('Wb', 'Fb', 'Xb')}
+    assert torch.equal(got['0']['Fb'], got['1']['Fb'])
+    for k in ('Wb', 'Xb'):
+        assert torch.equal(got['0'][k].view(torch.int16), got['1'][k].view(torch.int16)), k
+    assert got['1']['Xb'].view(torch.int16).ne(0).any()
+
+
 @pytest.mark.parametrize('switch,frames', [('GAST_FUSE_AGG_BN=0,GAST_FUSE_EXPAND_BN=0,GAST_LAZY_X0=0', 27),
                                            ('GAST_SPARSE_TAP_GRAD=0,GAST_SHRINK_KERNEL=0', 27), ('GAST_SPARSE_TAP_GRAD=0,GAST_SHRINK_KERNEL=0', 29)],
                          ids=['round4_plan', 'round5_tail', 'round5_tail_T29'])
