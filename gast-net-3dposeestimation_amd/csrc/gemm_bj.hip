@@ -73,12 +73,15 @@ __device__ __forceinline__ const char* uni(const char* p) {
 struct Frag { uint4 u; };
 
 // EPI: 0 PLAIN, 1 STATS, 2 BNRELU_BWD, 3 BNRELU_BWD with the dropout mask of the forward re-derived
-template <int EPI, int NJ>
+// H16 (round 6, PAIR = 3): C / C2 / X / addend are tensors of the 16-bit storage type -- two-byte buffer accesses, values rounded to the
+// storage type BEFORE they enter the column sums (the statistics are those of the tensor that is stored), as in gemm.hip / gemm_big.hip
+template <int EPI, int NJ, bool H16 = false>
 __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPlan& pl, unsigned char* smem, const f32x16 (&acc)[NJ],
                                             int m0, int n0, int mt) {
     constexpr int TN = tn_of(NJ);
     constexpr bool bwd = EPI >= 2, xdrop = EPI == 3;
     constexpr uint32_t OOB = 0x80000000u, RSRC3 = 0x00020000u;
+    constexpr uint32_t ESO = H16 ? 2u : 4u, QSTEP = 32u * ESO;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kg = w >> 2, wr = (w >> 1) & 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
     const int M = pl.M, N = a.N;
@@ -90,17 +93,19 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
     const bool add = a.addend != nullptr, has2 = bwd && a.C2 != nullptr;
     auto ldv = [&](const __amdgpu_buffer_rsrc_t& r, uint32_t off) -> float {
-        return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+        if constexpr (H16) return bf2f((bf16_t)__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+        else return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
     };
     auto stv = [&](float v, const __amdgpu_buffer_rsrc_t& r, uint32_t off) {
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0);
+        if constexpr (H16) __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), r, off, 0, 0);
+        else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, off, 0, 0);
     };
     // (a tensor that is absent gets a zero-sized descriptor: its loads return 0, its stores are dropped)
-    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * 4), RSRC3);
-    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * 4) : 0, RSRC3);
-    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(has2 ? a.C2 : a.C, 0, has2 ? (int)(((rowsC - 1) * a.ldc2 + N) * 4) : 0, RSRC3);
+    const __amdgpu_buffer_rsrc_t rC = __builtin_amdgcn_make_buffer_rsrc(a.C, 0, (int)(((rowsC - 1) * a.ldc + N) * ESO), RSRC3);
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc((void*)(bwd ? a.X : a.C), 0, bwd ? (int)(((rowsC - 1) * a.ldx + N) * ESO) : 0, RSRC3);
+    const __amdgpu_buffer_rsrc_t rC2 = __builtin_amdgcn_make_buffer_rsrc(has2 ? a.C2 : a.C, 0, has2 ? (int)(((rowsC - 1) * a.ldc2 + N) * ESO) : 0, RSRC3);
     const long rowsAdd = add ? (long)a.B * a.addmap.T_total * a.J : 1;
-    const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(add ? a.addend : a.C), 0, add ? (int)(((rowsAdd - 1) * a.ldadd + N) * 4) : 0, RSRC3);
+    const __amdgpu_buffer_rsrc_t rAdd = __builtin_amdgcn_make_buffer_rsrc((void*)(add ? a.addend : a.C), 0, add ? (int)(((rowsAdd - 1) * a.ldadd + N) * ESO) : 0, RSRC3);
     const int col0 = n0 + wc * (TN / 2) + li;          // the lane's first column; the others are + 32 q
     bool nin[NJ];
     float bias[NJ], xs[NJ], xh[NJ], s1[NJ], s2[NJ];
@@ -127,12 +132,12 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
         arow[u][0] = a4.x; arow[u][1] = a4.y; arow[u][2] = a4.z; arow[u][3] = a4.w;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const uint32_t offx = crow[u][r] >= 0 ? (uint32_t)(crow[u][r] * a.ldx + col0) * 4u : OOB;
-            const uint32_t offa = arow[u][r] >= 0 ? (uint32_t)(arow[u][r] * a.ldadd + col0) * 4u : OOB;
+            const uint32_t offx = crow[u][r] >= 0 ? (uint32_t)(crow[u][r] * a.ldx + col0) * ESO : OOB;
+            const uint32_t offa = arow[u][r] >= 0 ? (uint32_t)(arow[u][r] * a.ldadd + col0) * ESO : OOB;
 #pragma unroll
             for (int q = 0; q < NJ; ++q) {
-                xv[u][q][r] = bwd ? ldv(rX, offx + 128u * q) : 0.f;
-                av[u][q][r] = ldv(rAdd, offa + 128u * q);            // (no addend: zero-sized descriptor, reads 0)
+                xv[u][q][r] = bwd ? ldv(rX, offx + QSTEP * q) : 0.f;
+                av[u][q][r] = ldv(rAdd, offa + QSTEP * q);            // (no addend: zero-sized descriptor, reads 0)
             }
         }
     }
@@ -141,23 +146,25 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int cr = crow[u][r];
-            const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * 4u;
+            const uint32_t coff = (uint32_t)(cr * a.ldc + col0) * ESO;
 #pragma unroll
             for (int q = 0; q < NJ; ++q) {
                 const bool ok = cr >= 0 && nin[q];
                 float v = acc[q][8 * kg + 4 * u + r] + bias[q] + av[u][q][r];
                 if (bwd) {
-                    stv(v, rC2, ok ? (uint32_t)(cr * a.ldc2 + col0) * 4u + 128u * q : OOB);
+                    stv(v, rC2, ok ? (uint32_t)(cr * a.ldc2 + col0) * ESO + QSTEP * q : OOB);
                     const float x = xv[u][q][r];
                     v = fmaf(x, xs[q], xh[q]) > 0.f ? v : 0.f;
                     if (xdrop) v *= drop_mul(xkey, thresh, inv_keep, (uint32_t)(cr * a.ldx + col0 + 32 * q));
+                    if constexpr (H16) v = bf2f(f2bf(v));
                     s1[q] += ok ? v : 0.f;
                     s2[q] += ok ? v * x : 0.f;
                 } else if (EPI == 1) {
+                    if constexpr (H16) v = bf2f(f2bf(v));
                     s1[q] += ok ? v : 0.f;
                     s2[q] += ok ? v * v : 0.f;
                 }
-                stv(v, rC, ok ? coff + 128u * q : OOB);
+                stv(v, rC, ok ? coff + QSTEP * q : OOB);
             }
         }
     }
@@ -194,7 +201,7 @@ __device__ __forceinline__ void bj_epilogue(const gast_gemm_args& a, const BjPla
 // ---- the two k-groups' accumulators meet: group g keeps registers 8 g .. 8 g + 7 (rows 16 g .. 16 g + 15 of the wave tile) and hands the
 // other half over through LDS ([8 NJ][256] floats per direction, conflict-free); then the epilogue.  Called behind a barrier that
 // every wave reaches after its last fragment read.
-template <int NJ>
+template <int NJ, bool H16 = false>
 __device__ __forceinline__ void bj_finish(const gast_gemm_args& a, const BjPlan& pl, unsigned char* smem, f32x16 (&acc)[NJ], int m0, int n0, int mt) {
     const int tid = threadIdx.x, kg = tid >> 8;
     {
@@ -216,10 +223,10 @@ __device__ __forceinline__ void bj_finish(const gast_gemm_args& a, const BjPlan&
     }
     if (pl.ablate & 2) { if (acc[0][0] == 12345.678f) ((float*)a.C)[0] = acc[0][5]; return; }
     const int v = a.epi == GAST_EPI_BNRELU_BWD ? ((a.xdrop && a.drop.thresh != 0) ? 3 : 2) : a.epi;
-    if (v == 0) bj_epilogue<0, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else if (v == 1) bj_epilogue<1, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else if (v == 2) bj_epilogue<2, NJ>(a, pl, smem, acc, m0, n0, mt);
-    else bj_epilogue<3, NJ>(a, pl, smem, acc, m0, n0, mt);
+    if (v == 0) bj_epilogue<0, NJ, H16>(a, pl, smem, acc, m0, n0, mt);
+    else if (v == 1) bj_epilogue<1, NJ, H16>(a, pl, smem, acc, m0, n0, mt);
+    else if (v == 2) bj_epilogue<2, NJ, H16>(a, pl, smem, acc, m0, n0, mt);
+    else bj_epilogue<3, NJ, H16>(a, pl, smem, acc, m0, n0, mt);
 }
 
 // PAIR: 1 = bf16 hi/lo pairs (GAST_F32X3), 2 = fp16 pairs (GAST_F32X3H: forward epilogues, images of the f16 kind)
@@ -471,9 +478,19 @@ __device__ __forceinline__ void gload16s_o(u32x4& dst, uint32_t voff, const void
 // CHAINS = 2: the correction products accumulate in a register set of their own (two independent MFMA chains per step: what a lone
 // block per CU wants); CHAINS = 1: one accumulator, 80 registers -- three blocks per CU, for the grids that do not fit two per CU
 // (measured: N = 1024 launches 55 -> 50 and 47 -> 43 us; the 34-block output layer 22 -> 27 us with it, so it keeps two chains)
+// PAIR = 3 (round 6): 16-BIT STORAGE (GAST_BF16 tensors: bfloat16, or binary16 in the -DGAST_H16_F16 build), ONE product.  A step covers
+// 64 values: k-group g multiplies the 32-value half g, whose row image is [32 x 16 bit] = the same 64 bytes -- the byte geometry of the
+// activation loads (16 bytes per thread, 128 bytes per row and step, 512 per group of four), of the weight DMA (layout image of
+// gast_x3_image_multi kind 2) and of the fragment reads is the split kernel's; the chunk a lane reads for the first 16-deep MFMA is the
+// one that holds the hi halves there (chunk lh), for the second the lo one (chunk 2 + lh).  The conversion is a pass-through, or BN +
+// ReLU on the 8 unpacked values.  A group of four steps is 256 values: every K of the launch must be a multiple of 256.
 template <int PAIR, int CHAINS>
 __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPlan& pl, int blk, unsigned char* smem) {
     constexpr int NJ = 1, TN = tn_of(NJ), W_BYTES = w_bytes(NJ), OFF_TAB = off_tab_fast(), NW = 1;
+    constexpr bool H16 = PAIR == 3;
+    constexpr int ESZ = H16 ? 2 : 4, CV = 16 / ESZ;       // bytes per stored element, values per 16-byte chunk
+    constexpr int GSH = H16 ? 8 : 7;                      // log2(values per group of four steps)
+    constexpr int TSTEP = 8 * CV * 4;                     // bytes of the scale / shift tables per step: 128 / 256
     static_assert(FD % 4 == 0 && FD >= 4, "pipeline depth");
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, kg = w >> 2, wr = (w >> 1) & 1, wc = w & 1;
     const int li = lane & 31, lh = lane >> 5;
@@ -498,12 +515,12 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         sAdd[ra_row] = a.addend ? (int)map_row(a.addmap, pb, pt, pj, a.J) : -1;
     }
     // ---- activation loads: group base (scalar) + the thread's byte offset; groups of 4 steps = 128 values = 512 bytes
-    int a_seg = 0, a_grp = a.seg[0].K >> 7;
+    int a_seg = 0, a_grp = a.seg[0].K >> GSH;
     const char* a_ptr = (const char*)a.seg[0].A;
     uint32_t offA;
     auto a_row = [&](const gast_gemm_seg& sg) {      // (pl.fast: every frame of the domain maps into the segment's tensor)
         const uint32_t srow = (uint32_t)((pb * sg.map.T_total + pt * sg.map.t_stride + sg.map.t_off) * a.J + pj);
-        offA = (srow * (uint32_t)sg.lda + c8 * 4) * 4u;
+        offA = (srow * (uint32_t)sg.lda + c8 * CV) * (uint32_t)ESZ;
     };
     a_row(a.seg[0]);
     auto a_next_group = [&]() {
@@ -513,7 +530,7 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
                 ++a_seg;
                 const gast_gemm_seg& sg = a.seg[a_seg];
                 a_ptr = (const char*)sg.A;
-                a_grp = sg.K >> 7;
+                a_grp = sg.K >> GSH;
                 a_row(sg);
             } else { a_ptr -= 512; a_grp = 1; }      // past the last group: the last group again
         }
@@ -524,8 +541,8 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
     const int kgW = __builtin_amdgcn_readfirstlane(w >> 2), pieceW = __builtin_amdgcn_readfirstlane((w & 3) * NW);
     const uint32_t offW = (uint32_t)(n0 + pieceW * 16 + r16) * 64u + (uint32_t)((s4 ^ ((r16 >> 2) & 3)) << 4);
     const uint32_t sW0 = __builtin_amdgcn_readfirstlane(lds0 + OFF_W + kgW * (TN * ROWB) + pieceW * 1024);
-    int w_seg = 0, w_grp = a.seg[0].K >> 7;
-    long w_step = (long)a.seg[0].ldwx * 4;           // bytes per step: two 16-value groups of ldwx 16-bit elements
+    int w_seg = 0, w_grp = a.seg[0].K >> GSH;
+    long w_step = (long)a.seg[0].ldwx * 4;           // bytes per step: two k-groups (16 values each; PAIR = 3: 32) of ldwx 16-bit elements
     const char* w_cur = (const char*)a.seg[0].Wx + (w_step >> 1) * kgW;
     auto dma_w = [&](int stage) {
         glds16<0>(offW, uni(w_cur), sW0 + stage * W_BYTES);
@@ -535,42 +552,63 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         if (--w_grp == 0) {
             if (w_seg + 1 < nseg) {
                 ++w_seg;
-                w_grp = a.seg[w_seg].K >> 7;
+                w_grp = a.seg[w_seg].K >> GSH;
                 w_step = (long)a.seg[w_seg].ldwx * 4;
                 w_cur = (const char*)a.seg[w_seg].Wx + (w_step >> 1) * kgW;
             } else { w_cur -= 4 * w_step; w_grp = 1; }
         }
     };
     // ---- conversion facts: prologue of the segment? + the LDS address of the thread's scale / shift values of the group
-    int c_seg = 0, c_grp = a.seg[0].K >> 7;
+    int c_seg = 0, c_grp = a.seg[0].K >> GSH;
     bool c_pro = pl.taboff[0] >= 0;
     const int tab_sh = pl.ntab * 4;
-    int tabv = OFF_TAB + (c_pro ? pl.taboff[0] : 0) * 4 + c8 * 16;
+    int tabv = OFF_TAB + (c_pro ? pl.taboff[0] : 0) * 4 + c8 * (CV * 4);
     auto c_next_group = [&]() {
-        tabv += 512;
+        tabv += 4 * TSTEP;
         if (--c_grp == 0) {
             if (c_seg + 1 < nseg) {
                 ++c_seg;
-                c_grp = a.seg[c_seg].K >> 7;
+                c_grp = a.seg[c_seg].K >> GSH;
                 c_pro = pl.taboff[c_seg] >= 0;
-                tabv = OFF_TAB + (c_pro ? pl.taboff[c_seg] : 0) * 4 + c8 * 16;
-            } else { tabv -= 512; c_grp = 1; }
+                tabv = OFF_TAB + (c_pro ? pl.taboff[c_seg] : 0) * 4 + c8 * (CV * 4);
+            } else { tabv -= 4 * TSTEP; c_grp = 1; }
         }
     };
     float4 tsc = make_float4(1.f, 1.f, 1.f, 1.f), tsh = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 tsc2 = tsc, tsh2 = tsh;                   // (PAIR = 3: values 4 .. 7 of the thread's chunk)
     bool t_pro = false;                              // prologue flag of the tile whose scale / shift are held
     auto fetch_tab = [&](auto Jc) {
         constexpr int J = decltype(Jc)::value;
         t_pro = c_pro;
         if (c_pro) {
-            tsc = *(const float4*)(smem + tabv + J * 128);
-            tsh = *(const float4*)(smem + tabv + tab_sh + J * 128);
+            tsc = *(const float4*)(smem + tabv + J * TSTEP);
+            tsh = *(const float4*)(smem + tabv + tab_sh + J * TSTEP);
+            if constexpr (H16) {
+                tsc2 = *(const float4*)(smem + tabv + J * TSTEP + 16);
+                tsh2 = *(const float4*)(smem + tabv + tab_sh + J * TSTEP + 16);
+            }
         }
     };
     const int wa_key = (ra_row >> 2) & 3;
     const int wa_base = OFF_A + kgA * (TM * ROWB) + ra_row * ROWB + (cA & 1) * 8;
     const int wa_hi = wa_base + (((cA >> 1) ^ wa_key) << 4), wa_lo = wa_base + (((2 + (cA >> 1)) ^ wa_key) << 4);
+    const int wa_h16 = OFF_A + kgA * (TM * ROWB) + ra_row * ROWB + ((cA ^ wa_key) << 4);      // PAIR = 3: chunk cA of the row image, whole
     auto write_a = [&](int stage, const u32x4& r) {
+        if constexpr (H16) {
+            uint32_t w4[4] = {r.x, r.y, r.z, r.w};
+            if (t_pro) {     // BN + ReLU on the 8 unpacked values, rounded back to the storage type
+                const float sc8[8] = {tsc.x, tsc.y, tsc.z, tsc.w, tsc2.x, tsc2.y, tsc2.z, tsc2.w};
+                const float sh8[8] = {tsh.x, tsh.y, tsh.z, tsh.w, tsh2.x, tsh2.y, tsh2.z, tsh2.w};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    float lo, hi;
+                    h16x2_unpack(w4[p], lo, hi);
+                    w4[p] = pack_h16x2(fmaxf(fmaf(lo, sc8[2 * p], sh8[2 * p]), 0.f), fmaxf(fmaf(hi, sc8[2 * p + 1], sh8[2 * p + 1]), 0.f));
+                }
+            }
+            *(uint4*)(smem + stage * A_BYTES + wa_h16) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+            return;
+        }
         float x0 = __uint_as_float(r.x), x1 = __uint_as_float(r.y), x2 = __uint_as_float(r.z), x3 = __uint_as_float(r.w);
         if (t_pro) {         // BN + ReLU prologue
             x0 = fmaxf(fmaf(x0, tsc.x, tsh.x), 0.f);
@@ -579,11 +617,11 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
             x3 = fmaxf(fmaf(x3, tsc.w, tsh.w), 0.f);
         }
         uint2 h, l;
-        split_pair4<PAIR>(x0, x1, x2, x3, h, l);
+        split_pair4<H16 ? 1 : PAIR>(x0, x1, x2, x3, h, l);
         *(uint2*)(smem + stage * A_BYTES + wa_hi) = h;
         *(uint2*)(smem + stage * A_BYTES + wa_lo) = l;
     };
-    const int ntile = pl.ntile32;                    // (a multiple of 4)
+    const int ntile = pl.ntile32;                    // K steps of the launch (a multiple of 4)
     f32x16 acc[NJ], acl[CHAINS == 2 ? NJ : 1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; if (CHAINS == 2) acl[0][r] = 0.f; }
@@ -653,14 +691,22 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         bl.u = *(const uint4*)(fW + SW * W_BYTES + olo);
         if (wr_next) write_a(SA ^ 1, ra[SET]);
         if (do_mma) {
-            if constexpr (CHAINS == 2) {
-                acl[0] = mfma_pair<PAIR>(al.u, bh.u, acl[0]);
-                acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
-                acl[0] = mfma_pair<PAIR>(ah.u, bl.u, acl[0]);
+            if constexpr (H16) {      // k 0..15 of the k-group's 32 values (chunks lh), then k 16..31 (chunks 2 + lh)
+                if constexpr (CHAINS == 2) {
+                    acc[0] = mfma_h16(ah.u, bh.u, acc[0]);
+                    acl[0] = mfma_h16(al.u, bl.u, acl[0]);
+                } else {
+                    acc[0] = mfma_h16(ah.u, bh.u, acc[0]);
+                    acc[0] = mfma_h16(al.u, bl.u, acc[0]);
+                }
+            } else if constexpr (CHAINS == 2) {
+                acl[0] = mfma_pair<H16 ? 1 : PAIR>(al.u, bh.u, acl[0]);
+                acc[0] = mfma_pair<H16 ? 1 : PAIR>(ah.u, bh.u, acc[0]);
+                acl[0] = mfma_pair<H16 ? 1 : PAIR>(ah.u, bl.u, acl[0]);
             } else {       // small terms first
-                acc[0] = mfma_pair<PAIR>(al.u, bh.u, acc[0]);
-                acc[0] = mfma_pair<PAIR>(ah.u, bl.u, acc[0]);
-                acc[0] = mfma_pair<PAIR>(ah.u, bh.u, acc[0]);
+                acc[0] = mfma_pair<H16 ? 1 : PAIR>(al.u, bh.u, acc[0]);
+                acc[0] = mfma_pair<H16 ? 1 : PAIR>(ah.u, bl.u, acc[0]);
+                acc[0] = mfma_pair<H16 ? 1 : PAIR>(ah.u, bh.u, acc[0]);
             }
         }
         if ((U & 3) == 1) w_next_group();
@@ -696,7 +742,7 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
         for (int r = 0; r < 16; ++r) acc[0][r] += acl[0][r];
     }
     __syncthreads();
-    bj_finish<NJ>(a, pl, smem, acc, m0, n0, mt);
+    bj_finish<NJ, H16>(a, pl, smem, acc, m0, n0, mt);
 }
 
 struct BjBatch {
@@ -727,15 +773,17 @@ std::atomic<bool> bj_setup_done[64];
 
 typedef void (*bj_kernel_t)(const gast_gemm_args, const BjPlan);
 typedef void (*bj_multi_kernel_t)(const BjBatch);
+// (pair 3 -- 16-bit storage -- exists for the two-chain lean loop only: the plan refuses what it cannot run, and the 80-register variant
+//  would spill three registers inside the K loop -- compiler-issued scratch accesses break the counted waits)
 bj_kernel_t bj_kernel(int fast, int pair) {
-    if (fast == 2) return pair == 2 ? gemm_bj_kernel<1, 2, 2> : gemm_bj_kernel<1, 1, 2>;
-    if (fast) return pair == 2 ? gemm_bj_kernel<1, 2, 1> : gemm_bj_kernel<1, 1, 1>;
-    return pair == 2 ? gemm_bj_kernel<1, 2, 0> : gemm_bj_kernel<1, 1, 0>;
+    if (fast == 2 && pair != 3) return pair == 2 ? gemm_bj_kernel<1, 2, 2> : gemm_bj_kernel<1, 1, 2>;
+    if (fast) return pair == 3 ? gemm_bj_kernel<1, 3, 1> : pair == 2 ? gemm_bj_kernel<1, 2, 1> : gemm_bj_kernel<1, 1, 1>;
+    return pair == 3 ? nullptr : pair == 2 ? gemm_bj_kernel<1, 2, 0> : gemm_bj_kernel<1, 1, 0>;
 }
 bj_multi_kernel_t bj_multi_kernel(int fast, int pair) {
-    if (fast == 2) return pair == 2 ? gemm_bj_multi_kernel<1, 2, 2> : gemm_bj_multi_kernel<1, 1, 2>;
-    if (fast) return pair == 2 ? gemm_bj_multi_kernel<1, 2, 1> : gemm_bj_multi_kernel<1, 1, 1>;
-    return pair == 2 ? gemm_bj_multi_kernel<1, 2, 0> : gemm_bj_multi_kernel<1, 1, 0>;
+    if (fast == 2 && pair != 3) return pair == 2 ? gemm_bj_multi_kernel<1, 2, 2> : gemm_bj_multi_kernel<1, 1, 2>;
+    if (fast) return pair == 3 ? gemm_bj_multi_kernel<1, 3, 1> : pair == 2 ? gemm_bj_multi_kernel<1, 2, 1> : gemm_bj_multi_kernel<1, 1, 1>;
+    return pair == 3 ? nullptr : pair == 2 ? gemm_bj_multi_kernel<1, 2, 0> : gemm_bj_multi_kernel<1, 1, 0>;
 }
 int bj_lds_bytes(int ntab, int fast) {
     static const int pad = getenv("GAST_GEMM_BJ_LDS_PAD") ? atoi(getenv("GAST_GEMM_BJ_LDS_PAD")) : 0;      // (occupancy experiments: fewer blocks per CU)
@@ -749,7 +797,8 @@ void bj_setup() {
     dev &= 63;
     if (bj_setup_done[dev].load(std::memory_order_acquire)) return;
     for (int fast = 0; fast <= 2; ++fast)
-        for (int pair = 1; pair <= 2; ++pair) {
+        for (int pair = 1; pair <= 3; ++pair) {
+            if (!bj_kernel(fast, pair)) continue;
             const hipError_t e1 = hipFuncSetAttribute((const void*)bj_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
             const hipError_t e2 = hipFuncSetAttribute((const void*)bj_multi_kernel(fast, pair), hipFuncAttributeMaxDynamicSharedMemorySize, fast ? LDS_BLOCK_FAST : LDS_BLOCK);
             if (e1 != hipSuccess || e2 != hipSuccess) {
@@ -775,18 +824,23 @@ void bj_setup() {
 int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     static const int enabled = getenv("GAST_GEMM_BJ") ? atoi(getenv("GAST_GEMM_BJ")) : 1;
     static const int max_rows = getenv("GAST_GEMM_BJ_MAX_M") ? atoi(getenv("GAST_GEMM_BJ_MAX_M")) : 8191;
-    if (!enabled || (a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H)) return 0;
+    // Round 6: 16-bit storage (GAST_BF16 tensors: bfloat16, or binary16 in the f16 build; layout images of the weights) on the lean loop,
+    // every epilogue, 16-bit output only.  GAST_GEMM_BJ_H16=0: those GEMMs stay on gemm.hip's split-K path.
+    static const int h16_enabled = getenv("GAST_GEMM_BJ_H16") ? atoi(getenv("GAST_GEMM_BJ_H16")) : 1;
+    const bool h16 = a.dtype == GAST_BF16;
+    if (!enabled || (a.dtype != GAST_F32X3 && a.dtype != GAST_F32X3H && !(h16 && h16_enabled))) return 0;
     if (a.dtype == GAST_F32X3H && a.epi == GAST_EPI_BNRELU_BWD) return 0;     // (a gradient operand does not fit fp16's range)
     if (a.out_f32 || a.f8_scale) return 0;
-    pl.pair = a.dtype == GAST_F32X3H ? 2 : 1;
+    pl.pair = h16 ? 3 : a.dtype == GAST_F32X3H ? 2 : 1;
+    const int esz = h16 ? 2 : 4, cv = 16 / esz;
     const long Ml = (long)a.B * a.Tn * a.J;
     if (Ml < 1 || Ml > max_rows || a.N < 1) return 0;
     if (a.nseg < 1 || a.nseg > GAST_MAX_SEG || !a.C) return 0;
     int ntab = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_gemm_seg& g = a.seg[s];
-        if (!g.Wx || !aligned16(g.Wx) || g.ldwx % 8 || !g.A || !aligned16(g.A) || g.lda % 4 || g.K % 4 || g.K < 4) return 0;
-        if ((long)a.B * g.map.T_total * a.J * g.lda * 4 >= 0xffffffffL) return 0;      // 32-bit byte offsets into the activation tensor
+        if (!g.Wx || !aligned16(g.Wx) || g.ldwx % 8 || !g.A || !aligned16(g.A) || g.lda % cv || g.K % cv || g.K < cv) return 0;
+        if ((long)a.B * g.map.T_total * a.J * g.lda * esz >= 0xffffffffL) return 0;      // 32-bit byte offsets into the activation tensor
         if (g.pro == GAST_PRO_BNRELU_DROP) return 0;
         pl.taboff[s] = -1;
         if (g.pro == GAST_PRO_BNRELU) {
@@ -801,9 +855,9 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     if (a.epi != GAST_EPI_PLAIN && !a.partials) return 0;
     if (a.epi == GAST_EPI_BNRELU_BWD && (!a.X || !a.xscale || !a.xshift)) return 0;
     const long rowsC = (long)a.B * a.cmap.T_total * a.J;
-    if (rowsC * a.ldc * 4 >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * 4 >= 0x7fffffffL)) return 0;
-    if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || rowsC * a.ldc2 * 4 >= 0x7fffffffL)) return 0;
-    if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * 4 >= 0x7fffffffL) return 0;
+    if (rowsC * a.ldc * esz >= 0x7fffffffL || (a.epi == GAST_EPI_BNRELU_BWD && rowsC * a.ldx * esz >= 0x7fffffffL)) return 0;
+    if (a.C2 && (a.epi != GAST_EPI_BNRELU_BWD || rowsC * a.ldc2 * esz >= 0x7fffffffL)) return 0;
+    if (a.addend && (long)a.B * a.addmap.T_total * a.J * a.ldadd * esz >= 0x7fffffffL) return 0;
     pl.M = (int)Ml;
     // the lean K loop (bj_body_fast): K steps in groups of four for every segment, no zero rows anywhere
     static const int fast_ok = getenv("GAST_GEMM_BJ_FAST") ? atoi(getenv("GAST_GEMM_BJ_FAST")) : 1;
@@ -813,9 +867,10 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
         const gast_rowmap& mp = a.seg[s].map;
         const long lo = mp.t_stride >= 0 ? mp.t_off : (long)(a.Tn - 1) * mp.t_stride + mp.t_off;
         const long hi = mp.t_stride >= 0 ? (long)(a.Tn - 1) * mp.t_stride + mp.t_off : mp.t_off;
-        if (a.seg[s].K % 128 || lo < 0 || hi >= mp.T_total) pl.fast = 0;
-        pl.ntile32 += (a.seg[s].K + 31) / 32;
+        if (a.seg[s].K % (h16 ? 256 : 128) || lo < 0 || hi >= mp.T_total) pl.fast = 0;
+        pl.ntile32 += h16 ? (a.seg[s].K + 63) / 64 : (a.seg[s].K + 31) / 32;
     }
+    if (h16 && !pl.fast) return 0;          // (16-bit storage: the lean loop is the only one)
     // Where this kernel is used (measured on MI355X at M = 2 176, scripts/gemm_table.py bf16x3: one launch per graph replay, this kernel
     // against gemm.hip's split-K pair): with the lean loop it wins or ties on every shape of the stage whose K steps come in fours and
     // whose grid is at most ~2 blocks per CU -- 24 / 39 / 47 / 41 / 25 / 42 us against 34 / 52 / 54 / 52 / 34 / 61 (K <= 1024), 40 / 54 /
@@ -846,7 +901,7 @@ int gast_gemm_bj_launch_multi(const gast_gemm_args* args, BjPlan* pls, int n, hi
     long blocks = 0;
     for (int d = 0; d < n; ++d) { fast &= pls[d].fast; blocks += (long)pls[d].tilesM * ((args[d].N + 63) / 64); }      // (one kernel per launch: the lean loop when every job qualifies)
     static const int occ3_blocks = getenv("GAST_GEMM_BJ_OCC3_BLOCKS") ? atoi(getenv("GAST_GEMM_BJ_OCC3_BLOCKS")) : 512;
-    if (fast && FD == 4 && blocks > occ3_blocks) fast = 2;          // more blocks than two per CU: the 80-register variant, three per CU
+    if (fast && FD == 4 && blocks > occ3_blocks && pair != 3) fast = 2;          // more blocks than two per CU: the 80-register variant, three per CU
     for (int d = 0; d < n; ++d) {
         if (pls[d].pair != pair) return GAST_EINVAL;
         pls[d].nj = nj;

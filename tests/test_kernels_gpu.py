@@ -573,6 +573,62 @@ def test_gemm_bj_x3_multi(ops, first, pair):
         _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
+# Round 6: the M = B*J kernel's lean loop on 16-bit STORAGE (PAIR = 3): every K a multiple of 256 (a group of four 64-value steps), rows a
+# multiple of 64, full row maps; weights from the layout image
+GEMM_BJ_H16_CASES = [
+    ('bjh_pro_mix', (64, 2, 17), 96, [(256, 4, 1, 1, 1), (512, 2, 1, 0, 0), (256, 4, 2, 0, 1)], 1, False, 'neg'),
+    ('bjh_concat_bwd_add', (128, 1, 17), 192, [(256, 1, 1, 0, 0), (256, 3, 1, 2, 0)], 2, True, False),
+    ('bjh_one_group', (64, 1, 17), 64, [(256, 1, 1, 0, 1)], 1, False, True),
+    ('bjh_plain_n512', (128, 1, 17), 512, [(1024, 1, 1, 0, 1)], 0, False, False),
+    ('bjh_bwd_n1024', (128, 1, 17), 1024, [(512, 1, 1, 0, 0)], 2, False, False),
+]
+
+
+@pytest.mark.parametrize('nodrop', [False, True], ids=['xdrop', 'noxdrop'])
+@pytest.mark.parametrize('case', GEMM_BJ_H16_CASES, ids=[c[0] for c in GEMM_BJ_H16_CASES])
+def test_gemm_bj_bf16_storage(ops, case, nodrop):
+    """gemm_bj.hip on GAST_BF16 tensors (bfloat16 here, binary16 when the suite runs in the f16 flavour): one product per value, 64 K
+    values per step, every epilogue; same numpy contract as gemm.hip's 16-bit cases, and run-to-run bit-equal (no cross-block reduction
+    on the output, two commutative adds per statistics element)."""
+    if nodrop and case[4] != 2:
+        pytest.skip('only the BNRELU_BWD epilogue has a dropout variant')
+    if _os.environ.get('GAST_GEMM_BJ_FAST') == '0':
+        pytest.skip('16-bit storage runs on the lean loop only (the opt-in child run switched it off)')
+    outs = []
+    for rep in range(2):
+        jd, jh, bufs = _gemm_case(case, H16)
+        if nodrop:
+            jd['xdrop'] = jh['xdrop'] = False
+        assert ops.gemm_path(**_with_h16_images(ops, jd)) == 2, 'kernel selection (gemm_bj.hip = 2)'
+        ops.gemm(**jd)
+        torch.cuda.synchronize()
+        outs.append(bufs)
+    kc.gemm(**jh)
+    _gemm_check(case, H16, outs[1], 'bf16')
+    _assert_bit_equal(outs[1][0], outs[0][0], case[0] + ': output of two runs')
+    if case[4]:
+        _assert_bit_equal(outs[1][2].view(outs[1][2].shape[0], -1), outs[0][2].view(outs[0][2].shape[0], -1), case[0] + ': column statistics of two runs')
+
+
+def test_gemm_bj_bf16_storage_multi(ops):
+    if _os.environ.get('GAST_GEMM_BJ_FAST') == '0':
+        pytest.skip('16-bit storage runs on the lean loop only')
+    cases = GEMM_BJ_H16_CASES[:3]
+    built = [_gemm_case(c, H16) for c in cases]
+    ops.gemm_multi([_with_h16_images(ops, jd) for jd, _, _ in built])
+    torch.cuda.synchronize()
+    for c, (jd, jh, bufs) in zip(cases, built):
+        kc.gemm(**jh)
+        _gemm_check(c, H16, bufs, 'bf16')
+
+
+def test_gemm_bj_bf16_storage_keeps_irregular_shapes_on_the_small_kernel(ops):
+    """a K that is no multiple of 256, or rows that are no multiple of 64, stay on gemm.hip in 16-bit storage (the lean loop is the only one)"""
+    for case in [('k384', (128, 1, 17), 192, [(384, 1, 1, 0, 0)], 1, False, False), ('m2159', (127, 1, 17), 192, [(256, 1, 1, 0, 0)], 1, False, False)]:
+        jd, _, _ = _gemm_case(case, H16)
+        assert ops.gemm_path(**_with_h16_images(ops, jd)) == 0, case[0]
+
+
 @pytest.mark.parametrize('case', [c for c in GEMM_BJ_CASES if c[4] == 2], ids=lambda c: c[0])
 def test_gemm_bj_second_output(ops, case):
     """gast_gemm_args.C2 on the M = B*J kernel, with and without an addend: bit-equal to the PLAIN epilogue of the same GEMM; C and
