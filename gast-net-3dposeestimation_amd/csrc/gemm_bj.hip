@@ -464,7 +464,7 @@ __device__ __forceinline__ void bj_body(const gast_gemm_args& a, const BjPlan& p
     bj_finish<NJ>(a, pl, smem, acc, m0, n0, mt);
 }
 
-// The same kernel for the shapes the stage is made of -- every segment's K a multiple of 128, no zero rows (pl.fast) -- with a K
+// The same kernel for the shapes the stage is made of -- every segment's K a multiple of 128, full row maps (pl.fast) -- with a K
 // loop of a THIRD of the instructions.  SQ counters of the general loop above (profiles/r06_pmc_gemm_bj.txt): ~120 instructions per
 // wave and 32-value step for 3 MFMAs, a wave active (issuing) a third of its cycles, L2 read latency 340 cycles at a 74 % hit rate --
 // the loop is bound by its own instruction stream (a wave issues in order, ~4.5 cycles per instruction), not by memory.  Here the
@@ -506,13 +506,14 @@ __device__ __forceinline__ void bj_body_fast(const gast_gemm_args& a, const BjPl
     const int ra_row = tid >> 3, c8 = tid & 7, kgA = c8 >> 2, cA = c8 & 3;
     const int TJ = a.Tn * a.J;
     int pb, pt, pj;
+    const bool rin = m0 + ra_row < pl.M;             // (the last row tile may be ragged: its rows past M load row M - 1 and store nothing)
     {
-        const int m = m0 + ra_row;                   // (pl.fast: M is a multiple of the tile, every row exists)
+        const int m = rin ? m0 + ra_row : pl.M - 1;
         pb = m / TJ; const int rem = m - pb * TJ; pt = rem / a.J; pj = rem - pt * a.J;
     }
     if (c8 == 0) {
-        sCrow[ra_row] = (int)map_row(a.cmap, pb, pt, pj, a.J);
-        sAdd[ra_row] = a.addend ? (int)map_row(a.addmap, pb, pt, pj, a.J) : -1;
+        sCrow[ra_row] = rin ? (int)map_row(a.cmap, pb, pt, pj, a.J) : -1;
+        sAdd[ra_row] = (rin && a.addend) ? (int)map_row(a.addmap, pb, pt, pj, a.J) : -1;
     }
     // ---- activation loads: group base (scalar) + the thread's byte offset; groups of 4 steps = 128 values = 512 bytes
     int a_seg = 0, a_grp = a.seg[0].K >> GSH;
@@ -861,7 +862,7 @@ int gast_gemm_bj_plan(const gast_gemm_args& a, BjPlan& pl) {
     pl.M = (int)Ml;
     // the lean K loop (bj_body_fast): K steps in groups of four for every segment, no zero rows anywhere
     static const int fast_ok = getenv("GAST_GEMM_BJ_FAST") ? atoi(getenv("GAST_GEMM_BJ_FAST")) : 1;
-    pl.fast = fast_ok && Ml % TM == 0;
+    pl.fast = fast_ok != 0;                   // (any row count: the rows of a ragged last tile past M are clamped on load and never stored)
     pl.ntile32 = 0;
     for (int s = 0; s < a.nseg; ++s) {
         const gast_rowmap& mp = a.seg[s].map;

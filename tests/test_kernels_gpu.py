@@ -524,6 +524,9 @@ GEMM_BJ_CASES = GEMM_CASES + GEMM_SMALL_X3_CASES + [
     ('bj_fast_pro_mix', (64, 2, 17), 96, [(128, 4, 1, 1, 1), (384, 2, 1, 0, 0), (128, 4, 2, 0, 1)], 1, False, 'neg'),
     ('bj_fast_concat_bwd_add', (128, 1, 17), 192, [(256, 1, 1, 0, 0), (128, 3, 1, 2, 0)], 2, True, False),
     ('bj_fast_one_group', (64, 1, 17), 64, [(128, 1, 1, 0, 1)], 1, False, True),
+    # ... and a ragged last row tile (M = 119 and 2 159: rows past M are clamped on load, never stored, never counted)
+    ('bj_fast_ragged_m119', (7, 1, 17), 128, [(256, 1, 1, 0, 1)], 1, False, True),
+    ('bj_fast_ragged_bwd_add', (127, 1, 17), 192, [(128, 1, 1, 0, 0), (128, 3, 1, 2, 0)], 2, True, False),
 ]
 
 
@@ -573,14 +576,16 @@ def test_gemm_bj_x3_multi(ops, first, pair):
         _gemm_check(c, torch.float32, bufs, 'x3h' if f16 else 'x3')
 
 
-# Round 6: the M = B*J kernel's lean loop on 16-bit STORAGE (PAIR = 3): every K a multiple of 256 (a group of four 64-value steps), rows a
-# multiple of 64, full row maps; weights from the layout image
+# Round 6: the M = B*J kernel's lean loop on 16-bit STORAGE (PAIR = 3): every K a multiple of 256 (a group of four 64-value steps), full
+# row maps, any row count; weights from the layout image
 GEMM_BJ_H16_CASES = [
     ('bjh_pro_mix', (64, 2, 17), 96, [(256, 4, 1, 1, 1), (512, 2, 1, 0, 0), (256, 4, 2, 0, 1)], 1, False, 'neg'),
     ('bjh_concat_bwd_add', (128, 1, 17), 192, [(256, 1, 1, 0, 0), (256, 3, 1, 2, 0)], 2, True, False),
     ('bjh_one_group', (64, 1, 17), 64, [(256, 1, 1, 0, 1)], 1, False, True),
     ('bjh_plain_n512', (128, 1, 17), 512, [(1024, 1, 1, 0, 1)], 0, False, False),
     ('bjh_bwd_n1024', (128, 1, 17), 1024, [(512, 1, 1, 0, 0)], 2, False, False),
+    ('bjh_ragged_m2159', (127, 1, 17), 192, [(256, 1, 1, 0, 0), (256, 3, 1, 2, 1)], 2, True, False),
+    ('bjh_ragged_m45', (3, 1, 15), 64, [(256, 1, 1, 0, 1)], 1, False, 'neg'),
 ]
 
 
@@ -623,8 +628,8 @@ def test_gemm_bj_bf16_storage_multi(ops):
 
 
 def test_gemm_bj_bf16_storage_keeps_irregular_shapes_on_the_small_kernel(ops):
-    """a K that is no multiple of 256, or rows that are no multiple of 64, stay on gemm.hip in 16-bit storage (the lean loop is the only one)"""
-    for case in [('k384', (128, 1, 17), 192, [(384, 1, 1, 0, 0)], 1, False, False), ('m2159', (127, 1, 17), 192, [(256, 1, 1, 0, 0)], 1, False, False)]:
+    """a K that is no multiple of 256, or a row map that leaves the tensor, stays on gemm.hip in 16-bit storage (the lean loop is the only one)"""
+    for case in [('k384', (128, 1, 17), 192, [(384, 1, 1, 0, 0)], 1, False, False), ('tap_out_of_range', (64, 2, 17), 192, [(256, 2, 1, 1, 0)], 1, False, False)]:
         jd, _, _ = _gemm_case(case, H16)
         assert ops.gemm_path(**_with_h16_images(ops, jd)) == 0, case[0]
 
